@@ -1,0 +1,570 @@
+"""CPU restatement (NumPy, fp32 op-for-op) of the PFPN particle-policy hot path.
+
+*** TEST INFRASTRUCTURE -- NOT PRODUCT CODE. ***
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the shipped path (pfpn_amd/) never does and fails loudly when the
+HIP library is missing.
+
+PARITY UNPINNED: the reference (xupei0610/PFPN) ships no tests, no golden
+input/output vectors, and its arithmetic lives in un-vendored third-party
+packages (tensorflow-gpu==1.14, tensorflow_probability==0.7, requirements.txt:1-2)
+that cannot be installed here.  What IS pinned (tests/test_oracle_golden.py):
+the particle-grid initialisers and every scalar constant decoded from the shipped
+MetaGraphDef files (tests/golden/meta_constants.json, meta_samples*_init.npy).
+Everything else follows the reference Python source plus the op order decoded from
+the saved graphs; each function cites the lines it restates.
+
+RNG: TF's Philox streams cannot be reproduced without TF, so every random draw is
+an explicit input (u_cat, eps, gumbel, u_resample, u_noise).  Index-critical
+transcendentals are evaluated in float64 and (where the reference is fp32) rounded
+to fp32, so CPU and GPU agree bit-for-bit on indices (DESIGN.md "Index parity").
+
+Paths cited are relative to /root/reference.
+"""
+import numpy as np
+
+F = np.float32
+HALF_LOG_2PI = F(0.9189385175704956)   # saved graph: global_net/actor/Normal/prob/add/x
+LOG2 = F(np.log(2.0))
+
+
+# --------------------------------------------------------------------------- #
+# particle grid                                                               #
+# --------------------------------------------------------------------------- #
+def init_particles(A, N, tanh_mode=False, init_sigma=None):
+    """networks/actor_critic/a2c.py:476-534 (build_policy, identical particle count).
+
+    Bounds are forced to [-1, 1] (a2c.py:479-480).  Returns (loc[A,N], logstd[A,N]) fp32,
+    exactly what the `samples` / `samples_std` constant initialisers hold.
+    """
+    u = np.ones((A, N), dtype=np.float64)
+    l = -u
+    ar = np.arange(N, dtype=np.float64)[None, :]
+    if tanh_mode:
+        loc = l + (u - l) / N * (ar + 0.5)                       # a2c.py:486
+    else:
+        loc = l + (u - l) / (N - 1) * ar                         # a2c.py:488
+    if init_sigma:
+        std = np.broadcast_to(np.asarray(init_sigma, dtype=np.float64).reshape(-1, 1)
+                              if np.ndim(init_sigma) else np.float64(init_sigma), loc.shape).copy()
+        if tanh_mode:                                            # a2c.py:492-498
+            loc_ = loc
+            loc = np.arctanh(loc)
+            std = np.maximum(loc - np.arctanh(np.maximum(1e-6 - 1, loc_ - std)),
+                             np.arctanh(np.minimum(1 - 1e-6, loc_ + std)) - loc)
+    else:
+        std = (u - l) / (N - 1)                                  # a2c.py:500
+        if tanh_mode:                                            # a2c.py:501-512
+            assert N > 3
+            loc = np.arctanh(loc)
+            d0 = loc - loc[:, np.maximum(0, np.arange(N) - 1)]
+            d1 = loc[:, np.minimum(N - 1, np.arange(N) + 1)] - loc
+            std = np.maximum(d0, d1)
+    logstd = np.log(std)                                         # a2c.py:523
+    return loc.astype(F), logstd.astype(F)
+
+
+# --------------------------------------------------------------------------- #
+# mixture distribution (networks/utils.py:85-236)                             #
+# --------------------------------------------------------------------------- #
+def softmax(logits):
+    """TF `Softmax` on the last axis, fp32: exp(l - max) / sum  (Appendix A)."""
+    logits = np.asarray(logits, dtype=F)
+    v = logits - logits.max(axis=-1, keepdims=True)
+    e = np.exp(v, dtype=F)
+    return (e / e.sum(axis=-1, keepdims=True, dtype=F)).astype(F)
+
+
+def _normal_prob(x, loc, logstd):
+    """tf.distributions.Normal(loc, scale).prob(x[..., None]), op order of Appendix A:
+    z=(x-loc)/scale; exp(-0.5*z^2 - (0.9189385 + log(scale))), scale = exp(logstd)."""
+    scale = np.exp(logstd.astype(F), dtype=F)
+    z = ((x[..., None].astype(F) - loc[None]) / scale[None]).astype(F)
+    arg = (F(-0.5) * (z * z) - (HALF_LOG_2PI + np.log(scale, dtype=F))[None]).astype(F)
+    with np.errstate(under="ignore"):
+        phi = np.exp(arg, dtype=F)
+    return phi, z, scale
+
+
+def _tanh_correction(x):
+    """2*(log2 - x - softplus(-2x)) == log(1 - tanh(x)^2)  (utils.py:132-133)."""
+    x = x.astype(F)
+    sp = np.logaddexp(F(0), F(-2) * x).astype(F)         # tf.nn.softplus
+    return (F(2) * (LOG2 - x - sp)).astype(F)
+
+
+def mixture_log_prob(logits, x, loc, logstd, tanh_mode=False):
+    """MixtureGaussianDistribution.log_prob, networks/utils.py:108-134.
+
+    logits [B,A,N], x [B,A] (the pre-tanh value s_ when tanh_mode), loc/logstd [A,N].
+    Returns (logp[B], p[B,A]).  Computed in probability space like the reference (no
+    log-sum-exp): p may underflow to 0 -> logp = -inf.
+    """
+    w = softmax(logits)
+    phi, _, _ = _normal_prob(np.asarray(x, F), loc, logstd)
+    p = (w * phi).sum(axis=-1, dtype=F)
+    with np.errstate(divide="ignore"):
+        lp = np.log(p, dtype=F)
+    if tanh_mode:
+        lp = lp - _tanh_correction(np.asarray(x, F))
+    return lp.sum(axis=-1, dtype=F), p
+
+
+def mixture_log_prob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False):
+    """Autodiff of mixture_log_prob as TF builds it (Appendix A "Backward of log-prob",
+    NaN/Inf guard of utils.py:109-117 applied to d/dp right after Log_grad).
+
+    Returns dlogits[B,A,N], dloc[A,N], dlogstd[A,N], dx[B,A].
+    """
+    logits = np.asarray(logits, F)
+    x = np.asarray(x, F)
+    w = softmax(logits)
+    phi, z, scale = _normal_prob(x, loc, logstd)
+    p = (w * phi).sum(axis=-1, dtype=F)
+    g = np.asarray(dlogp, F)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        q = (g / p).astype(F)
+    q = np.where(np.isnan(q) | np.isinf(q), F(0), q).astype(F)       # foo() guard
+    qw = (q[..., None] * w).astype(F)
+    dlogits = (qw * (phi - p[..., None])).astype(F)                  # softmax grad
+    t = (qw * phi).astype(F)                                         # dL/dphi * phi
+    dloc = (t * z / scale[None]).sum(axis=0, dtype=F)
+    dlogstd = (t * (z * z - F(1))).sum(axis=0, dtype=F)
+    dx = -(t * z / scale[None]).sum(axis=-1, dtype=F)
+    if tanh_mode:
+        dx = dx + g * F(2) * np.tanh(x, dtype=F)
+    return dlogits, dloc.astype(F), dlogstd.astype(F), dx.astype(F)
+
+
+def categorical_entropy(logits):
+    """MixtureGaussianDistribution.entropy, networks/utils.py:146-151 -> H[B,A]."""
+    logits = np.asarray(logits, F)
+    v = logits - logits.max(axis=-1, keepdims=True)
+    s0 = np.exp(v, dtype=F)
+    s1 = s0.sum(axis=-1, keepdims=True, dtype=F)
+    p = s0 / s1
+    return (p * (np.log(s1, dtype=F) - v)).sum(axis=-1, dtype=F)
+
+
+def categorical_entropy_bwd(logits, dH):
+    """d/dlogits of categorical_entropy: -w * (log w + H) * dH."""
+    logits = np.asarray(logits, F)
+    v = logits - logits.max(axis=-1, keepdims=True)
+    s0 = np.exp(v, dtype=F)
+    s1 = s0.sum(axis=-1, keepdims=True, dtype=F)
+    w = s0 / s1
+    logw = v - np.log(s1, dtype=F)
+    H = -(w * logw).sum(axis=-1, keepdims=True, dtype=F)
+    return (-(w * (logw + H)) * np.asarray(dH, F)[..., None]).astype(F)
+
+
+def multinomial_index(logits2d, u):
+    """TF-1.14 CPU `Multinomial` draw rule (definition): per row
+    cdf_j = sum_{i<=j} exp(double(l_i) - max l) (fp64 running sum, left to right),
+    pick the first j with cdf_j > u * cdf_{N-1}  (std::upper_bound).
+
+    logits2d [R,N] fp32, u [R] or [R,S] in [0,1) fp64 -> int32 index [R] / [R,S]."""
+    l = np.asarray(logits2d, F).astype(np.float64)
+    m = l.max(axis=-1, keepdims=True)
+    e = np.exp(l - m)
+    cdf = np.empty_like(e)
+    run = np.zeros(e.shape[:-1], np.float64)
+    for j in range(e.shape[-1]):                 # explicit left-to-right order
+        run = run + e[..., j]
+        cdf[..., j] = run
+    u = np.asarray(u, np.float64)
+    if u.ndim == l.ndim - 1:
+        target = (u * run)[..., None]
+        k = (cdf <= target).sum(axis=-1)
+    else:                                        # several draws per row
+        target = u * run[..., None]
+        k = (cdf[..., None, :] <= target[..., None]).sum(axis=-1)
+    return np.minimum(k, l.shape[-1] - 1).astype(np.int32)
+
+
+def sample_plain(logits, loc, logstd, u_cat, eps_sel):
+    """MixtureGaussianDistribution.sample(1), plain branch, networks/utils.py:187-194.
+
+    k ~ Categorical(logits) via multinomial_index(u_cat[B,A]); a = loc[a,k] + scale[a,k]*eps.
+    The reference draws eps for all N particles and keeps one; `eps_sel[B,A]` is the
+    kept draw (same distribution).  Returns (k[B,A] int32, action[B,A] fp32)."""
+    B, A, N = logits.shape
+    k = multinomial_index(np.asarray(logits, F).reshape(B * A, N),
+                          np.asarray(u_cat, np.float64).reshape(B * A)).reshape(B, A)
+    scale = np.exp(logstd.astype(F), dtype=F)
+    ai = np.arange(A)[None, :]
+    a = (loc[ai, k] + scale[ai, k] * np.asarray(eps_sel, F)).astype(F)
+    return k, a
+
+
+def active_stats(logits, max_active, sum_active):
+    """a2c.py:356-360: max_active <- max(max_active, max_B w); sum_active += sum_B w."""
+    w = softmax(logits)
+    new_max = np.maximum(max_active, w.max(axis=0)).astype(F)
+    new_sum = (sum_active + w.sum(axis=0, dtype=F)).astype(F)
+    return new_max, new_sum
+
+
+def mean_action(logits, loc, tanh_mode=False):
+    """MixtureGaussianDistribution.mean, networks/utils.py:202-236: loc[a, argmax_N];
+    tanh(loc) in tanh mode (argmax of softmax == argmax of logits, first index on ties)."""
+    k = np.asarray(logits, F).argmax(axis=-1)
+    ai = np.arange(loc.shape[0])[None, :]
+    a = loc[ai, k].astype(F)
+    if tanh_mode:
+        a = np.tanh(a, dtype=F)
+    return k.astype(np.int32), a
+
+
+def rsample(logits, loc, logstd, gumbel, eps):
+    """MixtureGaussianDistribution.sample(1), rsample branch (SAC), utils.py:156-186.
+
+    gumbel [B,A,N] = -log(-log u) (TFP 0.7 ExpRelaxedOneHotCategorical, T=1), eps [B,A,N].
+    Returns (a=tanh(p_k) [B,A], s_=p_k [B,A], k [B,A] int32)."""
+    y = (np.asarray(logits, F) + np.asarray(gumbel, F)).astype(F)
+    k = y.argmax(axis=-1)
+    scale = np.exp(logstd.astype(F), dtype=F)
+    p = (loc[None] + scale[None] * np.asarray(eps, F)).astype(F)
+    pk = np.take_along_axis(p, k[..., None], axis=-1)[..., 0]
+    return np.tanh(pk, dtype=F), pk.astype(F), k.astype(np.int32)
+
+
+def rsample_bwd(logits, loc, logstd, gumbel, eps, da, ds):
+    """Custom gradients `mask` / `mask2` of utils.py:165-183 followed by the
+    softmax((logits+g)/1) Jacobian and p = loc + scale*eps.
+
+    da, ds [B,A]: upstream grads w.r.t. a (= tanh p_k) and s_ (= p_k).
+    Returns dlogits [B,A,N], dloc [A,N], dlogstd [A,N]."""
+    y = (np.asarray(logits, F) + np.asarray(gumbel, F)).astype(F)
+    w = softmax(y)
+    k = y.argmax(axis=-1)
+    scale = np.exp(logstd.astype(F), dtype=F)
+    eps = np.asarray(eps, F)
+    p = (loc[None] + scale[None] * eps).astype(F)
+    t = np.tanh(p, dtype=F)
+    tk = np.take_along_axis(t, k[..., None], axis=-1)
+    gap = (t - tk).astype(F)
+    da = np.asarray(da, F)[..., None]
+    ds = np.asarray(ds, F)[..., None]
+    gw = (gap * da + gap / np.maximum(F(1e-6), F(1) - tk * tk) * ds).astype(F)   # dL/dw
+    dlogits = (w * (gw - (gw * w).sum(axis=-1, keepdims=True, dtype=F))).astype(F)
+    m = np.zeros_like(p)
+    np.put_along_axis(m, k[..., None], F(1), axis=-1)
+    # a = sum m*tanh(p): grad to tanh_p is m*da, through tanh: (1-t^2); s_: m*ds
+    gp = (m * (da * (F(1) - t * t) + ds)).astype(F)
+    dloc = gp.sum(axis=0, dtype=F)
+    dlogstd = (gp * scale[None] * eps).sum(axis=0, dtype=F)
+    return dlogits, dloc.astype(F), dlogstd.astype(F)
+
+
+# --------------------------------------------------------------------------- #
+# dead-particle resampling (a2c.py:385-474)                                   #
+# --------------------------------------------------------------------------- #
+def _seq_sum_rows(x):
+    """Left-to-right fp32 row sum (the order the HIP kernel uses, so indices agree)."""
+    s = np.zeros(x.shape[0], F)
+    for j in range(x.shape[1]):
+        s = (s + x[:, j]).astype(F)
+    return s
+
+
+def resample_particles(loc, logstd, bias, weight, max_active, sum_active,
+                       u_resample, u_noise, threshold=None, tanh_mode=False):
+    """ParticleFilteringA2CNetwork.build_resample_ops, `resample == -1` branch
+    (a2c.py:385-474; the only branch the shipped settings use, deepmimic_dppo_pfpn.py:5).
+
+    loc, logstd, max_active, sum_active [A,N]; bias [A*N]; weight [H, A*N] (a particle is a
+    column).  u_resample [A,N] in [0,1): uniforms for `tf.random.categorical(log avg, N)`;
+    u_noise [A,N] in [-1,1): uniform for dead particle (a,j) (`tf.random.uniform(-1,1)`,
+    indexed by the dead particle's own slot so the kernel needs no compaction).
+    Returns new (loc, logstd, bias, weight) and `info` (dead mask, source index per slot).
+    Log of the average activation is fl32(log_f64(avg)) -- see module docstring.
+    """
+    A, N = loc.shape
+    thr = F(threshold) if threshold else F(.05 / N)              # a2c.py:391
+    s = _seq_sum_rows(sum_active.astype(F))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        avg = (sum_active.astype(F) / s[:, None]).astype(F)      # a2c.py:394
+        log_avg = np.log(avg.astype(np.float64)).astype(F)       # a2c.py:402 (tf.math.log)
+    dead = max_active.astype(F) < thr                            # a2c.py:395
+    cand = multinomial_index(log_avg, np.asarray(u_resample, np.float64))   # [A,N] draws
+    # choice = invalid[:,1] (a2c.py:403): dead particle (a,j) takes draw number j
+    src = cand                                                    # src[a,j] = cand[a, j]
+    loc = loc.astype(F).copy(); logstd = logstd.astype(F).copy()
+    bias = bias.astype(F).copy(); weight = weight.astype(F).copy()
+    old_loc, old_logstd, old_bias, old_weight = loc.copy(), logstd.copy(), bias.copy(), weight.copy()
+    scale = np.exp(old_logstd, dtype=F)
+    for a in range(A):
+        js = np.nonzero(dead[a])[0]
+        if js.size == 0:
+            continue
+        srcs = src[a, js]
+        # count[u] = #clones per unique source; delta = 1 if the source is itself dead (a2c.py:453-457)
+        cnt = np.bincount(srcs, minlength=N).astype(F)
+        delta = dead[a].astype(F)
+        new_bias_src = (old_bias[a * N:(a + 1) * N]
+                        - np.log((cnt + F(1) - delta).astype(F), dtype=F)).astype(F)   # per source col
+        # first scatter: bias[tc] = bias_new ; second: bias[c] = bias_new (a2c.py:465-466)
+        for sidx in np.unique(srcs):
+            bias[a * N + sidx] = new_bias_src[sidx]
+        for j, sidx in zip(js, srcs):
+            bias[a * N + j] = new_bias_src[sidx]
+            noise = (scale[a, sidx] * F(u_noise[a, j])).astype(F)                     # a2c.py:441
+            noise = (noise + (F(-1e-4) if noise < 0 else F(1e-4))).astype(F)          # a2c.py:442-444
+            nl = (old_loc[a, sidx] + noise).astype(F)                                 # a2c.py:445
+            if tanh_mode:   # a2c.py:448-450 (quirk: atanh of a pre-tanh value, and/or precedence)
+                nl = np.arctanh(np.clip(nl, F(1e-6 - 1), F(1 - 1e-6)), dtype=F)
+            loc[a, j] = nl
+            logstd[a, j] = np.clip(old_logstd[a, sidx], F(-20), F(2))                 # a2c.py:451
+            weight[:, a * N + j] = old_weight[:, a * N + sidx]                        # a2c.py:467-469
+    return loc, logstd, bias, weight, {"dead": dead, "src": src.astype(np.int32)}
+
+
+# --------------------------------------------------------------------------- #
+# GAE (a2c.py:30-40, utils.py:5-15)                                           #
+# --------------------------------------------------------------------------- #
+def gae(reward, value, gamma, gae_gamma):
+    """generalized_advantage_estimate: td = r + gamma*v' - v on fp32 arrays; reverse scan
+    adv_t = td_t + gae_gamma*adv_{t+1} with a float64 accumulator (NumPy<2 scalar promotion
+    of `np.float32 + python_float`), emitted as float64 list, cast to fp32 by flat_train
+    (distributed_model.py:324-326).  reward [T], value [T+1] -> adv [T] fp32."""
+    r = np.asarray(reward, dtype=F)
+    v = np.asarray(value[:-1], dtype=F)
+    v_ = np.asarray(value[1:], dtype=F)
+    td = (r + (F(gamma) * v_).astype(F)).astype(F)
+    td = (td - v).astype(F)
+    out = np.empty(len(td), np.float64)
+    acc = 0.0
+    f = float(gae_gamma)
+    for t in reversed(range(len(td))):
+        acc = float(td[t]) + f * acc
+        out[t] = acc
+    return out.astype(F)
+
+
+# --------------------------------------------------------------------------- #
+# state normaliser (actor_critic.py:223-244, utils.py:46-68)                  #
+# --------------------------------------------------------------------------- #
+def state_normalize(s, mean, std, clip=5.0):
+    x = ((np.asarray(s, F) - mean.astype(F)) / std.astype(F)).astype(F)
+    if clip:
+        x = np.maximum(np.minimum(x, F(clip)), F(-clip))
+    return x
+
+
+def state_norm_update(s, mean, std, step):
+    """online_normalizer(moving_average=True).update_op, utils.py:60-68.
+    d = min(0.9999, (1+step)/(10+step)); population variance over the batch."""
+    s = np.asarray(s, F)
+    stp = F(step)
+    d = np.minimum(F(0.9999), (F(1) + stp) / (F(10) + stp)).astype(F)
+    m = s.mean(axis=0, dtype=F)
+    var = ((s - m) ** 2).mean(axis=0, dtype=F)
+    new_mean = (d * mean + (F(1) - d) * m).astype(F)
+    new_std = np.maximum(F(1e-6), d * std + (F(1) - d) * np.sqrt(var, dtype=F)).astype(F)
+    return new_mean, new_std
+
+
+# --------------------------------------------------------------------------- #
+# dense layers (ops.py:82-118) and the actor-critic (actor_critic.py:206-218) #
+# --------------------------------------------------------------------------- #
+def relu6(x):
+    return np.minimum(np.maximum(x, F(0)), F(6))
+
+
+def fc(x, w, b, act):
+    y = (x @ w + b).astype(F)
+    return relu6(y) if act else y
+
+
+PARAM_ORDER = ["actor/fc1/weight", "actor/fc1/bias", "actor/fc2/weight", "actor/fc2/bias",
+               "actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
+               "critic/fc1/weight", "critic/fc1/bias", "critic/fc2/weight", "critic/fc2/bias",
+               "critic/fc3/weight", "critic/fc3/bias"]            # saved-graph variable order
+
+
+def init_params(rng, S, A, N, hidden=(1024, 512), tanh_mode=False, sigma=0.01):
+    """14 trainables, truncated-normal(0, 0.01) weights, zero biases (deepmimic_base.py:7-8)."""
+    def tn(shape):
+        x = rng.standard_normal(shape)
+        bad = np.abs(x) > 2
+        while bad.any():
+            x[bad] = rng.standard_normal(bad.sum())
+            bad = np.abs(x) > 2
+        return (x * sigma).astype(F)
+    h1, h2 = hidden
+    loc, logstd = init_particles(A, N, tanh_mode)
+    return {
+        "actor/fc1/weight": tn((S, h1)), "actor/fc1/bias": np.zeros(h1, F),
+        "actor/fc2/weight": tn((h1, h2)), "actor/fc2/bias": np.zeros(h2, F),
+        "actor/samples": loc, "actor/samples_std": logstd,
+        "actor/fc_policy/weight": tn((h2, A * N)), "actor/fc_policy/bias": np.zeros(A * N, F),
+        "critic/fc1/weight": tn((S, h1)), "critic/fc1/bias": np.zeros(h1, F),
+        "critic/fc2/weight": tn((h1, h2)), "critic/fc2/bias": np.zeros(h2, F),
+        "critic/fc3/weight": tn((h2, 1)), "critic/fc3/bias": np.zeros(1, F),
+    }
+
+
+def actor_forward(P, x, A, N):
+    h1 = fc(x, P["actor/fc1/weight"], P["actor/fc1/bias"], True)
+    h2 = fc(h1, P["actor/fc2/weight"], P["actor/fc2/bias"], True)
+    logits = fc(h2, P["actor/fc_policy/weight"], P["actor/fc_policy/bias"], False)
+    return logits.reshape(-1, A, N), (h1, h2)
+
+
+def critic_forward(P, x):
+    c1 = fc(x, P["critic/fc1/weight"], P["critic/fc1/bias"], True)
+    c2 = fc(c1, P["critic/fc2/weight"], P["critic/fc2/bias"], True)
+    v = fc(c2, P["critic/fc3/weight"], P["critic/fc3/bias"], False)[:, 0]
+    return v, (c1, c2)
+
+
+def _fc_bwd(x_in, w, y_out, dy, act):
+    if act:
+        dy = np.where((y_out > 0) & (y_out < 6), dy, F(0)).astype(F)   # Relu6Grad
+    dw = (x_in.T @ dy).astype(F)
+    db = dy.sum(axis=0, dtype=F)
+    dx = (dy @ w.T).astype(F)
+    return dx, dw, db
+
+
+# --------------------------------------------------------------------------- #
+# PPO loss (ppo.py:14-74, actor_critic.py:132-184)                            #
+# --------------------------------------------------------------------------- #
+def ppo_loss(logp, logp_old, adv, v, v_old, eps_clip=0.2, value_loss_coef=0.5, normalize_adv=True):
+    """Returns (loss, policy_loss, value_loss*coef, dlogp[B], dv[B])."""
+    logp = np.asarray(logp, F); adv = np.asarray(adv, F); v = np.asarray(v, F)
+    B = F(len(adv))
+    if normalize_adv:                                             # actor_critic.py:151-156
+        m = adv.mean(dtype=F)
+        var = ((adv - m) ** 2).mean(dtype=F)
+        nadv = ((adv - m) / (np.sqrt(var, dtype=F) + F(1e-8))).astype(F)
+    else:
+        nadv = adv
+    with np.errstate(over="ignore", invalid="ignore"):
+        ratio = np.exp(logp - np.asarray(logp_old, F), dtype=F)   # ppo.py:47-48
+        sur = (ratio * nadv).astype(F)
+        lo, hi = F(1.0 - eps_clip), F(1.0 + eps_clip)
+        cr = np.maximum(np.minimum(ratio, hi), lo)                # tf.clip_by_value
+        csur = (cr * nadv).astype(F)
+        policy_loss = -np.minimum(sur, csur).mean(dtype=F)        # ppo.py:54
+        target = (adv + np.asarray(v_old, F)).astype(F)           # ppo.py:31-34
+        value_loss = ((v - target) ** 2).mean(dtype=F) * F(value_loss_coef)
+        # backward.  tf.minimum grad goes to `sur` where sur <= csur, else to csur; the
+        # clip_by_value grad passes only where lo <= ratio <= hi (inclusive, TF semantics).
+        to_sur = sur <= csur
+        inside = (ratio >= lo) & (ratio <= hi)
+        dmin = F(-1) / B
+        dratio = np.where(to_sur, dmin * nadv, np.where(inside, dmin * nadv, F(0))).astype(F)
+        dlogp = (dratio * ratio).astype(F)
+    dv = (F(2) * (v - target) * F(value_loss_coef) / B).astype(F)
+    return F(policy_loss + value_loss), F(policy_loss), F(value_loss), dlogp, dv
+
+
+# --------------------------------------------------------------------------- #
+# optimiser (base_worker.py:97-102, TF ApplyAdam)                             #
+# --------------------------------------------------------------------------- #
+def clip_by_global_norm(grads, clip_norm=1.0):
+    """tf.clip_by_global_norm: norm = sqrt(2*sum_i L2Loss(g_i)); scale = c*min(1/norm, 1/c)."""
+    half = [F(0.5) * np.sum(np.square(g.astype(F)), dtype=F) for g in grads]
+    norm = np.sqrt(F(2) * np.sum(np.asarray(half, F), dtype=F), dtype=F)
+    c = F(clip_norm)
+    with np.errstate(divide="ignore"):
+        scale = c * np.minimum(F(1) / norm, F(1) / c)
+    if not np.isfinite(norm):
+        scale = F(np.nan)
+    return [(g * scale).astype(F) for g in grads], norm
+
+
+def tf_adam(p, g, m, v, b1p, b2p, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
+    """TF `ApplyAdam` CPU kernel form: alpha = lr*sqrt(1-b2^t)/(1-b1^t);
+    m += (g-m)*(1-b1); v += (g*g-v)*(1-b2); p -= m*alpha/(sqrt(v)+eps).
+    b1p/b2p are the fp32 `beta*_power` variables BEFORE this step's update (they start at
+    beta and are multiplied by beta after the applies).  Not torch.optim.Adam."""
+    lr, b1, b2, eps = F(lr), F(b1), F(b2), F(eps)
+    alpha = (lr * np.sqrt(F(1) - F(b2p), dtype=F) / (F(1) - F(b1p))).astype(F)
+    m = (m + (g - m) * (F(1) - b1)).astype(F)
+    v = (v + (g * g - v) * (F(1) - b2)).astype(F)
+    p = (p - (m * alpha) / (np.sqrt(v, dtype=F) + eps)).astype(F)
+    return p, m, v
+
+
+# --------------------------------------------------------------------------- #
+# one DPPO learner step                                          #
+# --------------------------------------------------------------------------- #
+def dppo_grads(P, norm_mean, norm_std, batch, A, N, eps_clip=0.2, value_loss_coef=0.5):
+    """Forward + backward of loss = policy_loss + 0.5*value_loss on one (rank-local) batch.
+    batch = dict(state[B,S], action[B,A], value[B], log_prob[B], advantage[B]).
+    Returns (losses, grads dict, aux)."""
+    x = state_normalize(batch["state"], norm_mean, norm_std, 5.0)
+    logits, (h1, h2) = actor_forward(P, x, A, N)
+    v, (c1, c2) = critic_forward(P, x)
+    logp, _ = mixture_log_prob(logits, batch["action"], P["actor/samples"], P["actor/samples_std"])
+    loss, pl, vl, dlogp, dv = ppo_loss(logp, batch["log_prob"], batch["advantage"], v, batch["value"],
+                                       eps_clip, value_loss_coef)
+    dlogits, dloc, dlogstd, _ = mixture_log_prob_bwd(logits, batch["action"], P["actor/samples"],
+                                                     P["actor/samples_std"], dlogp)
+    G = {"actor/samples": dloc, "actor/samples_std": dlogstd}
+    dl = dlogits.reshape(len(x), A * N)
+    dh2, G["actor/fc_policy/weight"], G["actor/fc_policy/bias"] = _fc_bwd(h2, P["actor/fc_policy/weight"], None, dl, False)
+    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True)
+    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True)
+    dc2, G["critic/fc3/weight"], G["critic/fc3/bias"] = _fc_bwd(c2, P["critic/fc3/weight"], None, dv[:, None], False)
+    dc1, G["critic/fc2/weight"], G["critic/fc2/bias"] = _fc_bwd(c1, P["critic/fc2/weight"], c2, dc2, True)
+    _, G["critic/fc1/weight"], G["critic/fc1/bias"] = _fc_bwd(x, P["critic/fc1/weight"], c1, dc1, True)
+    return (loss, pl, vl), G, {"logp": logp, "value": v, "logits": logits, "x": x}
+
+
+class DPPOState:
+    """Everything a learner replica owns (variables of the saved graph, Appendix A)."""
+
+    def __init__(self, rng, S=197, A=36, N=35, hidden=(1024, 512), resample_interval=368):
+        self.S, self.A, self.N = S, A, N
+        self.P = init_params(rng, S, A, N, hidden)
+        self.m = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.b1p, self.b2p = F(0.9), F(0.999)
+        self.norm_mean, self.norm_std = np.zeros(S, F), np.ones(S, F)
+        self.max_active, self.sum_active = np.zeros((A, N), F), np.zeros((A, N), F)
+        self.global_step = 0
+        self.train_flag = 0
+        self.resample_interval = resample_interval
+
+
+def dppo_learner_step(st, shards, lr=1e-4, clip_norm=1.0, u_resample=None, u_noise=None):
+    """One global learner step over W rank-local shards (W=1: a single batch).
+
+    Mirrors sync_model.py:62-101 + SURVEY App. B "State-norm EMA": each worker (a) updates
+    its LOCAL state-normaliser copy on its shard, (b) computes grads with the PS statistics of
+    the previous apply, (c) clips by global norm PER WORKER, then the PS takes the mean of the
+    clipped grads and of the 4 pushed stat tensors, applies TF-Adam, ticks the resampler.
+    Returns list of per-shard losses."""
+    W = len(shards)
+    losses, gsum, stat_sum = [], None, None
+    for b in shards:
+        lm, ls = state_norm_update(b["state"], st.norm_mean, st.norm_std, st.global_step)
+        (loss, pl, vl), G, _ = dppo_grads(st.P, st.norm_mean, st.norm_std, b, st.A, st.N)
+        names = PARAM_ORDER
+        clipped, _ = clip_by_global_norm([G[n] for n in names], clip_norm)
+        losses.append((loss, pl, vl))
+        stats = [lm, ls, st.max_active, st.sum_active]
+        if gsum is None:
+            gsum = [c.astype(F) for c in clipped]; stat_sum = [s.astype(F) for s in stats]
+        else:
+            gsum = [(a + c).astype(F) for a, c in zip(gsum, clipped)]
+            stat_sum = [(a + s).astype(F) for a, s in zip(stat_sum, stats)]
+    gmean = [(g / F(W)).astype(F) for g in gsum]
+    st.norm_mean, st.norm_std, st.max_active, st.sum_active = [(s / F(W)).astype(F) for s in stat_sum]
+    for n, g in zip(PARAM_ORDER, gmean):
+        st.P[n], st.m[n], st.v[n] = tf_adam(st.P[n], g, st.m[n], st.v[n], st.b1p, st.b2p, lr)
+    st.b1p, st.b2p = F(st.b1p * F(0.9)), F(st.b2p * F(0.999))
+    st.global_step += 1
+    st.train_flag += 1
+    if st.train_flag >= st.resample_interval:                      # a2c.py:370-383
+        if u_resample is not None:
+            (st.P["actor/samples"], st.P["actor/samples_std"], st.P["actor/fc_policy/bias"],
+             st.P["actor/fc_policy/weight"], _) = resample_particles(
+                st.P["actor/samples"], st.P["actor/samples_std"], st.P["actor/fc_policy/bias"],
+                st.P["actor/fc_policy/weight"], st.max_active, st.sum_active, u_resample, u_noise)
+        st.max_active[:] = 0; st.sum_active[:] = 0; st.train_flag = 0
+    return losses

@@ -1,0 +1,130 @@
+"""GPU parity: mixture log-prob kernels (through the C ABI) vs the NumPy oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # north_star: fp32 log-prob within 1e-5 rtol
+
+
+def make_inputs(oracle, B, A, N, seed, tanh_mode=False, spread=1.2):
+    rng = np.random.default_rng(seed)
+    loc, logstd = oracle.init_particles(A, N, tanh_mode)
+    loc = (loc + rng.normal(0, 0.05, loc.shape)).astype(np.float32)
+    logstd = (logstd + rng.normal(0, 0.1, logstd.shape)).astype(np.float32)
+    logits = rng.normal(0, 1, (B, A, N)).astype(np.float32)
+    x = rng.uniform(-spread, spread, (B, A)).astype(np.float32)
+    return logits, x, loc, logstd
+
+
+def to_dev(dev, *arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+SHAPES = [(1, 36, 35), (5, 36, 35), (7, 36, 35), (8, 36, 35), (64, 36, 35), (257, 36, 35), (4096, 36, 35),
+          (33, 6, 50), (19, 36, 16), (40, 3, 8), (9, 5, 35), (3, 1, 35),
+          (17, 36, 23), (6, 4, 100), (5, 3, 256), (4, 7, 64), (3, 2, 1)]
+
+
+@pytest.mark.parametrize("B,A,N", SHAPES)
+@pytest.mark.parametrize("tanh_mode", [False, True])
+def test_logprob_fwd(oracle, dev, B, A, N, tanh_mode):
+    from pfpn_amd import kernels
+    if tanh_mode and N <= 3:
+        pytest.skip("tanh grid needs N > 3")
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 100 + B + N, tanh_mode)
+    ref_lp, ref_p = oracle.mixture_log_prob(logits, x, loc, logstd, tanh_mode)
+    dl, dx, dloc, dls = to_dev(dev, logits, x, loc, logstd)
+    lp, p = kernels.logprob_fwd(dl, dx, dloc, dls, tanh_mode, want_pmix=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p.cpu().numpy(), ref_p, rtol=2e-5, atol=0)
+    np.testing.assert_allclose(lp.cpu().numpy(), ref_lp, rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,A,N", SHAPES)
+@pytest.mark.parametrize("tanh_mode", [False, True])
+def test_logprob_bwd(oracle, dev, B, A, N, tanh_mode):
+    from pfpn_amd import kernels
+    if tanh_mode and N <= 3:
+        pytest.skip("tanh grid needs N > 3")
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 200 + B + N, tanh_mode)
+    rng = np.random.default_rng(B * 7 + N)
+    g = rng.normal(0, 1, B).astype(np.float32)
+    r_dl, r_dloc, r_dls, r_dx = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, g, tanh_mode)
+    dl, dx, dloc, dls, dg = to_dev(dev, logits, x, loc, logstd, g)
+    o_dl, o_dloc, o_dls, o_dx = kernels.logprob_bwd(dl, dx, dloc, dls, dg, tanh_mode, want_dx=True)
+    torch.cuda.synchronize()
+    sc = np.abs(r_dl).max() + 1e-30
+    np.testing.assert_allclose(o_dl.cpu().numpy(), r_dl, rtol=1e-4, atol=1e-6 * sc)
+    np.testing.assert_allclose(o_dx.cpu().numpy(), r_dx, rtol=1e-4, atol=1e-5 * (np.abs(r_dx).max() + 1e-30))
+    # sums over B of fp32 terms: tolerance scales with the summed magnitude
+    for got, ref in ((o_dloc, r_dloc), (o_dls, r_dls)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * (np.abs(ref).max() + 1e-30))
+
+
+def test_logprob_underflow_guard(oracle, dev):
+    """x far from every particle: p underflows to 0, logp = -inf in the forward (reference computes in
+    probability space), and the backward guard zeroes the gradients (utils.py:109-117)."""
+    from pfpn_amd import kernels
+    B, A, N = 9, 36, 35
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 5)
+    x[3, 7] = 40.0
+    x[5, :] = -30.0
+    g = np.ones(B, np.float32)
+    ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+    r_dl, r_dloc, r_dls, _ = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, g)
+    assert np.isneginf(ref_lp[3]) and np.isneginf(ref_lp[5])
+    dl, dx, dloc, dls, dg = to_dev(dev, logits, x, loc, logstd, g)
+    lp = kernels.logprob_fwd(dl, dx, dloc, dls)
+    o_dl, o_dloc, o_dls = kernels.logprob_bwd(dl, dx, dloc, dls, dg)
+    lp = lp.cpu().numpy()
+    assert np.isneginf(lp[3]) and np.isneginf(lp[5])
+    ok = np.isfinite(ref_lp)
+    np.testing.assert_allclose(lp[ok], ref_lp[ok], rtol=RTOL, atol=1e-5)
+    o = o_dl.cpu().numpy()
+    assert np.all(np.isfinite(o))
+    assert np.all(o[3, 7] == 0) and np.all(o[5] == 0)
+    np.testing.assert_allclose(o, r_dl, rtol=1e-4, atol=1e-6 * np.abs(r_dl).max())
+    assert np.all(np.isfinite(o_dloc.cpu().numpy())) and np.all(np.isfinite(o_dls.cpu().numpy()))
+
+
+@pytest.mark.parametrize("B", [1, 7, 100, 4096])
+def test_ppo_fused(oracle, dev, B):
+    """Fused fwd + PPO loss + bwd kernel == oracle log_prob -> ppo_loss -> log_prob_bwd."""
+    from pfpn_amd import kernels
+    A, N = 36, 35
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 300 + B, spread=1.05)
+    rng = np.random.default_rng(B)
+    ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+    lp_old = (ref_lp + rng.normal(0, 0.15, B)).astype(np.float32)     # ratios on both sides of the clip
+    adv = rng.normal(0, 1, B).astype(np.float32)
+    v = rng.normal(0, 1, B).astype(np.float32)
+    v_old = rng.normal(0, 1, B).astype(np.float32)
+    loss, pl, vl, dlogp, dv = oracle.ppo_loss(ref_lp, lp_old, adv, v, v_old, 0.2, 0.5, normalize_adv=B > 1)
+    r_dl, r_dloc, r_dls, _ = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, dlogp)
+    d = to_dev(dev, logits, x, loc, logstd, lp_old, adv, v, v_old)
+    stats = kernels.adv_stats(d[5], normalize=B > 1)
+    out = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(out["dvalue"].cpu().numpy(), dv, rtol=1e-5, atol=1e-9)
+    got = out["loss3"].cpu().numpy()
+    np.testing.assert_allclose(got, [loss, pl, vl], rtol=2e-5, atol=1e-6)
+    sc = np.abs(r_dl).max() + 1e-30
+    np.testing.assert_allclose(out["dlogits"].cpu().numpy().reshape(B, A, N), r_dl, rtol=2e-4, atol=2e-6 * sc)
+    for k, ref in (("dloc", r_dloc), ("dlogstd", r_dls)):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref, rtol=1e-4, atol=5e-5 * (np.abs(ref).max() + 1e-30))
+
+
+def test_bitwise_reproducible(oracle, dev):
+    """Fixed-order slab reductions: two launches give identical bits."""
+    from pfpn_amd import kernels
+    B, A, N = 4096, 36, 35
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 9)
+    g = np.random.default_rng(1).normal(0, 1, B).astype(np.float32)
+    d = to_dev(dev, logits, x, loc, logstd, g)
+    a = kernels.logprob_bwd(*d)
+    b = kernels.logprob_bwd(*d)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

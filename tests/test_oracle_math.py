@@ -1,0 +1,182 @@
+"""CPU checks of the oracle against independent float64 torch-autograd formulations
+(the oracle is op-for-op fp32; these pin its math, not its rounding)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _inputs(oracle, B=13, A=6, N=35, seed=0, tanh_mode=False):
+    rng = np.random.default_rng(seed)
+    loc, logstd = oracle.init_particles(A, N, tanh_mode)
+    loc = (loc + rng.normal(0, 0.05, loc.shape)).astype(np.float32)
+    logstd = (logstd + rng.normal(0, 0.1, logstd.shape)).astype(np.float32)
+    logits = rng.normal(0, 1, (B, A, N)).astype(np.float32)
+    x = rng.uniform(-1.2, 1.2, (B, A)).astype(np.float32)
+    return logits, x, loc, logstd
+
+
+def _torch_logp(logits, x, loc, logstd, tanh_mode):
+    lw = torch.log_softmax(logits, -1)
+    comp = torch.distributions.Normal(loc, logstd.exp()).log_prob(x.unsqueeze(-1))
+    lp = torch.logsumexp(lw + comp, -1)
+    if tanh_mode:
+        lp = lp - torch.log1p(-torch.tanh(x) ** 2)
+    return lp.sum(-1)
+
+
+@pytest.mark.parametrize("tanh_mode", [False, True])
+def test_log_prob_matches_logsumexp(oracle, tanh_mode):
+    logits, x, loc, logstd = _inputs(oracle, tanh_mode=tanh_mode)
+    lp, p = oracle.mixture_log_prob(logits, x, loc, logstd, tanh_mode)
+    t = [torch.tensor(a, dtype=torch.float64) for a in (logits, x, loc, logstd)]
+    ref = _torch_logp(*t, tanh_mode).numpy()
+    np.testing.assert_allclose(lp, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tanh_mode", [False, True])
+def test_log_prob_bwd_matches_autograd(oracle, tanh_mode):
+    logits, x, loc, logstd = _inputs(oracle, seed=3, tanh_mode=tanh_mode)
+    g = np.random.default_rng(1).normal(0, 1, len(x)).astype(np.float32)
+    dl, dloc, dls, dx = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, g, tanh_mode)
+    t = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (logits, x, loc, logstd)]
+    (_torch_logp(*t, tanh_mode) * torch.tensor(g, dtype=torch.float64)).sum().backward()
+    for got, ref in zip((dl, dx, dloc, dls), (t[0].grad, t[1].grad, t[2].grad, t[3].grad)):
+        ref = ref.numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+
+
+def test_entropy_and_bwd(oracle):
+    logits, *_ = _inputs(oracle, seed=5)
+    H = oracle.categorical_entropy(logits)
+    t = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    ref = torch.distributions.Categorical(logits=t).entropy()
+    np.testing.assert_allclose(H, ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    g = np.random.default_rng(2).normal(0, 1, H.shape).astype(np.float32)
+    (ref * torch.tensor(g, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(oracle.categorical_entropy_bwd(logits, g), t.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_multinomial_rule(oracle):
+    """First index whose running fp64 sum of exp(l - max) exceeds u * total."""
+    rng = np.random.default_rng(0)
+    logits = rng.normal(0, 2, (500, 35)).astype(np.float32)
+    u = rng.random(500)
+    k = oracle.multinomial_index(logits, u)
+    w = np.exp(logits.astype(np.float64) - logits.max(-1, keepdims=True))
+    cdf = np.cumsum(w, -1)
+    for i in range(500):
+        exp_k = int(np.searchsorted(cdf[i], u[i] * cdf[i, -1], side="right"))
+        assert k[i] == min(exp_k, 34)
+    # edge: u = 0 picks the first particle with non-zero mass; u -> 1 picks the last
+    assert oracle.multinomial_index(logits[:1], np.array([0.0]))[0] == 0
+    assert oracle.multinomial_index(logits[:1], np.array([np.nextafter(1.0, 0)]))[0] == 34
+    # several draws per row
+    k2 = oracle.multinomial_index(logits[:4], rng.random((4, 35)))
+    assert k2.shape == (4, 35) and k2.dtype == np.int32
+    # empirical frequencies follow softmax
+    l1 = np.tile(logits[:1], (20000, 1))
+    kk = oracle.multinomial_index(l1, rng.random(20000))
+    freq = np.bincount(kk, minlength=35) / 20000
+    np.testing.assert_allclose(freq, oracle.softmax(logits[0]), atol=0.012)
+
+
+def test_rsample_bwd_matches_custom_grads(oracle):
+    """utils.py:156-186: d a/d w = tanh p - tanh p_k ; d s_/d w = that / max(1e-6, 1 - tanh^2 p_k);
+    d/d p = onehot; then softmax(logits + g) and p = loc + scale * eps via autograd."""
+    logits, _, loc, logstd = _inputs(oracle, B=7, A=4, N=35, seed=7, tanh_mode=True)
+    rng = np.random.default_rng(4)
+    gum = -np.log(-np.log(rng.uniform(1e-9, 1, logits.shape))).astype(np.float32)
+    eps = rng.normal(0, 1, logits.shape).astype(np.float32)
+    da = rng.normal(0, 1, logits.shape[:2]).astype(np.float32)
+    ds = rng.normal(0, 1, logits.shape[:2]).astype(np.float32)
+    a, s_, k = oracle.rsample(logits, loc, logstd, gum, eps)
+    dl, dloc, dls = oracle.rsample_bwd(logits, loc, logstd, gum, eps, da, ds)
+
+    T = lambda v, g=False: torch.tensor(v, dtype=torch.float64, requires_grad=g)
+    tl, tloc, tls = T(logits, True), T(loc, True), T(logstd, True)
+    w = torch.softmax(tl + T(gum), -1)
+    p = tloc + tls.exp() * T(eps)
+    kk = torch.tensor(k.astype(np.int64))
+    m = torch.nn.functional.one_hot(kk, logits.shape[-1]).double()
+    tp = torch.tanh(p)
+    tk = (m * tp).sum(-1, keepdim=True).detach()
+
+    class Mask(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, p, gap):
+            ctx.save_for_backward(gap)
+            return m * p
+        @staticmethod
+        def backward(ctx, dy):
+            (gap,) = ctx.saved_tensors
+            return gap * dy, m * dy, None
+    s_t = Mask.apply(w, p, ((tp - tk) / torch.clamp(1 - tk ** 2, min=1e-6)).detach()).sum(-1)
+    a_t = Mask.apply(w, tp, (tp - tk).detach()).sum(-1)
+    np.testing.assert_allclose(a, a_t.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(s_, s_t.detach().numpy(), rtol=1e-5, atol=1e-6)
+    ((a_t * T(da)).sum() + (s_t * T(ds)).sum()).backward()
+    for got, ref in ((dl, tl.grad), (dloc, tloc.grad), (dls, tls.grad)):
+        ref = ref.numpy()
+        np.testing.assert_allclose(got, ref, rtol=3e-4, atol=3e-5 * (np.abs(ref).max() + 1e-30))
+
+
+def test_gae_closed_form(oracle):
+    rng = np.random.default_rng(0)
+    T_ = 37
+    r = rng.normal(0, 1, T_).astype(np.float32)
+    v = rng.normal(0, 1, T_ + 1).astype(np.float32)
+    adv = oracle.gae(r, v, 0.95, 0.95 * 0.95)
+    td = r.astype(np.float64) + 0.95 * v[1:] - v[:-1]
+    ref = np.array([sum(td[t + i] * 0.9025 ** i for i in range(T_ - t)) for t in range(T_)])
+    np.testing.assert_allclose(adv, ref, rtol=1e-5, atol=1e-6)
+    assert adv.dtype == np.float32
+
+
+def test_ppo_loss_bwd_matches_autograd(oracle):
+    rng = np.random.default_rng(3)
+    B = 64
+    lp = rng.normal(-30, 1, B).astype(np.float32)
+    lp_old = (lp + rng.normal(0, 0.2, B)).astype(np.float32)
+    adv = rng.normal(0, 1, B).astype(np.float32)
+    v, v_old = rng.normal(0, 1, B).astype(np.float32), rng.normal(0, 1, B).astype(np.float32)
+    loss, pl, vl, dlogp, dv = oracle.ppo_loss(lp, lp_old, adv, v, v_old)
+    T = lambda a, g=False: torch.tensor(a, dtype=torch.float64, requires_grad=g)
+    tlp, tv = T(lp, True), T(v, True)
+    ta = T(adv)
+    na = (ta - ta.mean()) / (ta.var(unbiased=False).sqrt() + 1e-8)
+    ratio = (tlp - T(lp_old)).exp()
+    l_pi = -torch.minimum(ratio * na, ratio.clamp(0.8, 1.2) * na).mean()
+    l_v = 0.5 * ((tv - (ta + T(v_old))) ** 2).mean()
+    (l_pi + l_v).backward()
+    np.testing.assert_allclose([pl, vl, loss], [l_pi.item(), l_v.item(), (l_pi + l_v).item()], rtol=1e-5)
+    np.testing.assert_allclose(dlogp, tlp.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(dv, tv.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_tf_adam_differs_from_torch_adam_in_eps_placement(oracle):
+    """TF: p -= lr_t * m / (sqrt(v) + eps);  torch: p -= lr * m_hat / (sqrt(v_hat) + eps)."""
+    rng = np.random.default_rng(0)
+    p = rng.normal(0, 1, 50).astype(np.float32)
+    g = (rng.normal(0, 1, 50) * 1e-6).astype(np.float32)      # tiny grads: eps placement matters
+    p1, m1, v1 = oracle.tf_adam(p, g, np.zeros_like(p), np.zeros_like(p), 0.9, 0.999)
+    m = 0.1 * g.astype(np.float64); v = 0.001 * g.astype(np.float64) ** 2
+    alpha = 1e-4 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    np.testing.assert_allclose(p1, p - alpha * m / (np.sqrt(v) + 1e-8), rtol=1e-6, atol=1e-9)
+    tp = torch.tensor(p.copy(), requires_grad=True)
+    opt = torch.optim.Adam([tp], lr=1e-4, eps=1e-8)
+    tp.grad = torch.tensor(g)
+    opt.step()
+    assert np.abs(tp.detach().numpy() - p1).max() > 1e-6       # genuinely different update
+
+
+def test_clip_by_global_norm(oracle):
+    rng = np.random.default_rng(1)
+    gs = [rng.normal(0, 1, s).astype(np.float32) for s in ((5, 3), (7,), (2, 2))]
+    out, norm = oracle.clip_by_global_norm(gs, 1.0)
+    ref = np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in gs))
+    np.testing.assert_allclose(norm, ref, rtol=1e-6)
+    np.testing.assert_allclose(np.sqrt(sum((o.astype(np.float64) ** 2).sum() for o in out)), 1.0, rtol=1e-5)
+    small = [g * np.float32(1e-3) for g in gs]
+    out2, _ = oracle.clip_by_global_norm(small, 1.0)
+    for a, b in zip(out2, small):
+        assert np.array_equal(a, b)                              # scale == 1 exactly
