@@ -73,6 +73,104 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
                              float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue,
                              float* loss3, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Unfused PPO head on [B] vectors (same arithmetic as inside pfpn_ppo_mixture_fwd_bwd) --
+ * reference ppo.py:31-54: dlogp [B], dvalue [B], loss3 = {loss, policy_loss, value_loss*coef}. */
+int pfpn_ppo_loss(const float* logp, const float* logp_old, const float* adv, const float* value,
+                  const float* value_old, const float* adv_stats, int B, float clip_eps, float value_coef,
+                  float* dlogp, float* dvalue, float* loss3, void* stream);
+
+/* ---- rollout: sample / statistics / deterministic action / entropy (K3) ------------------- */
+size_t pfpn_rollout_workspace_bytes(int B, int A, int N);
+
+/* MixtureGaussianDistribution.sample(1), plain branch -- reference networks/utils.py:187-194, fused
+ * with the log-prob of the drawn action (ppo.py:27-29 build_action_sampler_with_log_prob) and the
+ * running activation statistics (a2c.py:356-365) when max_active/sum_active are non-NULL.
+ * u_cat [B,A] float64 in [0,1): one uniform per categorical draw (TF-1.14 CPU Multinomial rule:
+ * float64 running sum of exp(double(l)-max), first index whose sum exceeds u*total);
+ * eps_sel [B,A]: the standard-normal draw of the selected particle.
+ * k [B,A] int32, action [B,A] = loc[a,k] + exp(logstd[a,k])*eps, logp [B] (optional). */
+int pfpn_sample(const float* logits, const float* loc, const float* logstd, const double* u_cat,
+                const float* eps_sel, int B, int A, int N, int32_t* k, float* action, float* logp,
+                float* max_active, float* sum_active, void* workspace, size_t workspace_bytes, void* stream);
+
+/* max_active <- max(max_active, max_b softmax), sum_active += sum_b softmax -- a2c.py:356-360. */
+int pfpn_active_stats(const float* logits, int B, int A, int N, float* max_active, float* sum_active,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* MixtureGaussianDistribution.mean -- utils.py:202-236: loc[a, argmax_n logits] (tanh(.) in tanh mode). */
+int pfpn_mean_action(const float* logits, const float* loc, int B, int A, int N, int tanh_mode,
+                     int32_t* k, float* action, void* stream);
+
+/* MixtureGaussianDistribution.entropy -- utils.py:146-151: H [B,A]; bwd: dlogits (+)= dH * dH/dlogits. */
+int pfpn_entropy_fwd(const float* logits, int B, int A, int N, float* H, void* stream);
+int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, int accumulate,
+                     float* dlogits, void* stream);
+
+/* SAC reparameterised sample (K4) -- utils.py:156-186.  gumbel [B,A*N] = -log(-log u), eps [B,A*N]:
+ * k = argmax(logits+gumbel), s_out = p_k = loc+exp(logstd)*eps, a_out = tanh(p_k).
+ * bwd: custom gradients `mask`/`mask2` (utils.py:165-183) with upstream da, ds [B,A]. */
+int pfpn_rsample_fwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
+                     const float* eps, int B, int A, int N, int32_t* k, float* a_out, float* s_out,
+                     void* stream);
+int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
+                     const float* eps, const float* da, const float* ds, int B, int A, int N, int accumulate,
+                     float* dlogits, float* dloc, float* dlogstd, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ---- resample (K5) ------------------------------------------------------------------------ */
+/* ParticleFilteringA2CNetwork.build_resample_ops, resample == -1 -- a2c.py:385-474.  In place on
+ * loc/logstd [A,N], bias [A*N], weight [H, A*N] (fc_policy, a particle is a column).
+ * u_resample [A,N] float64 in [0,1): uniforms of tf.random.categorical(log avg, N);
+ * u_noise [A,N] in [-1,1): tf.random.uniform for dead slot (a,j).  threshold <= 0 -> 0.05/N.
+ * dead_out / src_out [A,N] int32: dead mask and drawn source index per slot.  The caller zeroes
+ * max_active/sum_active/train_flag afterwards (a2c.py:373-378). */
+int pfpn_resample(float* loc, float* logstd, float* bias, float* weight, int H,
+                  const float* max_active, const float* sum_active, const double* u_resample,
+                  const float* u_noise, int A, int N, float threshold, int tanh_mode,
+                  int32_t* dead_out, int32_t* src_out, void* stream);
+
+/* ---- learner utilities (K6, K8, K9, dense epilogues) ------------------------------------- */
+size_t pfpn_learner_workspace_bytes(int rows, int H);
+
+/* generalized_advantage_estimate + discount -- a2c.py:30-40, utils.py:5-15.  E ragged sequences:
+ * sequence e has T_e = offsets[e+1]-offsets[e] rewards at reward[offsets[e]..] and T_e+1 values at
+ * value[offsets[e]+e ..] (last one = bootstrap).  fp32 deltas, float64 sequential scan, fp32 out. */
+int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, int E, float gamma,
+             double gae_gamma, float* adv, void* stream);
+
+/* x = clip((s-mean)/std, +-clip) -- actor_critic.py:223-244 (clip <= 0: no clipping). */
+int pfpn_state_norm(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
+                    void* stream);
+/* online_normalizer(moving_average=True) -- utils.py:60-68, population moments over the batch. */
+int pfpn_state_norm_update(const float* s, int B, int S, float step, const float* mean_in, const float* std_in,
+                           float* mean_out, float* std_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* fc_layer epilogue -- ops.py:105-117: y <- act(y + bias); y [rows,H], bias [G,H], rows of group g are
+ * [g*group_rows, (g+1)*group_rows) (group_rows = 0: one group). */
+int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, int relu6, void* stream);
+/* Relu6Grad + BiasAddGrad: dy <- dy*[0<y<6] in place (relu6), db [G,H] = column sums of dy per group. */
+int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group_rows, int relu6, float* db,
+                           void* workspace, size_t workspace_bytes, void* stream);
+/* critic fc3 (H -> 1, squeeze) -- actor_critic.py:206-210: v[b] = h[b,:].w + bias[0]; backward gives
+ * dh = dv (x) w masked by the ReLU6 of h, dw [H], db [1]. */
+int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B, int H, float* v, void* stream);
+int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, int H, int relu6, float* dh,
+                        float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
+/* tf.clip_by_global_norm -- base_worker.py:97-102: norm_scale = {norm, clip*min(1/norm, 1/clip)};
+ * apply != 0 scales grads in place (needed before a data-parallel all-reduce). */
+int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply, float* norm_scale,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* TF ApplyAdam on a flat buffer (epsilon outside the bias-corrected sqrt; NOT torch.optim.Adam).
+ * beta_pow [2] = {beta1^t, beta2^t} device scalars, advanced when advance_beta_pow != 0.
+ * norm_scale (optional) multiplies the gradient by norm_scale[1]; grad_mul by a host scalar. */
+int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
+                 float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
+                 float grad_mul, void* stream);
+/* SAC soft target update -- sac.py:67-73. */
+int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

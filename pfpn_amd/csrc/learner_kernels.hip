@@ -1,0 +1,585 @@
+// Learner-side utility kernels for gfx950: GAE scan (K6), PPO loss head (K7, unfused form),
+// state normaliser + EMA moments (K8), dense-layer epilogues (bias+ReLU6 and its backward with
+// the bias-gradient column sum), the scalar value head, global-norm clip + TF-Adam (K9), SAC
+// soft target update.  All HBM-bound streaming kernels: float4 where rows allow, column
+// reductions through fixed-order chunk slabs (bitwise reproducible).
+#include "pfpn_common.h"
+
+namespace pfpn {
+
+// ---------------------------------------------------------------------------------------
+// K6: GAE.  One block per sequence.  delta_t = (r_t + gamma*v_{t+1}) - v_t in fp32 (two roundings,
+// the reference's NumPy op order, a2c.py:32-35), then adv_t = delta_t + c*adv_{t+1} with a float64
+// accumulator walked sequentially by one lane (utils.py:5-15 under NumPy<2 promotion): the same
+// operation order as the reference loop, so the fp32 output is bit-exact.
+// ---------------------------------------------------------------------------------------
+constexpr int GAE_CHUNK = 2048;
+
+__global__ __launch_bounds__(256) void k_gae(const float* __restrict__ reward, const float* __restrict__ value,
+                                             const int64_t* __restrict__ offsets, int E, float gamma,
+                                             double gae_gamma, float* __restrict__ adv) {
+    __shared__ float delta[GAE_CHUNK];
+    __shared__ double carry;
+    const int e = blockIdx.x;
+    const int64_t r0 = offsets[e];
+    const int T = (int)(offsets[e + 1] - r0);
+    const float* r = reward + r0;
+    const float* v = value + r0 + e;          // sequence e owns T+1 values
+    float* out = adv + r0;
+    if (threadIdx.x == 0) carry = 0.0;
+    for (int hi = T; hi > 0; hi -= GAE_CHUNK) {
+        const int lo = max(0, hi - GAE_CHUNK);
+        __syncthreads();
+        for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+            const float gv = gamma * v[t + 1];
+            const float s = r[t] + gv;
+            delta[t - lo] = s - v[t];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double acc = carry;
+            for (int t = hi - 1; t >= lo; --t) {
+                const double m = gae_gamma * acc;
+                acc = (double)delta[t - lo] + m;
+                delta[t - lo] = (float)acc;
+            }
+            carry = acc;
+        }
+        __syncthreads();
+        for (int t = lo + threadIdx.x; t < hi; t += blockDim.x) out[t] = delta[t - lo];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K7 (unfused): PPO loss head on [B] vectors; one block, fixed order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ppo_loss(
+    const float* __restrict__ logp, const float* __restrict__ logp_old, const float* __restrict__ adv,
+    const float* __restrict__ value, const float* __restrict__ value_old, const float* __restrict__ stats,
+    int B, float clip_lo, float clip_hi, float value_coef,
+    float* __restrict__ dlogp, float* __restrict__ dvalue, float* __restrict__ loss3)
+{
+    __shared__ float red[16];
+    const float mean = stats[0], rstd = stats[1];
+    const float inv_B = 1.0f / (float)B;
+    float ps = 0.f, vs = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float a = adv[b];
+        const float nadv = (a - mean) * rstd;
+        const float ratio = expf(logp[b] - logp_old[b]);
+        const float sur = ratio * nadv;
+        const float cr = fmaxf(fminf(ratio, clip_hi), clip_lo);
+        const float csur = cr * nadv;
+        ps += fminf(sur, csur);
+        const bool pass = (sur <= csur) || (ratio >= clip_lo && ratio <= clip_hi);
+        dlogp[b] = pass ? (-inv_B * nadv) * ratio : 0.f;
+        const float dvv = value[b] - (a + value_old[b]);
+        vs += dvv * dvv;
+        dvalue[b] = 2.f * dvv * value_coef * inv_B;
+    }
+    ps = block_sum(ps, red);
+    vs = block_sum(vs, red);
+    if (threadIdx.x == 0) {
+        const float pl = -ps * inv_B, vl = vs * inv_B * value_coef;
+        loss3[0] = pl + vl; loss3[1] = pl; loss3[2] = vl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K8: state normaliser
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_state_norm(const float* __restrict__ s, const float* __restrict__ mean,
+                                                    const float* __restrict__ std, int B, int S, float clip,
+                                                    float* __restrict__ x) {
+    const size_t n = (size_t)B * S;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % S);
+        float v = (s[i] - mean[c]) / std[c];                      // actor_critic.py:229-232
+        if (clip > 0.f) v = fmaxf(fminf(v, clip), -clip);         // clip_by_value: Minimum then Maximum
+        x[i] = v;
+    }
+}
+
+// column sums over a contiguous chunk of rows: thread <-> column; mode 0: sum x, mode 1: sum (x-mean)^2
+__global__ __launch_bounds__(64) void k_col_partial(const float* __restrict__ s, const float* __restrict__ mean,
+                                                    int B, int S, int chunk_len, int mode,
+                                                    float* __restrict__ partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= S) return;
+    const int ch = blockIdx.y;
+    const int b0 = ch * chunk_len, b1 = min(B, b0 + chunk_len);
+    float acc = 0.f;
+    if (mode == 0) {
+        for (int b = b0; b < b1; ++b) acc += s[(size_t)b * S + c];
+    } else {
+        const float m = mean[c];
+        for (int b = b0; b < b1; ++b) { const float d = s[(size_t)b * S + c] - m; acc += d * d; }
+    }
+    partial[(size_t)ch * S + c] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_col_mean(const float* __restrict__ partial, int C, int S, float inv_B,
+                                                  float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= S) return;
+    float acc = 0.f;
+    for (int ch = 0; ch < C; ++ch) acc += partial[(size_t)ch * S + c];
+    out[c] = acc * inv_B;
+}
+
+// EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step))
+__global__ __launch_bounds__(256) void k_norm_ema(const float* __restrict__ bmean, const float* __restrict__ bvar,
+                                                  int S, float step, const float* __restrict__ mean_in,
+                                                  const float* __restrict__ std_in, float* __restrict__ mean_out,
+                                                  float* __restrict__ std_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= S) return;
+    const float d = fminf(0.9999f, (1.f + step) / (10.f + step));
+    const float omd = 1.f - d;
+    const float nm = d * mean_in[c] + omd * bmean[c];
+    const float ns = fmaxf(1e-6f, d * std_in[c] + omd * sqrtf(bvar[c]));
+    mean_out[c] = nm;
+    std_out[c] = ns;
+}
+
+// ---------------------------------------------------------------------------------------
+// dense-layer epilogues.  y is [rows, H]; bias row = (row / group_rows) when group_rows > 0
+// (batched layers stacked as [G*rows, H] with bias [G, H]).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ y, const float* __restrict__ bias,
+                                                  int rows, int H, int group_rows, int relu6) {
+    const int H4 = H >> 2;
+    const size_t n4 = (size_t)rows * H4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / H4);
+        const int c4 = (int)(i - (size_t)row * H4);
+        const int g = group_rows > 0 ? row / group_rows : 0;
+        float4 v = reinterpret_cast<float4*>(y)[i];
+        const float4 b = reinterpret_cast<const float4*>(bias + (size_t)g * H)[c4];
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (relu6) {
+            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
+            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+        }
+        reinterpret_cast<float4*>(y)[i] = v;
+    }
+}
+
+// Relu6Grad + bias gradient: dy <- dy * [0 < y < 6] (in place when relu6), partial column sums
+// of the masked dy over a chunk of rows.  256-thread block = 64 float4 column groups x 4 row
+// lanes (each wave streams whole 1 KiB row pieces); the 4 row lanes are combined through LDS in
+// lane order, so the result is deterministic.
+__global__ __launch_bounds__(256) void k_act_bwd_partial(const float* __restrict__ y, float* __restrict__ dy,
+                                                         int rows, int H, int chunk_len, int relu6,
+                                                         float* __restrict__ partial) {
+    __shared__ float4 red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + cl;
+    const int H4 = H >> 2;
+    const int ch = blockIdx.y;
+    const int b0 = ch * chunk_len, b1 = min(rows, b0 + chunk_len);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < H4) {
+        for (int b = b0 + rl; b < b1; b += 4) {
+            const size_t i = (size_t)b * H4 + c4;
+            float4 g = reinterpret_cast<float4*>(dy)[i];
+            if (relu6) {
+                const float4 v = reinterpret_cast<const float4*>(y)[i];
+                g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
+                g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
+                g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
+                g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
+                reinterpret_cast<float4*>(dy)[i] = g;
+            }
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c4 < H4) {
+        float4 s = red[0][cl];
+        for (int k = 1; k < 4; ++k) { const float4 t = red[k][cl]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+        reinterpret_cast<float4*>(partial + (size_t)ch * H)[c4] = s;
+    }
+}
+
+// db[g, c] = sum over the chunks of group g, in chunk order
+__global__ __launch_bounds__(256) void k_bias_grad_final(const float* __restrict__ partial, int chunks_per_group,
+                                                         int G, int H, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * H) return;
+    const int g = i / H, c = i - g * H;
+    float acc = 0.f;
+    for (int ch = 0; ch < chunks_per_group; ++ch) acc += partial[(size_t)(g * chunks_per_group + ch) * H + c];
+    db[i] = acc;
+}
+
+// scalar value head: v[b] = h[b,:] . w + bias   (critic fc3, squeeze).  One wave per row.
+__global__ __launch_bounds__(256) void k_value_head_fwd(const float* __restrict__ h, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int B, int H,
+                                                        float* __restrict__ v) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= B) return;
+    const float4* hr = reinterpret_cast<const float4*>(h + (size_t)row * H);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float acc = 0.f;
+    for (int i = lane; i < (H >> 2); i += 64) {
+        const float4 a = hr[i], b = w4[i];
+        acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) v[row] = acc + bias[0];
+}
+
+// backward of the value head fused with the ReLU6 mask of the layer below:
+// dh[b,c] = dv[b]*w[c]*[0<h<6];  partial dw[c] = sum_b h[b,c]*dv[b] over a chunk of rows.
+__global__ __launch_bounds__(256) void k_value_head_bwd_partial(
+    const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ dv,
+    int B, int H, int chunk_len, int relu6, float* __restrict__ dh, float* __restrict__ partial)
+{
+    __shared__ float4 red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + cl;
+    const int H4 = H >> 2;
+    const int ch = blockIdx.y;
+    const int b0 = ch * chunk_len, b1 = min(B, b0 + chunk_len);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < H4) {
+        const float4 wv = reinterpret_cast<const float4*>(w)[c4];
+        for (int b = b0 + rl; b < b1; b += 4) {
+            const size_t i = (size_t)b * H4 + c4;
+            const float4 v = reinterpret_cast<const float4*>(h)[i];
+            const float g = dv[b];
+            acc.x += v.x * g; acc.y += v.y * g; acc.z += v.z * g; acc.w += v.w * g;
+            float4 d = make_float4(g * wv.x, g * wv.y, g * wv.z, g * wv.w);
+            if (relu6) {
+                d.x = (v.x > 0.f && v.x < 6.f) ? d.x : 0.f;
+                d.y = (v.y > 0.f && v.y < 6.f) ? d.y : 0.f;
+                d.z = (v.z > 0.f && v.z < 6.f) ? d.z : 0.f;
+                d.w = (v.w > 0.f && v.w < 6.f) ? d.w : 0.f;
+            }
+            reinterpret_cast<float4*>(dh)[i] = d;
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c4 < H4) {
+        float4 s = red[0][cl];
+        for (int k = 1; k < 4; ++k) { const float4 t = red[k][cl]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+        reinterpret_cast<float4*>(partial + (size_t)ch * H)[c4] = s;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_vec_sum(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// K9: global-norm clip + TF-Adam on one flat parameter buffer
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sqsum_partial(const float* __restrict__ g, size_t n,
+                                                       float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// norm = sqrt(2 * sum(0.5 * |g|^2)) ; scale = c * min(1/norm, 1/c), NaN when norm is not finite
+// (tf.clip_by_global_norm, reference models/workers/base_worker.py:97-102)
+__global__ __launch_bounds__(256) void k_clip_scale(const float* __restrict__ partial, int nblk, float clip_norm,
+                                                    float* __restrict__ norm_scale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(2.f * (0.5f * s));
+        float scale;
+        if (clip_norm > 0.f) {
+            scale = clip_norm * fminf(1.0f / norm, 1.0f / clip_norm);
+            if (!isfinite(norm)) scale = NAN;
+        } else {
+            scale = 1.0f;
+        }
+        norm_scale[0] = norm;
+        norm_scale[1] = scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale_inplace(float* __restrict__ g, size_t n,
+                                                       const float* __restrict__ norm_scale) {
+    const float sc = norm_scale[1];
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(g)[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        reinterpret_cast<float4*>(g)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] *= sc;
+}
+
+// TF ApplyAdam (CPU kernel form): alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1);
+// v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps).  g is first multiplied by the optional device
+// scalar norm_scale[1] (clip) and by grad_mul (1/W after an all-reduce sum).
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float alpha, float omb1, float omb2,
+                                      float eps) {
+    m = m + (g - m) * omb1;
+    v = v + (g * g - v) * omb2;
+    p = p - (m * alpha) / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(256) void k_tf_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                 float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                 float lr, float b1, float b2, float eps,
+                                                 const float* __restrict__ beta_pow,
+                                                 const float* __restrict__ norm_scale, float grad_mul) {
+    const float alpha = lr * sqrtf(1.f - beta_pow[1]) / (1.f - beta_pow[0]);
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    const float gs = norm_scale ? norm_scale[1] : 1.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        if (norm_scale) { gg.x *= gs; gg.y *= gs; gg.z *= gs; gg.w *= gs; }
+        if (grad_mul != 1.f) { gg.x *= grad_mul; gg.y *= grad_mul; gg.z *= grad_mul; gg.w *= grad_mul; }
+        adam1(pp.x, gg.x, mm.x, vv.x, alpha, omb1, omb2, eps);
+        adam1(pp.y, gg.y, mm.y, vv.y, alpha, omb1, omb2, eps);
+        adam1(pp.z, gg.z, mm.z, vv.z, alpha, omb1, omb2, eps);
+        adam1(pp.w, gg.w, mm.w, vv.w, alpha, omb1, omb2, eps);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
+            float gi = g[i];
+            if (norm_scale) gi *= gs;
+            if (grad_mul != 1.f) gi *= grad_mul;
+            adam1(p[i], gi, m[i], v[i], alpha, omb1, omb2, eps);
+        }
+    }
+}
+
+// beta powers advance after the applies (Adam/mul, Adam/mul_1 in the saved graph)
+__global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { beta_pow[0] *= b1; beta_pow[1] *= b2; }
+}
+
+// SAC soft target update (sac.py:67-73): t <- (1-tau)*t + tau*s
+__global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ t, const float* __restrict__ s, size_t n,
+                                                     float tau) {
+    const float omt = 1.f - tau;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        t[i] = omt * t[i] + tau * s[i];
+}
+
+static inline int row_chunks(int rows) {
+    int C = (rows + 31) / 32;
+    if (C > 128) C = 128;
+    if (C < 1) C = 1;
+    return C;
+}
+static inline int stream_grid(size_t n_items) {
+    size_t g = (n_items + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace pfpn
+
+using namespace pfpn;
+
+extern "C" {
+
+int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, int E, float gamma,
+             double gae_gamma, float* adv, void* stream) {
+    if (!reward || !value || !offsets || !adv || E < 0) return PFPN_ERR_ARG;
+    if (E == 0) return PFPN_OK;
+    hipLaunchKernelGGL(k_gae, dim3(E), dim3(256), 0, (hipStream_t)stream, reward, value, offsets, E, gamma,
+                       gae_gamma, adv);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_ppo_loss(const float* logp, const float* logp_old, const float* adv, const float* value,
+                  const float* value_old, const float* adv_stats, int B, float clip_eps, float value_coef,
+                  float* dlogp, float* dvalue, float* loss3, void* stream) {
+    if (!logp || !logp_old || !adv || !value || !value_old || !adv_stats || !dlogp || !dvalue || !loss3 || B < 1)
+        return PFPN_ERR_ARG;
+    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, logp_old, adv, value,
+                       value_old, adv_stats, B, 1.0f - clip_eps, 1.0f + clip_eps, value_coef, dlogp, dvalue, loss3);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_state_norm(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
+                    void* stream) {
+    if (!s || !mean || !std || !x || B < 0 || S < 1) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    hipLaunchKernelGGL(k_state_norm, dim3(stream_grid((size_t)B * S)), dim3(256), 0, (hipStream_t)stream, s, mean,
+                       std, B, S, clip, x);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+size_t pfpn_learner_workspace_bytes(int rows, int H) {
+    // chunk slabs [128][H] + 2 column vectors + norm partials
+    return ((size_t)130 * (size_t)(H > 0 ? H : 1) + 4096) * sizeof(float) + (size_t)rows * 0;
+}
+
+int pfpn_state_norm_update(const float* s, int B, int S, float step, const float* mean_in, const float* std_in,
+                           float* mean_out, float* std_out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    if (!s || !mean_in || !std_in || !mean_out || !std_out || B < 1 || S < 1) return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, S)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = row_chunks(B);
+    const int len = (B + C - 1) / C;
+    float* partial = (float*)workspace;
+    float* bmean = partial + (size_t)128 * S;
+    float* bvar = bmean + S;
+    const dim3 g((S + 63) / 64, C);
+    hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)nullptr, B, S, len, 0, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_col_mean, dim3((S + 255) / 256), dim3(256), 0, st, partial, C, S, 1.0f / (float)B, bmean);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)bmean, B, S, len, 1, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_col_mean, dim3((S + 255) / 256), dim3(256), 0, st, partial, C, S, 1.0f / (float)B, bvar);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_norm_ema, dim3((S + 255) / 256), dim3(256), 0, st, bmean, bvar, S, step, mean_in, std_in,
+                       mean_out, std_out);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, int relu6, void* stream) {
+    if (!y || !bias || rows < 0 || H < 4 || (H & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15))
+        return PFPN_ERR_ARG;
+    if (rows == 0) return PFPN_OK;
+    hipLaunchKernelGGL(k_bias_act, dim3(stream_grid((size_t)rows * (H >> 2))), dim3(256), 0, (hipStream_t)stream,
+                       y, bias, rows, H, group_rows, relu6);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group_rows, int relu6, float* db,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !db || (relu6 && !y) || rows < 1 || H < 4 || (H & 3) || ((uintptr_t)dy & 15)) return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(rows, H)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = group_rows > 0 ? rows / group_rows : 1;
+    const int grows = group_rows > 0 ? group_rows : rows;
+    if (group_rows > 0 && rows % group_rows) return PFPN_ERR_ARG;
+    int cpg = row_chunks(grows);                 // chunks per group
+    while (cpg * G > 128) --cpg;
+    if (cpg < 1) return PFPN_ERR_ARG;
+    int len = (grows + cpg - 1) / cpg;
+    // chunk boundaries must not straddle groups: chunk ch covers rows [g*grows + k*len, ...) of group g
+    float* partial = (float*)workspace;
+    if (G == 1) {
+        hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg), dim3(256), 0, st, y, dy, rows, H, len,
+                           relu6, partial);
+        PFPN_CHECK_LAUNCH();
+    } else {
+        for (int g = 0; g < G; ++g) {
+            const size_t off = (size_t)g * grows * H;
+            hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg), dim3(256), 0, st,
+                               y ? y + off : y, dy + off, grows, H, len, relu6, partial + (size_t)g * cpg * H);
+            PFPN_CHECK_LAUNCH();
+        }
+    }
+    hipLaunchKernelGGL(k_bias_grad_final, dim3((G * H + 255) / 256), dim3(256), 0, st, partial, cpg, G, H, db);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B, int H, float* v, void* stream) {
+    if (!h || !w || !bias || !v || B < 0 || H < 4 || (H & 3)) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    hipLaunchKernelGGL(k_value_head_fwd, dim3((B * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, h, w, bias,
+                       B, H, v);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, int H, int relu6, float* dh,
+                        float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !w || !dv || !dh || !dw || !db || B < 1 || H < 4 || (H & 3)) return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, H)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = row_chunks(B);
+    const int len = (B + C - 1) / C;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(k_value_head_bwd_partial, dim3(((H >> 2) + 63) / 64, C), dim3(256), 0, st, h, w, dv, B, H, len,
+                       relu6, dh, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 255) / 256), dim3(256), 0, st, partial, C, 1, H, dw);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(1024), 0, st, dv, B, db);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply, float* norm_scale,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!grads || !norm_scale || n < 1 || ((uintptr_t)grads & 15)) return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < 1024 * sizeof(float)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = stream_grid(n >> 2);
+    if (nblk > 1024) nblk = 1024;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(k_sqsum_partial, dim3(nblk), dim3(256), 0, st, grads, n, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, st, partial, nblk, clip_norm, norm_scale);
+    PFPN_CHECK_LAUNCH();
+    if (apply) {
+        hipLaunchKernelGGL(k_scale_inplace, dim3(stream_grid(n >> 2)), dim3(256), 0, st, grads, n, norm_scale);
+        PFPN_CHECK_LAUNCH();
+    }
+    return PFPN_OK;
+}
+
+int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
+                 float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
+                 float grad_mul, void* stream) {
+    if (!params || !grads || !m || !v || !beta_pow || n < 1) return PFPN_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_tf_adam, dim3(stream_grid(n >> 2)), dim3(256), 0, st, params, grads, m, v, n, lr, beta1,
+                       beta2, eps, beta_pow, norm_scale, grad_mul);
+    PFPN_CHECK_LAUNCH();
+    if (advance_beta_pow) {
+        hipLaunchKernelGGL(k_beta_pow_step, dim3(1), dim3(64), 0, st, beta_pow, beta1, beta2);
+        PFPN_CHECK_LAUNCH();
+    }
+    return PFPN_OK;
+}
+
+int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream) {
+    if (!target || !source) return PFPN_ERR_ARG;
+    if (n == 0) return PFPN_OK;
+    hipLaunchKernelGGL(k_soft_update, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, target, source, n,
+                       tau);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+}  // extern "C"

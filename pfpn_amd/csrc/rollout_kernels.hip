@@ -1,0 +1,419 @@
+// Rollout-side particle kernels for gfx950: categorical particle draw + Gaussian jitter + log-prob of
+// the drawn action (K3), activation statistics for the resampler, deterministic (argmax) action,
+// categorical entropy, and the Gumbel-softmax reparameterised sample of the SAC path (K4).
+//
+// Replaces the TF op subgraphs of MixtureGaussianDistribution.sample / .mean / .entropy
+// (reference networks/utils.py:146-236) and the running max/sum statistics of
+// ParticleFilteringA2CNetwork.init (reference networks/actor_critic/a2c.py:346-365).
+//
+// Index parity: the categorical draw reproduces the TF-1.14 CPU `Multinomial` rule -- a float64
+// running sum of exp(double(l) - max), left to right, first index whose sum exceeds u * total --
+// sequentially in one lane so the rounding order equals the oracle's (bit-exact indices).
+// Every random number is an explicit input (TF's Philox stream is not reproducible without TF).
+#include "pfpn_common.h"
+
+namespace pfpn {
+
+// One thread per (b, a) segment.  Outputs k, action, per-segment log p of the drawn action, and
+// the softmax normaliser (max, 1/sum) reused by the statistics kernel.
+__global__ __launch_bounds__(256) void k_sample_plain(
+    const float* __restrict__ logits, const float* __restrict__ loc, const float* __restrict__ logstd,
+    const double* __restrict__ u_cat, const float* __restrict__ eps_sel,
+    int B, int A, int N,
+    int* __restrict__ k_out, float* __restrict__ action, float* __restrict__ lpseg,
+    float* __restrict__ smax, float* __restrict__ sinv)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B * A) return;
+    const int a = s % A;
+    const float* row = logits + (size_t)s * N;
+    const float* locr = loc + a * N;
+    const float* lsr = logstd + a * N;
+    float mx = row[0];
+    for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
+    // TF Multinomial: max and exp in double
+    const double mxd = (double)mx;
+    double total = 0.0;
+    for (int n = 0; n < N; ++n) total += exp((double)row[n] - mxd);
+    const double target = u_cat[s] * total;
+    double run = 0.0;
+    int k = N - 1;
+    for (int n = 0; n < N; ++n) {
+        run += exp((double)row[n] - mxd);
+        if (run > target) { k = n; break; }
+    }
+    const float sck = expf(lsr[k]);
+    const float act = locr[k] + sck * eps_sel[s];
+    // log-prob of the drawn action under the same mixture (fp32, as pfpn_logprob_fwd)
+    float sum = 0.f, num = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float sc = expf(lsr[n]);
+        const float en = expf(row[n] - mx);
+        const float z = (act - locr[n]) * (1.0f / sc);
+        const float ph = expf(fmaf(-0.5f * z, z, -(PFPN_HALF_LOG_2PI + logf(sc))));
+        sum += en;
+        num += en * ph;
+    }
+    const float inv = 1.0f / sum;
+    k_out[s] = k;
+    action[s] = act;
+    lpseg[s] = logf(num * inv);
+    smax[s] = mx;
+    sinv[s] = inv;
+}
+
+// softmax normalisers only (for pfpn_active_stats without a draw)
+__global__ __launch_bounds__(256) void k_softmax_norm(const float* __restrict__ logits, int S, int N,
+                                                      float* __restrict__ smax, float* __restrict__ sinv) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float* row = logits + (size_t)s * N;
+    float mx = row[0];
+    for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += expf(row[n] - mx);
+    smax[s] = mx;
+    sinv[s] = 1.0f / sum;
+}
+
+// Column statistics of the softmax weights over a chunk of rows: thread <-> particle column
+// (a,n) (coalesced across the row), rows walked in order -> deterministic.
+// partial[c][0][col] = max_b w, partial[c][1][col] = sum_b w over rows b = c, c+C, ...? no:
+// contiguous chunks [c*len, (c+1)*len) so the final sum adds chunks in row order.
+__global__ __launch_bounds__(256) void k_stats_partial(
+    const float* __restrict__ logits, const float* __restrict__ smax, const float* __restrict__ sinv,
+    int B, int A, int N, int chunk_len, float* __restrict__ partial)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int AN = A * N;
+    if (col >= AN) return;
+    const int a = col / N;
+    const int c = blockIdx.y;
+    const int b0 = c * chunk_len, b1 = min(B, b0 + chunk_len);
+    float m = 0.f, s = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float w = expf(logits[(size_t)b * AN + col] - smax[b * A + a]) * sinv[b * A + a];
+        m = fmaxf(m, w);
+        s += w;
+    }
+    partial[((size_t)c * 2 + 0) * AN + col] = m;
+    partial[((size_t)c * 2 + 1) * AN + col] = s;
+}
+
+__global__ __launch_bounds__(256) void k_stats_apply(const float* __restrict__ partial, int C, int AN,
+                                                     float* __restrict__ max_active,
+                                                     float* __restrict__ sum_active) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= AN) return;
+    float m = 0.f, s = 0.f;
+    for (int c = 0; c < C; ++c) {
+        m = fmaxf(m, partial[((size_t)c * 2 + 0) * AN + col]);
+        s += partial[((size_t)c * 2 + 1) * AN + col];
+    }
+    max_active[col] = fmaxf(max_active[col], m);      // a2c.py:356
+    sum_active[col] = sum_active[col] + s;            // a2c.py:359
+}
+
+__global__ void k_row_sum2(const float* __restrict__ lpseg, int B, int A, float* __restrict__ logp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += lpseg[(size_t)b * A + a];
+    logp[b] = s;
+}
+
+// deterministic action: loc[a, argmax_n logits] (first index on ties), tanh in tanh mode
+__global__ __launch_bounds__(256) void k_mean_action(const float* __restrict__ logits,
+                                                     const float* __restrict__ loc, int B, int A, int N,
+                                                     int tanh_mode, int* __restrict__ k_out,
+                                                     float* __restrict__ action) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B * A) return;
+    const int a = s % A;
+    const float* row = logits + (size_t)s * N;
+    int k = 0;
+    float mx = row[0];
+    for (int n = 1; n < N; ++n) if (row[n] > mx) { mx = row[n]; k = n; }
+    float v = loc[a * N + k];
+    if (tanh_mode) v = tanhf(v);
+    if (k_out) k_out[s] = k;
+    action[s] = v;
+}
+
+// categorical entropy H[b,a] = log s1 - sum w v   (utils.py:146-151)
+__global__ __launch_bounds__(256) void k_entropy_fwd(const float* __restrict__ logits, int S, int N,
+                                                     float* __restrict__ H) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float* row = logits + (size_t)s * N;
+    float mx = row[0];
+    for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
+    float s1 = 0.f;
+    for (int n = 0; n < N; ++n) s1 += expf(row[n] - mx);
+    const float ls1 = logf(s1), inv = 1.0f / s1;
+    float h = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float v = row[n] - mx;
+        h += (expf(v) * inv) * (ls1 - v);
+    }
+    H[s] = h;
+}
+
+// dlogits = -w (log w + H) dH   (accumulate: += into an existing gradient)
+__global__ __launch_bounds__(256) void k_entropy_bwd(const float* __restrict__ logits,
+                                                     const float* __restrict__ dH, int S, int N,
+                                                     int accumulate, float* __restrict__ dlogits) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float* row = logits + (size_t)s * N;
+    float* drow = dlogits + (size_t)s * N;
+    float mx = row[0];
+    for (int n = 1; n < N; ++n) mx = fmaxf(mx, row[n]);
+    float s1 = 0.f;
+    for (int n = 0; n < N; ++n) s1 += expf(row[n] - mx);
+    const float ls1 = logf(s1), inv = 1.0f / s1;
+    float h = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float v = row[n] - mx;
+        h += (expf(v) * inv) * (ls1 - v);
+    }
+    const float g = dH[s];
+    for (int n = 0; n < N; ++n) {
+        const float v = row[n] - mx;
+        const float w = expf(v) * inv;
+        const float d = -(w * ((v - ls1) + h)) * g;
+        drow[n] = accumulate ? drow[n] + d : d;
+    }
+}
+
+// SAC reparameterised sample: y = logits + gumbel, k = argmax y, p = loc + scale * eps,
+// a = tanh(p_k), s_ = p_k   (utils.py:156-186)
+__global__ __launch_bounds__(256) void k_rsample_fwd(
+    const float* __restrict__ logits, const float* __restrict__ loc, const float* __restrict__ logstd,
+    const float* __restrict__ gumbel, const float* __restrict__ eps, int B, int A, int N,
+    int* __restrict__ k_out, float* __restrict__ a_out, float* __restrict__ s_out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B * A) return;
+    const int a = s % A;
+    const float* row = logits + (size_t)s * N;
+    const float* gr = gumbel + (size_t)s * N;
+    int k = 0;
+    float mx = row[0] + gr[0];
+    for (int n = 1; n < N; ++n) {
+        const float y = row[n] + gr[n];
+        if (y > mx) { mx = y; k = n; }
+    }
+    const float pk = loc[a * N + k] + expf(logstd[a * N + k]) * eps[(size_t)s * N + k];
+    k_out[s] = k;
+    s_out[s] = pk;
+    a_out[s] = tanhf(pk);
+}
+
+// backward of the custom gradients `mask`/`mask2` (utils.py:165-183) through softmax(logits+g)
+// and p = loc + scale*eps.  Per segment: dlogits row, and the (k, d p_k) pair for the parameter
+// scatter done by k_rsample_param_grad.
+__global__ __launch_bounds__(256) void k_rsample_bwd(
+    const float* __restrict__ logits, const float* __restrict__ loc, const float* __restrict__ logstd,
+    const float* __restrict__ gumbel, const float* __restrict__ eps,
+    const float* __restrict__ da, const float* __restrict__ ds, int B, int A, int N, int accumulate,
+    float* __restrict__ dlogits, int* __restrict__ k_tmp, float* __restrict__ gp_tmp,
+    float* __restrict__ gs_tmp)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B * A) return;
+    const int a = s % A;
+    const float* row = logits + (size_t)s * N;
+    const float* gr = gumbel + (size_t)s * N;
+    const float* er = eps + (size_t)s * N;
+    const float* locr = loc + a * N;
+    const float* lsr = logstd + a * N;
+    float* drow = dlogits + (size_t)s * N;
+    int k = 0;
+    float mx = row[0] + gr[0];
+    for (int n = 1; n < N; ++n) {
+        const float y = row[n] + gr[n];
+        if (y > mx) { mx = y; k = n; }
+    }
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += expf((row[n] + gr[n]) - mx);
+    const float inv = 1.0f / sum;
+    const float sck = expf(lsr[k]);
+    const float tk = tanhf(locr[k] + sck * er[k]);
+    const float one_m = 1.f - tk * tk;
+    const float gda = da[s], gds = ds[s];
+    const float cs = gds / fmaxf(1e-6f, one_m);
+    float dot = 0.f;                                        // sum_n gw_n w_n
+    for (int n = 0; n < N; ++n) {
+        const float w = expf((row[n] + gr[n]) - mx) * inv;
+        const float gap = tanhf(locr[n] + expf(lsr[n]) * er[n]) - tk;
+        dot += (gap * gda + gap * cs) * w;
+    }
+    for (int n = 0; n < N; ++n) {
+        const float w = expf((row[n] + gr[n]) - mx) * inv;
+        const float gap = tanhf(locr[n] + expf(lsr[n]) * er[n]) - tk;
+        const float d = w * ((gap * gda + gap * cs) - dot);
+        drow[n] = accumulate ? drow[n] + d : d;
+    }
+    const float gp = gda * one_m + gds;                     // d L / d p_k
+    k_tmp[s] = k;
+    gp_tmp[s] = gp;
+    gs_tmp[s] = gp * sck * er[k];                           // d L / d logstd_k
+}
+
+// dloc[a,n] (+)= sum_b [k[b,a]==n] gp[b,a]; dlogstd likewise.  Thread <-> (a,n), rows in order.
+__global__ __launch_bounds__(256) void k_rsample_param_grad(
+    const int* __restrict__ k_tmp, const float* __restrict__ gp_tmp, const float* __restrict__ gs_tmp,
+    int B, int A, int N, int accumulate, float* __restrict__ dloc, float* __restrict__ dlogstd)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= A * N) return;
+    const int a = col / N, n = col - a * N;
+    float sl = 0.f, ss = 0.f;
+    for (int b = 0; b < B; ++b) {
+        if (k_tmp[b * A + a] == n) { sl += gp_tmp[b * A + a]; ss += gs_tmp[b * A + a]; }
+    }
+    dloc[col] = accumulate ? dloc[col] + sl : sl;
+    dlogstd[col] = accumulate ? dlogstd[col] + ss : ss;
+}
+
+static inline int stats_chunks(int B) {
+    int C = (B + 63) / 64;
+    if (C > 64) C = 64;
+    if (C < 1) C = 1;
+    return C;
+}
+
+}  // namespace pfpn
+
+using namespace pfpn;
+
+extern "C" {
+
+size_t pfpn_rollout_workspace_bytes(int B, int A, int N) {
+    // lpseg, smax, sinv, gp, gs [B*A] floats + k [B*A] ints + stats partial [64][2][AN]
+    return ((size_t)B * A * 6 + (size_t)64 * 2 * A * N + 64) * sizeof(float);
+}
+
+static int stats_launch(const float* logits, const float* smax, const float* sinv, int B, int A, int N,
+                        float* partial, float* max_active, float* sum_active, hipStream_t st) {
+    const int AN = A * N;
+    const int C = stats_chunks(B);
+    const int len = (B + C - 1) / C;
+    hipLaunchKernelGGL(k_stats_partial, dim3((AN + 255) / 256, C), dim3(256), 0, st, logits, smax, sinv, B, A,
+                       N, len, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_stats_apply, dim3((AN + 255) / 256), dim3(256), 0, st, partial, C, AN, max_active,
+                       sum_active);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_sample(const float* logits, const float* loc, const float* logstd, const double* u_cat,
+                const float* eps_sel, int B, int A, int N, int32_t* k, float* action, float* logp,
+                float* max_active, float* sum_active, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logits || !loc || !logstd || !u_cat || !eps_sel || !k || !action || B < 0 || A < 1 || N < 1)
+        return PFPN_ERR_ARG;
+    if ((max_active == nullptr) != (sum_active == nullptr)) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    if (!workspace || workspace_bytes < pfpn_rollout_workspace_bytes(B, A, N)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* lpseg = (float*)workspace;
+    float* smax = lpseg + (size_t)B * A;
+    float* sinv = smax + (size_t)B * A;
+    float* partial = sinv + (size_t)B * A * 4;
+    const int S = B * A;
+    hipLaunchKernelGGL(k_sample_plain, dim3((S + 255) / 256), dim3(256), 0, st, logits, loc, logstd, u_cat,
+                       eps_sel, B, A, N, (int*)k, action, lpseg, smax, sinv);
+    PFPN_CHECK_LAUNCH();
+    if (logp) {
+        hipLaunchKernelGGL(k_row_sum2, dim3((B + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
+        PFPN_CHECK_LAUNCH();
+    }
+    if (max_active) return stats_launch(logits, smax, sinv, B, A, N, partial, max_active, sum_active, st);
+    return PFPN_OK;
+}
+
+int pfpn_active_stats(const float* logits, int B, int A, int N, float* max_active, float* sum_active,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logits || !max_active || !sum_active || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    if (!workspace || workspace_bytes < pfpn_rollout_workspace_bytes(B, A, N)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* smax = (float*)workspace + (size_t)B * A;
+    float* sinv = smax + (size_t)B * A;
+    float* partial = sinv + (size_t)B * A * 4;
+    const int S = B * A;
+    hipLaunchKernelGGL(k_softmax_norm, dim3((S + 255) / 256), dim3(256), 0, st, logits, S, N, smax, sinv);
+    PFPN_CHECK_LAUNCH();
+    return stats_launch(logits, smax, sinv, B, A, N, partial, max_active, sum_active, st);
+}
+
+int pfpn_mean_action(const float* logits, const float* loc, int B, int A, int N, int tanh_mode,
+                     int32_t* k, float* action, void* stream) {
+    if (!logits || !loc || !action || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    const int S = B * A;
+    hipLaunchKernelGGL(k_mean_action, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, loc, B,
+                       A, N, tanh_mode, (int*)k, action);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_entropy_fwd(const float* logits, int B, int A, int N, float* H, void* stream) {
+    if (!logits || !H || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    const int S = B * A;
+    hipLaunchKernelGGL(k_entropy_fwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, S, N, H);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, int accumulate,
+                     float* dlogits, void* stream) {
+    if (!logits || !dH || !dlogits || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    const int S = B * A;
+    hipLaunchKernelGGL(k_entropy_bwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, dH, S, N,
+                       accumulate, dlogits);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_rsample_fwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
+                     const float* eps, int B, int A, int N, int32_t* k, float* a_out, float* s_out,
+                     void* stream) {
+    if (!logits || !loc || !logstd || !gumbel || !eps || !k || !a_out || !s_out || B < 0 || A < 1 || N < 1)
+        return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    const int S = B * A;
+    hipLaunchKernelGGL(k_rsample_fwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, loc,
+                       logstd, gumbel, eps, B, A, N, (int*)k, a_out, s_out);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
+                     const float* eps, const float* da, const float* ds, int B, int A, int N, int accumulate,
+                     float* dlogits, float* dloc, float* dlogstd, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (!logits || !loc || !logstd || !gumbel || !eps || !da || !ds || !dlogits || !dloc || !dlogstd ||
+        B < 0 || A < 1 || N < 1)
+        return PFPN_ERR_ARG;
+    if (B == 0) return PFPN_OK;
+    if (!workspace || workspace_bytes < pfpn_rollout_workspace_bytes(B, A, N)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* gp = (float*)workspace;
+    float* gs = gp + (size_t)B * A;
+    int* kt = (int*)(gs + (size_t)B * A);
+    const int S = B * A;
+    hipLaunchKernelGGL(k_rsample_bwd, dim3((S + 255) / 256), dim3(256), 0, st, logits, loc, logstd, gumbel, eps,
+                       da, ds, B, A, N, accumulate, dlogits, kt, gp, gs);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_rsample_param_grad, dim3((A * N + 255) / 256), dim3(256), 0, st, kt, gp, gs, B, A, N,
+                       accumulate, dloc, dlogstd);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+}  // extern "C"

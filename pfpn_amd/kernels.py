@@ -120,3 +120,247 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
                                             out["loss3"].data_ptr(), ws, wsn, _stream()),
                "pfpn_ppo_mixture_fwd_bwd")
     return out
+
+
+# --------------------------------------------------------------------------------------- #
+# rollout                                                                                  #
+# --------------------------------------------------------------------------------------- #
+def _typed(t, dtype, *shape, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError("%s must be a contiguous %s CUDA tensor" % (name, dtype))
+    if shape and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t.data_ptr()
+
+
+def _roll_ws(B, A, N, device):
+    lib = _lib.load()
+    buf = workspace(lib.pfpn_rollout_workspace_bytes(B, A, N), device)
+    return buf.data_ptr(), buf.numel()
+
+
+def ppo_loss(logp, logp_old, adv, value, value_old, stats, clip_eps=0.2, value_coef=0.5):
+    lib = _lib.load()
+    B = logp.shape[0]
+    dev = logp.device
+    dlogp = torch.empty(B, dtype=torch.float32, device=dev)
+    dvalue = torch.empty(B, dtype=torch.float32, device=dev)
+    loss3 = torch.empty(3, dtype=torch.float32, device=dev)
+    _lib.check(lib.pfpn_ppo_loss(_f32(logp, B), _f32(logp_old, B), _f32(adv, B), _f32(value, B), _f32(value_old, B),
+                                 _f32(stats, 2), B, float(clip_eps), float(value_coef), dlogp.data_ptr(),
+                                 dvalue.data_ptr(), loss3.data_ptr(), _stream()), "pfpn_ppo_loss")
+    return dlogp, dvalue, loss3
+
+
+def sample(logits, loc, logstd, u_cat, eps_sel, max_active=None, sum_active=None, want_logp=True):
+    """-> k [B,A] int32, action [B,A], logp [B] (or None); updates max/sum_active in place if given."""
+    lib = _lib.load()
+    A, N = loc.shape
+    B = u_cat.shape[0]
+    dev = u_cat.device
+    pl = _f32(logits.view(B, A * N), B, A * N, name="logits")
+    k = torch.empty(B, A, dtype=torch.int32, device=dev)
+    action = torch.empty(B, A, dtype=torch.float32, device=dev)
+    logp = torch.empty(B, dtype=torch.float32, device=dev) if want_logp else None
+    ws, wsn = _roll_ws(B, A, N, dev)
+    _lib.check(lib.pfpn_sample(pl, _f32(loc, A, N), _f32(logstd, A, N), _typed(u_cat, torch.float64, B, A, name="u_cat"),
+                               _f32(eps_sel, B, A, name="eps_sel"), B, A, N, k.data_ptr(), action.data_ptr(),
+                               logp.data_ptr() if want_logp else None,
+                               _f32(max_active, A, N) if max_active is not None else None,
+                               _f32(sum_active, A, N) if sum_active is not None else None, ws, wsn, _stream()),
+               "pfpn_sample")
+    return k, action, logp
+
+
+def active_stats(logits, max_active, sum_active):
+    lib = _lib.load()
+    A, N = max_active.shape
+    B = logits.shape[0]
+    ws, wsn = _roll_ws(B, A, N, logits.device)
+    _lib.check(lib.pfpn_active_stats(_f32(logits.view(B, A * N), B, A * N), B, A, N, _f32(max_active, A, N),
+                                     _f32(sum_active, A, N), ws, wsn, _stream()), "pfpn_active_stats")
+
+
+def mean_action(logits, loc, tanh_mode=False):
+    lib = _lib.load()
+    A, N = loc.shape
+    B = logits.shape[0]
+    k = torch.empty(B, A, dtype=torch.int32, device=logits.device)
+    action = torch.empty(B, A, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.pfpn_mean_action(_f32(logits.view(B, A * N), B, A * N), _f32(loc, A, N), B, A, N, int(tanh_mode),
+                                    k.data_ptr(), action.data_ptr(), _stream()), "pfpn_mean_action")
+    return k, action
+
+
+def entropy_fwd(logits, A, N):
+    lib = _lib.load()
+    B = logits.shape[0]
+    H = torch.empty(B, A, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.pfpn_entropy_fwd(_f32(logits.view(B, A * N), B, A * N), B, A, N, H.data_ptr(), _stream()),
+               "pfpn_entropy_fwd")
+    return H
+
+
+def entropy_bwd(logits, dH, A, N, dlogits=None):
+    lib = _lib.load()
+    B = logits.shape[0]
+    acc = dlogits is not None
+    if dlogits is None:
+        dlogits = torch.empty(B, A * N, dtype=torch.float32, device=logits.device)
+    _lib.check(lib.pfpn_entropy_bwd(_f32(logits.view(B, A * N), B, A * N), _f32(dH, B, A), B, A, N, int(acc),
+                                    _f32(dlogits.view(B, A * N), B, A * N), _stream()), "pfpn_entropy_bwd")
+    return dlogits
+
+
+def rsample_fwd(logits, loc, logstd, gumbel, eps):
+    lib = _lib.load()
+    A, N = loc.shape
+    B = logits.shape[0]
+    dev = logits.device
+    k = torch.empty(B, A, dtype=torch.int32, device=dev)
+    a = torch.empty(B, A, dtype=torch.float32, device=dev)
+    s_ = torch.empty(B, A, dtype=torch.float32, device=dev)
+    _lib.check(lib.pfpn_rsample_fwd(_f32(logits.view(B, A * N), B, A * N), _f32(loc, A, N), _f32(logstd, A, N),
+                                    _f32(gumbel.view(B, A * N), B, A * N), _f32(eps.view(B, A * N), B, A * N), B, A, N,
+                                    k.data_ptr(), a.data_ptr(), s_.data_ptr(), _stream()), "pfpn_rsample_fwd")
+    return a, s_, k
+
+
+def rsample_bwd(logits, loc, logstd, gumbel, eps, da, ds, dlogits=None, dloc=None, dlogstd=None):
+    """accumulates into dlogits/dloc/dlogstd when all three are given."""
+    lib = _lib.load()
+    A, N = loc.shape
+    B = logits.shape[0]
+    dev = logits.device
+    acc = dlogits is not None
+    if not acc:
+        dlogits = torch.empty(B, A * N, dtype=torch.float32, device=dev)
+        dloc = torch.empty(A, N, dtype=torch.float32, device=dev)
+        dlogstd = torch.empty(A, N, dtype=torch.float32, device=dev)
+    ws, wsn = _roll_ws(B, A, N, dev)
+    _lib.check(lib.pfpn_rsample_bwd(_f32(logits.view(B, A * N), B, A * N), _f32(loc, A, N), _f32(logstd, A, N),
+                                    _f32(gumbel.view(B, A * N), B, A * N), _f32(eps.view(B, A * N), B, A * N),
+                                    _f32(da, B, A), _f32(ds, B, A), B, A, N, int(acc),
+                                    _f32(dlogits.view(B, A * N), B, A * N), _f32(dloc, A, N), _f32(dlogstd, A, N),
+                                    ws, wsn, _stream()), "pfpn_rsample_bwd")
+    return dlogits, dloc, dlogstd
+
+
+def resample(loc, logstd, bias, weight, max_active, sum_active, u_resample, u_noise, threshold=0.0,
+             tanh_mode=False):
+    """In place on loc/logstd/bias/weight.  Returns (dead [A,N] int32, src [A,N] int32)."""
+    lib = _lib.load()
+    A, N = loc.shape
+    H = weight.shape[0]
+    dev = loc.device
+    dead = torch.empty(A, N, dtype=torch.int32, device=dev)
+    src = torch.empty(A, N, dtype=torch.int32, device=dev)
+    _lib.check(lib.pfpn_resample(_f32(loc, A, N), _f32(logstd, A, N), _f32(bias, A * N), _f32(weight, H, A * N), H,
+                                 _f32(max_active, A, N), _f32(sum_active, A, N),
+                                 _typed(u_resample, torch.float64, A, N, name="u_resample"), _f32(u_noise, A, N),
+                                 A, N, float(threshold), int(tanh_mode), dead.data_ptr(), src.data_ptr(), _stream()),
+               "pfpn_resample")
+    return dead, src
+
+
+# --------------------------------------------------------------------------------------- #
+# learner utilities                                                                        #
+# --------------------------------------------------------------------------------------- #
+def _learn_ws(rows, H, device):
+    lib = _lib.load()
+    buf = workspace(max(lib.pfpn_learner_workspace_bytes(rows, H), 4096 * 4), device)
+    return buf.data_ptr(), buf.numel()
+
+
+def gae(reward, value, offsets, gamma, gae_gamma):
+    """reward [Ttot] f32, value [Ttot+E] f32, offsets [E+1] int64 (device) -> adv [Ttot] f32."""
+    lib = _lib.load()
+    E = offsets.shape[0] - 1
+    adv = torch.empty_like(reward)
+    _lib.check(lib.pfpn_gae(_f32(reward), _f32(value), _typed(offsets, torch.int64, E + 1, name="offsets"), E,
+                            float(gamma), float(gae_gamma), adv.data_ptr(), _stream()), "pfpn_gae")
+    return adv
+
+
+def state_norm(s, mean, std, clip=5.0, out=None):
+    lib = _lib.load()
+    B, S = s.shape
+    if out is None:
+        out = torch.empty_like(s)
+    _lib.check(lib.pfpn_state_norm(_f32(s, B, S), _f32(mean, S), _f32(std, S), B, S, float(clip or 0.0),
+                                   _f32(out, B, S), _stream()), "pfpn_state_norm")
+    return out
+
+
+def state_norm_update(s, step, mean, std, mean_out=None, std_out=None):
+    lib = _lib.load()
+    B, S = s.shape
+    if mean_out is None:
+        mean_out, std_out = torch.empty_like(mean), torch.empty_like(std)
+    ws, wsn = _learn_ws(B, S, s.device)
+    _lib.check(lib.pfpn_state_norm_update(_f32(s, B, S), B, S, float(step), _f32(mean, S), _f32(std, S),
+                                          _f32(mean_out, S), _f32(std_out, S), ws, wsn, _stream()),
+               "pfpn_state_norm_update")
+    return mean_out, std_out
+
+
+def bias_act(y, bias, relu6=True, group_rows=0):
+    lib = _lib.load()
+    rows, H = y.shape
+    _lib.check(lib.pfpn_bias_act(_f32(y, rows, H), _f32(bias), rows, H, int(group_rows), int(relu6), _stream()),
+               "pfpn_bias_act")
+    return y
+
+
+def act_bwd_bias_grad(y, dy, db, relu6=True, group_rows=0):
+    lib = _lib.load()
+    rows, H = dy.shape
+    ws, wsn = _learn_ws(rows, H, dy.device)
+    _lib.check(lib.pfpn_act_bwd_bias_grad(_f32(y, rows, H) if y is not None else None, _f32(dy, rows, H), rows, H,
+                                          int(group_rows), int(relu6), _f32(db), ws, wsn, _stream()),
+               "pfpn_act_bwd_bias_grad")
+    return dy, db
+
+
+def value_head_fwd(h, w, bias, out=None):
+    lib = _lib.load()
+    B, H = h.shape
+    if out is None:
+        out = torch.empty(B, dtype=torch.float32, device=h.device)
+    _lib.check(lib.pfpn_value_head_fwd(_f32(h, B, H), _f32(w), _f32(bias), B, H, _f32(out, B), _stream()),
+               "pfpn_value_head_fwd")
+    return out
+
+
+def value_head_bwd(h, w, dv, dh, dw, db, relu6=True):
+    lib = _lib.load()
+    B, H = h.shape
+    ws, wsn = _learn_ws(B, H, h.device)
+    _lib.check(lib.pfpn_value_head_bwd(_f32(h, B, H), _f32(w), _f32(dv, B), B, H, int(relu6), _f32(dh, B, H),
+                                       _f32(dw), _f32(db), ws, wsn, _stream()), "pfpn_value_head_bwd")
+    return dh, dw, db
+
+
+def clip_by_global_norm(grads_flat, clip_norm, norm_scale, apply=True):
+    lib = _lib.load()
+    n = grads_flat.numel()
+    ws, wsn = _learn_ws(1, 1, grads_flat.device)
+    _lib.check(lib.pfpn_clip_by_global_norm(_f32(grads_flat), n, float(clip_norm or 0.0), int(apply),
+                                            _f32(norm_scale, 2), ws, wsn, _stream()), "pfpn_clip_by_global_norm")
+    return norm_scale
+
+
+def tf_adam(params, grads, m, v, beta_pow, lr, beta1=0.9, beta2=0.999, eps=1e-8, advance=True, norm_scale=None,
+            grad_mul=1.0):
+    lib = _lib.load()
+    n = params.numel()
+    _lib.check(lib.pfpn_tf_adam(_f32(params), _f32(grads), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
+                                float(eps), _f32(beta_pow, 2), int(advance),
+                                _f32(norm_scale, 2) if norm_scale is not None else None, float(grad_mul), _stream()),
+               "pfpn_tf_adam")
+
+
+def soft_update(target, source, tau):
+    lib = _lib.load()
+    _lib.check(lib.pfpn_soft_update(_f32(target), _f32(source), target.numel(), float(tau), _stream()),
+               "pfpn_soft_update")

@@ -1,0 +1,162 @@
+"""GPU parity: GAE, state normaliser, dense epilogues, value head, clip + TF-Adam vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_mixture import to_dev
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+@pytest.mark.parametrize("lens", [[512] * 8, [1], [3, 600, 1, 77], [5000, 2049, 2048]])
+def test_gae_bit_exact(oracle, dev, lens):
+    """fp32 deltas + sequential float64 scan in the reference's op order -> bit-exact fp32 output."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(len(lens))
+    rs = [rng.normal(0, 1, T).astype(F) for T in lens]
+    vs = [rng.normal(0, 3, T + 1).astype(F) for T in lens]
+    ref = np.concatenate([oracle.gae(r, v, 0.95, 0.95 * 0.95) for r, v in zip(rs, vs)])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dr, dv, do = to_dev(dev, np.concatenate(rs), np.concatenate(vs), offs)
+    adv = kernels.gae(dr, dv, do, 0.95, 0.95 * 0.95)
+    assert np.array_equal(adv.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("B", [1, 32, 4096])
+def test_state_norm_and_update(oracle, dev, B):
+    from pfpn_amd import kernels
+    S = 197
+    rng = np.random.default_rng(B)
+    s = (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F)
+    s[0, :5] = 100.0
+    mean = rng.normal(0, 0.1, S).astype(F)
+    std = (1 + rng.random(S)).astype(F)
+    x_ref = oracle.state_normalize(s, mean, std, 5.0)
+    ds, dm, dsd = to_dev(dev, s, mean, std)
+    x = kernels.state_norm(ds, dm, dsd, 5.0)
+    np.testing.assert_allclose(x.cpu().numpy(), x_ref, rtol=1e-6, atol=1e-7)
+    assert x.max().item() <= 5.0 and x.min().item() >= -5.0
+    for step in (0, 5, 100000):
+        m_ref, s_ref = oracle.state_norm_update(s, mean, std, step)
+        m, sd = kernels.state_norm_update(ds, step, dm, dsd)
+        np.testing.assert_allclose(m.cpu().numpy(), m_ref, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sd.cpu().numpy(), s_ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,H,G", [(4096, 2048, 1), (33, 512, 1), (2 * 4096, 512, 2), (2 * 7, 512, 2), (5, 1260, 1)])
+def test_bias_act_and_bwd(dev, rows, H, G):
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(rows + H)
+    y0 = rng.normal(0, 3, (rows, H)).astype(F)
+    bias = rng.normal(0, 1, (G, H)).astype(F)
+    gr = rows // G if G > 1 else 0
+    ref = np.clip(y0 + np.repeat(bias, rows // G, axis=0), 0, 6)
+    dy0, db0 = to_dev(dev, y0, bias)
+    y = kernels.bias_act(dy0, db0, True, gr)
+    np.testing.assert_array_equal(y.cpu().numpy(), ref.astype(F))
+    g = rng.normal(0, 1, (rows, H)).astype(F)
+    mask = (ref > 0) & (ref < 6)
+    g_ref = np.where(mask, g, 0).astype(F)
+    db_ref = g_ref.reshape(G, rows // G, H).sum(1, dtype=np.float64)
+    dg, = to_dev(dev, g)
+    db = torch.empty(G, H, device=dev)
+    kernels.act_bwd_bias_grad(y, dg, db, True, gr)
+    np.testing.assert_array_equal(dg.cpu().numpy(), g_ref)
+    np.testing.assert_allclose(db.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-4)
+    # linear layer (no activation): dy untouched, db = column sums
+    dg2, = to_dev(dev, g)
+    kernels.act_bwd_bias_grad(None, dg2, db, False, gr)
+    np.testing.assert_array_equal(dg2.cpu().numpy(), g)
+    np.testing.assert_allclose(db.cpu().numpy(), g.reshape(G, rows // G, H).sum(1, dtype=np.float64), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B", [1, 100, 4096])
+def test_value_head(dev, B):
+    from pfpn_amd import kernels
+    H = 512
+    rng = np.random.default_rng(B)
+    h = np.clip(rng.normal(1, 3, (B, H)), 0, 6).astype(F)
+    w = rng.normal(0, 0.05, H).astype(F)
+    b = np.array([0.3], F)
+    dv = rng.normal(0, 1, B).astype(F)
+    dh_, dw_, db_, ddv = to_dev(dev, h, w, b, dv)
+    v = kernels.value_head_fwd(dh_, dw_, db_)
+    np.testing.assert_allclose(v.cpu().numpy(), h.astype(np.float64) @ w + 0.3, rtol=1e-5, atol=1e-5)
+    dh = torch.empty(B, H, device=dev); dw = torch.empty(H, device=dev); db = torch.empty(1, device=dev)
+    kernels.value_head_bwd(dh_, dw_, ddv, dh, dw, db, True)
+    mask = (h > 0) & (h < 6)
+    np.testing.assert_allclose(dh.cpu().numpy(), np.where(mask, dv[:, None] * w[None], 0), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(dw.cpu().numpy(), h.astype(np.float64).T @ dv, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), [dv.sum(dtype=np.float64)], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,scale", [(2104517, 1.0), (2104517, 1e-4), (1003, 1.0)])
+def test_clip_and_tf_adam(oracle, dev, n, scale):
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(n)
+    p = rng.normal(0, 0.01, n).astype(F)
+    g = (rng.normal(0, 1, n) * scale / np.sqrt(n) * 3).astype(F)
+    m = (rng.normal(0, 1, n) * 1e-3).astype(F)
+    v = (rng.random(n) * 1e-6).astype(F)
+    (gc,), norm = oracle.clip_by_global_norm([g], 1.0)
+    p_ref, m_ref, v_ref = oracle.tf_adam(p, gc, m, v, F(0.9) ** 3, F(0.999) ** 3, 1e-4)
+    dp, dg, dm, dv = to_dev(dev, p, g, m, v)
+    bp = torch.tensor([F(0.9) ** 3, F(0.999) ** 3], device=dev, dtype=torch.float32)
+    ns = torch.empty(2, device=dev)
+    kernels.clip_by_global_norm(dg, 1.0, ns, apply=True)
+    np.testing.assert_allclose(ns.cpu().numpy()[0], norm, rtol=2e-6)
+    np.testing.assert_allclose(dg.cpu().numpy(), gc, rtol=2e-6, atol=0)
+    kernels.tf_adam(dp, dg, dm, dv, bp, 1e-4)
+    if norm < 1.0:
+        # scale == 1 exactly -> the whole update is bit-exact against the oracle
+        assert np.array_equal(dg.cpu().numpy(), g)
+        assert np.array_equal(dm.cpu().numpy(), m_ref) and np.array_equal(dv.cpu().numpy(), v_ref)
+        assert np.array_equal(dp.cpu().numpy(), p_ref)
+    else:
+        np.testing.assert_allclose(dm.cpu().numpy(), m_ref, rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(dv.cpu().numpy(), v_ref, rtol=1e-5, atol=1e-15)
+        np.testing.assert_allclose(dp.cpu().numpy(), p_ref, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(bp.cpu().numpy(), [F(0.9) ** 4, F(0.999) ** 4], rtol=1e-7)
+
+
+def test_adam_fused_scale_matches_two_pass(dev):
+    """norm_scale/grad_mul folded into the Adam kernel == scaling the gradient first."""
+    from pfpn_amd import kernels
+    n = 40001
+    rng = np.random.default_rng(0)
+    p, g = rng.normal(0, 1, n).astype(F), rng.normal(0, 1, n).astype(F)
+    a = to_dev(dev, p, g, np.zeros(n, F), np.zeros(n, F))
+    b = to_dev(dev, p, g, np.zeros(n, F), np.zeros(n, F))
+    ns = torch.empty(2, device=dev)
+    kernels.clip_by_global_norm(a[1], 1.0, ns, apply=False)
+    bp1 = torch.tensor([0.9, 0.999], device=dev); bp2 = bp1.clone()
+    kernels.tf_adam(a[0], a[1], a[2], a[3], bp1, 1e-4, norm_scale=ns, grad_mul=0.125)
+    kernels.clip_by_global_norm(b[1], 1.0, ns, apply=True)
+    b[1].mul_(0.125)
+    kernels.tf_adam(b[0], b[1], b[2], b[3], bp2, 1e-4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+def test_soft_update(dev):
+    from pfpn_amd import kernels
+    t = torch.randn(10007, device=dev); s = torch.randn(10007, device=dev)
+    ref = (1 - 0.005) * t + 0.005 * s
+    kernels.soft_update(t, s, 0.005)
+    torch.testing.assert_close(t, ref, rtol=1e-6, atol=1e-7)
+
+
+def test_ppo_loss_unfused(oracle, dev):
+    from pfpn_amd import kernels
+    B = 3000
+    rng = np.random.default_rng(2)
+    lp = rng.normal(-30, 1, B).astype(F)
+    lp_old = (lp + rng.normal(0, 0.2, B)).astype(F)
+    adv, v, v_old = (rng.normal(0, 1, B).astype(F) for _ in range(3))
+    loss, pl, vl, dlogp, dv = oracle.ppo_loss(lp, lp_old, adv, v, v_old)
+    d = to_dev(dev, lp, lp_old, adv, v, v_old)
+    st = kernels.adv_stats(d[2])
+    g_lp, g_v, l3 = kernels.ppo_loss(*d, st)
+    np.testing.assert_allclose(l3.cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(g_lp.cpu().numpy(), dlogp, rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(g_v.cpu().numpy(), dv, rtol=1e-5, atol=1e-10)
