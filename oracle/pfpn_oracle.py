@@ -302,8 +302,9 @@ def resample_particles(loc, logstd, bias, weight, max_active, sum_active,
         # count[u] = #clones per unique source; delta = 1 if the source is itself dead (a2c.py:453-457)
         cnt = np.bincount(srcs, minlength=N).astype(F)
         delta = dead[a].astype(F)
-        new_bias_src = (old_bias[a * N:(a + 1) * N]
-                        - np.log((cnt + F(1) - delta).astype(F), dtype=F)).astype(F)   # per source col
+        with np.errstate(divide="ignore"):      # entries with cnt == 0 are never used
+            new_bias_src = (old_bias[a * N:(a + 1) * N]
+                            - np.log((cnt + F(1) - delta).astype(F), dtype=F)).astype(F)   # per source col
         # first scatter: bias[tc] = bias_new ; second: bias[c] = bias_new (a2c.py:465-466)
         for sidx in np.unique(srcs):
             bias[a * N + sidx] = new_bias_src[sidx]

@@ -114,9 +114,9 @@ def test_clip_and_tf_adam(oracle, dev, n, scale):
         assert np.array_equal(dm.cpu().numpy(), m_ref) and np.array_equal(dv.cpu().numpy(), v_ref)
         assert np.array_equal(dp.cpu().numpy(), p_ref)
     else:
-        np.testing.assert_allclose(dm.cpu().numpy(), m_ref, rtol=1e-5, atol=1e-12)
-        np.testing.assert_allclose(dv.cpu().numpy(), v_ref, rtol=1e-5, atol=1e-15)
-        np.testing.assert_allclose(dp.cpu().numpy(), p_ref, rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(dm.cpu().numpy(), m_ref, rtol=1e-5, atol=1e-9)     # |m| ~ 1e-3, fp32 resolution
+        np.testing.assert_allclose(dv.cpu().numpy(), v_ref, rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(dp.cpu().numpy(), p_ref, rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(bp.cpu().numpy(), [F(0.9) ** 4, F(0.999) ** 4], rtol=1e-7)
 
 
