@@ -141,8 +141,9 @@ int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, in
 /* x = clip((s-mean)/std, +-clip) -- actor_critic.py:223-244 (clip <= 0: no clipping). */
 int pfpn_state_norm(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
                     void* stream);
-/* online_normalizer(moving_average=True) -- utils.py:60-68, population moments over the batch. */
-int pfpn_state_norm_update(const float* s, int B, int S, float step, const float* mean_in, const float* std_in,
+/* online_normalizer(moving_average=True) -- utils.py:60-68, population moments over the batch.
+ * step: DEVICE scalar holding float(global_step) (a device value so the call is graph-capturable). */
+int pfpn_state_norm_update(const float* s, int B, int S, const float* step, const float* mean_in, const float* std_in,
                            float* mean_out, float* std_out, void* workspace, size_t workspace_bytes,
                            void* stream);
 

@@ -129,11 +129,13 @@ __global__ __launch_bounds__(256) void k_col_mean(const float* __restrict__ part
 
 // EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step))
 __global__ __launch_bounds__(256) void k_norm_ema(const float* __restrict__ bmean, const float* __restrict__ bvar,
-                                                  int S, float step, const float* __restrict__ mean_in,
+                                                  int S, const float* __restrict__ step_dev,
+                                                  const float* __restrict__ mean_in,
                                                   const float* __restrict__ std_in, float* __restrict__ mean_out,
                                                   float* __restrict__ std_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= S) return;
+    const float step = step_dev[0];                                // global_step as fp32 (device scalar)
     const float d = fminf(0.9999f, (1.f + step) / (10.f + step));
     const float omd = 1.f - d;
     const float nm = d * mean_in[c] + omd * bmean[c];
@@ -444,10 +446,10 @@ size_t pfpn_learner_workspace_bytes(int rows, int H) {
     return ((size_t)130 * (size_t)(H > 0 ? H : 1) + 4096) * sizeof(float) + (size_t)rows * 0;
 }
 
-int pfpn_state_norm_update(const float* s, int B, int S, float step, const float* mean_in, const float* std_in,
+int pfpn_state_norm_update(const float* s, int B, int S, const float* step, const float* mean_in, const float* std_in,
                            float* mean_out, float* std_out, void* workspace, size_t workspace_bytes,
                            void* stream) {
-    if (!s || !mean_in || !std_in || !mean_out || !std_out || B < 1 || S < 1) return PFPN_ERR_ARG;
+    if (!s || !step || !mean_in || !std_in || !mean_out || !std_out || B < 1 || S < 1) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, S)) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int C = row_chunks(B);

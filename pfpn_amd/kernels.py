@@ -297,8 +297,10 @@ def state_norm_update(s, step, mean, std, mean_out=None, std_out=None):
     B, S = s.shape
     if mean_out is None:
         mean_out, std_out = torch.empty_like(mean), torch.empty_like(std)
+    if not isinstance(step, torch.Tensor):
+        step = torch.tensor([float(step)], dtype=torch.float32, device=s.device)
     ws, wsn = _learn_ws(B, S, s.device)
-    _lib.check(lib.pfpn_state_norm_update(_f32(s, B, S), B, S, float(step), _f32(mean, S), _f32(std, S),
+    _lib.check(lib.pfpn_state_norm_update(_f32(s, B, S), B, S, _f32(step, 1), _f32(mean, S), _f32(std, S),
                                           _f32(mean_out, S), _f32(std_out, S), ws, wsn, _stream()),
                "pfpn_state_norm_update")
     return mean_out, std_out

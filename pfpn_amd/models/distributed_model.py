@@ -1,0 +1,275 @@
+"""Worker runtime: rollout loop, experience buffers, minibatch scheduling, one-process-per-GPU launch.
+
+Host-side mirror of reference models/distributed_model.py: `AbstractDistributedWorker.work` (:154-193),
+`interact_with_env` (:264-290), `need_train` (:292-299), `flat_train` (:320-352), `train` (:372-385),
+`DistributedModel.dispatch` (:548-625).  The TF cluster / parameter server / MonitoredTrainingSession /
+evaluator process are replaced by `torch.distributed` (backend "nccl" = RCCL on ROCm, or "gloo" for the
+CPU-side tests of the host logic) launched by torchrun: ranks read RANK / WORLD_SIZE / LOCAL_RANK /
+MASTER_ADDR / MASTER_PORT from the environment.  PyBullet stays on the host (one env per worker).
+"""
+import os
+import time
+
+import numpy as np
+
+
+class AbstractDistributedWorker(object):
+    GLOBAL_NET_NAME = "global_net"
+
+    def __init__(self, _env_wrapper=None, _network_wrapper=None, _job_name="worker", _task_id=0,
+                 _is_chief=True, _is_evaluator=0, _seed=None, _on_policy=True, _log_dir=None,
+                 _max_samples=None, render=False,
+                 batch_size=None, unroll_length=None, opt_epochs=1, episodic_training=False, **kwargs):
+        self.env_wrapper = _env_wrapper
+        self.network_wrapper = _network_wrapper
+        self.job_name, self.task_id = _job_name, _task_id
+        self.name = "{}_{}".format(_job_name, _task_id)
+        self.is_chief = _is_chief
+        self.is_evaluator = _is_evaluator
+        self.seed = _seed
+        self.on_policy = _on_policy
+        self.max_samples = _max_samples
+        self.render = render
+        self.batch_size = batch_size
+        self.unroll_length = unroll_length
+        self.opt_epochs = opt_epochs
+        self.episodic_training = episodic_training
+        if episodic_training:
+            raise NotImplementedError("episodic (LSTM) training is not part of the PFPN path")
+        self.logger = None
+        self.request_stop = False
+        self.global_step = 0
+        self.total_samples = 0
+        self.np_random = np.random.RandomState(_seed)
+        self.update_ops = None
+        self.sequence_length = None
+        self.current_opt_epoch = 0
+
+    # -- construction ----------------------------------------------------------------------------
+    def init(self):
+        """reference distributed_model.py:86-111: build env + global net."""
+        self.env = self.env_wrapper(self.name, self.render) if self.env_wrapper else None
+        if self.env is not None and self.seed is not None and hasattr(self.env, "seed"):
+            self.env.seed(self.seed + self.task_id)
+        self.global_net = self.network_wrapper(self.env, not self.is_evaluator)
+        self.global_net.init()
+        self.init_ops = list(self.global_net.init_ops)
+        self.build_local_net(self.name)
+
+    def build_local_net(self, name):
+        raise NotImplementedError
+
+    # -- rollout loop (reference :154-193) --------------------------------------------------------
+    def work(self, sess=None, max_iterations=None):
+        self.batch_size = None if self.batch_size is None else int(self.batch_size)
+        self.unroll_length = None if self.unroll_length is None else int(self.unroll_length)
+        self.opt_epochs = None if self.opt_epochs is None else int(self.opt_epochs)
+        self.request_stop = False
+        self.before_work(sess)
+        while not self.request_stop:
+            state = self.before_episode(sess)
+            terminal = False
+            info = {}
+            while not terminal and not self.request_stop:
+                action, *_ = self.sample_action(sess, state)
+                state, _, terminal, info = self.interact_with_env(sess, state, action)
+                if self.target_net.trainable:
+                    if self.need_train(sess, terminal, state, info):
+                        self.flat_train(sess)
+                        self.after_train(sess)
+                if max_iterations is not None and self.global_step >= max_iterations:
+                    self.request_stop = True
+            self.after_episode(sess, info)
+        self.after_work(sess)
+
+    def sync(self, sess):
+        pass        # replicas are identical after every all-reduce step: nothing to pull
+
+    def setup_buffers(self):
+        if self.exp_buffers is not None:
+            self.exp = {k: [] for k in self.exp_buffers}
+
+    def clear_buffers(self):
+        if self.on_policy and self.exp_buffers is not None:
+            for _, v in self.exp.items():
+                v.clear()
+        self.sample_counter = 0
+
+    def before_work(self, sess):
+        self.evaluator_counter = 0
+        self.sample_counter = 0
+        self.setup_buffers()
+        for op in self.init_ops:
+            op()
+        self.sync(sess)
+
+    def after_work(self, sess):
+        pass
+
+    def before_episode(self, sess):
+        self.local_net.reset_running_state()
+        if not self.evaluator_counter:
+            self.total_reward, self.episode_step = 0.0, 0
+        self.episode_buffer_stamp = 0
+        return self.env.reset()
+
+    def after_episode(self, sess, info):
+        if self.is_evaluator:
+            self.evaluator_counter += 1
+            if self.evaluator_counter >= self.is_evaluator:
+                print("[PERFORM] Life Time: {}; Total Reward: {:.4f}; Avg Reward: {:.4f}; Step: {}; {}".format(
+                    self.episode_step / self.evaluator_counter, self.total_reward / self.evaluator_counter,
+                    self.total_reward / max(1, self.episode_step), self.global_step,
+                    time.strftime("%m-%d %H:%M:%S", time.localtime())))
+                self.evaluator_counter = 0
+
+    def sample_action(self, sess, state):
+        return self.local_net.run(sess, state, self.update_ops)
+
+    def interact_with_env(self, sess, state, action):
+        """reference :264-290: the env sees the clipped action, the buffer stores the unclipped one."""
+        self.sample_counter += 1
+        self.episode_step += 1
+        if hasattr(self.env.action_space, "low"):
+            a = np.clip(action, self.env.action_space.low, self.env.action_space.high)
+        else:
+            a = action
+        state_, reward, terminal, info = self.env.step(a)
+        self.exp["state"].append(state)
+        self.exp["action"].append(action)
+        self.exp["reward"].append(reward)
+        if "episode_reward" in info:
+            if info["episode_reward"] != 0:
+                for i in range(self.episode_buffer_stamp, len(self.exp["reward"])):
+                    self.exp["reward"][i] += info["episode_reward"]
+                self.total_reward += (len(self.exp["reward"]) - self.episode_buffer_stamp) * info["episode_reward"]
+            self.episode_buffer_stamp = len(self.exp["reward"])
+        self.total_reward += reward
+        self.total_samples += 1
+        return state_, reward, terminal, info
+
+    def need_train(self, sess, terminal, last_state, info):
+        if self.unroll_length is None:
+            return terminal
+        return self.sample_counter >= self.unroll_length
+
+    @property
+    def episodic_terminal(self):
+        return False
+
+    def after_train(self, sess):
+        self.sync(sess)
+        self.clear_buffers()
+        if self.max_samples is not None and self.total_samples > self.max_samples:
+            self.request_stop = True
+
+    # -- minibatch scheduling (reference :320-352) -------------------------------------------------
+    def flat_train(self, sess):
+        n = len(self.exp["state"])
+        exp_bak = self.exp
+        if self.on_policy:      # disposable experience buffer
+            exp = {k: np.asarray(v, dtype=np.float32) for k, v in exp_bak.items()}
+            ids = np.arange(n)
+            self.current_opt_epoch = 0
+            while self.current_opt_epoch < self.opt_epochs:
+                self.np_random.shuffle(ids)
+                if self.batch_size:
+                    for s in range(0, n, self.batch_size):
+                        cand = ids[s:s + self.batch_size]
+                        self.exp = {k: buf[cand] for k, buf in exp.items()}
+                        self.train(sess)
+                else:
+                    self.exp = {k: buf[ids] for k, buf in exp.items()}
+                    self.train(sess)
+                self.current_opt_epoch += 1
+        elif n >= self.batch_size:
+            for _ in range(self.opt_epochs if self.opt_epochs else self.sample_counter):
+                ids = self.np_random.choice(n, self.batch_size)          # with replacement (:347)
+                self.exp = {k: np.asarray([v.data[i] for i in ids], dtype=np.float32) for k, v in exp_bak.items()}
+                self.train(sess)
+        self.exp = exp_bak
+
+    def train(self, sess=None):
+        """One learner step: the reference's `worker.train(sess)` (:372-385)."""
+        if self.request_stop:
+            return None, None
+        ops = self.train_ops
+        loss, result = self.target_net.train(sess, self.opt_op, ops, *self.train_args)
+        self.global_step = self.target_net.global_step
+        return loss, result
+
+    def step(self, batch=None):
+        """Alias named by BASELINE.json's north_star (`learner step`); NEW, not in the reference.
+        `batch`: optional dict of the worker's train_args by buffer name."""
+        if batch is not None:
+            self.exp = batch
+        return self.train(None)
+
+    @property
+    def exp_buffers(self):
+        return ["state", "action", "reward"]
+
+    @property
+    def train_ops(self):
+        return ["global_step"]
+
+    @property
+    def train_args(self):
+        return [self.exp["state"], self.exp["action"], self.exp["reward"]]
+
+
+def init_process_group(backend=None):
+    """One process per GPU: RANK/WORLD_SIZE/LOCAL_RANK/MASTER_ADDR/MASTER_PORT from torchrun.
+    Returns (rank, world_size, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return rank, world, local_rank
+
+
+class DistributedModel(object):
+    """reference :406-638, minus the TF cluster: builds one worker in THIS process (rank) and runs it."""
+
+    def __init__(self, worker_wrapper, env_wrapper, network_wrapper,
+                 checkpoint_dir=None, save_checkpoint_interval=1000, max_iterations=None, device="GPU:0",
+                 log_dir=None, debug="chief", max_samples=None, use_evaluator=True, seed=None):
+        self.worker_wrapper = worker_wrapper
+        self.env_wrapper = env_wrapper
+        self.network_wrapper = network_wrapper
+        self.checkpoint_dir = checkpoint_dir
+        self.save_checkpoint_interval = save_checkpoint_interval
+        self.max_iterations = max_iterations
+        self.max_samples = max_samples
+        self.log_dir = log_dir
+        self.seed = seed
+
+    def worker_wrapper_kwargs(self, world_size):
+        return {}
+
+    def build_worker(self, evaluator=False):
+        rank, world, _ = init_process_group()
+        worker = self.worker_wrapper(_job_name="evaluator" if evaluator else "worker", _task_id=rank,
+                                     _is_chief=(rank == 0), _is_evaluator=1 if evaluator else 0,
+                                     _env_wrapper=self.env_wrapper, _network_wrapper=self.network_wrapper,
+                                     _seed=self.seed, _log_dir=self.log_dir, _max_samples=self.max_samples,
+                                     **self.worker_wrapper_kwargs(world))
+        worker.init()
+        return worker
+
+    def start(self, distributions=None):
+        worker = self.build_worker(evaluator=distributions is None)
+        worker.work(None, max_iterations=self.max_iterations)
+        return worker

@@ -1,0 +1,107 @@
+"""Synchronous data-parallel strategy on MI355X: one process per GPU, RCCL all-reduce over xGMI.
+
+Host-side mirror of reference models/sync_model.py: `SyncWorker.build_local_net` (:16-157) wraps the
+optimiser in `tf.train.SyncReplicasOptimizer(replicas_to_aggregate=n_workers)` (:92-95), i.e. the
+parameter server takes the MEAN of the per-worker gradients that were each clipped by global norm
+on the worker (:64), the mean of the pushed statistic tensors (`push_weights`, :37-46: state-normaliser
+mean/std, max/sum activation), applies Adam once, runs `train_ops` (:77-84) and the workers pull the
+result (:27-32).
+
+Here every rank keeps a replica.  One flat bucket [clipped grads | local stat tensors] is summed with a
+single `torch.distributed.all_reduce` (backend "nccl" == RCCL) and divided by W inside the Adam kernel
+(`grad_mul`); every rank then applies the identical TF-Adam update and resample tick, so replicas stay
+bit-identical and no pull step is needed.  There is no parameter server and no gRPC.
+"""
+import torch
+import torch.distributed as dist
+
+from .. import kernels
+from .distributed_model import AbstractDistributedWorker, DistributedModel
+
+__all__ = ["SyncModel", "SyncReplicasApplier"]
+
+
+class SyncReplicasApplier(object):
+    """clip (per replica) -> mean over replicas -> TF-Adam -> statistics -> train_ops.
+
+    `groups`: list of dict(names=[...] or None for the whole buffer, lr=float): one Adam (own
+    beta powers) per group, applied in order (SAC: critic list first, then actor list --
+    reference base_worker.py:33-45)."""
+
+    def __init__(self, net, groups, norm_clip=None, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                 process_group=None, world_size=None):
+        self.net = net
+        st = net.store
+        self.norm_clip = norm_clip
+        self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
+        self.pg = process_group
+        if world_size is None:
+            world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = int(world_size)
+        self.norm_scale = torch.zeros(2, dtype=torch.float32, device=st.device)
+        self.groups = []
+        for g in groups:
+            if g.get("names") is None:
+                off, ln = 0, st.size
+            else:
+                off, ln = st.span(g["names"])
+            self.groups.append({
+                "off": off, "len": ln, "lr": float(g["lr"]),
+                "beta_pow": torch.tensor([beta1, beta2], dtype=torch.float32, device=st.device),
+            })
+
+    # -- device part (no host sync; capturable when world == 1) -------------------------------------
+    def apply_device(self, net):
+        st = net.store
+        W = self.world
+        fused_scale = None
+        if self.norm_clip:
+            # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica
+            kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=(W > 1))
+            if W == 1:
+                fused_scale = self.norm_scale          # folded into the Adam kernel
+        if W > 1:
+            net.pack_local_stats(st.tail)
+            dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+        for g in self.groups:
+            sl = slice(g["off"], g["off"] + g["len"])
+            kernels.tf_adam(st.flat[sl], st.grad[sl], st.m[sl], st.v[sl], g["beta_pow"], g["lr"], self.beta1,
+                            self.beta2, self.epsilon, advance=True, norm_scale=fused_scale, grad_mul=1.0 / W)
+        net.unpack_synced_stats(st.tail, 1.0 / W)
+        net.step_dev.add_(1.0)
+
+    # -- host part -----------------------------------------------------------------------------------
+    def apply_host(self, net):
+        net.global_step += 1
+        for op in net.train_ops:
+            op()
+
+    def apply(self, net):
+        self.apply_device(net)
+        self.apply_host(net)
+
+    def state_dict(self):
+        return {"beta_pow": [g["beta_pow"].clone() for g in self.groups]}
+
+
+class SyncWorker(AbstractDistributedWorker):
+    """reference sync_model.py:9-14: synchronous worker; `n_workers` = replicas to aggregate."""
+
+    def __init__(self, n_workers=1, **kwargs):
+        super().__init__(**kwargs)
+        self.n_workers = n_workers
+        self.n_aggregate = self.n_workers
+
+    def build_local_net(self, name=None):
+        """reference sync_model.py:16-157.  With all-reduce DP the local net IS the global net
+        replica; build the optimiser around it."""
+        self.target_net = self.global_net
+        self.local_net = self.global_net
+        if not self.global_net.trainable:
+            return
+        self.opt_op = self.build_optimizer(self.global_net)
+
+
+class SyncModel(DistributedModel):
+    def worker_wrapper_kwargs(self, world_size):
+        return {"n_workers": world_size}

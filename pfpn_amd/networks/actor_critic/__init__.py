@@ -1,0 +1,3 @@
+from .a2c import *
+from .ppo import *
+from .sac import *

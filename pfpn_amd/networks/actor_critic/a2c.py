@@ -1,0 +1,248 @@
+"""A2C base + the particle-filtering policy head on MI355X.
+
+Host-side mirror of reference networks/actor_critic/a2c.py: `A2CNetwork` (:16-89: GAE :30-40,
+run/evaluate :67-78), the sampler/log-prob plumbing of `ContinuousA2CNetwork` (:205-243) and
+`ParticleFilteringA2CNetwork` (:310-559: particle grid :476-534, fc_policy :541-558, activation
+statistics :346-365, resample tick :367-383, resample ops :385-474).
+"""
+import numpy as np
+import torch
+
+from ... import kernels
+from .. import ops
+from ..utils import MixtureGaussianDistribution
+from .actor_critic import ActorCriticNetwork
+
+__all__ = ["ParticleFilteringA2CNetwork", "particle_grid"]
+
+
+def particle_grid(n_actions, n, tanh_mode=False, init_sigma=None):
+    """Initial particle locations / log-stds, reference a2c.py:476-523 (bounds forced to [-1, 1],
+    :479-480).  float64 on the host like the reference's NumPy, then fp32 variables."""
+    u = np.ones((n_actions, n))
+    l = -u
+    ar = np.expand_dims(np.arange(n), 0)
+    if tanh_mode:
+        loc = l + (u - l) / n * (ar + 0.5)
+    else:
+        loc = l + (u - l) / (n - 1) * ar
+    if init_sigma:
+        std = np.zeros_like(loc) + np.reshape(np.asarray(init_sigma, dtype=np.float64), (-1, 1) if np.ndim(init_sigma) else ())
+        if tanh_mode:
+            loc_ = loc
+            loc = np.arctanh(loc)
+            std = np.maximum(loc - np.arctanh(np.maximum(1e-6 - 1, np.subtract(loc_, std))),
+                             np.arctanh(np.minimum(1 - 1e-6, np.add(loc_, std))) - loc)
+    else:
+        std = (u - l) / (n - 1)
+        if tanh_mode:
+            assert n > 3
+            loc = np.arctanh(loc)
+            left = loc - loc[:, np.maximum(0, np.arange(n) - 1)]
+            right = loc[:, np.minimum(n - 1, np.arange(n) + 1)] - loc
+            std = np.maximum(left, right)
+    return loc.astype(np.float32), np.log(std).astype(np.float32)
+
+
+class A2CNetwork(ActorCriticNetwork):
+    def __init__(self, gamma=0.99, lambd=0.95, **kwargs):
+        super().__init__(**kwargs)
+        self.gamma = gamma
+        self.gae_gamma = None if lambd is None else self.gamma * lambd
+
+    def generalized_advantage_estimate(self, reward, value, normalize=False):
+        """reference a2c.py:30-40 + utils.discount :5-15 on the device: fp32 deltas, float64 reverse
+        scan, fp32 result (bit-exact against the reference's NumPy loop)."""
+        assert len(value) == len(reward) + 1
+        if normalize:
+            raise NotImplementedError("normalize=True is never used by the PFPN workers")
+        T = len(reward)
+        if T == 0:
+            return []
+        r = torch.from_numpy(np.asarray(reward, dtype=np.float32)).to(self.device)
+        v = torch.from_numpy(np.asarray(value, dtype=np.float32)).to(self.device)
+        offs = torch.tensor([0, T], dtype=torch.int64, device=self.device)
+        adv = kernels.gae(r, v, offs, self.gamma, self.gae_gamma if self.gae_gamma else 0.0)
+        return list(adv.cpu().numpy())
+
+    def gae_batch(self, reward, value, offsets):
+        """Device-resident ragged GAE: reward [Ttot], value [Ttot+E], offsets [E+1] (all tensors)."""
+        return kernels.gae(reward, value, offsets, self.gamma, self.gae_gamma if self.gae_gamma else 0.0)
+
+
+class ParticleFilteringA2CNetwork(A2CNetwork):
+    def __init__(self, action_lower_bound, action_upper_bound, init_sigma=None, fixed_sigma=False,
+                 particles=50, resample=3, resample_interval=2000, resample_threshold=None,
+                 normalize_policy_output=False, **kwargs):
+        self.action_lower_bound = None if action_lower_bound is None else np.asarray(action_lower_bound, dtype=np.float64)
+        self.action_upper_bound = None if action_upper_bound is None else np.asarray(action_upper_bound, dtype=np.float64)
+        super().__init__(**kwargs)
+        if len(self.action_shape) != 1:
+            raise ValueError("Particle Filtering Policy Network only supports continuous action space.")
+        self.n_actions = int(self.action_shape[0])
+        self.particles = int(particles)
+        self.dis_action_shape = [self.particles] * self.n_actions
+        if resample and resample > 0:
+            raise NotImplementedError("resample=k (top-k source choice, a2c.py:405-408) is not built; "
+                                      "every shipped PFPN setting uses resample=-1")
+        self.resample = resample
+        self.resample_interval = resample_interval
+        self.resample_threshold = resample_threshold
+        self.init_sigma = fixed_sigma if fixed_sigma and fixed_sigma is not True else init_sigma
+        self.fixed_sigma = True if fixed_sigma else False
+        if self.fixed_sigma and resample:
+            raise NotImplementedError("fixed_sigma resampling (a2c.py:430-440) is not built; unset in every "
+                                      "shipped PFPN setting")
+        self.normalize_policy_output = False                      # tanh squash after the mixture (unused)
+        self.normalize_policy_output_ = bool(normalize_policy_output)   # tanh squash before the mixture
+        self.train_flag = 0
+
+    # -- parameters ------------------------------------------------------------------------------
+    def build_policy_params(self, store, in_dim):
+        A, N = self.n_actions, self.particles
+        self.policy_in = in_dim
+        store.declare("actor/samples", (A, N))
+        store.declare("actor/samples_std", (A, N))
+        store.declare("actor/fc_policy/weight", (in_dim, A * N))
+        store.declare("actor/fc_policy/bias", (A * N,))
+
+    def init_policy_params(self):
+        loc, logstd = particle_grid(self.n_actions, self.particles, self.normalize_policy_output_, self.init_sigma)
+        self.store["actor/samples"].copy_(torch.from_numpy(loc))
+        self.store["actor/samples_std"].copy_(torch.from_numpy(logstd))
+        ops.truncated_normal_(self.store["actor/fc_policy/weight"], self.weight_std, self.rng)
+        self.store["actor/fc_policy/bias"].zero_()
+
+    def _bucket_extra(self):
+        extra = super()._bucket_extra()
+        if self.trainable and self.resample:
+            extra += 2 * self.n_actions * self.particles
+        return extra
+
+    def _post_init(self):
+        A, N = self.n_actions, self.particles
+        self.loc = self.store["actor/samples"]
+        self.logstd = self.store["actor/samples_std"]
+        self.policy_weight = self.store["actor/fc_policy/weight"]
+        self.policy_bias = self.store["actor/fc_policy/bias"]
+        self.resample_rng = torch.Generator(device=self.device)      # identical on every DP rank
+        self.resample_rng.manual_seed(int(self.seed) if self.seed is not None else 0)
+        if self.trainable and self.resample:
+            self.max_active = torch.zeros(A, N, dtype=torch.float32, device=self.device)
+            self.sum_active = torch.zeros(A, N, dtype=torch.float32, device=self.device)
+            self.local_update_variables += ["max_active", "sum_active"]
+            self.running_update_ops += ["update_max_active", "update_sum_active"]
+            self.train_ops.append(self.resample_tick)
+        else:
+            self.max_active = self.sum_active = None
+        if self.normalize_state and self.trainable:
+            self.local_update_variables = ["state_normalizer/mean", "state_normalizer/std"] + self.local_update_variables
+
+    def _alloc_policy_buffers(self, B):
+        AN = self.n_actions * self.particles
+        self.logits = torch.empty(B, AN, dtype=torch.float32, device=self.device)
+
+    def stat_slots(self):
+        slots = super().stat_slots()
+        if self.max_active is not None:
+            AN = self.n_actions * self.particles
+            base = 2 * self.S if (self.normalize_state and self.trainable) else 0
+            slots += [(self.max_active, base, AN, False), (self.sum_active, base + AN, AN, False)]
+        return slots
+
+    # -- forward -----------------------------------------------------------------------------------
+    def _policy_logits(self, ha):
+        """fc_policy: logits [B, A*N] = h W + b (a2c.py:541-554)."""
+        torch.mm(ha, self.policy_weight, out=self.logits)
+        kernels.bias_act(self.logits, self.policy_bias, relu6=False)
+        return self.logits
+
+    def _forward(self, state):
+        """state [B,S] device tensor -> (policy distribution, actor hidden, critic hidden)."""
+        B = state.shape[0]
+        self._ensure_buffers(B)
+        x = self._normalize(state)
+        ha, hc = self._trunks_forward(x)
+        logits = self._policy_logits(ha)
+        policy = MixtureGaussianDistribution(logits, self.loc, self.logstd, self.normalize_policy_output_)
+        return policy, ha, hc
+
+    def _value(self, hc):
+        return kernels.value_head_fwd(hc, self.store["critic/fc3/weight"].view(-1), self.store["critic/fc3/bias"],
+                                      out=self.value_buf)
+
+    def denormalize_action(self, a):
+        """a2c.py:246-261 (only active in tanh mode): scale/offset from [-1,1] to the env bounds."""
+        if self.normalize_policy_output_ and self.action_upper_bound is not None:
+            gap = self.action_upper_bound - self.action_lower_bound
+            if np.any(gap != 2):
+                a = a * torch.as_tensor(gap * 0.5, dtype=torch.float32, device=a.device)
+            s = self.action_upper_bound + self.action_lower_bound
+            if np.any(s != 0):
+                a = a + torch.as_tensor(s * 0.5, dtype=torch.float32, device=a.device)
+        return a
+
+    def run_batch(self, states, noise=None, running_update=True):
+        """Batched rollout inference for E environments at once: one launch sequence for
+        sample + log-prob + value + activation statistics.  Returns device tensors
+        (action [E,A], log_prob [E] or None, value [E] or None)."""
+        st = self._to_dev(states).view(-1, self.S)
+        policy, ha, hc = self._forward(st)
+        upd = running_update and self.trainable and self.max_active is not None
+        mx, sm = (self.max_active, self.sum_active) if upd else (None, None)
+        logp = None
+        if self.random_action:
+            if self.normalize_policy_output_:
+                a, s_ = policy.sample(1, noise, self.rng, mx, sm)
+                action = self.denormalize_action(a)
+                self._last_sample = (a, s_)
+            else:
+                action, logp = policy.sample(1, noise, self.rng, mx, sm, want_logp=True)
+        else:
+            action = self.denormalize_action(policy.mean())
+            if upd:
+                kernels.active_stats(policy.logits, mx, sm)
+        self.policy = policy
+        value = self._value(hc) if self.trainable else None
+        return action, logp, value
+
+    def run(self, sess, state, ops=None):
+        """reference a2c.py:67-73 / actor_critic.py:368-380: one state -> [action, value]."""
+        action, _, value = self.run_batch(np.asarray(state, dtype=np.float32)[None])
+        out = [action[0].cpu().numpy()]
+        if self.trainable:
+            out.append(float(value[0].item()))
+        return out
+
+    def evaluate(self, sess, state):
+        """reference a2c.py:75-78: V(state) (no statistics update beyond what _run does)."""
+        st = self._to_dev(np.asarray(state, dtype=np.float32)[None])
+        _, _, hc = self._forward(st)
+        if self.trainable and self.max_active is not None:
+            # _run appends running_update_ops to every fetch (actor_critic.py:369-371)
+            kernels.active_stats(self.logits, self.max_active, self.sum_active)
+        return float(self._value(hc)[0].item())
+
+    # -- resample ----------------------------------------------------------------------------------
+    def resample_tick(self):
+        """train op run after every optimiser apply (a2c.py:367-383)."""
+        self.train_flag += 1
+        if self.train_flag >= self.resample_interval:
+            self.resample_now()
+            self.max_active.zero_()
+            self.sum_active.zero_()
+            self.train_flag = 0
+            return True
+        return False
+
+    def resample_now(self, u_resample=None, u_noise=None):
+        """build_resample_ops (a2c.py:385-474) on the device.  Adam slots are not touched."""
+        A, N = self.n_actions, self.particles
+        if u_resample is None:
+            u_resample = torch.rand(A, N, dtype=torch.float64, device=self.device, generator=self.resample_rng)
+            u_noise = torch.rand(A, N, dtype=torch.float32, device=self.device, generator=self.resample_rng) * 2 - 1
+        thr = float(self.resample_threshold) if self.resample_threshold else 0.0
+        self.last_resample = kernels.resample(self.loc, self.logstd, self.policy_bias, self.policy_weight,
+                                              self.max_active, self.sum_active, u_resample, u_noise, thr,
+                                              self.normalize_policy_output_)
+        return self.last_resample

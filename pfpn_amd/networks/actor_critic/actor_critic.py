@@ -1,0 +1,231 @@
+"""Actor-critic assembler for the MI355X build.
+
+Host-side mirror of reference networks/actor_critic/actor_critic.py: `ActorCriticNetwork.__init__`
+(:7-42), `init` (:74-184: state-norm -> actor trunk -> policy -> sampler -> critic -> losses),
+`build_state_normalizer_op` (:223-244), `_run` (:368-380), `_train` (:382-404).
+
+The TF graph becomes explicit forward/backward code over preallocated device buffers: GEMMs through
+PyTorch-ROCm, everything else through the HIP kernels.  `sess` arguments are accepted and ignored.
+Out-of-scope options of the reference (value normaliser, conv/lstm layers, regularisers, a shared
+`common_net`) raise NotImplementedError instead of being silently ignored.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..ops import DenseStack, ParamStore
+from ..utils import OnlineNormalizer
+
+
+class ActorCriticNetwork(object):
+    def __init__(self, trainable, state_shape, action_shape,
+                 common_net_shape, critic_net_shape, actor_net_shape,
+                 weight_initializer=None, activator="relu6",
+                 normalize_state=False, clip_state=False,
+                 normalize_value=False, clip_value=False,
+                 normalize_advantage=False, clip_advantage=False,
+                 critic_regularizer=None, actor_regularizer=None,
+                 entropy_beta=None, value_loss_coef=0.5,
+                 log=True, device=None, seed=None, **kwargs):
+        self.trainable = trainable
+        self.random_action = self.trainable
+        self.state_shape = list(state_shape) if hasattr(state_shape, "__len__") else [state_shape]
+        self.action_shape = list(action_shape) if hasattr(action_shape, "__len__") else [action_shape]
+        if common_net_shape:
+            raise NotImplementedError("common_net_shape: no shipped PFPN setting uses a shared trunk")
+        if normalize_value or clip_value:
+            raise NotImplementedError("value normaliser: normalize_value=False in every DeepMimic setting")
+        if clip_advantage:
+            raise NotImplementedError("clip_advantage is unset in every DeepMimic setting")
+        if critic_regularizer or actor_regularizer:
+            raise NotImplementedError("L2 regularisers are unset in every DeepMimic setting")
+        act_name = getattr(activator, "__name__", activator)
+        if act_name not in ("relu6", None):
+            raise NotImplementedError("only the ReLU6 activator of deepmimic_base.py:8 is built")
+        for shp in (critic_net_shape, actor_net_shape):
+            if any(hasattr(s, "__len__") for s in shp):
+                raise NotImplementedError("conv layers are never instantiated by the PFPN settings")
+        self.common_net_shape = []
+        self.critic_net_shape = list(critic_net_shape)
+        self.actor_net_shape = list(actor_net_shape)
+        self.weight_initializer = weight_initializer      # None -> truncated_normal(0, 0.01)
+        self.weight_std = 0.01
+        self.normalize_state = normalize_state
+        self.clip_state = clip_state
+        self.normalize_advantage = normalize_advantage
+        self.entropy_beta = entropy_beta
+        self.value_loss_coef = value_loss_coef
+        self.init_ops, self.train_ops, self.running_update_ops = [], [], []
+        self.local_update_variables = []
+        self.summaries = {}
+        self.log = log
+        self.device = torch.device(device) if device is not None else None
+        self.seed = seed
+        self.global_step = 0
+
+    # compatible with the reference's LSTM hooks
+    def reset(self):
+        pass
+
+    def reset_running_state(self):
+        pass
+
+    def reset_training_state(self):
+        pass
+
+    def add_summary(self, key, val, val_wrapper=None):
+        if self.log:
+            self.summaries[key] = val
+
+    # ------------------------------------------------------------------------------------------
+    def init(self):
+        if self.device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("pfpn_amd needs an MI355X (HIP) device; there is no CPU execution path")
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.S = int(np.prod(self.state_shape))
+        self.rng = torch.Generator(device=self.device)
+        self.rng.manual_seed(int(self.seed) if self.seed is not None else 0)
+        self.store = ParamStore(self.device)
+        self._declare(self.store)
+        self.store.allocate(extra=self._bucket_extra(), with_optimizer=self.trainable)
+        self._init_weights()
+        self.state_normalizer = OnlineNormalizer(self.S, self.device) if (self.normalize_state or self.clip_state) else None
+        self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.device)   # float(global_step)
+        self._B = None
+        # names of the reference's placeholders/tensors, kept for workers that look them up
+        self.state, self.action, self.action_hist = "state", "action", "action_hist"
+        self.advantage, self.value = "advantage", "value"
+        self.loss = self.policy_loss = self.value_loss = None
+        self.policy_entropy = None
+        self._post_init()
+
+    # hooks for subclasses ---------------------------------------------------------------------
+    def _declare(self, store):
+        """Declare parameters: twin actor/critic trunks when their shapes agree (all shipped
+        settings: [1024, 512] both, deepmimic_base.py:4-6)."""
+        if self.actor_net_shape == self.critic_net_shape:
+            self.trunk = DenseStack(store, ["actor", "critic"], self.S, self.actor_net_shape)
+            self.actor_trunk = self.critic_trunk = None
+        else:
+            self.trunk = None
+            self.actor_trunk = DenseStack(store, ["actor"], self.S, self.actor_net_shape)
+            self.critic_trunk = DenseStack(store, ["critic"], self.S, self.critic_net_shape)
+        self.build_policy_params(store, self.actor_net_shape[-1] if self.actor_net_shape else self.S)
+        hc = self.critic_net_shape[-1] if self.critic_net_shape else self.S
+        store.declare("critic/fc3/weight", (hc, 1))
+        store.declare("critic/fc3/bias", (1,))
+
+    def _bucket_extra(self):
+        return 2 * self.S if self.normalize_state else 0
+
+    def _init_weights(self):
+        for t in (self.trunk, self.actor_trunk, self.critic_trunk):
+            if t is not None:
+                t.init_weights(self.rng, self.weight_std)
+        ops.truncated_normal_(self.store["critic/fc3/weight"], self.weight_std, self.rng)
+        self.store["critic/fc3/bias"].zero_()
+        self.init_policy_params()
+
+    def _post_init(self):
+        pass
+
+    def build_policy_params(self, store, in_dim):
+        raise NotImplementedError
+
+    def init_policy_params(self):
+        raise NotImplementedError
+
+    # reference-named parameter access (checkpoint / tests) ---------------------------------------
+    def variables(self):
+        """{reference variable name: tensor view} for the trainables of the saved graph."""
+        out = {}
+        for t in (self.trunk, self.actor_trunk, self.critic_trunk):
+            if t is not None:
+                for ref, (name, g) in t.reference_names().items():
+                    out[ref] = self.store[name][g]
+        for n in self.store.names():
+            if "|" not in n:
+                out[n] = self.store[n]
+        return out
+
+    def gradients(self):
+        out = {}
+        for t in (self.trunk, self.actor_trunk, self.critic_trunk):
+            if t is not None:
+                for ref, (name, g) in t.reference_names().items():
+                    out[ref] = self.store.g(name)[g]
+        for n in self.store.names():
+            if "|" not in n:
+                out[n] = self.store.g(n)
+        return out
+
+    def load_variables(self, values):
+        v = self.variables()
+        with torch.no_grad():
+            for k, arr in values.items():
+                v[k].copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(self.device).view(v[k].shape))
+
+    # forward pieces -------------------------------------------------------------------------------
+    def _ensure_buffers(self, B):
+        if self._B == B:
+            return
+        dev = self.device
+        self.xn = torch.empty(B, self.S, dtype=torch.float32, device=dev)
+        self.value_buf = torch.empty(B, dtype=torch.float32, device=dev)
+        self._alloc_policy_buffers(B)
+        self._B = B
+
+    def _alloc_policy_buffers(self, B):
+        pass
+
+    def _normalize(self, state):
+        """x = stop_gradient(clip((s - mean)/std, +-clip))  (actor_critic.py:76-80, :223-244)."""
+        if self.state_normalizer is None:
+            return state
+        if self.normalize_state:
+            return self.state_normalizer.normalize(state, self.clip_state or 0.0, out=self.xn)
+        return torch.clamp(state, -self.clip_state, self.clip_state, out=self.xn)
+
+    def _trunks_forward(self, x):
+        """-> (actor hidden [B,Ha], critic hidden [B,Hc]) (views of the stacks' activation buffers)."""
+        if self.trunk is not None:
+            h = self.trunk.forward(x)
+            return h[0], h[1]
+        return self.actor_trunk.forward(x)[0], self.critic_trunk.forward(x)[0]
+
+    def _to_dev(self, a, dtype=torch.float32):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, dtype).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(self.device, dtype)
+
+    def valid_data_mask(self, x):
+        return x
+
+    # -- data-parallel statistics (reference sync_model.py:37-46 push_weights) -----------------------
+    def stat_slots(self):
+        """[(tensor, offset in the bucket tail, length, computed_in_tail)] of the tensors that are
+        averaged over the data-parallel replicas together with the gradients."""
+        slots = []
+        if self.normalize_state and self.trainable:
+            nz = self.state_normalizer
+            slots += [(nz.mean, 0, self.S, True), (nz.std, self.S, self.S, True)]
+        return slots
+
+    def pack_local_stats(self, tail):
+        for t, off, n, in_tail in self.stat_slots():
+            if not in_tail:
+                tail[off:off + n].copy_(t.view(-1))
+
+    def unpack_synced_stats(self, tail, inv_world):
+        for t, off, n, in_tail in self.stat_slots():
+            if inv_world != 1.0:
+                torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
+            elif in_tail:
+                t.view(-1).copy_(tail[off:off + n])
+
+    def actor_param_names(self):
+        return [n for n in self.store.names() if n.startswith("actor")]
+
+    def critic_param_names(self):
+        return [n for n in self.store.names() if n.startswith("critic")]

@@ -1,0 +1,186 @@
+"""Dense-layer plumbing for the MI355X build: one flat fp32 parameter buffer, GEMMs through
+PyTorch-ROCm (fp32 MFMA via hipBLASLt/rocBLAS, `allow_tf32` off), bias/ReLU6 epilogues and their
+backward through the HIP kernels of libpfpn_hip.so.
+
+Mirrors reference networks/ops.py (`fc_layer` :82-118, `clip_by_value_with_gradient` :4-9); the
+reference's conv/lstm layers are never instantiated by the DeepMimic settings and
+are not provided.  No autograd: the backward is written out so every buffer is preallocated, every
+gradient lands directly in the flat gradient buffer (one RCCL bucket, one Adam launch), and the whole
+step can be captured in a hipGraph.
+"""
+import math
+
+import torch
+
+from .. import kernels
+
+torch.backends.cuda.matmul.allow_tf32 = False
+
+
+def truncated_normal_(t, std=0.01, generator=None):
+    """tf.truncated_normal_initializer(0, std): resample outside 2 sigma (deepmimic_base.py:7)."""
+    with torch.no_grad():
+        torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=generator)
+    return t
+
+
+class ParamStore:
+    """Named fp32 tensors carved out of ONE flat buffer (+ matching flat grad / Adam m / Adam v).
+
+    Every tensor starts on a 16-byte boundary (sizes padded to 4 floats; padding stays zero) so the
+    float4 streaming kernels (clip, Adam, all-reduce bucket) run over the whole buffer in one launch.
+    `extra` floats are reserved behind the gradients for tensors that ride in the same all-reduce
+    bucket (state-normaliser moments, activation statistics: reference sync_model.py:37-46)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.specs = []       # (name, shape, offset)
+        self.size = 0
+        self.flat = self.grad = self.m = self.v = None
+        self.extra = 0
+        self._views = {}
+        self._gviews = {}
+
+    def declare(self, name, shape):
+        n = int(math.prod(shape)) if len(shape) else 1
+        self.specs.append((name, tuple(shape), self.size))
+        self.size += (n + 3) // 4 * 4
+        return name
+
+    def allocate(self, extra=0, with_optimizer=True):
+        self.extra = (int(extra) + 3) // 4 * 4
+        self.flat = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        self.bucket = torch.zeros(self.size + self.extra, dtype=torch.float32, device=self.device)
+        self.grad = self.bucket[:self.size]
+        self.tail = self.bucket[self.size:]
+        if with_optimizer:
+            self.m = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+            self.v = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        for name, shape, off in self.specs:
+            n = int(math.prod(shape)) if len(shape) else 1
+            self._views[name] = self.flat[off:off + n].view(shape)
+            self._gviews[name] = self.grad[off:off + n].view(shape)
+        return self
+
+    def __getitem__(self, name):
+        return self._views[name]
+
+    def g(self, name):
+        return self._gviews[name]
+
+    def names(self):
+        return [s[0] for s in self.specs]
+
+    def span(self, names):
+        """(offset, length) of the contiguous flat range covering `names` (declared adjacently)."""
+        offs = {s[0]: (s[2], (int(math.prod(s[1])) + 3) // 4 * 4) for s in self.specs}
+        lo = min(offs[n][0] for n in names)
+        hi = max(offs[n][0] + offs[n][1] for n in names)
+        return lo, hi - lo
+
+    def state_dict(self):
+        return {name: self._views[name].detach().clone() for name in self.names()}
+
+    def load_state_dict(self, sd):
+        for name in self.names():
+            if name in sd:
+                self._views[name].copy_(torch.as_tensor(sd[name]).to(self.device).view(self._views[name].shape))
+
+
+class DenseStack:
+    """G parallel MLP trunks with identical layer shapes (G=2: the actor and critic trunks of the
+    DeepMimic settings, or the twin Q networks of SAC).  Activations are group-major [G, B, H]; layer
+    i > 0 is one batched GEMM over the G groups, so the chip sees G x more tiles per launch.
+
+    Reference: build_conv_fc_net / fc_layer (networks/utils.py:17-43, ops.py:82-118):
+    y = relu6(x W + b), truncated-normal(0, 0.01) weights, zero bias."""
+
+    def __init__(self, store, prefixes, in_dim, hidden, first_name_index=1, shared_input=True):
+        self.store = store
+        self.G = len(prefixes)
+        self.prefixes = prefixes
+        self.dims = [in_dim] + list(hidden)
+        self.L = len(hidden)
+        self.shared_input = shared_input
+        self.wn, self.bn = [], []
+        # declare group-major tensors; reference names are views of them
+        for i in range(self.L):
+            self.wn.append(store.declare("%s|fc%d/weight" % ("+".join(prefixes), i + first_name_index),
+                                         (self.G, self.dims[i], self.dims[i + 1])))
+            self.bn.append(store.declare("%s|fc%d/bias" % ("+".join(prefixes), i + first_name_index),
+                                         (self.G, self.dims[i + 1])))
+        self.first_name_index = first_name_index
+        self._B = None
+
+    def reference_names(self):
+        """reference variable name -> (store name, group index)."""
+        out = {}
+        for i in range(self.L):
+            for g, p in enumerate(self.prefixes):
+                out["%s/fc%d/weight" % (p, i + self.first_name_index)] = (self.wn[i], g)
+                out["%s/fc%d/bias" % (p, i + self.first_name_index)] = (self.bn[i], g)
+        return out
+
+    def init_weights(self, generator=None, std=0.01):
+        for i in range(self.L):
+            truncated_normal_(self.store[self.wn[i]], std, generator)
+            self.store[self.bn[i]].zero_()
+
+    def _buffers(self, B):
+        if self._B == B:
+            return
+        dev = self.store.device
+        self.act = [torch.empty(self.G, B, self.dims[i + 1], dtype=torch.float32, device=dev) for i in range(self.L)]
+        self.dact = [torch.empty(self.G, B, self.dims[i + 1], dtype=torch.float32, device=dev) for i in range(self.L)]
+        self._B = B
+
+    def forward(self, x):
+        """x: [B, in] shared by all groups, or [G, B, in] per group.  Returns act[-1]  [G, B, H_last]."""
+        B = x.shape[-2]
+        self._buffers(B)
+        self.x = x
+        for i in range(self.L):
+            w, b, out = self.store[self.wn[i]], self.store[self.bn[i]], self.act[i]
+            if i == 0 and x.dim() == 2:
+                for g in range(self.G):
+                    torch.mm(x, w[g], out=out[g])
+            else:
+                src = x if i == 0 else self.act[i - 1]
+                torch.bmm(src, w, out=out)
+            kernels.bias_act(out.view(self.G * B, -1), b, relu6=True, group_rows=B)
+        return self.act[-1]
+
+    def backward(self, dlast, need_dx=False):
+        """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output; masked in place.
+        Weight/bias gradients are written into the store's flat gradient buffer."""
+        B = self._B
+        d = dlast
+        dx = None
+        for i in reversed(range(self.L)):
+            w = self.store[self.wn[i]]
+            kernels.act_bwd_bias_grad(self.act[i].view(self.G * B, -1), d.view(self.G * B, -1),
+                                      self.store.g(self.bn[i]), relu6=True, group_rows=B)
+            gw = self.store.g(self.wn[i])
+            if i == 0 and self.x.dim() == 2:
+                xt = self.x.t()
+                for g in range(self.G):
+                    torch.mm(xt, d[g], out=gw[g])
+                if need_dx:
+                    dx = torch.mm(d[0], w[0].t())
+                    for g in range(1, self.G):
+                        dx.addmm_(d[g], w[g].t())
+            else:
+                src = self.x if i == 0 else self.act[i - 1]
+                torch.bmm(src.transpose(1, 2), d, out=gw)
+                if i > 0:
+                    torch.bmm(d, w.transpose(1, 2), out=self.dact[i - 1])
+                    d = self.dact[i - 1]
+                elif need_dx:
+                    dx = torch.bmm(d, w.transpose(1, 2))
+        return dx
+
+
+def clip_by_value_with_gradient(x, l=-1.0, u=1.0):
+    """reference ops.py:4-9: forward clip, identity gradient (the backward is written by hand here,
+    so this is just the forward)."""
+    return torch.clamp(x, l, u)

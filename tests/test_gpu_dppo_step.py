@@ -1,0 +1,122 @@
+"""GPU parity of the whole DPPO learner step (reference-shaped API) vs the NumPy oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+NET_OPTS = dict(common_net_shape=[], critic_net_shape=[1024, 512], actor_net_shape=[1024, 512],
+                value_loss_coef=0.5, gamma=0.95, normalize_state=True, clip_state=5.0,
+                normalize_value=False, clip_value=None, normalize_advantage=True, clip_advantage=None,
+                particles=35, resample=-1, resample_interval=368)
+
+
+def make_net(dev, S=197, A=36, seed=34114, **over):
+    from pfpn_amd.networks import ParticleFilteringClipPPONetwork
+    opts = dict(NET_OPTS); opts.update(over)
+    net = ParticleFilteringClipPPONetwork(trainable=True, state_shape=[S], action_shape=[A],
+                                          action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
+                                          device=dev, seed=seed, **opts)
+    net.init()
+    return net
+
+
+def make_batch(rng, B, S=197, A=36):
+    return {"state": (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F),
+            "action": rng.uniform(-1.1, 1.1, (B, A)).astype(F),
+            "value": rng.normal(0, 0.1, B).astype(F),
+            "log_prob": None,
+            "advantage": rng.normal(0, 1, B).astype(F)}
+
+
+def sync_oracle_state(oracle, net, st):
+    for k, v in net.variables().items():
+        st.P[k] = v.detach().cpu().numpy().reshape(st.P[k].shape).copy()
+
+
+@pytest.mark.parametrize("B", [32, 256])
+def test_dppo_step_matches_oracle(oracle, dev, B):
+    from pfpn_amd.models import SyncReplicasApplier
+    net = make_net(dev)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    st = oracle.DPPOState(np.random.default_rng(0))
+    sync_oracle_state(oracle, net, st)
+    rng = np.random.default_rng(B)
+    for it in range(3):
+        batch = make_batch(rng, B)
+        # old log-prob: the current policy's log-prob of the action, perturbed (ratios around 1)
+        x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
+        logits, _ = oracle.actor_forward(st.P, x, 36, 35)
+        lp, _ = oracle.mixture_log_prob(logits, batch["action"], st.P["actor/samples"], st.P["actor/samples_std"])
+        batch["log_prob"] = (lp + rng.normal(0, 0.1, B)).astype(F)
+        # oracle gradients of this step (before its update) for a direct gradient check
+        (l_ref, pl_ref, vl_ref), G_ref, aux = oracle.dppo_grads(st.P, st.norm_mean, st.norm_std, batch, 36, 35)
+        losses = oracle.dppo_learner_step(st, [batch])
+        loss, extra = net.train(None, opt, ["global_step"], batch["state"], batch["action"], batch["value"],
+                                batch["log_prob"], batch["advantage"])
+        assert extra == [it + 1]
+        np.testing.assert_allclose([loss[0], loss[2], loss[3]], [l_ref, pl_ref, vl_ref], rtol=1e-4, atol=2e-5)
+        assert loss[1] is None
+        np.testing.assert_allclose(net.train_out["logp"].cpu().numpy(), aux["logp"], rtol=1e-5, atol=2e-4)
+        np.testing.assert_allclose(net.value_buf.cpu().numpy(), aux["value"], rtol=1e-4, atol=1e-6)
+        # gradients (before clipping) -- GEMM accumulation order differs from BLAS: rtol on the tensor scale
+        G = net.gradients()
+        for name, g_ref in G_ref.items():
+            got = G[name].cpu().numpy().reshape(g_ref.shape)
+            sc = np.abs(g_ref).max() + 1e-30
+            np.testing.assert_allclose(got, g_ref, rtol=2e-3, atol=2e-4 * sc, err_msg=name)
+        # parameters and Adam state after the update
+        for name, v in net.variables().items():
+            ref = st.P[name]
+            np.testing.assert_allclose(v.cpu().numpy().reshape(ref.shape), ref, rtol=1e-4, atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(net.state_normalizer.mean.cpu().numpy(), st.norm_mean, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(net.state_normalizer.std.cpu().numpy(), st.norm_std, rtol=1e-5, atol=1e-6)
+    assert net.global_step == 3 and net.train_flag == 3
+
+
+def test_resample_tick_and_policy_api(oracle, dev):
+    """run()/evaluate()/GAE surface + the resample tick firing at resample_interval."""
+    from pfpn_amd.models import SyncReplicasApplier
+    net = make_net(dev, resample_interval=4)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    rng = np.random.default_rng(1)
+    s = rng.normal(0, 1, 197).astype(F)
+    a, lp, v = net.run(None, s)
+    assert a.shape == (36,) and np.isfinite(lp) and np.isfinite(v)
+    assert abs(net.evaluate(None, s) - v) < 1e-6
+    assert net.sum_active.sum().item() == pytest.approx(2 * 36, rel=1e-4)     # run + evaluate each add softmax rows
+    # log_prob returned by run() == log_prob of that action under the policy
+    st = torch.from_numpy(s[None]).to(dev)
+    policy, _, _ = net._forward(st)
+    lp2 = policy.log_prob(torch.from_numpy(a[None]).to(dev))[0].item()
+    assert abs(lp2 - lp) < 1e-4 * abs(lp)
+    adv = net.generalized_advantage_estimate(list(rng.normal(0, 1, 9).astype(F)), list(rng.normal(0, 1, 10).astype(F)))
+    assert len(adv) == 9
+    # drive a few particles dead, then 4 train steps trigger the resample and zero the statistics
+    for _ in range(40):
+        net.run(None, rng.normal(0, 1, 197).astype(F))
+    before = net.loc.clone()
+    for it in range(4):
+        b = make_batch(rng, 32)
+        b["log_prob"] = np.full(32, -40.0, F)
+        net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+    assert net.train_flag == 0 and net.sum_active.abs().sum().item() == 0 and net.max_active.abs().sum().item() == 0
+    dead, src = net.last_resample
+    # with near-uniform weights (1/35 >> 0.05/35) nothing is dead: resample must have been a no-op
+    assert dead.sum().item() == 0 and torch.equal(before, before)
+
+
+def test_deterministic_evaluator(dev):
+    from pfpn_amd.networks import ParticleFilteringClipPPONetwork
+    A = 36
+    net = ParticleFilteringClipPPONetwork(trainable=False, state_shape=[197], action_shape=[A],
+                                          action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
+                                          device=dev, seed=1, **NET_OPTS)
+    net.init()
+    s = np.random.default_rng(0).normal(0, 1, 197).astype(F)
+    out1, out2 = net.run(None, s), net.run(None, s)
+    assert len(out1) == 1 and np.array_equal(out1[0], out2[0])
+    # deterministic action = loc[a, argmax logits]: a grid point of the (untrained) particle grid
+    grid = -1 + 2 * np.arange(35) / 34
+    assert np.all(np.abs(out1[0][:, None] - grid[None]).min(1) < 1e-6)
