@@ -118,13 +118,12 @@ __global__ __launch_bounds__(64) void k_col_partial(const float* __restrict__ s,
     partial[(size_t)ch * S + c] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_col_mean(const float* __restrict__ partial, int C, int S, float inv_B,
-                                                  float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= S) return;
-    float acc = 0.f;
-    for (int ch = 0; ch < C; ++ch) acc += partial[(size_t)ch * S + c];
-    out[c] = acc * inv_B;
+__global__ __launch_bounds__(1024) void k_col_mean(const float* __restrict__ partial, int C, int S, float inv_B,
+                                                   float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float s = slab_reduce_1024<false>(partial, C, (size_t)S, c, c < S, red);
+    if ((threadIdx.x >> 6) == 0 && c < S) out[c] = s * inv_B;
 }
 
 // EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step))
@@ -205,15 +204,15 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial(const float* __restrict
     }
 }
 
-// db[g, c] = sum over the chunks of group g, in chunk order
-__global__ __launch_bounds__(256) void k_bias_grad_final(const float* __restrict__ partial, int chunks_per_group,
-                                                         int G, int H, float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= G * H) return;
-    const int g = i / H, c = i - g * H;
-    float acc = 0.f;
-    for (int ch = 0; ch < chunks_per_group; ++ch) acc += partial[(size_t)(g * chunks_per_group + ch) * H + c];
-    db[i] = acc;
+// db[g, c] = sum over the chunks of group g, fixed order.  Grid (ceil(H/64), G), block 1024.
+__global__ __launch_bounds__(1024) void k_bias_grad_final(const float* __restrict__ partial, int chunks_per_group,
+                                                          int G, int H, float* __restrict__ db) {
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = blockIdx.y;
+    const float s = slab_reduce_1024<false>(partial + (size_t)g * chunks_per_group * H, chunks_per_group, (size_t)H,
+                                            c, c < H, red);
+    if ((threadIdx.x >> 6) == 0 && c < H) db[(size_t)g * H + c] = s;
 }
 
 // scalar value head: v[b] = h[b,:] . w + bias   (critic fc3, squeeze).  One wave per row.
@@ -412,6 +411,7 @@ extern "C" {
 
 int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, int E, float gamma,
              double gae_gamma, float* adv, void* stream) {
+    PFPN_BEGIN();
     if (!reward || !value || !offsets || !adv || E < 0) return PFPN_ERR_ARG;
     if (E == 0) return PFPN_OK;
     hipLaunchKernelGGL(k_gae, dim3(E), dim3(256), 0, (hipStream_t)stream, reward, value, offsets, E, gamma,
@@ -423,6 +423,7 @@ int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, in
 int pfpn_ppo_loss(const float* logp, const float* logp_old, const float* adv, const float* value,
                   const float* value_old, const float* adv_stats, int B, float clip_eps, float value_coef,
                   float* dlogp, float* dvalue, float* loss3, void* stream) {
+    PFPN_BEGIN();
     if (!logp || !logp_old || !adv || !value || !value_old || !adv_stats || !dlogp || !dvalue || !loss3 || B < 1)
         return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, logp_old, adv, value,
@@ -433,6 +434,7 @@ int pfpn_ppo_loss(const float* logp, const float* logp_old, const float* adv, co
 
 int pfpn_state_norm(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
                     void* stream) {
+    PFPN_BEGIN();
     if (!s || !mean || !std || !x || B < 0 || S < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipLaunchKernelGGL(k_state_norm, dim3(stream_grid((size_t)B * S)), dim3(256), 0, (hipStream_t)stream, s, mean,
@@ -449,6 +451,7 @@ size_t pfpn_learner_workspace_bytes(int rows, int H) {
 int pfpn_state_norm_update(const float* s, int B, int S, const float* step, const float* mean_in, const float* std_in,
                            float* mean_out, float* std_out, void* workspace, size_t workspace_bytes,
                            void* stream) {
+    PFPN_BEGIN();
     if (!s || !step || !mean_in || !std_in || !mean_out || !std_out || B < 1 || S < 1) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, S)) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -460,11 +463,11 @@ int pfpn_state_norm_update(const float* s, int B, int S, const float* step, cons
     const dim3 g((S + 63) / 64, C);
     hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)nullptr, B, S, len, 0, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_col_mean, dim3((S + 255) / 256), dim3(256), 0, st, partial, C, S, 1.0f / (float)B, bmean);
+    hipLaunchKernelGGL(k_col_mean, dim3((S + 63) / 64), dim3(1024), 0, st, partial, C, S, 1.0f / (float)B, bmean);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)bmean, B, S, len, 1, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_col_mean, dim3((S + 255) / 256), dim3(256), 0, st, partial, C, S, 1.0f / (float)B, bvar);
+    hipLaunchKernelGGL(k_col_mean, dim3((S + 63) / 64), dim3(1024), 0, st, partial, C, S, 1.0f / (float)B, bvar);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_norm_ema, dim3((S + 255) / 256), dim3(256), 0, st, bmean, bvar, S, step, mean_in, std_in,
                        mean_out, std_out);
@@ -473,6 +476,7 @@ int pfpn_state_norm_update(const float* s, int B, int S, const float* step, cons
 }
 
 int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, int relu6, void* stream) {
+    PFPN_BEGIN();
     if (!y || !bias || rows < 0 || H < 4 || (H & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15))
         return PFPN_ERR_ARG;
     if (rows == 0) return PFPN_OK;
@@ -484,6 +488,7 @@ int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, 
 
 int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group_rows, int relu6, float* db,
                            void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!dy || !db || (relu6 && !y) || rows < 1 || H < 4 || (H & 3) || ((uintptr_t)dy & 15)) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(rows, H)) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -508,12 +513,13 @@ int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group
             PFPN_CHECK_LAUNCH();
         }
     }
-    hipLaunchKernelGGL(k_bias_grad_final, dim3((G * H + 255) / 256), dim3(256), 0, st, partial, cpg, G, H, db);
+    hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 63) / 64, G), dim3(1024), 0, st, partial, cpg, G, H, db);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
 
 int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B, int H, float* v, void* stream) {
+    PFPN_BEGIN();
     if (!h || !w || !bias || !v || B < 0 || H < 4 || (H & 3)) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipLaunchKernelGGL(k_value_head_fwd, dim3((B * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, h, w, bias,
@@ -524,6 +530,7 @@ int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B
 
 int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, int H, int relu6, float* dh,
                         float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!h || !w || !dv || !dh || !dw || !db || B < 1 || H < 4 || (H & 3)) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, H)) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -533,7 +540,7 @@ int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, 
     hipLaunchKernelGGL(k_value_head_bwd_partial, dim3(((H >> 2) + 63) / 64, C), dim3(256), 0, st, h, w, dv, B, H, len,
                        relu6, dh, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 255) / 256), dim3(256), 0, st, partial, C, 1, H, dw);
+    hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 63) / 64, 1), dim3(1024), 0, st, partial, C, 1, H, dw);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(1024), 0, st, dv, B, db);
     PFPN_CHECK_LAUNCH();
@@ -542,6 +549,7 @@ int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, 
 
 int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply, float* norm_scale,
                              void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!grads || !norm_scale || n < 1 || ((uintptr_t)grads & 15)) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < 1024 * sizeof(float)) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -562,6 +570,7 @@ int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply,
 int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
                  float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
                  float grad_mul, void* stream) {
+    PFPN_BEGIN();
     if (!params || !grads || !m || !v || !beta_pow || n < 1) return PFPN_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -576,6 +585,7 @@ int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n
 }
 
 int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream) {
+    PFPN_BEGIN();
     if (!target || !source) return PFPN_ERR_ARG;
     if (n == 0) return PFPN_OK;
     hipLaunchKernelGGL(k_soft_update, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)stream, target, source, n,

@@ -367,28 +367,26 @@ __global__ void k_row_sum(const float* __restrict__ lpseg, int B, int A, float* 
 
 // Fixed-order reduction of per-block slabs: out[i] = sum_k partial[k*stride + i], i < n.
 // Also emits the loss scalars of the fused PPO kernel when `loss_out` is given:
-// loss_out = {loss, policy_loss, value_loss*coef}.
-__global__ void k_finalize(const float* __restrict__ partial, int nslab, int stride, int n,
-                           float* __restrict__ out0, float* __restrict__ out1, int n0,
-                           float* __restrict__ loss_out, float inv_B, float value_coef) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// loss_out = {loss, policy_loss, value_loss*coef}.  Grid: ceil((n+2)/64) blocks of 1024.
+__global__ __launch_bounds__(1024) void k_finalize(const float* __restrict__ partial, int nslab, int stride, int n,
+                                                   float* __restrict__ out0, float* __restrict__ out1, int n0,
+                                                   float* __restrict__ loss_out, float inv_B, float value_coef) {
+    __shared__ float red[16][64];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ncol = loss_out ? n + 2 : n;           // the two loss sums sit right behind the n columns
+    const float s = slab_reduce_1024<false>(partial, nslab, (size_t)stride, i, i < ncol, red);
+    if ((threadIdx.x >> 6) != 0 || i >= ncol) return;
     if (i < n) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * stride + i];
         if (i < n0) out0[i] = s; else out1[i - n0] = s;
+    } else if (i == n) {
+        loss_out[1] = -s * inv_B;                     // policy loss
+    } else {
+        loss_out[2] = s * inv_B * value_coef;         // value loss * coef
     }
-    if (loss_out && i == 0) {
-        float ps = 0.f, vs = 0.f;
-        for (int k = 0; k < nslab; ++k) {
-            ps += partial[(size_t)k * stride + n];
-            vs += partial[(size_t)k * stride + n + 1];
-        }
-        const float pl = -ps * inv_B;
-        const float vl = vs * inv_B * value_coef;
-        loss_out[0] = pl + vl;
-        loss_out[1] = pl;
-        loss_out[2] = vl;
-    }
+}
+
+__global__ void k_loss_total(float* __restrict__ loss3) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) loss3[0] = loss3[1] + loss3[2];
 }
 
 // adv_stats = {mean, 1/(sqrt(var)+1e-8)} with population variance (reference
@@ -481,6 +479,7 @@ size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
 int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, const float* logstd,
                      int B, int A, int N, int tanh_mode, float* logp, float* pmix,
                      void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !x || !loc || !logstd || !logp || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -511,6 +510,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
                      const float* dlogp, int B, int A, int N, int tanh_mode,
                      float* dlogits, float* dloc, float* dlogstd, float* dx,
                      void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !x || !loc || !logstd || !dlogp || !dlogits || !dloc || !dlogstd || B < 0 || A < 1 || N < 1)
         return PFPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -529,7 +529,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         launch_packed<MODE_BWD>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, nullptr, nullptr,
                                 dlogits, dx, partial, none);
         PFPN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 255) / 256), dim3(256), 0, st, partial, pl.grid,
+        hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, pl.grid,
                            2 * AN + 4, 2 * AN, dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
@@ -541,13 +541,14 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     hipLaunchKernelGGL((k_mix_wave<MODE_BWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, dlogp,
                        B, A, N, C, tanh_mode, (float*)nullptr, (float*)nullptr, dlogits, dx, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 255) / 256), dim3(256), 0, st, partial, C, 2 * AN, 2 * AN,
+    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
                        dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
 
 int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* stream) {
+    PFPN_BEGIN();
     if (!adv || !stats || B < 1) return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_adv_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, adv, B, normalize, stats);
     PFPN_CHECK_LAUNCH();
@@ -560,6 +561,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
                              int B, int A, int N, float clip_eps, float value_coef,
                              float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue,
                              float* loss3, void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats ||
         !logp || !dlogits || !dloc || !dlogstd || !dvalue || !loss3 || B < 1 || A < 1 || N < 1)
         return PFPN_ERR_ARG;
@@ -577,8 +579,10 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     launch_packed<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
                             nullptr, partial, pa);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 255) / 256), dim3(256), 0, st, partial, pl.grid, 2 * AN + 4,
+    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 2 + 63) / 64), dim3(1024), 0, st, partial, pl.grid, 2 * AN + 4,
                        2 * AN, dloc, dlogstd, AN, loss3, pa.inv_B, value_coef);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_loss_total, dim3(1), dim3(64), 0, st, loss3);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -12,6 +12,10 @@
 #define PFPN_WAVE 64
 #define PFPN_HALF_LOG_2PI 0.9189385175704956f   // saved graph: actor/Normal/prob/add/x
 
+// Clear any stale sticky error left by other HIP users of this thread (e.g. PyTorch's benign
+// hipErrorNotReady from event queries) so PFPN_CHECK_LAUNCH reports only our own launches.
+#define PFPN_BEGIN() (void)hipGetLastError()
+
 #define PFPN_CHECK_LAUNCH()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \
@@ -61,6 +65,40 @@ __device__ __forceinline__ float tanh_log_det(float x) {
     const float t = -2.f * x;
     const float sp = fmaxf(t, 0.f) + log1pf(expf(-fabsf(t)));
     return 2.f * (0.6931471805599453f - x - sp);
+}
+
+// Deterministic column reduction of K slabs: out[c] = sum_k slab[k*stride + c] (or max).
+// 1024-thread block = 64 columns x 16 k-lanes; every k-lane walks k = lane, lane+16, ... with its
+// loads issued 4 at a time (independent of the running sum), then the 16 partials are combined
+// through LDS in lane order.  Replaces a serial K-long dependent-load loop (K * ~0.5 us).
+template <bool IS_MAX>
+__device__ __forceinline__ float slab_reduce_1024(const float* __restrict__ slab, int K, size_t stride, int col,
+                                                  bool col_ok, float (*red)[64]) {
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;       // 16 k-lanes
+    float acc = IS_MAX ? -INFINITY : 0.f;
+    if (col_ok) {
+        int k = kl;
+        for (; k + 48 < K; k += 64) {
+            const float a0 = slab[(size_t)k * stride + col];
+            const float a1 = slab[(size_t)(k + 16) * stride + col];
+            const float a2 = slab[(size_t)(k + 32) * stride + col];
+            const float a3 = slab[(size_t)(k + 48) * stride + col];
+            if (IS_MAX) acc = fmaxf(fmaxf(fmaxf(fmaxf(acc, a0), a1), a2), a3);
+            else acc = (((acc + a0) + a1) + a2) + a3;
+        }
+        for (; k < K; k += 16) {
+            const float a0 = slab[(size_t)k * stride + col];
+            acc = IS_MAX ? fmaxf(acc, a0) : acc + a0;
+        }
+    }
+    red[kl][cl] = acc;
+    __syncthreads();
+    float s = red[0][cl];
+    if (kl == 0) {
+        for (int j = 1; j < 16; ++j) s = IS_MAX ? fmaxf(s, red[j][cl]) : s + red[j][cl];
+    }
+    __syncthreads();
+    return s;          // valid on k-lane 0
 }
 
 }  // namespace pfpn

@@ -119,6 +119,7 @@ extern "C" int pfpn_resample(float* loc, float* logstd, float* bias, float* weig
                              const float* max_active, const float* sum_active, const double* u_resample,
                              const float* u_noise, int A, int N, float threshold, int tanh_mode,
                              int32_t* dead_out, int32_t* src_out, void* stream) {
+    PFPN_BEGIN();
     if (!loc || !logstd || !bias || !weight || !max_active || !sum_active || !u_resample || !u_noise ||
         !dead_out || !src_out || A < 1 || N < 1 || N > RS_MAXN || H < 1)
         return PFPN_ERR_ARG;

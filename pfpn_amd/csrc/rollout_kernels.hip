@@ -100,18 +100,18 @@ __global__ __launch_bounds__(256) void k_stats_partial(
     partial[((size_t)c * 2 + 1) * AN + col] = s;
 }
 
-__global__ __launch_bounds__(256) void k_stats_apply(const float* __restrict__ partial, int C, int AN,
-                                                     float* __restrict__ max_active,
-                                                     float* __restrict__ sum_active) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= AN) return;
-    float m = 0.f, s = 0.f;
-    for (int c = 0; c < C; ++c) {
-        m = fmaxf(m, partial[((size_t)c * 2 + 0) * AN + col]);
-        s += partial[((size_t)c * 2 + 1) * AN + col];
+__global__ __launch_bounds__(1024) void k_stats_apply(const float* __restrict__ partial, int C, int AN,
+                                                      float* __restrict__ max_active,
+                                                      float* __restrict__ sum_active) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    // slab c holds [max | sum] rows of AN floats: stride 2*AN between chunks
+    const float m = slab_reduce_1024<true>(partial, C, (size_t)2 * AN, col, col < AN, red);
+    const float s = slab_reduce_1024<false>(partial + AN, C, (size_t)2 * AN, col, col < AN, red);
+    if ((threadIdx.x >> 6) == 0 && col < AN) {
+        max_active[col] = fmaxf(max_active[col], m);      // a2c.py:356
+        sum_active[col] = sum_active[col] + s;            // a2c.py:359
     }
-    max_active[col] = fmaxf(max_active[col], m);      // a2c.py:356
-    sum_active[col] = sum_active[col] + s;            // a2c.py:359
 }
 
 __global__ void k_row_sum2(const float* __restrict__ lpseg, int B, int A, float* __restrict__ logp) {
@@ -303,7 +303,7 @@ static int stats_launch(const float* logits, const float* smax, const float* sin
     hipLaunchKernelGGL(k_stats_partial, dim3((AN + 255) / 256, C), dim3(256), 0, st, logits, smax, sinv, B, A,
                        N, len, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_stats_apply, dim3((AN + 255) / 256), dim3(256), 0, st, partial, C, AN, max_active,
+    hipLaunchKernelGGL(k_stats_apply, dim3((AN + 63) / 64), dim3(1024), 0, st, partial, C, AN, max_active,
                        sum_active);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
@@ -312,6 +312,7 @@ static int stats_launch(const float* logits, const float* smax, const float* sin
 int pfpn_sample(const float* logits, const float* loc, const float* logstd, const double* u_cat,
                 const float* eps_sel, int B, int A, int N, int32_t* k, float* action, float* logp,
                 float* max_active, float* sum_active, void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !loc || !logstd || !u_cat || !eps_sel || !k || !action || B < 0 || A < 1 || N < 1)
         return PFPN_ERR_ARG;
     if ((max_active == nullptr) != (sum_active == nullptr)) return PFPN_ERR_ARG;
@@ -336,6 +337,7 @@ int pfpn_sample(const float* logits, const float* loc, const float* logstd, cons
 
 int pfpn_active_stats(const float* logits, int B, int A, int N, float* max_active, float* sum_active,
                       void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !max_active || !sum_active || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     if (!workspace || workspace_bytes < pfpn_rollout_workspace_bytes(B, A, N)) return PFPN_ERR_WORKSPACE;
@@ -351,6 +353,7 @@ int pfpn_active_stats(const float* logits, int B, int A, int N, float* max_activ
 
 int pfpn_mean_action(const float* logits, const float* loc, int B, int A, int N, int tanh_mode,
                      int32_t* k, float* action, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !loc || !action || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     const int S = B * A;
@@ -361,6 +364,7 @@ int pfpn_mean_action(const float* logits, const float* loc, int B, int A, int N,
 }
 
 int pfpn_entropy_fwd(const float* logits, int B, int A, int N, float* H, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !H || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     const int S = B * A;
@@ -371,6 +375,7 @@ int pfpn_entropy_fwd(const float* logits, int B, int A, int N, float* H, void* s
 
 int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, int accumulate,
                      float* dlogits, void* stream) {
+    PFPN_BEGIN();
     if (!logits || !dH || !dlogits || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     const int S = B * A;
@@ -383,6 +388,7 @@ int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, 
 int pfpn_rsample_fwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
                      const float* eps, int B, int A, int N, int32_t* k, float* a_out, float* s_out,
                      void* stream) {
+    PFPN_BEGIN();
     if (!logits || !loc || !logstd || !gumbel || !eps || !k || !a_out || !s_out || B < 0 || A < 1 || N < 1)
         return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
@@ -397,6 +403,7 @@ int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd,
                      const float* eps, const float* da, const float* ds, int B, int A, int N, int accumulate,
                      float* dlogits, float* dloc, float* dlogstd, void* workspace, size_t workspace_bytes,
                      void* stream) {
+    PFPN_BEGIN();
     if (!logits || !loc || !logstd || !gumbel || !eps || !da || !ds || !dlogits || !dloc || !dlogstd ||
         B < 0 || A < 1 || N < 1)
         return PFPN_ERR_ARG;
