@@ -60,6 +60,10 @@ def load():
         raise PfpnLibraryError(
             "libpfpn_hip.so not found at %s -- build it with `python -m pfpn_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  The kernels share streams and
+    # device pointers with torch, so they MUST bind to the runtime instance torch uses: import torch
+    # first, then the dynamic loader resolves our NEEDED libamdhip64.so.7 to the already-loaded copy.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (ret, argtypes, _) in parse_header().items():
         try:

@@ -65,16 +65,21 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     const int tile_floats = R * AN;
     const int tile_f4 = (tile_floats + 3) >> 2;
     float* tile = reinterpret_cast<float*>(smem4);
-    float4* bank = smem4 + tile_f4;                       // [AN] {loc, 1/scale, cterm, scale}
+    float4* bank = smem4 + tile_f4;                       // [AN] {loc, isc2, cterm2, isc*c}  (see below)
     float* segbuf = reinterpret_cast<float*>(bank + AN);  // [R*A] per-segment log p
     float* rowbuf = segbuf + R * A;                       // [R]   per-row dlogp
     float* lossbuf = rowbuf + R;                          // [2R]
 
     const int t = threadIdx.x;
-    // particle bank -> LDS (scale = exp(logstd), log(scale) as the reference graph computes it)
+    // particle bank -> LDS.  scale = exp(logstd), cterm = 0.5log(2pi) + log(scale) as the reference
+    // graph computes them; then everything is pre-scaled to base 2 so the per-particle work is
+    //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - cterm2)      (3 VALU + 1 transcendental)
+    // with isc2 = sqrt(0.5*log2 e)/scale and cterm2 = cterm*log2 e; the true z = c*z', c = sqrt(2 ln 2).
     for (int i = t; i < AN; i += PACK_BLOCK) {
         const float sc = expf(logstd[i]);
-        bank[i] = make_float4(loc[i], 1.0f / sc, PFPN_HALF_LOG_2PI + logf(sc), sc);
+        const float isc = 1.0f / sc;
+        bank[i] = make_float4(loc[i], isc * PFPN_SQRT_HALF_LOG2E, (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E,
+                              isc * PFPN_SQRT_2LN2);
     }
 
     const int sidx = t >> 2;                // segment slot in the tile
@@ -134,15 +139,17 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                 if (i < NP - 1 || last_ok) mx = fmaxf(mx, seg[PACK_G * i]);
             mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            const float mxl = mx * PFPN_LOG2E;
             float sum = 0.f, num = 0.f;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 ephi[i] = 0.f;
                 if (i < NP - 1 || last_ok) {
                     const float4 k4 = bk[PACK_G * i];
-                    const float en = expf(seg[PACK_G * i] - mx);
-                    const float z = (xv - k4.x) * k4.y;
-                    const float ph = expf(fmaf(-0.5f * z, z, -k4.z));
+                    // softmax numerator: raw v_exp_f32 (tiny values may flush; they carry no mass)
+                    const float en = __builtin_amdgcn_exp2f(fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl));
+                    const float zq = (xv - k4.x) * k4.y;
+                    const float ph = exp2f(fmaf(-zq, zq, -k4.z));      // denormal-correct
                     if (MODE != MODE_FWD) seg[PACK_G * i] = en;
                     ephi[i] = en * ph;
                     sum += en;
@@ -198,18 +205,18 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
             const float gup = rowbuf[r];
             const float q = guard_finite(gup / p);
             const float qs = q * inv_sum;
+            const float qp = qs * p;
             float dxa = 0.f;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 if (i < NP - 1 || last_ok) {
                     const float4 k4 = bk[PACK_G * i];
                     const float tt = qs * ephi[i];                          // q * w_n * phi_n
-                    seg[PACK_G * i] = tt - (qs * seg[PACK_G * i]) * p;     // q * w_n * (phi_n - p)
-                    const float z = (xv - k4.x) * k4.y;
-                    const float zi = z * k4.y;
-                    acc_loc[i] = fmaf(tt, zi, acc_loc[i]);
-                    acc_ls[i] = fmaf(tt, fmaf(z, z, -1.f), acc_ls[i]);
-                    dxa = fmaf(tt, zi, dxa);
+                    seg[PACK_G * i] = fmaf(-seg[PACK_G * i], qp, tt);      // q * w_n * (phi_n - p)
+                    const float zq = (xv - k4.x) * k4.y;                    // z / c
+                    acc_loc[i] = fmaf(tt, zq, acc_loc[i]);                  // scaled by isc*c in the tail
+                    acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);   // tt*(z^2 - 1)
+                    if (dx_out) dxa = fmaf(tt * zq, k4.w, dxa);
                 }
             }
             if (dx_out) {
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         for (int i = t; i < AN; i += PACK_BLOCK) {
             float s = 0.f;
             for (int rr = 0; rr < R; ++rr) s += tile[rr * AN + i];
-            slab[which * AN + i] = s;
+            slab[which * AN + i] = which ? s : s * bank[i].w;      // dloc: sum tt*z' times c/scale
         }
     }
     if (MODE == MODE_PPO) {

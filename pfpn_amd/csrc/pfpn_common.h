@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #define PFPN_OK 0
 #define PFPN_ERR_ARG 1
@@ -11,15 +12,23 @@
 
 #define PFPN_WAVE 64
 #define PFPN_HALF_LOG_2PI 0.9189385175704956f   // saved graph: actor/Normal/prob/add/x
+#define PFPN_LOG2E 1.4426950408889634f
+#define PFPN_SQRT_HALF_LOG2E 0.8493218002880191f   // sqrt(0.5 * log2 e)
+#define PFPN_SQRT_2LN2 1.1774100225154747f         // sqrt(2 ln 2) = 1 / sqrt(0.5 log2 e)
+#define PFPN_2LN2 1.3862943611198906f              // 2 ln 2
 
 // Clear any stale sticky error left by other HIP users of this thread (e.g. PyTorch's benign
 // hipErrorNotReady from event queries) so PFPN_CHECK_LAUNCH reports only our own launches.
 #define PFPN_BEGIN() (void)hipGetLastError()
 
-#define PFPN_CHECK_LAUNCH()                                   \
-    do {                                                      \
-        hipError_t e__ = hipGetLastError();                   \
-        if (e__ != hipSuccess) return PFPN_ERR_LAUNCH;        \
+#define PFPN_CHECK_LAUNCH()                                                              \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) {                                                         \
+            fprintf(stderr, "[pfpn] %s:%d launch failed: %s\n", __FILE__, __LINE__,      \
+                    hipGetErrorString(e__));                                             \
+            return PFPN_ERR_LAUNCH;                                                      \
+        }                                                                                \
     } while (0)
 
 namespace pfpn {
