@@ -100,31 +100,48 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
 
     const int ntiles = (B + R - 1) / R;
+    const int wave = t >> 6, lane = t & 63;
+    // Software pipeline: the NEXT tile's logits are fetched into registers (3 float4 per thread)
+    // while the current tile is processed, so the HBM latency hides behind the compute phases.
+    float4 buf[PACK_MAXV];
+    auto fetch = [&](int tileid) {
+        const int row0 = tileid * R;
+        const int nv = (min(R, B - row0) * AN) >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN);
+#pragma unroll
+        for (int j = 0; j < PACK_MAXV; ++j)        // clamped index: all loads unconditional
+            buf[j] = g4[min(t + j * PACK_BLOCK, nv - 1)];
+    };
+    if (vec_ok && (int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
         const int row0 = tileid * R;
         const int rows = min(R, B - row0);
         const int nfl = rows * AN;
-        const float* gsrc = logits + (size_t)row0 * AN;
         __syncthreads();   // previous tile's LDS reads (store-out) are done; bank is written
         if (vec_ok) {
             const int nv = nfl >> 2;            // AN % 4 == 0 guaranteed by vec_ok
-            float4 buf[PACK_MAXV];
-#pragma unroll
-            for (int j = 0; j < PACK_MAXV; ++j) {      // clamped index: all loads unconditional
-                const int i = min(t + j * PACK_BLOCK, nv - 1);
-                buf[j] = reinterpret_cast<const float4*>(gsrc)[i];
-            }
 #pragma unroll
             for (int j = 0; j < PACK_MAXV; ++j) {
                 const int i = t + j * PACK_BLOCK;
                 if (i < nv) reinterpret_cast<float4*>(tile)[i] = buf[j];
             }
+            if (tileid + (int)gridDim.x < ntiles) fetch(tileid + gridDim.x);
         } else {
+            const float* gsrc = logits + (size_t)row0 * AN;
             for (int i = t; i < nfl; i += PACK_BLOCK) tile[i] = gsrc[i];
         }
         const bool active = seg_thread && r < rows;
         float xv = 0.f;
         if (active) xv = x[(size_t)row0 * A + sidx];
+        // row scalars for the row stage: wave w owns row w of the tile; fetched now, used later
+        float r_dlogp = 0.f, r_adv = 0.f, r_lpold = 0.f, r_val = 0.f, r_vold = 0.f;
+        if (wave < rows && lane == 0) {
+            const int b = row0 + wave;
+            if (MODE == MODE_BWD) r_dlogp = dlogp_in[b];
+            if (MODE == MODE_PPO) {
+                r_adv = ppo.adv[b]; r_lpold = ppo.logp_old[b]; r_val = ppo.value[b]; r_vold = ppo.value_old[b];
+            }
+        }
         __syncthreads();
 
         // ---- forward on my quarter of the segment ---------------------------------------
@@ -171,30 +188,38 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         }
         __syncthreads();
 
-        // ---- row stage: log-prob of the row, PPO head ---------------------------------
-        if (t < rows) {
-            float s = 0.f;
-            for (int i = 0; i < A; ++i) s += segbuf[t * A + i];
-            const int b = row0 + t;
-            if (MODE != MODE_BWD) logp_out[b] = s;
-            if (MODE == MODE_BWD) rowbuf[t] = dlogp_in[b];
-            if (MODE == MODE_PPO) {
-                const float adv = ppo.adv[b];
-                const float nadv = (adv - adv_mean) * adv_rstd;
-                const float ratio = expf(s - ppo.logp_old[b]);
-                const float sur = ratio * nadv;
-                const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
-                const float csur = cr * nadv;
-                pol_sum += fminf(sur, csur);
-                // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
-                // clip_by_value passes where lo <= ratio <= hi.
-                const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
-                rowbuf[t] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-                const float target = adv + ppo.value_old[b];
-                const float dvv = ppo.value[b] - target;
-                val_sum += dvv * dvv;
-                ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
-                if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
+        // ---- row stage: wave w reduces the A segment log-probs of rows w, w+16, ... (shuffle tree,
+        //      fixed order) and its lane 0 runs the PPO head (first row: prefetched scalars)
+        for (int rw = wave; rw < rows; rw += PACK_BLOCK / 64) {
+            float sacc = 0.f;
+            for (int i = lane; i < A; i += 64) sacc += segbuf[rw * A + i];
+            const float s = wave_sum(sacc);
+            if (lane == 0) {
+                const int b = row0 + rw;
+                if (rw != wave) {           // only when a tile holds more than 16 rows (small A)
+                    if (MODE == MODE_BWD) r_dlogp = dlogp_in[b];
+                    if (MODE == MODE_PPO) {
+                        r_adv = ppo.adv[b]; r_lpold = ppo.logp_old[b]; r_val = ppo.value[b]; r_vold = ppo.value_old[b];
+                    }
+                }
+                if (MODE != MODE_BWD) logp_out[b] = s;
+                if (MODE == MODE_BWD) rowbuf[rw] = r_dlogp;
+                if (MODE == MODE_PPO) {
+                    const float nadv = (r_adv - adv_mean) * adv_rstd;
+                    const float ratio = expf(s - r_lpold);
+                    const float sur = ratio * nadv;
+                    const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
+                    const float csur = cr * nadv;
+                    pol_sum += fminf(sur, csur);
+                    // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
+                    // clip_by_value passes where lo <= ratio <= hi.
+                    const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+                    rowbuf[rw] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+                    const float dvv = r_val - (r_adv + r_vold);
+                    val_sum += dvv * dvv;
+                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                    if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
+                }
             }
         }
         if (MODE == MODE_FWD) continue;
@@ -262,11 +287,12 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         }
     }
     if (MODE == MODE_PPO) {
-        if (t < R) { lossbuf[t] = pol_sum; lossbuf[R + t] = val_sum; }
+        const int nwr = min(R, PACK_BLOCK / 64);          // waves that own rows
+        if (wave < nwr && lane == 0) { lossbuf[wave] = pol_sum; lossbuf[nwr + wave] = val_sum; }
         __syncthreads();
         if (t == 0) {
             float ps = 0.f, vs = 0.f;
-            for (int i = 0; i < R; ++i) { ps += lossbuf[i]; vs += lossbuf[R + i]; }
+            for (int i = 0; i < nwr; ++i) { ps += lossbuf[i]; vs += lossbuf[nwr + i]; }
             slab[2 * AN + 0] = ps;
             slab[2 * AN + 1] = vs;
         }
@@ -434,14 +460,8 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     pl.lds = (size_t)tile_f4 * 16 + (size_t)AN * 16 + (size_t)(R * A + R + 2 * R + 4) * 4;
     pl.vec_ok = (AN % 4 == 0) && ((uintptr_t)logits % 16 == 0) && (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
     const int ntiles = (B + R - 1) / R;
-    // balanced passes over 256 CUs x up to 2 resident 1024-thread blocks
-    int grid = ntiles;
-    const int cap = 256 * 2;
-    if (grid > cap) {
-        const int per = (ntiles + cap - 1) / cap;
-        grid = (ntiles + per - 1) / per;
-    }
-    pl.grid = grid;
+    // one resident 1024-thread block per CU, tiles strided over the blocks (max load = ceil(ntiles/256))
+    pl.grid = ntiles < 256 ? ntiles : 256;
     pl.ok = pl.lds <= 64 * 1024;
     return pl;
 }
