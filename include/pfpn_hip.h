@@ -36,6 +36,8 @@ extern "C" {
 
 /* library / ABI version, and a cheap "is the device code loadable" probe (no compute). */
 int pfpn_abi_version(void);
+/* diagnostic only: phase-skip mask for timing ablations of the packed mixture kernel (0 = normal). */
+void pfpn_debug_set(int mask);
 
 /* ---- mixture log-prob (K1/K2) ------------------------------------------------------------ */
 /* scratch needed by the mixture entry points for this shape */
@@ -169,6 +171,14 @@ int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply,
 int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
                  float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
                  float grad_mul, void* stream);
+/* SAC loss head -- sac.py:123-139 (vf_target, q_target) and :160-173 (Q and policy losses).
+ * q_pi, q_run, q_tgt are [2,B] (Q1 row then Q2 row): Q(s, a_pi), Q(s, action_hist), Q'(s', a').
+ * Outputs dq_pi [2,B] (d policy_loss/dQ through tf.minimum), dq_run [2,B] (d value_loss/dQ),
+ * dlogp [B] (= alpha/B), dlog_alpha [1], loss3 = {loss, policy_loss, value_loss*coef}. */
+int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, const float* logp, const float* logp_t,
+                  const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
+                  float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
+                  float* dlog_alpha, float* loss3, void* stream);
 /* SAC soft target update -- sac.py:67-73. */
 int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream);
 

@@ -569,3 +569,148 @@ def dppo_learner_step(st, shards, lr=1e-4, clip_norm=1.0, u_resample=None, u_noi
                 st.P["actor/fc_policy/weight"], st.max_active, st.sum_active, u_resample, u_noise)
         st.max_active[:] = 0; st.sum_active[:] = 0; st.train_flag = 0
     return losses
+
+
+# --------------------------------------------------------------------------- #
+# SAC-PFPN (networks/actor_critic/sac.py:12-175)                  #
+# --------------------------------------------------------------------------- #
+SAC_ACTOR = ["actor/fc1/weight", "actor/fc1/bias", "actor/fc2/weight", "actor/fc2/bias",
+             "actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
+             "alpha/log_alpha"]
+SAC_CRITIC = ["critic/%s/fc%d/%s" % (q, i, k) for q in ("q1", "q2") for i in (1, 2, 3) for k in ("weight", "bias")]
+
+
+def init_sac_params(rng, S, A, N, hidden=(1024, 512), sigma=0.01):
+    P = init_params(rng, S, A, N, hidden, tanh_mode=True, sigma=sigma)
+    P = {k: v for k, v in P.items() if k.startswith("actor")}
+    h1, h2 = hidden
+
+    def tn(shape):
+        x = rng.standard_normal(shape)
+        bad = np.abs(x) > 2
+        while bad.any():
+            x[bad] = rng.standard_normal(bad.sum())
+            bad = np.abs(x) > 2
+        return (x * sigma).astype(F)
+    for q in ("q1", "q2"):
+        P["critic/%s/fc1/weight" % q] = tn((S + A, h1)); P["critic/%s/fc1/bias" % q] = np.zeros(h1, F)
+        P["critic/%s/fc2/weight" % q] = tn((h1, h2)); P["critic/%s/fc2/bias" % q] = np.zeros(h2, F)
+        P["critic/%s/fc3/weight" % q] = tn((h2, 1)); P["critic/%s/fc3/bias" % q] = np.zeros(1, F)
+    P["alpha/log_alpha"] = np.zeros((), F)
+    return P
+
+
+def q_forward(P, q, xa):
+    c1 = fc(xa, P["critic/%s/fc1/weight" % q], P["critic/%s/fc1/bias" % q], True)
+    c2 = fc(c1, P["critic/%s/fc2/weight" % q], P["critic/%s/fc2/bias" % q], True)
+    v = fc(c2, P["critic/%s/fc3/weight" % q], P["critic/%s/fc3/bias" % q], False)[:, 0]
+    return v, (c1, c2)
+
+
+def _q_backward(P, q, xa, acts, dq, G=None):
+    """returns d xa; fills G with parameter grads when G is a dict."""
+    c1, c2 = acts
+    dc2, dw3, db3 = _fc_bwd(c2, P["critic/%s/fc3/weight" % q], None, dq[:, None], False)
+    dc1, dw2, db2 = _fc_bwd(c1, P["critic/%s/fc2/weight" % q], c2, dc2, True)
+    dxa, dw1, db1 = _fc_bwd(xa, P["critic/%s/fc1/weight" % q], c1, dc1, True)
+    if G is not None:
+        for i, (dw, db) in zip((1, 2, 3), ((dw1, db1), (dw2, db2), (dw3, db3))):
+            G["critic/%s/fc%d/weight" % (q, i)] = dw
+            G["critic/%s/fc%d/bias" % (q, i)] = db
+    return dxa
+
+
+def sac_grads(P, PT, norm_mean, norm_std, batch, noise, A, N, gamma=0.95, value_loss_coef=0.5):
+    """One SAC-PFPN forward/backward.  P: eval params (actor + q1/q2 + log_alpha), PT: target q1/q2.
+    batch: state, action, reward, not_terminal, state_.  noise: gumbel/eps for the eval draw and
+    gumbel_/eps_ for the target draw, each [B,A,N].
+    Returns (loss tuple (loss, policy_loss, value_loss*coef), grads dict, aux)."""
+    B = len(batch["state"])
+    loc, logstd = P["actor/samples"], P["actor/samples_std"]
+    alpha = np.exp(P["alpha/log_alpha"], dtype=F)                          # sac.py:38 (stop-grad)
+    x = state_normalize(batch["state"], norm_mean, norm_std, 5.0)
+    logits, (h1, h2) = actor_forward(P, x, A, N)
+    a, s_, k = rsample(logits, loc, logstd, noise["gumbel"], noise["eps"])
+    logp, _ = mixture_log_prob(logits, s_, loc, logstd, tanh_mode=True)    # sac.py:128-130
+    xa = np.concatenate([x, a], -1).astype(F)
+    q1p, acts1p = q_forward(P, "q1", xa)
+    q2p, acts2p = q_forward(P, "q2", xa)
+    xh = np.concatenate([x, np.asarray(batch["action"], F)], -1).astype(F)
+    q1r, acts1r = q_forward(P, "q1", xh)
+    q2r, acts2r = q_forward(P, "q2", xh)
+    # target net: shared actor + normaliser, own Q1', Q2' (sac.py:141-153)
+    x2 = state_normalize(batch["state_"], norm_mean, norm_std, 5.0)
+    logits2, _ = actor_forward(P, x2, A, N)
+    a2, s2, _ = rsample(logits2, loc, logstd, noise["gumbel_"], noise["eps_"])
+    logp2, _ = mixture_log_prob(logits2, s2, loc, logstd, tanh_mode=True)
+    xa2 = np.concatenate([x2, a2], -1).astype(F)
+    vf2 = (np.minimum(q_forward(PT, "q1", xa2)[0], q_forward(PT, "q2", xa2)[0]) - alpha * logp2).astype(F)
+    q_target = (np.asarray(batch["reward"], F) + F(gamma) * np.asarray(batch["not_terminal"], F) * vf2).astype(F)
+    value_loss = ((q_target - q1r) ** 2 + (q_target - q2r) ** 2).mean(dtype=F) * F(value_loss_coef)
+    qmin = np.minimum(q1p, q2p)
+    target_entropy = F(-A)
+    l = (alpha * logp - qmin - P["alpha/log_alpha"] * (logp + target_entropy)).astype(F)
+    policy_loss = l.mean(dtype=F)
+    G = {}
+    invB = F(1) / F(B)
+    # critic grads: d value_loss / d q_running
+    _q_backward(P, "q1", xh, acts1r, (F(-2) * (q_target - q1r) * F(value_loss_coef) * invB).astype(F), G)
+    _q_backward(P, "q2", xh, acts2r, (F(-2) * (q_target - q2r) * F(value_loss_coef) * invB).astype(F), G)
+    # actor grads: policy_loss w.r.t. actor variables and log_alpha only (sac.py:166-173)
+    G["alpha/log_alpha"] = F(-(logp + target_entropy).mean(dtype=F))
+    sel1 = q1p <= q2p                                                     # tf.minimum grad routing
+    dxa = _q_backward(P, "q1", xa, acts1p, np.where(sel1, -invB, F(0)).astype(F)) \
+        + _q_backward(P, "q2", xa, acts2p, np.where(sel1, F(0), -invB).astype(F))
+    da = dxa[:, -A:].astype(F)
+    dlogp = np.full(B, alpha * invB, F)
+    dl1, dloc1, dls1, dxs = mixture_log_prob_bwd(logits, s_, loc, logstd, dlogp, tanh_mode=True)
+    dl2, dloc2, dls2 = rsample_bwd(logits, loc, logstd, noise["gumbel"], noise["eps"], da, dxs)
+    dlogits = (dl1 + dl2).reshape(B, A * N).astype(F)
+    G["actor/samples"] = (dloc1 + dloc2).astype(F)
+    G["actor/samples_std"] = (dls1 + dls2).astype(F)
+    dh2, G["actor/fc_policy/weight"], G["actor/fc_policy/bias"] = _fc_bwd(h2, P["actor/fc_policy/weight"], None, dlogits, False)
+    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True)
+    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True)
+    aux = {"logp": logp, "a": a, "s_": s_, "k": k, "q_target": q_target, "q1r": q1r, "q1p": q1p, "alpha": alpha}
+    return (F(policy_loss + value_loss), F(policy_loss), F(value_loss)), G, aux
+
+
+class SACState:
+    def __init__(self, rng, S=197, A=36, N=35, hidden=(1024, 512), resample_interval=12000):
+        self.S, self.A, self.N = S, A, N
+        self.P = init_sac_params(rng, S, A, N, hidden)
+        self.PT = {k: v.copy() for k, v in self.P.items() if k.startswith("critic")}   # hard sync at init
+        self.m = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.bp_c = [F(0.9), F(0.999)]
+        self.bp_a = [F(0.9), F(0.999)]
+        self.norm_mean, self.norm_std = np.zeros(S, F), np.ones(S, F)
+        self.max_active, self.sum_active = np.zeros((A, N), F), np.zeros((A, N), F)
+        self.global_step = 0
+        self.train_flag = 0
+        self.resample_interval = resample_interval
+
+
+def sac_learner_step(st, batch, noise, lr_c=1e-4, lr_a=1e-4, clip_norm=1.0, tau=0.005, gamma=0.95):
+    """Single-worker SAC update (workers == 1, deepmimic_sac_base.py:4): grads -> ONE joint global-norm
+    clip over critic+actor gradients (base_worker.py:97-102) -> critic Adam then actor Adam
+    (base_worker.py:33-45) -> soft target update (sac.py:67-73) -> resample tick."""
+    lm, ls = state_norm_update(batch["state"], st.norm_mean, st.norm_std, st.global_step)
+    losses, G, aux = sac_grads(st.P, st.PT, st.norm_mean, st.norm_std, batch, noise, st.A, st.N, gamma)
+    names = SAC_CRITIC + SAC_ACTOR
+    clipped, _ = clip_by_global_norm([np.asarray(G[n], F) for n in names], clip_norm)
+    Gc = dict(zip(names, clipped))
+    for n in SAC_CRITIC:
+        st.P[n], st.m[n], st.v[n] = tf_adam(st.P[n], Gc[n], st.m[n], st.v[n], st.bp_c[0], st.bp_c[1], lr_c)
+    st.bp_c = [F(st.bp_c[0] * F(0.9)), F(st.bp_c[1] * F(0.999))]
+    for n in SAC_ACTOR:
+        st.P[n], st.m[n], st.v[n] = tf_adam(st.P[n], Gc[n], st.m[n], st.v[n], st.bp_a[0], st.bp_a[1], lr_a)
+    st.bp_a = [F(st.bp_a[0] * F(0.9)), F(st.bp_a[1] * F(0.999))]
+    st.norm_mean, st.norm_std = lm, ls
+    for n in st.PT:
+        st.PT[n] = ((F(1) - F(tau)) * st.PT[n] + F(tau) * st.P[n]).astype(F)
+    st.global_step += 1
+    st.train_flag += 1
+    if st.train_flag >= st.resample_interval:
+        st.max_active[:] = 0; st.sum_active[:] = 0; st.train_flag = 0
+    return losses, aux

@@ -390,6 +390,51 @@ __global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ t, cons
         t[i] = omt * t[i] + tau * s[i];
 }
 
+// SAC loss head (reference networks/actor_critic/sac.py:123-139, 160-173) on [B] vectors, one block:
+//   vf' = min(q1', q2') - alpha*logp'          (target net, stop-grad)
+//   q_target = r + gamma*not_terminal*vf'
+//   value_loss = coef * mean((q_target-q1r)^2 + (q_target-q2r)^2)
+//   policy_loss = mean(alpha*logp - min(q1p,q2p) - log_alpha*sg(logp + target_entropy))
+// q_* are [2,B] group-major.  Outputs the gradients the backward pass needs.
+__global__ __launch_bounds__(1024) void k_sac_loss(
+    const float* __restrict__ q_pi, const float* __restrict__ q_run, const float* __restrict__ q_tgt,
+    const float* __restrict__ logp, const float* __restrict__ logp_t, const float* __restrict__ reward,
+    const float* __restrict__ not_terminal, const float* __restrict__ log_alpha, int B, float gamma,
+    float value_coef, float target_entropy,
+    float* __restrict__ dq_pi, float* __restrict__ dq_run, float* __restrict__ dlogp,
+    float* __restrict__ dlog_alpha, float* __restrict__ loss3)
+{
+    __shared__ float red[16];
+    const float la = log_alpha[0];
+    const float alpha = expf(la);
+    const float inv_B = 1.0f / (float)B;
+    float ps = 0.f, vs = 0.f, es = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float vft = fminf(q_tgt[b], q_tgt[B + b]) - alpha * logp_t[b];
+        const float qt = reward[b] + gamma * not_terminal[b] * vft;
+        const float d1 = qt - q_run[b], d2 = qt - q_run[B + b];
+        vs += d1 * d1 + d2 * d2;
+        dq_run[b] = -2.f * d1 * value_coef * inv_B;
+        dq_run[B + b] = -2.f * d2 * value_coef * inv_B;
+        const float q1 = q_pi[b], q2 = q_pi[B + b];
+        const bool sel1 = q1 <= q2;                       // tf.minimum routes its gradient to x where x <= y
+        const float lp = logp[b];
+        ps += alpha * lp - fminf(q1, q2) - la * (lp + target_entropy);
+        es += lp + target_entropy;
+        dq_pi[b] = sel1 ? -inv_B : 0.f;
+        dq_pi[B + b] = sel1 ? 0.f : -inv_B;
+        dlogp[b] = alpha * inv_B;
+    }
+    ps = block_sum(ps, red);
+    vs = block_sum(vs, red);
+    es = block_sum(es, red);
+    if (threadIdx.x == 0) {
+        const float pl = ps * inv_B, vl = vs * inv_B * value_coef;
+        loss3[0] = pl + vl; loss3[1] = pl; loss3[2] = vl;
+        dlog_alpha[0] = -es * inv_B;
+    }
+}
+
 static inline int row_chunks(int rows) {
     int C = (rows + 31) / 32;
     if (C > 128) C = 128;
@@ -581,6 +626,21 @@ int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n
         hipLaunchKernelGGL(k_beta_pow_step, dim3(1), dim3(64), 0, st, beta_pow, beta1, beta2);
         PFPN_CHECK_LAUNCH();
     }
+    return PFPN_OK;
+}
+
+int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, const float* logp, const float* logp_t,
+                  const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
+                  float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
+                  float* dlog_alpha, float* loss3, void* stream) {
+    PFPN_BEGIN();
+    if (!q_pi || !q_run || !q_tgt || !logp || !logp_t || !reward || !not_terminal || !log_alpha || !dq_pi ||
+        !dq_run || !dlogp || !dlog_alpha || !loss3 || B < 1)
+        return PFPN_ERR_ARG;
+    hipLaunchKernelGGL(k_sac_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, q_pi, q_run, q_tgt, logp, logp_t,
+                       reward, not_terminal, log_alpha, B, gamma, value_coef, target_entropy, dq_pi, dq_run, dlogp,
+                       dlog_alpha, loss3);
+    PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
 

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
     float* __restrict__ dx_out,              // [B,A] optional (BWD)
     float* __restrict__ partial,             // [grid][2*A*N + 4] (BWD, PPO)
-    PpoArgs ppo)
+    PpoArgs ppo, int dbg)
 {
     constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
     extern __shared__ float4 smem4[];
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         // stays in registers for the backward.
         float ephi[NP];
         float inv_sum = 0.f, p = 0.f;
-        if (active) {
+        if (active && !(dbg & 1)) {
             float mx = seg[0];
 #pragma unroll
             for (int i = 1; i < NP; ++i)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
 
         // ---- row stage: wave w reduces the A segment log-probs of rows w, w+16, ... (shuffle tree,
         //      fixed order) and its lane 0 runs the PPO head (first row: prefetched scalars)
-        for (int rw = wave; rw < rows; rw += PACK_BLOCK / 64) {
+        for (int rw = wave; rw < rows && !(dbg & 8); rw += PACK_BLOCK / 64) {
             float sacc = 0.f;
             for (int i = lane; i < A; i += 64) sacc += segbuf[rw * A + i];
             const float s = wave_sum(sacc);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         __syncthreads();
 
         // ---- backward on my quarter (dlogits overwrite the LDS slot) ---------------------
-        if (active) {
+        if (active && !(dbg & 2)) {
             const float gup = rowbuf[r];
             const float q = guard_finite(gup / p);
             const float qs = q * inv_sum;
@@ -256,6 +256,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         }
         __syncthreads();
         float* gdst = dlogits + (size_t)row0 * AN;
+        if (dbg & 4) continue;
         if (vec_ok) {
             const int nv = nfl >> 2;
 #pragma unroll
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------
 struct PackPlan { int R; int grid; size_t lds; int vec_ok; bool ok; };
+static int g_dbg = 0;        // diagnostic phase mask (pfpn_debug_set); 0 in production
 
 static PackPlan plan_packed(int B, int A, int N, const void* logits, const void* dlogits) {
     PackPlan pl{};
@@ -473,7 +475,7 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
 #define PFPN_LAUNCH_PACKED(NN)                                                                          \
     hipLaunchKernelGGL((k_mix_packed<NN, MODE>), dim3(pl.grid), dim3(PACK_BLOCK), pl.lds, st, logits, x, \
                        loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.vec_ok, logp, pmix, dlogits, dx,   \
-                       partial, ppo)
+                       partial, ppo, g_dbg)
     switch (N) {
         case 35: PFPN_LAUNCH_PACKED(35); break;
         case 50: PFPN_LAUNCH_PACKED(50); break;
@@ -495,6 +497,8 @@ using namespace pfpn;
 // C ABI (declared in include/pfpn_hip.h)
 // =======================================================================================
 extern "C" {
+
+void pfpn_debug_set(int mask) { g_dbg = mask; }
 
 size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
     // slabs: packed path <= 768 blocks x (2AN+4); wave path C<=64 chunks x 2AN; + lpseg [B*A]

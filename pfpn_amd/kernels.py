@@ -366,3 +366,16 @@ def soft_update(target, source, tau):
     lib = _lib.load()
     _lib.check(lib.pfpn_soft_update(_f32(target), _f32(source), target.numel(), float(tau), _stream()),
                "pfpn_soft_update")
+
+
+def sac_loss(q_pi, q_run, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, gamma, value_coef, target_entropy,
+             out):
+    """out: dict(dq_pi [2,B], dq_run [2,B], dlogp [B], dlog_alpha [1], loss3 [3])."""
+    lib = _lib.load()
+    B = logp.shape[0]
+    _lib.check(lib.pfpn_sac_loss(_f32(q_pi, 2, B), _f32(q_run, 2, B), _f32(q_tgt, 2, B), _f32(logp, B),
+                                 _f32(logp_t, B), _f32(reward, B), _f32(not_terminal, B), _f32(log_alpha),
+                                 B, float(gamma), float(value_coef), float(target_entropy),
+                                 _f32(out["dq_pi"], 2, B), _f32(out["dq_run"], 2, B), _f32(out["dlogp"], B),
+                                 _f32(out["dlog_alpha"]), _f32(out["loss3"], 3), _stream()), "pfpn_sac_loss")
+    return out

@@ -172,14 +172,10 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
                                       out=self.value_buf)
 
     def denormalize_action(self, a):
-        """a2c.py:246-261 (only active in tanh mode): scale/offset from [-1,1] to the env bounds."""
-        if self.normalize_policy_output_ and self.action_upper_bound is not None:
-            gap = self.action_upper_bound - self.action_lower_bound
-            if np.any(gap != 2):
-                a = a * torch.as_tensor(gap * 0.5, dtype=torch.float32, device=a.device)
-            s = self.action_upper_bound + self.action_lower_bound
-            if np.any(s != 0):
-                a = a + torch.as_tensor(s * 0.5, dtype=torch.float32, device=a.device)
+        """reference a2c.py:246-261 scales only when `self.normalize_policy_output` is set, and the
+        particle network forces that flag to False (a2c.py:327; its tanh squash is the
+        `normalize_policy_output_` flag): the tanh action in (-1, 1) goes to the env unscaled.
+        Reference behaviour kept as is."""
         return a
 
     def run_batch(self, states, noise=None, running_update=True):

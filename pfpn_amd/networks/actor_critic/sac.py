@@ -1,1 +1,276 @@
-__all__ = []
+"""Soft actor-critic wrapper over the particle-filtering policy (off-policy resample path).
+
+Host-side mirror of reference networks/actor_critic/sac.py: `sac_network_wrapper` (:12-175) -- twin Q
+critics on concat(normalised state, action) (:107-121), target network sharing the actor and the state
+normaliser (:141-153), learnable log_alpha with alpha = stop_gradient(exp(log_alpha)) (:36-39),
+`vf_target = min(Q1,Q2) - alpha*logp` (:123-126), `q_target = r + gamma*not_terminal*V'(s')` (:132-139),
+Q loss (:160-164), policy loss with target_entropy = -|A| (:166-173), soft target update tau (:67-73),
+hard sync at init (:75-86), `run` -> [action] (:91-95), `train` feed (:97-105).
+The policy sample is the Gumbel-softmax rsample branch of MixtureGaussianDistribution (utils.py:156-186).
+"""
+import numpy as np
+import torch
+
+from ... import kernels
+from .. import ops
+from ..ops import DenseStack, ParamStore
+from ..utils import MixtureGaussianDistribution
+from .a2c import ParticleFilteringA2CNetwork
+
+__all__ = ["ParticleFilteringSACNetwork"]
+
+
+def sac_network_wrapper(base_class):
+    class AbstractSACNetwork(base_class):
+        def __init__(self, alpha=0.2, tau=0.005, **kwargs):
+            if "normalize_policy_output" not in kwargs:
+                kwargs["normalize_policy_output"] = True          # sac.py:15-16
+            super().__init__(**kwargs)
+            self.alpha = alpha       # replaced by exp(log_alpha) for the trainable net (sac.py:36-39)
+            self.tau = tau
+            self.reward, self.not_terminal = "reward", "not_terminal"
+
+        # -- parameters: critic tensors first, then actor tensors (the two Adam groups) ------------
+        def _declare(self, store):
+            A = int(self.action_shape[0])
+            self.trunk = None
+            self.critic_trunk = None
+            hc = self.critic_net_shape[-1]
+            self.q_stack = DenseStack(store, ["critic/q1", "critic/q2"], self.S + A, self.critic_net_shape)
+            store.declare("critic/q1+critic/q2|fc3/weight", (2, hc))
+            store.declare("critic/q1+critic/q2|fc3/bias", (2, 4))      # [g,0] is the bias, rest padding
+            self.actor_trunk = DenseStack(store, ["actor"], self.S, self.actor_net_shape)
+            self.build_policy_params(store, self.actor_net_shape[-1])
+            store.declare("alpha/log_alpha", (1,))
+
+        def _init_weights(self):
+            self.q_stack.init_weights(self.rng, self.weight_std)
+            ops.truncated_normal_(self.store["critic/q1+critic/q2|fc3/weight"], self.weight_std, self.rng)
+            self.store["critic/q1+critic/q2|fc3/bias"].zero_()
+            self.actor_trunk.init_weights(self.rng, self.weight_std)
+            self.init_policy_params()
+            self.store["alpha/log_alpha"].zero_()                      # sac.py:37
+
+        def _post_init(self):
+            super()._post_init()
+            st = self.store
+            self.q_w3 = st["critic/q1+critic/q2|fc3/weight"]
+            self.q_b3 = st["critic/q1+critic/q2|fc3/bias"]
+            self.log_alpha = st["alpha/log_alpha"]
+            if self.trainable:
+                # target net = own copies of the Q tensors only; actor + normaliser are shared (sac.py:141-153)
+                self.target_store = ParamStore(self.device)
+                for name, shape, _ in st.specs:
+                    if "critic" in name:
+                        self.target_store.declare(name, shape)
+                self.target_store.allocate(with_optimizer=False)
+                self.critic_span = st.span(self.critic_param_names())
+                self.target_net = self                                  # attribute read by the workers
+                self.init_ops.append(self.sync_target_net_hard)
+                self.train_ops.insert(0, self.sync_target_net_soft)    # before the resample tick
+                self._target_initialised = False
+
+        def critic_param_names(self):
+            return [n for n in self.store.names() if "critic" in n]
+
+        def actor_param_names(self):
+            return [n for n in self.store.names() if "critic" not in n]
+
+        def variables(self):
+            out = {}
+            for ref, (name, g) in self.q_stack.reference_names().items():
+                out[ref] = self.store[name][g]
+            for g, q in enumerate(("q1", "q2")):
+                out["critic/%s/fc3/weight" % q] = self.q_w3[g]
+                out["critic/%s/fc3/bias" % q] = self.q_b3[g, :1]
+            for ref, (name, g) in self.actor_trunk.reference_names().items():
+                out[ref] = self.store[name][g]
+            for n in ("actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
+                      "alpha/log_alpha"):
+                out[n] = self.store[n]
+            return out
+
+        def gradients(self):
+            st = self.store
+            out = {}
+            for ref, (name, g) in self.q_stack.reference_names().items():
+                out[ref] = st.g(name)[g]
+            for g, q in enumerate(("q1", "q2")):
+                out["critic/%s/fc3/weight" % q] = st.g("critic/q1+critic/q2|fc3/weight")[g]
+                out["critic/%s/fc3/bias" % q] = st.g("critic/q1+critic/q2|fc3/bias")[g, :1]
+            for ref, (name, g) in self.actor_trunk.reference_names().items():
+                out[ref] = st.g(name)[g]
+            for n in ("actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
+                      "alpha/log_alpha"):
+                out[n] = st.g(n)
+            return out
+
+        def target_variables(self):
+            ts = self.target_store
+            out = {}
+            for ref, (name, g) in self.q_stack.reference_names().items():
+                out[ref] = ts[name][g]
+            for g, q in enumerate(("q1", "q2")):
+                out["critic/%s/fc3/weight" % q] = ts["critic/q1+critic/q2|fc3/weight"][g]
+                out["critic/%s/fc3/bias" % q] = ts["critic/q1+critic/q2|fc3/bias"][g, :1]
+            return out
+
+        # -- target network maintenance ---------------------------------------------------------------
+        def sync_target_net_hard(self):
+            """init op (sac.py:75-86): copy once."""
+            if not self._target_initialised:
+                off, ln = self.critic_span
+                self.target_store.flat[:ln].copy_(self.store.flat[off:off + ln])
+                self._target_initialised = True
+
+        def sync_target_net_soft(self):
+            """train op (sac.py:67-73): theta' <- (1-tau) theta' + tau theta."""
+            off, ln = self.critic_span
+            kernels.soft_update(self.target_store.flat[:ln], self.store.flat[off:off + ln], self.tau)
+
+        # -- buffers ----------------------------------------------------------------------------------
+        def _alloc_policy_buffers(self, B):
+            dev, A, AN = self.device, self.n_actions, self.n_actions * self.particles
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+            self.logits = f(B, AN)
+            self.logits2 = f(B, AN)
+            self.xn2 = f(B, self.S)
+            self.xa, self.xh, self.xa2 = f(B, self.S + A), f(B, self.S + A), f(B, self.S + A)
+            self.q_pi, self.q_run, self.q_tgt = f(2, B), f(2, B), f(2, B)
+            hc = self.critic_net_shape[-1]
+            self.dh_run, self.dh_pi = f(2, B, hc), f(2, B, hc)
+            self.dha = f(1, B, self.actor_net_shape[-1])
+            self.sac_out = {"dq_pi": f(2, B), "dq_run": f(2, B), "dlogp": f(B), "dlog_alpha": self.store.g("alpha/log_alpha"),
+                            "loss3": f(3)}
+            self.scratch_w3, self.scratch_b3 = f(hc), f(1)
+
+        # -- rollout ----------------------------------------------------------------------------------
+        def _actor_logits(self, x, slot, out):
+            ha = self.actor_trunk.forward(x, slot=slot)[0]
+            torch.mm(ha, self.policy_weight, out=out)
+            kernels.bias_act(out, self.policy_bias, relu6=False)
+            return ha
+
+        def run_batch(self, states, noise=None, running_update=True):
+            st = self._to_dev(states).view(-1, self.S)
+            B = st.shape[0]
+            self._ensure_buffers(B)
+            x = self._normalize(st)
+            self._actor_logits(x, 0, self.logits)
+            policy = MixtureGaussianDistribution(self.logits, self.loc, self.logstd, True)
+            upd = running_update and self.trainable and self.max_active is not None
+            mx, sm = (self.max_active, self.sum_active) if upd else (None, None)
+            if self.random_action:
+                a, s_ = policy.sample(1, noise, self.rng, mx, sm)
+            else:
+                a = policy.mean()
+                if upd:
+                    kernels.active_stats(policy.logits, mx, sm)
+            self.policy = policy
+            return self.denormalize_action(a), None, None
+
+        def run(self, sess, state, ops=None):
+            """reference sac.py:91-95: [action]."""
+            action, _, _ = self.run_batch(np.asarray(state, dtype=np.float32)[None])
+            return [action[0].cpu().numpy()]
+
+        def evaluate(self, sess, state):
+            raise NotImplementedError("SAC has no state-value head; the SAC worker never calls evaluate()")
+
+        # -- learner step -----------------------------------------------------------------------------
+        def _q_forward(self, xin, slot, out, target=False):
+            params = self.target_store if target else None
+            h = self.q_stack.forward(xin, slot=slot, params=params)
+            w3 = (self.target_store if target else self.store)["critic/q1+critic/q2|fc3/weight"]
+            b3 = (self.target_store if target else self.store)["critic/q1+critic/q2|fc3/bias"]
+            for g in range(2):
+                kernels.value_head_fwd(h[g], w3[g], b3[g], out=out[g])
+            return h
+
+        def make_train_noise(self, B):
+            AN = self.n_actions * self.particles
+            tiny = float(np.finfo(np.float32).tiny)
+            out = {}
+            for k in ("gumbel", "gumbel_"):
+                u = torch.rand(B, AN, device=self.device, generator=self.rng).clamp_(min=tiny)
+                out[k] = -torch.log(-torch.log(u))
+            for k in ("eps", "eps_"):
+                out[k] = torch.randn(B, AN, device=self.device, generator=self.rng)
+            return out
+
+        def compute_gradients(self, state, action, reward, not_terminal, state_, noise=None):
+            B, S, A = state.shape[0], self.S, self.n_actions
+            st = self.store
+            self._ensure_buffers(B)
+            if not self._target_initialised:
+                self.sync_target_net_hard()
+            noise = noise or self.make_train_noise(B)
+            x = self._normalize(state)
+            x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
+            if self.normalize_state:
+                self.state_normalizer.updated(state, self.step_dev, st.tail[:S], st.tail[S:2 * S])
+            # eval actor on s, shared actor on s' (sac.py:141-153)
+            ha = self._actor_logits(x, 0, self.logits)
+            self._actor_logits(x2, 1, self.logits2)
+            loc, logstd = self.loc, self.logstd
+            a, s_, k = kernels.rsample_fwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"])
+            logp = kernels.logprob_fwd(self.logits, s_, loc, logstd, True)
+            a2, s2, _ = kernels.rsample_fwd(self.logits2, loc, logstd, noise["gumbel_"], noise["eps_"])
+            logp2 = kernels.logprob_fwd(self.logits2, s2, loc, logstd, True)
+            self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
+            # Q inputs
+            for buf, xs, act in ((self.xa, x, a), (self.xh, x, action), (self.xa2, x2, a2)):
+                buf[:, :S].copy_(xs)
+                buf[:, S:].copy_(act)
+            hq_pi = self._q_forward(self.xa, 0, self.q_pi)
+            hq_run = self._q_forward(self.xh, 1, self.q_run)
+            self._q_forward(self.xa2, 2, self.q_tgt, target=True)
+            out = kernels.sac_loss(self.q_pi, self.q_run, self.q_tgt, logp, logp2, reward, not_terminal,
+                                   self.log_alpha, self.gamma, self.value_loss_coef, -float(A), self.sac_out)
+            # critic gradients (value loss through Q(s, action_hist))
+            gw3, gb3 = st.g("critic/q1+critic/q2|fc3/weight"), st.g("critic/q1+critic/q2|fc3/bias")
+            gb3.zero_()
+            for g in range(2):
+                kernels.value_head_bwd(hq_run[g], self.q_w3[g], out["dq_run"][g], self.dh_run[g], gw3[g],
+                                       gb3[g, :1], relu6=True)
+            self.q_stack.backward(self.dh_run, slot=1, need_dw=True)
+            # actor gradients: through Q(s, a_pi) to the action only (Q parameters are skipped, sac.py:167)
+            for g in range(2):
+                kernels.value_head_bwd(hq_pi[g], self.q_w3[g], out["dq_pi"][g], self.dh_pi[g], self.scratch_w3,
+                                       self.scratch_b3, relu6=True)
+            dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True)
+            da = dxa[:, S:].contiguous()
+            dlogits, dloc, dlogstd, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True)
+            dlogits = dlogits.view(B, -1)
+            kernels.rsample_bwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"], da, dxs,
+                                dlogits, dloc, dlogstd)
+            st.g("actor/samples").copy_(dloc)
+            st.g("actor/samples_std").copy_(dlogstd)
+            torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+            kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+            torch.mm(dlogits, self.policy_weight.t(), out=self.dha[0])
+            self.actor_trunk.backward(self.dha, slot=0)
+            return out["loss3"]
+
+        def train_device(self, optimizer, state, action, reward, not_terminal, state_, noise=None):
+            loss3 = self.compute_gradients(state, action, reward, not_terminal, state_, noise)
+            optimizer.apply(self)
+            return loss3
+
+        def train(self, sess, optimizer, ops, state, action, reward, not_terminal, state_):
+            """reference sac.py:97-105 + actor_critic.py:382-404."""
+            args = [self._to_dev(a) for a in (state, action, reward, not_terminal, state_)]
+            args[0] = args[0].view(-1, self.S)
+            args[1] = args[1].view(-1, self.n_actions)
+            args[4] = args[4].view(-1, self.S)
+            loss3 = self.train_device(optimizer, *args).cpu().numpy()
+            loss = (float(loss3[0]), None, float(loss3[1]), float(loss3[2]))
+            extra = []
+            for o in (ops if hasattr(ops, "__len__") else ([ops] if ops else [])):
+                extra.append(self.global_step if o in ("global_step", "step") else (o() if callable(o) else None))
+            return loss, extra
+
+    return AbstractSACNetwork
+
+
+ParticleFilteringSACNetwork = sac_network_wrapper(ParticleFilteringA2CNetwork)

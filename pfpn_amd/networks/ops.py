@@ -110,7 +110,8 @@ class DenseStack:
             self.bn.append(store.declare("%s|fc%d/bias" % ("+".join(prefixes), i + first_name_index),
                                          (self.G, self.dims[i + 1])))
         self.first_name_index = first_name_index
-        self._B = None
+        self._bufs = {}
+        self._last = None
 
     def reference_names(self):
         """reference variable name -> (store name, group index)."""
@@ -126,58 +127,85 @@ class DenseStack:
             truncated_normal_(self.store[self.wn[i]], std, generator)
             self.store[self.bn[i]].zero_()
 
-    def _buffers(self, B):
-        if self._B == B:
-            return
+    def _buffers(self, B, slot):
+        key = (B, slot)
+        if key in self._bufs:
+            return self._bufs[key]
         dev = self.store.device
-        self.act = [torch.empty(self.G, B, self.dims[i + 1], dtype=torch.float32, device=dev) for i in range(self.L)]
-        self.dact = [torch.empty(self.G, B, self.dims[i + 1], dtype=torch.float32, device=dev) for i in range(self.L)]
-        self._B = B
+        act = [torch.empty(self.G, B, self.dims[i + 1], dtype=torch.float32, device=dev) for i in range(self.L)]
+        dact = [torch.empty(self.G, B, self.dims[i + 1], dtype=torch.float32, device=dev) for i in range(self.L)]
+        self._bufs[key] = {"act": act, "dact": dact, "x": None, "B": B}
+        return self._bufs[key]
 
-    def forward(self, x):
-        """x: [B, in] shared by all groups, or [G, B, in] per group.  Returns act[-1]  [G, B, H_last]."""
+    @property
+    def act(self):
+        return self._last["act"]
+
+    def forward(self, x, slot=0, params=None):
+        """x: [B, in] shared by all groups, or [G, B, in] per group.  Returns act[-1]  [G, B, H_last].
+        `slot` selects an activation set (a stack evaluated on several inputs in one step keeps one
+        set per input for the backward); `params` = another ParamStore with the same layout (SAC
+        target network)."""
         B = x.shape[-2]
-        self._buffers(B)
-        self.x = x
+        st = params if params is not None else self.store
+        buf = self._buffers(B, slot)
+        buf["x"] = x
+        self._last = buf
+        act = buf["act"]
         for i in range(self.L):
-            w, b, out = self.store[self.wn[i]], self.store[self.bn[i]], self.act[i]
+            w, b, out = st[self.wn[i]], st[self.bn[i]], act[i]
             if i == 0 and x.dim() == 2:
                 for g in range(self.G):
                     torch.mm(x, w[g], out=out[g])
             else:
-                src = x if i == 0 else self.act[i - 1]
+                src = x if i == 0 else act[i - 1]
                 torch.bmm(src, w, out=out)
             kernels.bias_act(out.view(self.G * B, -1), b, relu6=True, group_rows=B)
-        return self.act[-1]
+        return act[-1]
 
-    def backward(self, dlast, need_dx=False):
+    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output; masked in place.
-        Weight/bias gradients are written into the store's flat gradient buffer."""
-        B = self._B
+        Weight/bias gradients are written into the store's flat gradient buffer (need_dw)."""
+        if B is None:
+            B = dlast.shape[1]
+        buf = self._bufs[(B, slot)]
+        act, dact, x = buf["act"], buf["dact"], buf["x"]
         d = dlast
         dx = None
         for i in reversed(range(self.L)):
             w = self.store[self.wn[i]]
-            kernels.act_bwd_bias_grad(self.act[i].view(self.G * B, -1), d.view(self.G * B, -1),
-                                      self.store.g(self.bn[i]), relu6=True, group_rows=B)
-            gw = self.store.g(self.wn[i])
-            if i == 0 and self.x.dim() == 2:
-                xt = self.x.t()
-                for g in range(self.G):
-                    torch.mm(xt, d[g], out=gw[g])
+            if need_dw:
+                kernels.act_bwd_bias_grad(act[i].view(self.G * B, -1), d.view(self.G * B, -1),
+                                          self.store.g(self.bn[i]), relu6=True, group_rows=B)
+                gw = self.store.g(self.wn[i])
+            else:
+                kernels.act_bwd_bias_grad(act[i].view(self.G * B, -1), d.view(self.G * B, -1),
+                                          self._scratch_bias(i), relu6=True, group_rows=B)
+            if i == 0 and x.dim() == 2:
+                if need_dw:
+                    xt = x.t()
+                    for g in range(self.G):
+                        torch.mm(xt, d[g], out=gw[g])
                 if need_dx:
                     dx = torch.mm(d[0], w[0].t())
                     for g in range(1, self.G):
                         dx.addmm_(d[g], w[g].t())
             else:
-                src = self.x if i == 0 else self.act[i - 1]
-                torch.bmm(src.transpose(1, 2), d, out=gw)
+                src = x if i == 0 else act[i - 1]
+                if need_dw:
+                    torch.bmm(src.transpose(1, 2), d, out=gw)
                 if i > 0:
-                    torch.bmm(d, w.transpose(1, 2), out=self.dact[i - 1])
-                    d = self.dact[i - 1]
+                    torch.bmm(d, w.transpose(1, 2), out=dact[i - 1])
+                    d = dact[i - 1]
                 elif need_dx:
                     dx = torch.bmm(d, w.transpose(1, 2))
         return dx
+
+    def _scratch_bias(self, i):
+        k = ("sb", i)
+        if k not in self._bufs:
+            self._bufs[k] = torch.empty(self.G, self.dims[i + 1], dtype=torch.float32, device=self.store.device)
+        return self._bufs[k]
 
 
 def clip_by_value_with_gradient(x, l=-1.0, u=1.0):

@@ -180,3 +180,87 @@ def test_clip_by_global_norm(oracle):
     out2, _ = oracle.clip_by_global_norm(small, 1.0)
     for a, b in zip(out2, small):
         assert np.array_equal(a, b)                              # scale == 1 exactly
+
+
+def test_sac_grads_match_autograd(oracle):
+    """oracle.sac_grads (hand-written backward) vs float64 torch autograd of the same graph with the
+    reference's custom gradients (utils.py:165-183) and stop-gradients (sac.py:36-39, 123-126, 137-139)."""
+    rng = np.random.default_rng(5)
+    S, A, N, B = 11, 3, 35, 9
+    st = oracle.SACState(rng, S, A, N, hidden=(16, 8))
+    for k in st.P:                       # larger weights so every path carries signal
+        if k.endswith("weight"):
+            st.P[k] = (st.P[k] * 30).astype(np.float32)
+    st.PT = {k: (v * 1.1).astype(np.float32) for k, v in st.P.items() if k.startswith("critic")}
+    st.P["alpha/log_alpha"] = np.float32(-0.3)
+    batch = {"state": rng.normal(0, 1, (B, S)).astype(np.float32), "action": np.tanh(rng.normal(0, 1, (B, A))).astype(np.float32),
+             "reward": rng.random(B).astype(np.float32), "not_terminal": (rng.random(B) < 0.8).astype(np.float32),
+             "state_": rng.normal(0, 1, (B, S)).astype(np.float32)}
+    noise = {k: (-np.log(-np.log(rng.uniform(1e-9, 1, (B, A, N)))) if k.startswith("g") else rng.normal(0, 1, (B, A, N))).astype(np.float32)
+             for k in ("gumbel", "eps", "gumbel_", "eps_")}
+    (loss, pl, vl), G, aux = oracle.sac_grads(st.P, st.PT, st.norm_mean, st.norm_std, batch, noise, A, N)
+
+    T = lambda v, g=False: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=g)
+    P = {k: T(v, True) for k, v in st.P.items()}
+    PT = {k: T(v) for k, v in st.PT.items()}
+    relu6 = lambda t: torch.clamp(t, 0, 6)
+
+    def actor(x):
+        h = relu6(x @ P["actor/fc1/weight"] + P["actor/fc1/bias"])
+        h = relu6(h @ P["actor/fc2/weight"] + P["actor/fc2/bias"])
+        return (h @ P["actor/fc_policy/weight"] + P["actor/fc_policy/bias"]).view(-1, A, N)
+
+    def qnet(Pd, q, xa):
+        h = relu6(xa @ Pd["critic/%s/fc1/weight" % q] + Pd["critic/%s/fc1/bias" % q])
+        h = relu6(h @ Pd["critic/%s/fc2/weight" % q] + Pd["critic/%s/fc2/bias" % q])
+        return (h @ Pd["critic/%s/fc3/weight" % q] + Pd["critic/%s/fc3/bias" % q])[:, 0]
+
+    def rsample(logits, gum, eps):
+        w = torch.softmax(logits + T(gum), -1)
+        p = P["actor/samples"] + P["actor/samples_std"].exp() * T(eps)
+        k = (logits + T(gum)).argmax(-1)
+        m = torch.nn.functional.one_hot(k, N).double()
+        tp = torch.tanh(p)
+        tk = (m * tp).sum(-1, keepdim=True).detach()
+
+        class Mask(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, w, p, gap):
+                ctx.save_for_backward(gap)
+                return m * p
+            @staticmethod
+            def backward(ctx, dy):
+                return ctx.saved_tensors[0] * dy, m * dy, None
+        s_ = Mask.apply(w, p, ((tp - tk) / torch.clamp(1 - tk ** 2, min=1e-6)).detach()).sum(-1)
+        a = Mask.apply(w, tp, (tp - tk).detach()).sum(-1)
+        return a, s_
+
+    def logprob(logits, s_):
+        lw = torch.log_softmax(logits, -1)
+        comp = torch.distributions.Normal(P["actor/samples"], P["actor/samples_std"].exp()).log_prob(s_.unsqueeze(-1))
+        return (torch.logsumexp(lw + comp, -1) - torch.log1p(-torch.tanh(s_) ** 2)).sum(-1)
+
+    x, x2 = T(batch["state"]).clamp(-5, 5), T(batch["state_"]).clamp(-5, 5)     # mean 0, std 1 normaliser
+    alpha = P["alpha/log_alpha"].exp().detach()
+    logits = actor(x)
+    a, s_ = rsample(logits, noise["gumbel"], noise["eps"])
+    logp = logprob(logits, s_)
+    q1p, q2p = qnet(P, "q1", torch.cat([x, a], -1)), qnet(P, "q2", torch.cat([x, a], -1))
+    xh = torch.cat([x, T(batch["action"])], -1)
+    q1r, q2r = qnet(P, "q1", xh), qnet(P, "q2", xh)
+    with torch.no_grad():
+        l2 = actor(x2)
+        a2, s2 = rsample(l2, noise["gumbel_"], noise["eps_"])
+        vf2 = torch.minimum(qnet(PT, "q1", torch.cat([x2, a2], -1)), qnet(PT, "q2", torch.cat([x2, a2], -1))) - alpha * logprob(l2, s2)
+        qt = T(batch["reward"]) + 0.95 * T(batch["not_terminal"]) * vf2
+    value_loss = 0.5 * ((qt - q1r) ** 2 + (qt - q2r) ** 2).mean()
+    policy_loss = (alpha * logp - torch.minimum(q1p, q2p) - P["alpha/log_alpha"] * (logp - A).detach()).mean()
+    np.testing.assert_allclose([pl, vl], [policy_loss.item(), value_loss.item()], rtol=2e-4, atol=1e-5)
+    crit = [k for k in P if k.startswith("critic")]
+    act = [k for k in P if not k.startswith("critic")]
+    gc = torch.autograd.grad(value_loss, [P[k] for k in crit], retain_graph=True, allow_unused=True)
+    ga = torch.autograd.grad(policy_loss, [P[k] for k in act], allow_unused=True)
+    for k, g in list(zip(crit, gc)) + list(zip(act, ga)):
+        ref = g.numpy()
+        got = np.asarray(G[k]).reshape(ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * (np.abs(ref).max() + 1e-12), err_msg=k)
