@@ -61,14 +61,21 @@ class SyncReplicasApplier(object):
             if W == 1:
                 fused_scale = self.norm_scale          # folded into the Adam kernel
         if W > 1:
-            net.pack_local_stats(st.tail)
-            dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+            self.reduce(net)
         for g in self.groups:
             sl = slice(g["off"], g["off"] + g["len"])
             kernels.tf_adam(st.flat[sl], st.grad[sl], st.m[sl], st.v[sl], g["beta_pow"], g["lr"], self.beta1,
                             self.beta2, self.epsilon, advance=True, norm_scale=fused_scale, grad_mul=1.0 / W)
         net.unpack_synced_stats(st.tail, 1.0 / W)
         net.step_dev.add_(1.0)
+
+    def reduce(self, net):
+        """The exchange step: ONE all-reduce (sum) of the flat bucket [clipped grads | local statistics]
+        (reference sync_model.py:92-95 accumulators 0-13 for the gradients, 14-17 for push_weights).
+        Plain torch ops only, so the same code runs over gloo on CPU tensors in the tests."""
+        st = net.store
+        net.pack_local_stats(st.tail)
+        dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM, group=self.pg)
 
     # -- host part -----------------------------------------------------------------------------------
     def apply_host(self, net):
@@ -99,6 +106,9 @@ class SyncWorker(AbstractDistributedWorker):
         self.local_net = self.global_net
         if not self.global_net.trainable:
             return
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # replicas start identical (the reference's initial pull_weights, distributed_model.py:195-197)
+            dist.broadcast(self.global_net.store.flat, src=0)
         self.opt_op = self.build_optimizer(self.global_net)
 
 

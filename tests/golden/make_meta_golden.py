@@ -214,6 +214,10 @@ def main():
         info["resample_ops"] = rs[:600]
         info["cond_ops"] = [(n["name"], n["op"]) for n in nodes if n["name"].startswith("cond/")
                             and n["op"] not in ("Const", "Identity", "Shape", "StridedSlice", "Pack", "Switch", "Merge")]
+        info["logprob_ops"] = [(n["name"], n["op"], n["input"]) for n in nodes
+                               if n["name"].startswith(("global_net/policy_loss/pi_target/",
+                                                        "global_net/actor/Normal/prob_1/"))
+                               and n["op"] not in ("Const", "Shape", "StridedSlice", "Pack")]
         info["multinomial"] = [
             {"name": n["name"], "seed": n["attr"].get("seed", {}).get("i"), "seed2": n["attr"].get("seed2", {}).get("i"),
              "output_dtype": n["attr"].get("output_dtype", {}).get("type")}

@@ -1,0 +1,163 @@
+"""CPU: host-side logic of the reference-shaped runtime -- replay Buffer, minibatch scheduling
+(flat_train), PPO worker bookkeeping (bootstrap value, GAE segments, buffer_stamp), SAC worker
+(not_terminal, warm-up), launcher flags.  The network is a duck-typed stub (the real one needs a GPU)."""
+import numpy as np
+import pytest
+
+from pfpn_amd.envs import SyntheticDeepMimicEnv
+from pfpn_amd.models import DPPOWorker, SyncSACWorker
+from pfpn_amd.models.workers.ddpg import Buffer
+
+
+class StubNet(object):
+    """records what the workers feed; GAE via the oracle (checker) so numbers are the reference's."""
+    def __init__(self, oracle, trainable=True, sac=False):
+        self.trainable, self.sac, self.oracle = trainable, sac, oracle
+        self.init_ops, self.train_ops = [], []
+        self.global_step = 0
+        self.trained = []
+        self.rng = np.random.default_rng(0)
+        self.evaluated = []
+
+    def init(self):
+        pass
+
+    def reset_running_state(self):
+        pass
+
+    def run(self, sess, state, ops=None):
+        a = self.rng.uniform(-1.5, 1.5, 36).astype(np.float32)
+        return [a] if self.sac else [a, float(self.rng.normal()), float(np.sum(state[:3]))]
+
+    def evaluate(self, sess, state):
+        self.evaluated.append(np.asarray(state).copy())
+        return 7.0
+
+    def generalized_advantage_estimate(self, reward, value):
+        return list(self.oracle.gae(reward, value, 0.95, 0.95 * 0.95))
+
+    def train(self, sess, optimizer, ops, *args):
+        self.trained.append([np.asarray(a).copy() for a in args])
+        self.global_step += 1
+        return (0.1, None, 0.05, 0.05), [self.global_step]
+
+
+def make_worker(cls, net, **opts):
+    w = cls(_env_wrapper=lambda name, render: SyntheticDeepMimicEnv(episode_length=50, seed=3),
+            _network_wrapper=lambda env, trainable: net, _seed=5, n_workers=1, **opts)
+    w.build_optimizer = lambda n: "opt"
+    w.init()
+    return w
+
+
+def test_ring_buffer():
+    b = Buffer(3)
+    for i in range(5):
+        b.append(i)
+    assert len(b) == 3 and sorted(b.data) == [2, 3, 4] and b.pointer == 2
+    b.clear()
+    assert len(b) == 0
+
+
+def test_ppo_worker_rollout_and_minibatches(oracle):
+    net = StubNet(oracle)
+    w = make_worker(DPPOWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=1, batch_size=32,
+                    unroll_length=128)
+    w.work(None, max_iterations=8)
+    # 128 samples -> 4 minibatches of 32 per round, two rounds
+    assert len(net.trained) == 8 and w.global_step == 8
+    state, action, value, log_prob, adv = net.trained[0]
+    assert state.shape == (32, 197) and action.shape == (32, 36) and adv.shape == (32,) and adv.dtype == np.float32
+    # the unclipped action is stored (distributed_model.py:264-290)
+    assert np.abs(np.concatenate([t[1] for t in net.trained])).max() > 1.0
+    # one round's minibatches are a permutation of the 128 samples (no duplicates)
+    rows = np.concatenate([t[0] for t in net.trained[:4]])
+    assert len({r.tobytes() for r in rows}) == 128
+    # episodes are 50 steps with a time-limit truncation -> bootstrap by evaluate(last_state), not 0
+    assert len(net.evaluated) >= 2
+
+
+class RecordingEnv(SyntheticDeepMimicEnv):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.log = []          # (reward, terminal, truncated)
+
+    def step(self, a):
+        s, r, t, info = super().step(a)
+        self.log.append((r, t, bool(info.get("TimeLimit.truncated", False))))
+        return s, r, t, info
+
+
+def test_ppo_worker_gae_segments_match_reference_loop(oracle):
+    """advantages = per-segment GAE over [buffer_stamp:] with bootstrap 0.0 on a true terminal and
+    V(last_state) on a time-limit truncation or unroll boundary (workers/ppo.py:50-73)."""
+    net = StubNet(oracle)
+    env = RecordingEnv(episode_length=50, seed=3)
+    w = DPPOWorker(_env_wrapper=lambda name, render: env, _network_wrapper=lambda e, t: net, _seed=5, n_workers=1,
+                   lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=1, batch_size=None, unroll_length=120)
+    w.build_optimizer = lambda n: "opt"
+    w.init()
+    w.np_random.shuffle = lambda ids: None          # keep rollout order so rows can be matched
+    w.work(None, max_iterations=1)
+    state, action, value, log_prob, adv = net.trained[0]
+    assert len(adv) == 120 and len(env.log) == 120
+    expect, start = [], 0
+    for t, (r, term, trunc) in enumerate(env.log):
+        end_of_unroll = (t == 119)
+        if term or end_of_unroll:
+            boot = 0.0 if (term and not trunc) else 7.0
+            rs = [e[0] for e in env.log[start:t + 1]]
+            vs = list(value[start:t + 1]) + [boot]
+            expect.extend(oracle.gae(rs, vs, 0.95, 0.95 * 0.95))
+            start = t + 1
+    np.testing.assert_array_equal(adv, np.asarray(expect, np.float32))
+
+
+def test_sac_worker_not_terminal_and_replay(oracle):
+    net = StubNet(oracle, sac=True)
+    w = make_worker(SyncSACWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=1, opt_epochs=None, batch_size=16,
+                    unroll_length=1, buffer_capacity=1000, observations=0)
+    w.work(None, max_iterations=40)
+    assert w.separate_optimizer is True
+    assert len(net.trained) == 40
+    s, a, r, nt, s2 = net.trained[-1]
+    assert s.shape == (16, 197) and s2.shape == (16, 197) and nt.shape == (16,)
+    # time-limit truncation keeps not_terminal = 1 (ddpg.py:72)
+    allnt = np.concatenate([t[3] for t in net.trained])
+    assert set(np.unique(allnt)) <= {0.0, 1.0} and allnt.mean() > 0.9
+    # no training until the buffer holds batch_size samples
+    assert w.total_samples >= 16 + 40 - 1
+
+
+def test_flat_train_epochs(oracle):
+    net = StubNet(oracle)
+    w = make_worker(DPPOWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=3, batch_size=20,
+                    unroll_length=50)
+    w.work(None, max_iterations=9)
+    # 50 samples / batch 20 -> 3 minibatches (20,20,10) x 3 epochs
+    assert [len(t[0]) for t in net.trained[:9]] == [20, 20, 10] * 3
+
+
+def test_launcher_flags_and_names():
+    from pfpn_amd import main, models, networks
+    st = main.parse(["--env", "DeepMimicWalk-v0", "--seed", "34114", "--setting",
+                     "settings.deepmimic.deepmimic_dppo_pfpn", "--particles", "35", "--train"])
+    assert st.network == "ParticleFilteringClipPPONetwork" and st.worker == "DPPOWorker" and st.model == "SyncModel"
+    assert st.network_opts["particles"] == 35 and st.train
+    assert st.checkpoint_dir == "ckpt_DeepMimicWalk-v0/deepmimic_dppo_pfpn_particle35/34114"   # main.py:52
+    for name in ("ParticleFilteringClipPPONetwork", "ParticleFilteringSACNetwork", "ParticleFilteringA2CNetwork"):
+        assert hasattr(networks, name)
+    for name in ("SyncModel", "DPPOWorker", "SyncSACWorker"):
+        assert hasattr(models, name)
+
+
+def test_out_of_scope_options_raise():
+    from pfpn_amd.networks import ParticleFilteringClipPPONetwork
+    base = dict(trainable=True, state_shape=[5], action_shape=[2], action_lower_bound=[-1, -1],
+                action_upper_bound=[1, 1], common_net_shape=[], critic_net_shape=[8], actor_net_shape=[8])
+    with pytest.raises(NotImplementedError):
+        ParticleFilteringClipPPONetwork(normalize_value=True, **base)
+    with pytest.raises(NotImplementedError):
+        ParticleFilteringClipPPONetwork(resample=3, **base)
+    with pytest.raises(NotImplementedError):
+        ParticleFilteringClipPPONetwork(**dict(base, common_net_shape=[16]))
