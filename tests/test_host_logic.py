@@ -97,7 +97,10 @@ def test_ppo_worker_gae_segments_match_reference_loop(oracle):
                    lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=1, batch_size=None, unroll_length=120)
     w.build_optimizer = lambda n: "opt"
     w.init()
-    w.np_random.shuffle = lambda ids: None          # keep rollout order so rows can be matched
+    class NoShuffle(object):                         # keep rollout order so rows can be matched
+        def shuffle(self, ids):
+            pass
+    w.np_random = NoShuffle()
     w.work(None, max_iterations=1)
     state, action, value, log_prob, adv = net.trained[0]
     assert len(adv) == 120 and len(env.log) == 120
