@@ -36,8 +36,6 @@ extern "C" {
 
 /* library / ABI version, and a cheap "is the device code loadable" probe (no compute). */
 int pfpn_abi_version(void);
-/* diagnostic only: phase-skip mask for timing ablations of the packed mixture kernel (0 = normal). */
-void pfpn_debug_set(int mask);
 
 /* ---- mixture log-prob (K1/K2) ------------------------------------------------------------ */
 /* scratch needed by the mixture entry points for this shape */

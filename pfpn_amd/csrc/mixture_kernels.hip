@@ -19,6 +19,7 @@
 // Reductions over the batch (dloc, dlogstd, loss sums) go through per-block partial slabs and
 // a fixed-order finalize kernel: results are bitwise reproducible (no float atomics).
 #include "pfpn_common.h"
+#include <stdlib.h>
 
 namespace pfpn {
 
@@ -38,14 +39,47 @@ struct PpoArgs {
 };
 
 constexpr int PACK_G = 4;                            // lanes per (row, action-dim) segment
-constexpr int PACK_BLOCK = 1024;                     // 16 waves share one tile
-constexpr int PACK_SEGS = PACK_BLOCK / PACK_G;       // 256 segments per tile
-constexpr int PACK_MAXV = 3;                         // float4 per thread per tile
-constexpr int PACK_TILE_BYTES = PACK_BLOCK * PACK_MAXV * 16;   // 48 KiB of logits per tile
+constexpr int PACK_BLOCK = 1024;                     // launch bound; actual block = waves*64
+constexpr int PACK_WSEG = 64 / PACK_G;               // 16 segments per wave
 
 // ---------------------------------------------------------------------------------------
-// packed path
+// packed path ("wave-sliced")
+//
+// A tile is Rt whole batch rows = Rt*A segments, laid out in LDS exactly as in HBM.  Wave w owns
+// the 16 consecutive segments [16w, 16w+16) of the tile -- a contiguous 64*N-byte slice that the
+// wave itself loads (float4, prefetched one tile ahead into registers), transforms in place and
+// stores back: NO block barrier in steady state.  4 lanes share a segment (particles g, g+4, ...),
+// their softmax/mixture reductions are two DPP shuffles.  The particle bank of a lane's (a, n) set
+// is constant across tiles (same slot -> same action dim), so it lives in REGISTERS.
+// The only cross-wave dependency is the row log-prob (a row's A segments span 2-4 waves): waves
+// publish per-segment log p to LDS and bump a per-row arrival counter (monotonic, never reset);
+// a wave waits only for the rows it touches.
 // ---------------------------------------------------------------------------------------
+// Prefetch registers as NAMED float4s (an indexed array that is conditionally written across loop
+// iterations gets demoted to scratch by hipcc).
+struct Pref { float4 v0, v1, v2, v3; };
+
+template <int NV>
+__device__ __forceinline__ void fetch_slice(Pref& pf, const float* __restrict__ logits, int row0, int nfl,
+                                            int slice, int AN, int soff, int lane) {
+    const int nv = max(0, min(nfl, slice)) >> 2;
+    const int last = nv > 0 ? nv - 1 : 0;
+    const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN + (size_t)soff);
+    pf.v0 = g4[min(lane, last)];
+    if (NV > 1) pf.v1 = g4[min(lane + 64, last)];
+    if (NV > 2) pf.v2 = g4[min(lane + 128, last)];
+    if (NV > 3) pf.v3 = g4[min(lane + 192, last)];
+}
+
+template <int NV>
+__device__ __forceinline__ void put_slice(const Pref& pf, float* slice, int nv, int lane) {
+    float4* s4 = reinterpret_cast<float4*>(slice);
+    if (lane < nv) s4[lane] = pf.v0;
+    if (NV > 1 && lane + 64 < nv) s4[lane + 64] = pf.v1;
+    if (NV > 2 && lane + 128 < nv) s4[lane + 128] = pf.v2;
+    if (NV > 3 && lane + 192 < nv) s4[lane + 192] = pf.v3;
+}
+
 template <int N, int MODE>
 __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     const float* __restrict__ logits, const float* __restrict__ x,
@@ -57,41 +91,48 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
     float* __restrict__ dx_out,              // [B,A] optional (BWD)
     float* __restrict__ partial,             // [grid][2*A*N + 4] (BWD, PPO)
-    PpoArgs ppo, int dbg)
+    PpoArgs ppo)
 {
     constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
+    constexpr int SLICE = PACK_WSEG * N;                  // floats per wave slice (16 segments)
+    constexpr int NV = (SLICE / 4 + 63) / 64;             // float4 per lane per slice (3 for N=35)
     extern __shared__ float4 smem4[];
     const int AN = A * N;
-    const int tile_floats = R * AN;
-    const int tile_f4 = (tile_floats + 3) >> 2;
-    float* tile = reinterpret_cast<float*>(smem4);
-    float4* bank = smem4 + tile_f4;                       // [AN] {loc, isc2, cterm2, isc*c}  (see below)
-    float* segbuf = reinterpret_cast<float*>(bank + AN);  // [R*A] per-segment log p
-    float* rowbuf = segbuf + R * A;                       // [R]   per-row dlogp
-    float* lossbuf = rowbuf + R;                          // [2R]
+    const int nseg = R * A;                               // segments per full tile
+    const int nwaves = blockDim.x >> 6;
+    float* tile = reinterpret_cast<float*>(smem4);        // [nwaves*SLICE] >= R*AN
+    float* segbuf = tile + nwaves * SLICE;                // [2][nseg]  per-segment log p (double buffered)
+    int* cnt = reinterpret_cast<int*>(segbuf + 2 * nseg); // [R] row arrival counters
+    float* lossbuf = reinterpret_cast<float*>(cnt + R);   // [2*nwaves]
 
     const int t = threadIdx.x;
-    // particle bank -> LDS.  scale = exp(logstd), cterm = 0.5log(2pi) + log(scale) as the reference
-    // graph computes them; then everything is pre-scaled to base 2 so the per-particle work is
-    //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - cterm2)      (3 VALU + 1 transcendental)
-    // with isc2 = sqrt(0.5*log2 e)/scale and cterm2 = cterm*log2 e; the true z = c*z', c = sqrt(2 ln 2).
-    for (int i = t; i < AN; i += PACK_BLOCK) {
-        const float sc = expf(logstd[i]);
-        const float isc = 1.0f / sc;
-        bank[i] = make_float4(loc[i], isc * PFPN_SQRT_HALF_LOG2E, (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E,
-                              isc * PFPN_SQRT_2LN2);
-    }
-
-    const int sidx = t >> 2;                // segment slot in the tile
-    const int g = t & 3;                    // lane in the segment: particles g, g+4, g+8, ...
-    const int nseg = R * A;                 // <= PACK_SEGS
-    const bool seg_thread = sidx < nseg;
-    const int r = seg_thread ? sidx / A : 0;
-    const int a = seg_thread ? sidx - r * A : 0;
-    const float4* bk = bank + a * N + g;    // particle g+4i at bk[4i]
-    float* seg = tile + sidx * N + g;       // (r*A + a)*N == sidx*N
+    const int wave = t >> 6, lane = t & 63;
+    const int q = lane >> 2, g = lane & 3;
+    const int sidx = wave * PACK_WSEG + q;                // segment slot in the tile
+    const bool seg_lane = sidx < nseg;
+    const int r = seg_lane ? sidx / A : 0;
+    const int a = seg_lane ? sidx - r * A : 0;
+    float* slice = tile + wave * SLICE;
+    float* seg = slice + q * N + g;                       // == tile + sidx*N + g
     const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
+    // rows this wave touches
+    const int s_lo = wave * PACK_WSEG, s_hi = min(nseg, s_lo + PACK_WSEG) - 1;     // inclusive
+    const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
 
+    for (int i = t; i < R; i += blockDim.x) cnt[i] = 0;
+
+    // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
+    // as the reference graph computes them, pre-scaled to base 2:
+    //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale, ct2 = cterm*log2 e
+    float b_loc[NP], b_isc[NP], b_ct[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int n = min(g + PACK_G * i, N - 1);
+        const float sc = expf(logstd[a * N + n]);
+        b_loc[i] = loc[a * N + n];
+        b_isc[i] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
+        b_ct[i] = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+    }
     float acc_loc[NP], acc_ls[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) { acc_loc[i] = 0.f; acc_ls[i] = 0.f; }
@@ -100,56 +141,37 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
 
     const int ntiles = (B + R - 1) / R;
-    const int wave = t >> 6, lane = t & 63;
-    // Software pipeline: the NEXT tile's logits are fetched into registers (3 float4 per thread)
-    // while the current tile is processed, so the HBM latency hides behind the compute phases.
-    float4 buf[PACK_MAXV];
-    auto fetch = [&](int tileid) {
-        const int row0 = tileid * R;
-        const int nv = (min(R, B - row0) * AN) >> 2;
-        const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN);
-#pragma unroll
-        for (int j = 0; j < PACK_MAXV; ++j)        // clamped index: all loads unconditional
-            buf[j] = g4[min(t + j * PACK_BLOCK, nv - 1)];
-    };
-    if (vec_ok && (int)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (int tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
+    static_assert(NV <= 4, "slice prefetch holds at most 4 float4 per lane");
+    Pref pf;
+    pf.v0 = pf.v1 = pf.v2 = pf.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // my slice of tile `tid_` -> registers (clamped indices: every load is unconditional)
+#define PFPN_FETCH_SLICE(tid_)                                                                           \
+    fetch_slice<NV>(pf, logits, (tid_) * R, min(R, B - (tid_) * R) * AN - s_lo * N, SLICE, AN, s_lo * N, lane)
+    if (vec_ok && (int)blockIdx.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE((int)blockIdx.x);
+    __syncthreads();                                       // cnt zeroed
+
+    int it = 0;
+    for (int tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x, ++it) {
         const int row0 = tileid * R;
         const int rows = min(R, B - row0);
-        const int nfl = rows * AN;
-        __syncthreads();   // previous tile's LDS reads (store-out) are done; bank is written
+        const int nact = rows * A;                         // active segments in this tile
+        const int nfl = max(0, min(nact * N - s_lo * N, SLICE));   // valid floats in my slice
+        float* sb = segbuf + (it & 1) * nseg;
         if (vec_ok) {
-            const int nv = nfl >> 2;            // AN % 4 == 0 guaranteed by vec_ok
-#pragma unroll
-            for (int j = 0; j < PACK_MAXV; ++j) {
-                const int i = t + j * PACK_BLOCK;
-                if (i < nv) reinterpret_cast<float4*>(tile)[i] = buf[j];
-            }
-            if (tileid + (int)gridDim.x < ntiles) fetch(tileid + gridDim.x);
+            put_slice<NV>(pf, slice, nfl >> 2, lane);
+            if (tileid + (int)gridDim.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE(tileid + (int)gridDim.x);
         } else {
-            const float* gsrc = logits + (size_t)row0 * AN;
-            for (int i = t; i < nfl; i += PACK_BLOCK) tile[i] = gsrc[i];
+            const float* gsrc = logits + (size_t)row0 * AN + (size_t)s_lo * N;
+            for (int i = lane; i < nfl; i += 64) slice[i] = gsrc[i];
         }
-        const bool active = seg_thread && r < rows;
+        const bool active = seg_lane && sidx < nact;
         float xv = 0.f;
         if (active) xv = x[(size_t)row0 * A + sidx];
-        // row scalars for the row stage: wave w owns row w of the tile; fetched now, used later
-        float r_dlogp = 0.f, r_adv = 0.f, r_lpold = 0.f, r_val = 0.f, r_vold = 0.f;
-        if (wave < rows && lane == 0) {
-            const int b = row0 + wave;
-            if (MODE == MODE_BWD) r_dlogp = dlogp_in[b];
-            if (MODE == MODE_PPO) {
-                r_adv = ppo.adv[b]; r_lpold = ppo.logp_old[b]; r_val = ppo.value[b]; r_vold = ppo.value_old[b];
-            }
-        }
-        __syncthreads();
 
-        // ---- forward on my quarter of the segment ---------------------------------------
-        // exp(l - max) goes back to the LDS slot (the logits are not needed again), e*phi
-        // stays in registers for the backward.
+        // ---- forward on my quarter of the segment (wave-private LDS slice: no barrier) -------
         float ephi[NP];
         float inv_sum = 0.f, p = 0.f;
-        if (active && !(dbg & 1)) {
+        if (active) {
             float mx = seg[0];
 #pragma unroll
             for (int i = 1; i < NP; ++i)
@@ -162,11 +184,10 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
             for (int i = 0; i < NP; ++i) {
                 ephi[i] = 0.f;
                 if (i < NP - 1 || last_ok) {
-                    const float4 k4 = bk[PACK_G * i];
                     // softmax numerator: raw v_exp_f32 (tiny values may flush; they carry no mass)
                     const float en = __builtin_amdgcn_exp2f(fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl));
-                    const float zq = (xv - k4.x) * k4.y;
-                    const float ph = exp2f(fmaf(-zq, zq, -k4.z));      // denormal-correct
+                    const float zq = (xv - b_loc[i]) * b_isc[i];
+                    const float ph = exp2f(fmaf(-zq, zq, -b_ct[i]));      // denormal-correct
                     if (MODE != MODE_FWD) seg[PACK_G * i] = en;
                     ephi[i] = en * ph;
                     sum += en;
@@ -183,65 +204,73 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                 float lp = logf(p);
                 if (tanh_mode) lp -= tanh_log_det(xv);
                 if (pmix_out) pmix_out[(size_t)row0 * A + sidx] = p;
-                segbuf[sidx] = lp;
+                sb[sidx] = lp;
             }
         }
-        __syncthreads();
 
-        // ---- row stage: wave w reduces the A segment log-probs of rows w, w+16, ... (shuffle tree,
-        //      fixed order) and its lane 0 runs the PPO head (first row: prefetched scalars)
-        for (int rw = wave; rw < rows && !(dbg & 8); rw += PACK_BLOCK / 64) {
-            float sacc = 0.f;
-            for (int i = lane; i < A; i += 64) sacc += segbuf[rw * A + i];
-            const float s = wave_sum(sacc);
-            if (lane == 0) {
-                const int b = row0 + rw;
-                if (rw != wave) {           // only when a tile holds more than 16 rows (small A)
-                    if (MODE == MODE_BWD) r_dlogp = dlogp_in[b];
-                    if (MODE == MODE_PPO) {
-                        r_adv = ppo.adv[b]; r_lpold = ppo.logp_old[b]; r_val = ppo.value[b]; r_vold = ppo.value_old[b];
-                    }
-                }
-                if (MODE != MODE_BWD) logp_out[b] = s;
-                if (MODE == MODE_BWD) rowbuf[rw] = r_dlogp;
+        // ---- row stage ------------------------------------------------------------------------
+        float my_g = 0.f;                                   // d loss / d logp of my row
+        if (MODE == MODE_BWD) {
+            if (active) my_g = dlogp_in[row0 + r];
+        } else {
+            // publish: my segments of each touched row have arrived
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const int rr_l = r_lo + lane;
+            if (rr_l <= r_hi && rr_l < rows) {
+                const int n_r = min(min((rr_l + 1) * A, s_hi + 1), nact) - max(rr_l * A, s_lo);
+                if (n_r > 0) atomicAdd(&cnt[rr_l], n_r);
+                const int target = A * (it + 1);
+                while (__hip_atomic_load(&cnt[rr_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int rr = r_lo; rr <= r_hi && rr < rows; ++rr) {
+                float sacc = 0.f;
+                for (int i = lane; i < A; i += 64) sacc += sb[rr * A + i];
+                const float s = wave_sum(sacc);                       // same value in every touching wave
+                const int b = row0 + rr;
+                const bool owner = (rr * A) / PACK_WSEG == wave;      // wave holding the row's first segment
+                float gval = 0.f;
                 if (MODE == MODE_PPO) {
-                    const float nadv = (r_adv - adv_mean) * adv_rstd;
-                    const float ratio = expf(s - r_lpold);
+                    const float adv = ppo.adv[b];
+                    const float nadv = (adv - adv_mean) * adv_rstd;
+                    const float ratio = expf(s - ppo.logp_old[b]);
                     const float sur = ratio * nadv;
                     const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
                     const float csur = cr * nadv;
-                    pol_sum += fminf(sur, csur);
                     // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
                     // clip_by_value passes where lo <= ratio <= hi.
                     const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
-                    rowbuf[rw] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-                    const float dvv = r_val - (r_adv + r_vold);
-                    val_sum += dvv * dvv;
-                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
-                    if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
+                    gval = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+                    if (owner && lane == 0) {
+                        pol_sum += fminf(sur, csur);
+                        const float dvv = ppo.value[b] - (adv + ppo.value_old[b]);
+                        val_sum += dvv * dvv;
+                        ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                        if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
+                    }
                 }
+                if (owner && lane == 0) logp_out[b] = s;
+                if (r == rr) my_g = gval;
             }
         }
         if (MODE == MODE_FWD) continue;
-        __syncthreads();
 
-        // ---- backward on my quarter (dlogits overwrite the LDS slot) ---------------------
-        if (active && !(dbg & 2)) {
-            const float gup = rowbuf[r];
-            const float q = guard_finite(gup / p);
-            const float qs = q * inv_sum;
+        // ---- backward on my quarter (dlogits overwrite the LDS slot) ---------------------------
+        if (active) {
+            const float q_ = guard_finite(my_g / p);
+            const float qs = q_ * inv_sum;
             const float qp = qs * p;
             float dxa = 0.f;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 if (i < NP - 1 || last_ok) {
-                    const float4 k4 = bk[PACK_G * i];
                     const float tt = qs * ephi[i];                          // q * w_n * phi_n
                     seg[PACK_G * i] = fmaf(-seg[PACK_G * i], qp, tt);      // q * w_n * (phi_n - p)
-                    const float zq = (xv - k4.x) * k4.y;                    // z / c
+                    const float zq = (xv - b_loc[i]) * b_isc[i];            // z / c
                     acc_loc[i] = fmaf(tt, zq, acc_loc[i]);                  // scaled by isc*c in the tail
                     acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);   // tt*(z^2 - 1)
-                    if (dx_out) dxa = fmaf(tt * zq, k4.w, dxa);
+                    if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);        // isc*c = isc2*2ln2
                 }
             }
             if (dx_out) {
@@ -249,51 +278,50 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                 dxa += __shfl_xor(dxa, 2, 64);
                 if (g == 0) {
                     float d = -dxa;
-                    if (tanh_mode) d += gup * 2.f * tanhf(xv);
+                    if (tanh_mode) d += my_g * 2.f * tanhf(xv);
                     dx_out[(size_t)row0 * A + sidx] = d;
                 }
             }
         }
-        __syncthreads();
-        float* gdst = dlogits + (size_t)row0 * AN;
-        if (dbg & 4) continue;
+        // my slice -> HBM (same wave wrote it: in-order LDS, no barrier)
+        float* gdst = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;
         if (vec_ok) {
             const int nv = nfl >> 2;
 #pragma unroll
-            for (int j = 0; j < PACK_MAXV; ++j) {
-                const int i = t + j * PACK_BLOCK;
-                if (i < nv) reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(tile)[i];
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + 64 * j;
+                if (i < nv) reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(slice)[i];
             }
         } else {
-            for (int i = t; i < nfl; i += PACK_BLOCK) gdst[i] = tile[i];
+            for (int i = lane; i < nfl; i += 64) gdst[i] = slice[i];
         }
     }
 
     if (MODE == MODE_FWD) return;
     // ---- block partials: dloc / dlogstd summed over the R segments that share an action dim,
-    //      in row order; loss sums in row-slot order.  Slab layout [2*AN + 4] per block.
+    //      in row order; loss sums in wave order.  Slab layout [2*AN + 4] per block.
     float* slab = partial + (size_t)blockIdx.x * (2 * AN + 4);
     for (int which = 0; which < 2; ++which) {
         __syncthreads();
-        if (seg_thread) {
+        if (seg_lane) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
-                if (i < NP - 1 || last_ok) seg[PACK_G * i] = which ? acc_ls[i] : acc_loc[i];
+                if (i < NP - 1 || last_ok)
+                    seg[PACK_G * i] = which ? acc_ls[i] : acc_loc[i] * (b_isc[i] * PFPN_2LN2);   // dloc *= c/scale
         }
         __syncthreads();
-        for (int i = t; i < AN; i += PACK_BLOCK) {
+        for (int i = t; i < AN; i += blockDim.x) {
             float s = 0.f;
             for (int rr = 0; rr < R; ++rr) s += tile[rr * AN + i];
-            slab[which * AN + i] = which ? s : s * bank[i].w;      // dloc: sum tt*z' times c/scale
+            slab[which * AN + i] = s;
         }
     }
     if (MODE == MODE_PPO) {
-        const int nwr = min(R, PACK_BLOCK / 64);          // waves that own rows
-        if (wave < nwr && lane == 0) { lossbuf[wave] = pol_sum; lossbuf[nwr + wave] = val_sum; }
+        if (lane == 0) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
         __syncthreads();
         if (t == 0) {
             float ps = 0.f, vs = 0.f;
-            for (int i = 0; i < nwr; ++i) { ps += lossbuf[i]; vs += lossbuf[nwr + i]; }
+            for (int i = 0; i < nwaves; ++i) { ps += lossbuf[i]; vs += lossbuf[nwaves + i]; }
             slab[2 * AN + 0] = ps;
             slab[2 * AN + 1] = vs;
         }
@@ -390,6 +418,153 @@ __global__ __launch_bounds__(256) void k_mix_wave(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// wide path (N % 4 == 0, N >= 64; the 128 x 256 stress shape): one wavefront per segment, a lane
+// owns M float4s (4 consecutive particles each): a segment is fetched as whole 1-KiB coalesced
+// wave-loads straight into registers (no LDS).  Wave (a, c) keeps its action dim, so the particle
+// bank and the dloc/dlogstd accumulators of its 4*M particles stay in registers while it walks rows
+// b = c, c+C, ...; U rows are in flight per wave (U float4 loads per lane outstanding) to cover the
+// HBM latency.  Reductions over a segment are wave shuffles.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int M, int MODE>
+__global__ __launch_bounds__(256) void k_mix_wide(
+    const float* __restrict__ logits, const float* __restrict__ x,
+    const float* __restrict__ loc, const float* __restrict__ logstd,
+    const float* __restrict__ dlogp_in,
+    int B, int A, int N, int C, int tanh_mode,
+    float* __restrict__ lpseg_out,           // [B,A] per-segment log p (FWD)
+    float* __restrict__ pmix_out,            // [B,A] optional
+    float* __restrict__ dlogits,             // BWD
+    float* __restrict__ dx_out,              // BWD optional
+    float* __restrict__ partial)             // [C][2*A*N]  (BWD)
+{
+    constexpr int U = 2;                                    // rows in flight per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wave >= A * C) return;
+    const int a = wave % A;                                 // neighbouring waves -> neighbouring dims
+    const int c = wave / A;
+    const int AN = A * N;
+    const int nq = N >> 2;                                  // float4s per segment
+    bool ok[M];
+    float4 b_loc[M], b_isc[M], b_ct[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int qi = lane + 64 * j;
+        ok[j] = qi < nq;
+        const int o = a * N + 4 * (ok[j] ? qi : 0);
+        const float4 lo = ld4(loc + o), ls = ld4(logstd + o);
+        b_loc[j] = lo;
+        float sc;
+        sc = expf(ls.x); b_isc[j].x = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].x = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        sc = expf(ls.y); b_isc[j].y = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].y = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        sc = expf(ls.z); b_isc[j].z = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].z = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        sc = expf(ls.w); b_isc[j].w = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].w = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+    }
+    float4 acc_loc[M], acc_ls[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) { acc_loc[j] = make_float4(0.f, 0.f, 0.f, 0.f); acc_ls[j] = acc_loc[j]; }
+
+    for (int b0 = c; b0 < B; b0 += C * U) {
+        float4 l[U][M];
+        float xv[U], gv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = min(b0 + u * C, B - 1);            // clamped: loads unconditional
+            const float* row = logits + (size_t)b * AN + (size_t)a * N;
+#pragma unroll
+            for (int j = 0; j < M; ++j) l[u][j] = ld4(row + 4 * (ok[j] ? lane + 64 * j : 0));
+            xv[u] = x[(size_t)b * A + a];
+            gv[u] = (MODE == MODE_BWD) ? dlogp_in[b] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u * C;
+            if (b >= B) break;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (ok[j]) mx = fmaxf(mx, fmaxf(fmaxf(l[u][j].x, l[u][j].y), fmaxf(l[u][j].z, l[u][j].w)));
+            mx = wave_max(mx);
+            const float mxl = mx * PFPN_LOG2E;
+            float4 e[M], ef[M], zq[M];
+            float sum = 0.f, num = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                e[j] = ef[j] = zq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[j]) {
+#define PFPN_EL(c_)                                                                              \
+    e[j].c_ = __builtin_amdgcn_exp2f(fmaf(l[u][j].c_, PFPN_LOG2E, -mxl));                         \
+    zq[j].c_ = (xv[u] - b_loc[j].c_) * b_isc[j].c_;                                              \
+    ef[j].c_ = e[j].c_ * exp2f(fmaf(-zq[j].c_, zq[j].c_, -b_ct[j].c_));
+                    PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
+#undef PFPN_EL
+                    sum += (e[j].x + e[j].y) + (e[j].z + e[j].w);
+                    num += (ef[j].x + ef[j].y) + (ef[j].z + ef[j].w);
+                }
+            }
+            sum = wave_sum(sum);
+            num = wave_sum(num);
+            const float inv_sum = 1.0f / sum;
+            const float p = num * inv_sum;
+            if (MODE == MODE_FWD) {
+                if (lane == 0) {
+                    float lp = logf(p);
+                    if (tanh_mode) lp -= tanh_log_det(xv[u]);
+                    lpseg_out[(size_t)b * A + a] = lp;
+                    if (pmix_out) pmix_out[(size_t)b * A + a] = p;
+                }
+            } else {
+                const float q_ = guard_finite(gv[u] / p);
+                const float qs = q_ * inv_sum;
+                const float qp = qs * p;
+                float dxa = 0.f;
+                float* drow = dlogits + (size_t)b * AN + (size_t)a * N;
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    if (ok[j]) {
+                        float4 d;
+#define PFPN_EL(c_)                                                                              \
+    {                                                                                            \
+        const float tt = qs * ef[j].c_;                                                          \
+        d.c_ = fmaf(-e[j].c_, qp, tt);                                                           \
+        acc_loc[j].c_ = fmaf(tt, zq[j].c_, acc_loc[j].c_);                                       \
+        acc_ls[j].c_ = fmaf(tt, fmaf(zq[j].c_ * zq[j].c_, PFPN_2LN2, -1.f), acc_ls[j].c_);       \
+        dxa = fmaf(tt * zq[j].c_, b_isc[j].c_ * PFPN_2LN2, dxa);                                 \
+    }
+                        PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
+#undef PFPN_EL
+                        *reinterpret_cast<float4*>(drow + 4 * (lane + 64 * j)) = d;
+                    }
+                }
+                if (dx_out) {
+                    dxa = wave_sum(dxa);
+                    if (lane == 0) {
+                        float dd = -dxa;
+                        if (tanh_mode) dd += gv[u] * 2.f * tanhf(xv[u]);
+                        dx_out[(size_t)b * A + a] = dd;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_BWD) {
+        float* slab = partial + (size_t)c * 2 * AN + (size_t)a * N;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            if (ok[j]) {
+                float4 dl;
+                dl.x = acc_loc[j].x * (b_isc[j].x * PFPN_2LN2); dl.y = acc_loc[j].y * (b_isc[j].y * PFPN_2LN2);
+                dl.z = acc_loc[j].z * (b_isc[j].z * PFPN_2LN2); dl.w = acc_loc[j].w * (b_isc[j].w * PFPN_2LN2);
+                *reinterpret_cast<float4*>(slab + 4 * (lane + 64 * j)) = dl;
+                *reinterpret_cast<float4*>(slab + AN + 4 * (lane + 64 * j)) = acc_ls[j];
+            }
+        }
+    }
+}
+
 // logp[b] = sum_a lpseg[b,a], left to right (deterministic)
 __global__ void k_row_sum(const float* __restrict__ lpseg, int B, int A, float* __restrict__ logp) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,27 +619,43 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // ---------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------
-struct PackPlan { int R; int grid; size_t lds; int vec_ok; bool ok; };
-static int g_dbg = 0;        // diagnostic phase mask (pfpn_debug_set); 0 in production
+struct PackPlan { int R; int grid; int threads; size_t lds; int vec_ok; bool ok; };
+
+static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
 static PackPlan plan_packed(int B, int A, int N, const void* logits, const void* dlogits) {
     PackPlan pl{};
     pl.ok = false;
-    if (N > 64 || A > PACK_SEGS || A < 1 || B < 1) return pl;
+    if (N > 64 || N < 1 || A < 1 || B < 1) return pl;
     const int AN = A * N;
-    int R = PACK_SEGS / A;
-    const int rcap = PACK_TILE_BYTES / (AN * 4);
-    if (rcap < 1) return pl;
-    if (R > rcap) R = rcap;
-    if (R > B) R = B;
+    // rows per tile: the smallest R0 with R0*A a multiple of 16 segments (full waves), repeated while the
+    // block stays <= 12 waves (A=36: R=4, 9 waves, every lane busy)
+    const int R0 = PACK_WSEG / gcd_i(A, PACK_WSEG);
+    const int W0 = R0 * A / PACK_WSEG;
+    if (W0 > 16) return pl;
+    int k = 12 / W0;
+    if (k < 1) k = 1;
+    int R = R0 * k;
+    static const int env_rows = getenv("PFPN_MIX_ROWS") ? atoi(getenv("PFPN_MIX_ROWS")) : 0;   // tuning knob
+    if (env_rows > 0 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 16) R = env_rows;
+    if (R > B) R = B;                                   // small batches: one partial tile
+    const int waves = (R * A + PACK_WSEG - 1) / PACK_WSEG;
     pl.R = R;
-    const int tile_f4 = (R * AN + 3) / 4;
-    pl.lds = (size_t)tile_f4 * 16 + (size_t)AN * 16 + (size_t)(R * A + R + 2 * R + 4) * 4;
+    pl.threads = waves * 64;
+    pl.lds = (size_t)waves * PACK_WSEG * N * 4 + (size_t)(2 * R * A + R + 2 * waves + 8) * 4;
     pl.vec_ok = (AN % 4 == 0) && ((uintptr_t)logits % 16 == 0) && (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
     const int ntiles = (B + R - 1) / R;
-    // one resident 1024-thread block per CU, tiles strided over the blocks (max load = ceil(ntiles/256))
-    pl.grid = ntiles < 256 ? ntiles : 256;
-    pl.ok = pl.lds <= 64 * 1024;
+    // resident blocks per CU by wave slots (<= 96 VGPRs: 5 waves/SIMD = 20 waves/CU) and LDS
+    int per_cu = 20 / waves;
+    const int by_lds = (int)((size_t)(150 * 1024) / (pl.lds ? pl.lds : 1));
+    if (per_cu > by_lds) per_cu = by_lds;
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    static const int env_pcu = getenv("PFPN_MIX_PER_CU") ? atoi(getenv("PFPN_MIX_PER_CU")) : 0;   // tuning knob
+    if (env_pcu > 0) per_cu = env_pcu;
+    const int cap = 256 * per_cu;
+    pl.grid = ntiles < cap ? ntiles : cap;
+    pl.ok = pl.lds <= 64 * 1024 && waves <= 16;
     return pl;
 }
 
@@ -473,9 +664,9 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
                          const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
                          float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
 #define PFPN_LAUNCH_PACKED(NN)                                                                          \
-    hipLaunchKernelGGL((k_mix_packed<NN, MODE>), dim3(pl.grid), dim3(PACK_BLOCK), pl.lds, st, logits, x, \
+    hipLaunchKernelGGL((k_mix_packed<NN, MODE>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
                        loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.vec_ok, logp, pmix, dlogits, dx,   \
-                       partial, ppo, g_dbg)
+                       partial, ppo)
     switch (N) {
         case 35: PFPN_LAUNCH_PACKED(35); break;
         case 50: PFPN_LAUNCH_PACKED(50); break;
@@ -489,6 +680,20 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
 
 static bool packed_has(int N) { return N == 35 || N == 50 || N == 16 || N == 8; }
 
+// wide path: float4 per lane, up to 4 float4s per lane (N <= 1024)
+static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
+    return N >= 64 && N % 4 == 0 && N <= 1024 && ((uintptr_t)logits % 16 == 0) &&
+           (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
+}
+// waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
+static int wide_chunks(int B, int A) {
+    int C = (256 * 16 + A - 1) / A;
+    if (C > 64) C = 64;
+    if (C > (B + 1) / 2) C = (B + 1) / 2;
+    if (C < 1) C = 1;
+    return C;
+}
+
 }  // namespace pfpn
 
 using namespace pfpn;
@@ -498,12 +703,10 @@ using namespace pfpn;
 // =======================================================================================
 extern "C" {
 
-void pfpn_debug_set(int mask) { g_dbg = mask; }
-
 size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
-    // slabs: packed path <= 768 blocks x (2AN+4); wave path C<=64 chunks x 2AN; + lpseg [B*A]
+    // slabs: packed path <= 1024 blocks x (2AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]
     const size_t AN = (size_t)A * N;
-    const size_t slabs = (size_t)768 * (2 * AN + 4);
+    const size_t slabs = (N <= 64 ? (size_t)1024 : (size_t)64) * (2 * AN + 4);
     return (slabs + (size_t)B * A + 64) * sizeof(float);
 }
 
@@ -524,6 +727,21 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
     }
     if (!workspace || workspace_bytes < (size_t)B * A * sizeof(float)) return PFPN_ERR_WORKSPACE;
     float* lpseg = (float*)workspace;
+    if (wide_ok(A, N, logits, nullptr)) {
+        const int C = wide_chunks(B, A);
+        const int blocks = (A * C * 64 + 255) / 256;
+        const int M = (N / 4 + 63) / 64;
+#define PFPN_WIDE_FWD(MM)                                                                                      \
+    hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd,     \
+                       (const float*)nullptr, B, A, N, C, tanh_mode, lpseg, pmix, (float*)nullptr,              \
+                       (float*)nullptr, (float*)nullptr)
+        if (M == 1) PFPN_WIDE_FWD(1); else if (M == 2) PFPN_WIDE_FWD(2); else PFPN_WIDE_FWD(4);
+#undef PFPN_WIDE_FWD
+        PFPN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_row_sum, dim3((B + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
+        PFPN_CHECK_LAUNCH();
+        return PFPN_OK;
+    }
     int C = (B < 64) ? B : 64;
     while ((size_t)A * C < 2048 && C < B) C = (C * 2 < B) ? C * 2 : B;
     const int waves = A * C;
@@ -562,6 +780,22 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         PFPN_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, pl.grid,
                            2 * AN + 4, 2 * AN, dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
+        PFPN_CHECK_LAUNCH();
+        return PFPN_OK;
+    }
+    if (wide_ok(A, N, logits, dlogits)) {
+        const int C = wide_chunks(B, A);
+        if (workspace_bytes < (size_t)C * 2 * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
+        const int blocks = (A * C * 64 + 255) / 256;
+        const int M = (N / 4 + 63) / 64;
+#define PFPN_WIDE_BWD(MM)                                                                                      \
+    hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd,     \
+                       dlogp, B, A, N, C, tanh_mode, (float*)nullptr, (float*)nullptr, dlogits, dx, partial)
+        if (M == 1) PFPN_WIDE_BWD(1); else if (M == 2) PFPN_WIDE_BWD(2); else PFPN_WIDE_BWD(4);
+#undef PFPN_WIDE_BWD
+        PFPN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
+                           dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
     }

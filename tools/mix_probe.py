@@ -32,14 +32,7 @@ def timeit(f, n=20, reps=10):
     for _ in range(reps): g.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)*1e3/(n*reps)
-for mask, name in [(0,"full"),(1,"-fwd"),(2,"-bwd"),(4,"-store"),(8,"-rowstage"),(3,"-fwd-bwd"),(15,"load+lds only"),]:
-    lib.pfpn_debug_set(mask)
-    t_ppo = timeit(lambda: kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st, out=out))
-    t_fwd = timeit(lambda: kernels.logprob_fwd(logits, x, loc, logstd))
-    t_bwd = timeit(lambda: kernels.logprob_bwd(logits, x, loc, logstd, dl))
-    print("%-16s ppo %.1f us   fwd %.1f us   bwd %.1f us" % (name, t_ppo, t_fwd, t_bwd))
-lib.pfpn_debug_set(0)
-# copy baseline
-a = torch.empty_like(logits)
-print("torch copy 20MB: %.1f us" % timeit(lambda: a.copy_(logits)))
-print("empty kernel pair (adv_stats): %.1f us" % timeit(lambda: kernels.adv_stats(adv, out=st)))
+t_ppo = timeit(lambda: kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st, out=out))
+t_fwd = timeit(lambda: kernels.logprob_fwd(logits, x, loc, logstd))
+t_bwd = timeit(lambda: kernels.logprob_bwd(logits, x, loc, logstd, dl))
+print("ROWS=%s PER_CU=%s  ppo %.1f us   fwd %.1f us   bwd %.1f us" % (os.environ.get("PFPN_MIX_ROWS"), os.environ.get("PFPN_MIX_PER_CU"), t_ppo, t_fwd, t_bwd))

@@ -1,0 +1,31 @@
+"""HBM-roofline probe of the mixture kernels on the stress shape (BASELINE.json config 5: 128 action dims x
+256 particles, batch 8192 -> 1 GiB of logits)."""
+import os, sys, json, torch, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from pfpn_amd import kernels
+dev = torch.device("cuda:0")
+B, A, N = int(os.environ.get("SB", 8192)), int(os.environ.get("SA", 128)), int(os.environ.get("SN", 256))
+g = torch.Generator(device=dev); g.manual_seed(0)
+logits = torch.randn(B, A * N, device=dev, generator=g)
+x = torch.rand(B, A, device=dev, generator=g) * 2.2 - 1.1
+loc = torch.linspace(-1, 1, N, device=dev).repeat(A, 1).contiguous()
+logstd = torch.full((A, N), float(np.log(2 / (N - 1))), device=dev)
+dl = torch.randn(B, device=dev, generator=g)
+def timeit(f, n=10):
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+L, X, V, P = 4 * B * A * N, 4 * B * A, 4 * B, 8 * A * N
+t_f = timeit(lambda: kernels.logprob_fwd(logits, x, loc, logstd))
+t_b = timeit(lambda: kernels.logprob_bwd(logits, x, loc, logstd, dl))
+cp = torch.empty_like(logits)
+t_c = timeit(lambda: cp.copy_(logits))
+out = {"shape": [B, A, N],
+       "fwd": {"us": t_f, "bytes": L + X + V + P, "GBps": (L + X + V + P) / t_f / 1e3, "frac_of_8TBps": (L + X + V + P) / t_f / 1e3 / 8000},
+       "bwd": {"us": t_b, "bytes": 2 * L + X + 2 * V + 2 * P, "GBps": (2 * L + X + 2 * V + 2 * P) / t_b / 1e3, "frac_of_8TBps": (2 * L + X + 2 * V + 2 * P) / t_b / 1e3 / 8000},
+       "torch_copy": {"us": t_c, "GBps": 2 * L / t_c / 1e3}}
+print(json.dumps(out))
