@@ -440,14 +440,18 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     float* __restrict__ dx_out,              // BWD optional
     float* __restrict__ partial)             // [C][2*A*N]  (BWD)
 {
-    constexpr int U = 2;                                    // rows in flight per wave
+    constexpr int U = 4;                                    // rows in flight per wave (reduced together)
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // wave-uniform indices through readfirstlane: row/segment address arithmetic goes to the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (wave >= A * C) return;
     const int a = wave % A;                                 // neighbouring waves -> neighbouring dims
     const int c = wave / A;
     const int AN = A * N;
     const int nq = N >> 2;                                  // float4s per segment
+    // bank in registers: loc, isc2 = sqrt(.5 log2 e)/scale, ct64 = 64 - (0.5log2pi + log scale)*log2 e.
+    // e*phi = exp2(l*log2e - max*log2e - z'^2 + ct64) * 2^-64 in ONE v_exp_f32: the +64 keeps every
+    // product that matters far above the flush-to-zero threshold of the raw instruction.
     bool ok[M];
     float4 b_loc[M], b_isc[M], b_ct[M];
 #pragma unroll
@@ -458,14 +462,17 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         const float4 lo = ld4(loc + o), ls = ld4(logstd + o);
         b_loc[j] = lo;
         float sc;
-        sc = expf(ls.x); b_isc[j].x = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].x = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
-        sc = expf(ls.y); b_isc[j].y = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].y = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
-        sc = expf(ls.z); b_isc[j].z = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].z = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
-        sc = expf(ls.w); b_isc[j].w = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E; b_ct[j].w = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+#define PFPN_BANK(c_)                                                                       \
+    sc = expf(ls.c_);                                                                       \
+    b_isc[j].c_ = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;                                        \
+    b_ct[j].c_ = 64.f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        PFPN_BANK(x) PFPN_BANK(y) PFPN_BANK(z) PFPN_BANK(w)
+#undef PFPN_BANK
     }
     float4 acc_loc[M], acc_ls[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) { acc_loc[j] = make_float4(0.f, 0.f, 0.f, 0.f); acc_ls[j] = acc_loc[j]; }
+    const float two_m64 = 5.421010862427522e-20f;           // 2^-64
 
     for (int b0 = c; b0 < B; b0 += C * U) {
         float4 l[U][M];
@@ -479,48 +486,64 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             xv[u] = x[(size_t)b * A + a];
             gv[u] = (MODE == MODE_BWD) ? dlogp_in[b] : 0.f;
         }
+        // ---- max over each of the U segments (one transposing butterfly for all U) -------------
+        float mx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mx[u] = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (ok[j]) mx[u] = fmaxf(mx[u], fmaxf(fmaxf(l[u][j].x, l[u][j].y), fmaxf(l[u][j].z, l[u][j].w)));
+        }
+        wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
+        // ---- e = exp2(..), e*phi, lane-local sums ---------------------------------------------
+        float4 e[U][M], ef[U][M], zq[U][M];
+        float sum[U], num[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float mxl = mx[u] * PFPN_LOG2E;
+            sum[u] = 0.f; num[u] = 0.f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                e[u][j] = ef[u][j] = zq[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[j]) {
+#define PFPN_EL(c_)                                                                              \
+    {                                                                                            \
+        const float le = fmaf(l[u][j].c_, PFPN_LOG2E, -mxl);                                     \
+        zq[u][j].c_ = (xv[u] - b_loc[j].c_) * b_isc[j].c_;                                       \
+        e[u][j].c_ = __builtin_amdgcn_exp2f(le);                                                 \
+        ef[u][j].c_ = __builtin_amdgcn_exp2f(le + fmaf(-zq[u][j].c_, zq[u][j].c_, b_ct[j].c_));  \
+    }
+                    PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
+#undef PFPN_EL
+                    sum[u] += (e[u][j].x + e[u][j].y) + (e[u][j].z + e[u][j].w);
+                    num[u] += (ef[u][j].x + ef[u][j].y) + (ef[u][j].z + ef[u][j].w);
+                }
+            }
+        }
+        wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
+        wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
+        float dxa[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = b0 + u * C;
-            if (b >= B) break;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < M; ++j)
-                if (ok[j]) mx = fmaxf(mx, fmaxf(fmaxf(l[u][j].x, l[u][j].y), fmaxf(l[u][j].z, l[u][j].w)));
-            mx = wave_max(mx);
-            const float mxl = mx * PFPN_LOG2E;
-            float4 e[M], ef[M], zq[M];
-            float sum = 0.f, num = 0.f;
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                e[j] = ef[j] = zq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[j]) {
-#define PFPN_EL(c_)                                                                              \
-    e[j].c_ = __builtin_amdgcn_exp2f(fmaf(l[u][j].c_, PFPN_LOG2E, -mxl));                         \
-    zq[j].c_ = (xv[u] - b_loc[j].c_) * b_isc[j].c_;                                              \
-    ef[j].c_ = e[j].c_ * exp2f(fmaf(-zq[j].c_, zq[j].c_, -b_ct[j].c_));
-                    PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
-#undef PFPN_EL
-                    sum += (e[j].x + e[j].y) + (e[j].z + e[j].w);
-                    num += (ef[j].x + ef[j].y) + (ef[j].z + ef[j].w);
-                }
-            }
-            sum = wave_sum(sum);
-            num = wave_sum(num);
-            const float inv_sum = 1.0f / sum;
-            const float p = num * inv_sum;
+            const bool live = b < B;
+            const float inv_sum = __builtin_amdgcn_rcpf(sum[u]);    // wave-uniform: one v_rcp, not an IEEE divide
+            float p = (num[u] * two_m64) * inv_sum;
+            if (p < 1.401298464324817e-45f) p = 0.f;         // below the smallest fp32 denormal: the reference's p is 0
+            dxa[u] = 0.f;
             if (MODE == MODE_FWD) {
-                if (lane == 0) {
-                    float lp = logf(p);
+                if (lane == 0 && live) {
+                    float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;     // v_log_f32 is log2
                     if (tanh_mode) lp -= tanh_log_det(xv[u]);
                     lpseg_out[(size_t)b * A + a] = lp;
                     if (pmix_out) pmix_out[(size_t)b * A + a] = p;
                 }
             } else {
-                const float q_ = guard_finite(gv[u] / p);
+                const float q_ = live ? guard_finite(gv[u] * __builtin_amdgcn_rcpf(p)) : 0.f;
                 const float qs = q_ * inv_sum;
                 const float qp = qs * p;
-                float dxa = 0.f;
+                const float qs64 = qs * two_m64;
                 float* drow = dlogits + (size_t)b * AN + (size_t)a * N;
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
@@ -528,24 +551,29 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                         float4 d;
 #define PFPN_EL(c_)                                                                              \
     {                                                                                            \
-        const float tt = qs * ef[j].c_;                                                          \
-        d.c_ = fmaf(-e[j].c_, qp, tt);                                                           \
-        acc_loc[j].c_ = fmaf(tt, zq[j].c_, acc_loc[j].c_);                                       \
-        acc_ls[j].c_ = fmaf(tt, fmaf(zq[j].c_ * zq[j].c_, PFPN_2LN2, -1.f), acc_ls[j].c_);       \
-        dxa = fmaf(tt * zq[j].c_, b_isc[j].c_ * PFPN_2LN2, dxa);                                 \
+        const float tt = qs64 * ef[u][j].c_;                                                     \
+        const float z_ = zq[u][j].c_;                                                            \
+        d.c_ = fmaf(-e[u][j].c_, qp, tt);                                                        \
+        acc_loc[j].c_ = fmaf(tt, z_, acc_loc[j].c_);                                             \
+        acc_ls[j].c_ = fmaf(tt, fmaf(z_ * z_, PFPN_2LN2, -1.f), acc_ls[j].c_);                   \
+        if (dx_out) dxa[u] = fmaf(tt * z_, b_isc[j].c_ * PFPN_2LN2, dxa[u]);                     \
     }
                         PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
 #undef PFPN_EL
-                        *reinterpret_cast<float4*>(drow + 4 * (lane + 64 * j)) = d;
+                        if (live) *reinterpret_cast<float4*>(drow + 4 * (lane + 64 * j)) = d;
                     }
                 }
-                if (dx_out) {
-                    dxa = wave_sum(dxa);
-                    if (lane == 0) {
-                        float dd = -dxa;
-                        if (tanh_mode) dd += gv[u] * 2.f * tanhf(xv[u]);
-                        dx_out[(size_t)b * A + a] = dd;
-                    }
+            }
+        }
+        if (MODE == MODE_BWD && dx_out) {
+            wave_reduce4<false>(dxa[0], dxa[1], dxa[2], dxa[3], lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * C;
+                if (lane == 0 && b < B) {
+                    float dd = -dxa[u];
+                    if (tanh_mode) dd += gv[u] * 2.f * tanhf(xv[u]);
+                    dx_out[(size_t)b * A + a] = dd;
                 }
             }
         }
@@ -687,9 +715,9 @@ static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
 }
 // waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
 static int wide_chunks(int B, int A) {
-    int C = (256 * 16 + A - 1) / A;
+    int C = (256 * 32 + A - 1) / A;
     if (C > 64) C = 64;
-    if (C > (B + 1) / 2) C = (B + 1) / 2;
+    if (C > (B + 3) / 4) C = (B + 3) / 4;      // at least U = 4 rows per wave
     if (C < 1) C = 1;
     return C;
 }

@@ -49,6 +49,64 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Full-wavefront reductions on the DPP network (no LDS crossbar): row_shr 1/2/4/8 inside each row of
+// 16 lanes, then row_bcast:15 and row_bcast:31 carry the row totals upward; the grand total lands in
+// lane 63 and is returned as a wave-uniform (scalar) value.  6 DPP steps + one v_readlane, versus
+// 6 ds_bpermute round trips for the __shfl_xor tree.  Fixed order -> deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_shift(float v, float fill) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, ROW_MASK, 0xf,
+                                                      false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_shift<0x111, 0xf>(v, 0.f);      // row_shr:1
+    v += dpp_shift<0x112, 0xf>(v, 0.f);      // row_shr:2
+    v += dpp_shift<0x114, 0xf>(v, 0.f);      // row_shr:4
+    v += dpp_shift<0x118, 0xf>(v, 0.f);      // row_shr:8   -> lane 15 of every row holds the row sum
+    v += dpp_shift<0x142, 0xa>(v, 0.f);      // row_bcast:15 into rows 1 and 3
+    v += dpp_shift<0x143, 0xc>(v, 0.f);      // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    const float ninf = -INFINITY;
+    v = fmaxf(v, dpp_shift<0x111, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_shift<0x112, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_shift<0x114, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_shift<0x118, 0xf>(v, ninf));
+    v = fmaxf(v, dpp_shift<0x142, 0xa>(v, ninf));
+    v = fmaxf(v, dpp_shift<0x143, 0xc>(v, ninf));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Four independent wave reductions for the price of ~one: a transposing butterfly.  Lanes first trade
+// rows (xor 1, xor 2: afterwards lane class (lane & 3) = {0,1,2,3} carries a 4-lane partial of row
+// {0,2,1,3}), then ONE value per lane is combined over the remaining 16 lane groups (row_ror 4/8 inside
+// a row of 16, then xor 16 / xor 32 across rows).  ~13 cross-lane ops for 4 rows instead of 24; results
+// come back wave-uniform through v_readlane.  Fixed combination order -> deterministic.
+template <bool IS_MAX>
+__device__ __forceinline__ float red_comb(float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; }
+
+template <bool IS_MAX>
+__device__ __forceinline__ void wave_reduce4(float& r0, float& r1, float& r2, float& r3, int lane) {
+    const float id = IS_MAX ? -INFINITY : 0.f;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float k0 = b0 ? r2 : r0, k1 = b0 ? r3 : r1;
+    const float s0 = b0 ? r0 : r2, s1 = b0 ? r1 : r3;
+    k0 = red_comb<IS_MAX>(k0, dpp_shift<0xB1, 0xf>(s0, id));      // quad_perm [1,0,3,2]  (xor 1)
+    k1 = red_comb<IS_MAX>(k1, dpp_shift<0xB1, 0xf>(s1, id));
+    float k = b1 ? k1 : k0;
+    const float sn = b1 ? k0 : k1;
+    k = red_comb<IS_MAX>(k, dpp_shift<0x4E, 0xf>(sn, id));        // quad_perm [2,3,0,1]  (xor 2)
+    k = red_comb<IS_MAX>(k, dpp_shift<0x124, 0xf>(k, id));        // row_ror:4
+    k = red_comb<IS_MAX>(k, dpp_shift<0x128, 0xf>(k, id));        // row_ror:8
+    k = red_comb<IS_MAX>(k, __shfl_xor(k, 16, 64));
+    k = red_comb<IS_MAX>(k, __shfl_xor(k, 32, 64));
+    r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 0));
+    r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 1));
+    r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 2));
+    r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 3));
+}
+
 // Block-wide sum in a fixed order (deterministic): wave shuffle, then wave 0 adds the
 // per-wave partials left to right.  `red` needs >= blockDim.x/64 floats of LDS.
 __device__ __forceinline__ float block_sum(float v, float* red) {
