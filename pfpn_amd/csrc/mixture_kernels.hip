@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     float* __restrict__ pmix_out,            // [B,A] optional
     float* __restrict__ dlogits,             // BWD
     float* __restrict__ dx_out,              // BWD optional
-    float* __restrict__ partial)             // [C][2*A*N]  (BWD)
+    float* __restrict__ partial,             // [C][2*A*N]  (BWD)
+    int abl)                                 // timing-ablation mask (0 in production)
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
     const int lane = threadIdx.x & 63;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             for (int j = 0; j < M; ++j)
                 if (ok[j]) mx[u] = fmaxf(mx[u], fmaxf(fmaxf(l[u][j].x, l[u][j].y), fmaxf(l[u][j].z, l[u][j].w)));
         }
-        wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
+        if (!(abl & 2)) wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
         // ---- e = exp2(..), e*phi, lane-local sums ---------------------------------------------
         float4 e[U][M], ef[U][M], zq[U][M];
         float sum[U], num[U];
@@ -511,8 +512,9 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     {                                                                                            \
         const float le = fmaf(l[u][j].c_, PFPN_LOG2E, -mxl);                                     \
         zq[u][j].c_ = (xv[u] - b_loc[j].c_) * b_isc[j].c_;                                       \
-        e[u][j].c_ = __builtin_amdgcn_exp2f(le);                                                 \
-        ef[u][j].c_ = __builtin_amdgcn_exp2f(le + fmaf(-zq[u][j].c_, zq[u][j].c_, b_ct[j].c_));  \
+        const float ar_ = le + fmaf(-zq[u][j].c_, zq[u][j].c_, b_ct[j].c_);                      \
+        e[u][j].c_ = (abl & 1) ? le : __builtin_amdgcn_exp2f(le);                                \
+        ef[u][j].c_ = (abl & 1) ? ar_ : __builtin_amdgcn_exp2f(ar_);                             \
     }
                     PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
 #undef PFPN_EL
@@ -521,8 +523,10 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 }
             }
         }
-        wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
-        wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
+        if (!(abl & 2)) {
+            wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
+            wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
+        }
         float dxa[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -713,10 +717,13 @@ static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
     return N >= 64 && N % 4 == 0 && N <= 1024 && ((uintptr_t)logits % 16 == 0) &&
            (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
 }
+static int wide_abl() { static const int v = getenv("PFPN_WIDE_ABL") ? atoi(getenv("PFPN_WIDE_ABL")) : 0; return v; }
+static int wide_c_env() { static const int v = getenv("PFPN_WIDE_C") ? atoi(getenv("PFPN_WIDE_C")) : 0; return v; }
 // waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
 static int wide_chunks(int B, int A) {
     int C = (256 * 32 + A - 1) / A;
     if (C > 64) C = 64;
+    if (wide_c_env() > 0) C = wide_c_env();
     if (C > (B + 3) / 4) C = (B + 3) / 4;      // at least U = 4 rows per wave
     if (C < 1) C = 1;
     return C;
@@ -762,7 +769,7 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
 #define PFPN_WIDE_FWD(MM)                                                                                      \
     hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd,     \
                        (const float*)nullptr, B, A, N, C, tanh_mode, lpseg, pmix, (float*)nullptr,              \
-                       (float*)nullptr, (float*)nullptr)
+                       (float*)nullptr, (float*)nullptr, wide_abl())
         if (M == 1) PFPN_WIDE_FWD(1); else if (M == 2) PFPN_WIDE_FWD(2); else PFPN_WIDE_FWD(4);
 #undef PFPN_WIDE_FWD
         PFPN_CHECK_LAUNCH();
@@ -818,7 +825,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         const int M = (N / 4 + 63) / 64;
 #define PFPN_WIDE_BWD(MM)                                                                                      \
     hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd,     \
-                       dlogp, B, A, N, C, tanh_mode, (float*)nullptr, (float*)nullptr, dlogits, dx, partial)
+                       dlogp, B, A, N, C, tanh_mode, (float*)nullptr, (float*)nullptr, dlogits, dx, partial, wide_abl())
         if (M == 1) PFPN_WIDE_BWD(1); else if (M == 2) PFPN_WIDE_BWD(2); else PFPN_WIDE_BWD(4);
 #undef PFPN_WIDE_BWD
         PFPN_CHECK_LAUNCH();
