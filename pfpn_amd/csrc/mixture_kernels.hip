@@ -428,18 +428,19 @@ __global__ __launch_bounds__(256) void k_mix_wave(
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int M, int MODE>
+template <bool V> struct BoolTag { static constexpr bool value = V; };
+
+template <int M, int MODE, bool TANH>
 __global__ __launch_bounds__(256) void k_mix_wide(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ dlogp_in,
-    int B, int A, int N, int C, int tanh_mode,
+    int B, int A, int N, int C,
     float* __restrict__ lpseg_out,           // [B,A] per-segment log p (FWD)
     float* __restrict__ pmix_out,            // [B,A] optional
     float* __restrict__ dlogits,             // BWD
     float* __restrict__ dx_out,              // BWD optional
-    float* __restrict__ partial,             // [C][2*A*N]  (BWD)
-    int abl)                                 // timing-ablation mask (0 in production)
+    float* __restrict__ partial)             // [C][2*A*N]  (BWD)
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
     const int lane = threadIdx.x & 63;
@@ -475,32 +476,12 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     for (int j = 0; j < M; ++j) { acc_loc[j] = make_float4(0.f, 0.f, 0.f, 0.f); acc_ls[j] = acc_loc[j]; }
     const float two_m64 = 5.421010862427522e-20f;           // 2^-64
 
-    // Register double buffering: the loads of the NEXT U rows are issued before the current U rows are
-    // processed, so a wave's own compute (~1.5 us per 4 segments) overlaps its HBM latency instead of
-    // adding to it (measured: 4.2 -> see DESIGN.md TB/s at equal occupancy).
-    float4 ln[U][M];
-    float xn[U], gn[U];
-#define PFPN_WIDE_LOAD(b0_)                                                                        \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
-        const int b_ = min((b0_) + u * C, B - 1);            /* clamped: loads unconditional */     \
-        const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;                              \
-        _Pragma("unroll") for (int j = 0; j < M; ++j) ln[u][j] = ld4(row_ + 4 * (ok[j] ? lane + 64 * j : 0)); \
-        xn[u] = x[(size_t)b_ * A + a];                                                             \
-        gn[u] = (MODE == MODE_BWD) ? dlogp_in[b_] : 0.f;                                           \
-    }
-    PFPN_WIDE_LOAD(c)
-    for (int b0 = c; b0 < B; b0 += C * U) {
-        float4 l[U][M];
-        float xv[U], gv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int j = 0; j < M; ++j) l[u][j] = ln[u][j];
-            xv[u] = xn[u];
-            gv[u] = gn[u];
-        }
-        if (b0 + C * U < B) { PFPN_WIDE_LOAD(b0 + C * U) }
-        // ---- max over each of the U segments (one transposing butterfly for all U) -------------
+    // One group of U rows.  FULL = every row of the group exists: the body is then BRANCH-FREE straight-line
+    // code (stores unconditional), so hipcc's waitcnt pass can count the stores younger than the prefetch
+    // loads and emit s_waitcnt vmcnt(k) instead of vmcnt(0) -- otherwise every iteration would also wait for
+    // its own stores to be acknowledged (~1 us exposed per iteration; CDNA4 vmcnt counts stores).
+    auto group = [&](int b0, const float4 (&l)[U][M], const float (&xv)[U], const float (&gv)[U], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         float mx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -509,8 +490,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             for (int j = 0; j < M; ++j)
                 if (ok[j]) mx[u] = fmaxf(mx[u], fmaxf(fmaxf(l[u][j].x, l[u][j].y), fmaxf(l[u][j].z, l[u][j].w)));
         }
-        if (!(abl & 2)) wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
-        // ---- e = exp2(..), e*phi, lane-local sums ---------------------------------------------
+        wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
         float4 e[U][M], ef[U][M], zq[U][M];
         float sum[U], num[U];
 #pragma unroll
@@ -525,9 +505,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     {                                                                                            \
         const float le = fmaf(l[u][j].c_, PFPN_LOG2E, -mxl);                                     \
         zq[u][j].c_ = (xv[u] - b_loc[j].c_) * b_isc[j].c_;                                       \
-        const float ar_ = le + fmaf(-zq[u][j].c_, zq[u][j].c_, b_ct[j].c_);                      \
-        e[u][j].c_ = (abl & 1) ? le : __builtin_amdgcn_exp2f(le);                                \
-        ef[u][j].c_ = (abl & 1) ? ar_ : __builtin_amdgcn_exp2f(ar_);                             \
+        e[u][j].c_ = __builtin_amdgcn_exp2f(le);                                                 \
+        ef[u][j].c_ = __builtin_amdgcn_exp2f(le + fmaf(-zq[u][j].c_, zq[u][j].c_, b_ct[j].c_));  \
     }
                     PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
 #undef PFPN_EL
@@ -536,23 +515,22 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 }
             }
         }
-        if (!(abl & 2)) {
-            wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
-            wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
-        }
+        wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
+        wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
         float dxa[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = b0 + u * C;
-            const bool live = b < B;
+            const bool live = FULL || b < B;
             const float inv_sum = __builtin_amdgcn_rcpf(sum[u]);    // wave-uniform: one v_rcp, not an IEEE divide
             float p = (num[u] * two_m64) * inv_sum;
             if (p < 1.401298464324817e-45f) p = 0.f;         // below the smallest fp32 denormal: the reference's p is 0
             dxa[u] = 0.f;
             if (MODE == MODE_FWD) {
-                if (lane == 0 && live) {
-                    float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;     // v_log_f32 is log2
-                    if (tanh_mode) lp -= tanh_log_det(xv[u]);
+                float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;     // v_log_f32 is log2
+                if (TANH) lp -= tanh_log_det(xv[u]);
+                // every lane stores the same value to the same address (one transaction, no branch)
+                if (live) {
                     lpseg_out[(size_t)b * A + a] = lp;
                     if (pmix_out) pmix_out[(size_t)b * A + a] = p;
                 }
@@ -587,14 +565,45 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int b = b0 + u * C;
-                if (lane == 0 && b < B) {
+                if (FULL || b < B) {
                     float dd = -dxa[u];
-                    if (tanh_mode) dd += gv[u] * 2.f * tanhf(xv[u]);
+                    if (TANH) dd += gv[u] * 2.f * tanhf(xv[u]);
                     dx_out[(size_t)b * A + a] = dd;
                 }
             }
         }
+    };
+
+    // Register double buffering: the loads of the NEXT group are issued before the current group is
+    // processed, so a wave's own compute overlaps its HBM latency instead of adding to it.
+    float4 ln[U][M];
+    float xn[U], gn[U];
+#define PFPN_WIDE_LOAD(b0_)                                                                        \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
+        const int b_ = min((b0_) + u * C, B - 1);            /* clamped: loads unconditional */     \
+        const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;                              \
+        _Pragma("unroll") for (int j = 0; j < M; ++j) ln[u][j] = ld4(row_ + 4 * (ok[j] ? lane + 64 * j : 0)); \
+        xn[u] = x[(size_t)b_ * A + a];                                                             \
+        gn[u] = (MODE == MODE_BWD) ? dlogp_in[b_] : 0.f;                                           \
     }
+    const int step = C * U;
+    int b0 = c;
+    PFPN_WIDE_LOAD(b0)
+    for (; b0 + (U - 1) * C < B; b0 += step) {               // full groups: branch-free body
+        float4 l[U][M];
+        float xv[U], gv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < M; ++j) l[u][j] = ln[u][j];
+            xv[u] = xn[u];
+            gv[u] = gn[u];
+        }
+        PFPN_WIDE_LOAD(b0 + step)                            // clamped rows: harmless beyond the end
+        group(b0, l, xv, gv, BoolTag<true>{});
+    }
+    if (b0 < B) group(b0, ln, xn, gn, BoolTag<false>{});     // ragged tail (1..U-1 live rows)
+#undef PFPN_WIDE_LOAD
     if (MODE == MODE_BWD) {
         float* slab = partial + (size_t)c * 2 * AN + (size_t)a * N;
 #pragma unroll
@@ -730,7 +739,6 @@ static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
     return N >= 64 && N % 4 == 0 && N <= 1024 && ((uintptr_t)logits % 16 == 0) &&
            (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
 }
-static int wide_abl() { static const int v = getenv("PFPN_WIDE_ABL") ? atoi(getenv("PFPN_WIDE_ABL")) : 0; return v; }
 static int wide_c_env() { static const int v = getenv("PFPN_WIDE_C") ? atoi(getenv("PFPN_WIDE_C")) : 0; return v; }
 // waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
 static int wide_chunks(int B, int A) {
@@ -779,11 +787,12 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
         const int C = wide_chunks(B, A);
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
-#define PFPN_WIDE_FWD(MM)                                                                                      \
-    hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd,     \
-                       (const float*)nullptr, B, A, N, C, tanh_mode, lpseg, pmix, (float*)nullptr,              \
-                       (float*)nullptr, (float*)nullptr, wide_abl())
-        if (M == 1) PFPN_WIDE_FWD(1); else if (M == 2) PFPN_WIDE_FWD(2); else PFPN_WIDE_FWD(4);
+#define PFPN_WIDE_FWD(MM, TT)                                                                                  \
+    hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
+                       (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr, (float*)nullptr,        \
+                       (float*)nullptr)
+        if (tanh_mode) { if (M == 1) PFPN_WIDE_FWD(1, true); else if (M == 2) PFPN_WIDE_FWD(2, true); else PFPN_WIDE_FWD(4, true); }
+        else { if (M == 1) PFPN_WIDE_FWD(1, false); else if (M == 2) PFPN_WIDE_FWD(2, false); else PFPN_WIDE_FWD(4, false); }
 #undef PFPN_WIDE_FWD
         PFPN_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_row_sum, dim3((B + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
@@ -836,10 +845,11 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         if (workspace_bytes < (size_t)C * 2 * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
-#define PFPN_WIDE_BWD(MM)                                                                                      \
-    hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd,     \
-                       dlogp, B, A, N, C, tanh_mode, (float*)nullptr, (float*)nullptr, dlogits, dx, partial, wide_abl())
-        if (M == 1) PFPN_WIDE_BWD(1); else if (M == 2) PFPN_WIDE_BWD(2); else PFPN_WIDE_BWD(4);
+#define PFPN_WIDE_BWD(MM, TT)                                                                                  \
+    hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
+                       dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial)
+        if (tanh_mode) { if (M == 1) PFPN_WIDE_BWD(1, true); else if (M == 2) PFPN_WIDE_BWD(2, true); else PFPN_WIDE_BWD(4, true); }
+        else { if (M == 1) PFPN_WIDE_BWD(1, false); else if (M == 2) PFPN_WIDE_BWD(2, false); else PFPN_WIDE_BWD(4, false); }
 #undef PFPN_WIDE_BWD
         PFPN_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
