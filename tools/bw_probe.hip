@@ -62,6 +62,13 @@ int main() {
     const int B = 8192, A = 128, N = 256;
     const size_t n = (size_t)B * A * N;
     float *p, *out; hipMalloc(&p, n * 4); hipMalloc(&out, 4); hipMemset(p, 0, n * 4);
+    if (getenv("RANDOM_DATA")) {
+        float* h = (float*)malloc(n * 4);
+        unsigned s = 12345u;
+        for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) * (1.0f / 16777216.0f)) * 4.f - 2.f; }
+        hipMemcpy(p, h, n * 4, hipMemcpyHostToDevice);
+        free(h);
+    }
     const double gb = n * 4 / 1e9;
     for (int grid : {2048, 4096, 8192, 16384}) {
         float us = timeit([&] { hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, 0, (const float4*)p, n / 4, out); });
