@@ -619,13 +619,17 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     }
 }
 
-// logp[b] = sum_a lpseg[b,a], left to right (deterministic)
-__global__ void k_row_sum(const float* __restrict__ lpseg, int B, int A, float* __restrict__ logp) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// logp[b] = sum_a lpseg[b,a]: one wavefront per row, lanes read the row coalesced, fixed-order
+// butterfly (deterministic).  (A serial per-thread loop here costs A dependent-load latencies.)
+__global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ lpseg, int B, int A,
+                                                 float* __restrict__ logp) {
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= B) return;
     float s = 0.f;
-    for (int a = 0; a < A; ++a) s += lpseg[(size_t)b * A + a];
-    logp[b] = s;
+    for (int a = lane; a < A; a += 64) s += lpseg[(size_t)b * A + a];
+    s = wave_sum(s);
+    if (lane == 0) logp[b] = s;
 }
 
 // Fixed-order reduction of per-block slabs: out[i] = sum_k partial[k*stride + i], i < n.
@@ -795,7 +799,7 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
         else { if (M == 1) PFPN_WIDE_FWD(1, false); else if (M == 2) PFPN_WIDE_FWD(2, false); else PFPN_WIDE_FWD(4, false); }
 #undef PFPN_WIDE_FWD
         PFPN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_row_sum, dim3((B + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
+        hipLaunchKernelGGL(k_row_sum, dim3((B * 64 + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
     }
@@ -807,7 +811,7 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
                        (const float*)nullptr, B, A, N, C, tanh_mode, lpseg, pmix, (float*)nullptr,
                        (float*)nullptr, (float*)nullptr);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_row_sum, dim3((B + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
+    hipLaunchKernelGGL(k_row_sum, dim3((B * 64 + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -114,12 +114,15 @@ __global__ __launch_bounds__(1024) void k_stats_apply(const float* __restrict__ 
     }
 }
 
-__global__ void k_row_sum2(const float* __restrict__ lpseg, int B, int A, float* __restrict__ logp) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_row_sum2(const float* __restrict__ lpseg, int B, int A,
+                                                  float* __restrict__ logp) {
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= B) return;
     float s = 0.f;
-    for (int a = 0; a < A; ++a) s += lpseg[(size_t)b * A + a];
-    logp[b] = s;
+    for (int a = lane; a < A; a += 64) s += lpseg[(size_t)b * A + a];
+    s = wave_sum(s);
+    if (lane == 0) logp[b] = s;
 }
 
 // deterministic action: loc[a, argmax_n logits] (first index on ties), tanh in tanh mode
@@ -328,7 +331,7 @@ int pfpn_sample(const float* logits, const float* loc, const float* logstd, cons
                        eps_sel, B, A, N, (int*)k, action, lpseg, smax, sinv);
     PFPN_CHECK_LAUNCH();
     if (logp) {
-        hipLaunchKernelGGL(k_row_sum2, dim3((B + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
+        hipLaunchKernelGGL(k_row_sum2, dim3((B * 64 + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
         PFPN_CHECK_LAUNCH();
     }
     if (max_active) return stats_launch(logits, smax, sinv, B, A, N, partial, max_active, sum_active, st);
