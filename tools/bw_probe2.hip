@@ -80,6 +80,12 @@ int main() {
         free(h);
     }
     const double gb = n * 4 / 1e9;
+    if (getenv("ONLY_V3")) {
+        const int C = 32, blocks = (A * C * 64 + 255) / 256;
+        float us = timeit([&] { hipLaunchKernelGGL((k<3, true>), dim3(blocks), dim3(256), 0, 0, p, x, B, A, N, C, out); });
+        printf("V3 PF C=32: %.1f us %.2f TB/s\n", us, gb / us * 1e3);
+        return 0;
+    }
     for (int C : {8, 16, 32, 64}) {
         const int blocks = (A * C * 64 + 255) / 256;
 #define RUN(V, PF) timeit([&] { hipLaunchKernelGGL((k<V, PF>), dim3(blocks), dim3(256), 0, 0, p, x, B, A, N, C, out); })
