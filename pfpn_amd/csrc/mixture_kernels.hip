@@ -430,7 +430,7 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 
-template <int M, int MODE, bool TANH>
+template <int M, int MODE, bool TANH, bool FULLN>
 __global__ __launch_bounds__(256) void k_mix_wide(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int qi = lane + 64 * j;
-        ok[j] = qi < nq;
+        ok[j] = FULLN || qi < nq;                            // FULLN: N == 256*M, every lane owns particles
         const int o = a * N + 4 * (ok[j] ? qi : 0);
         const float4 lo = ld4(loc + o), ls = ld4(logstd + o);
         b_loc[j] = lo;
@@ -792,9 +792,16 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
 #define PFPN_WIDE_FWD(MM, TT)                                                                                  \
-    hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
-                       (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr, (float*)nullptr,        \
-                       (float*)nullptr)
+    do {                                                                                                       \
+        if (N == 256 * MM)                                                                                     \
+            hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, true>), dim3(blocks), dim3(256), 0, st, logits, x, loc,   \
+                               logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,         \
+                               (float*)nullptr, (float*)nullptr);                                               \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, false>), dim3(blocks), dim3(256), 0, st, logits, x, loc,  \
+                               logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,         \
+                               (float*)nullptr, (float*)nullptr);                                               \
+    } while (0)
         if (tanh_mode) { if (M == 1) PFPN_WIDE_FWD(1, true); else if (M == 2) PFPN_WIDE_FWD(2, true); else PFPN_WIDE_FWD(4, true); }
         else { if (M == 1) PFPN_WIDE_FWD(1, false); else if (M == 2) PFPN_WIDE_FWD(2, false); else PFPN_WIDE_FWD(4, false); }
 #undef PFPN_WIDE_FWD
@@ -850,8 +857,14 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
 #define PFPN_WIDE_BWD(MM, TT)                                                                                  \
-    hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
-                       dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial)
+    do {                                                                                                       \
+        if (N == 256 * MM)                                                                                     \
+            hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, true>), dim3(blocks), dim3(256), 0, st, logits, x, loc,   \
+                               logstd, dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, false>), dim3(blocks), dim3(256), 0, st, logits, x, loc,  \
+                               logstd, dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial); \
+    } while (0)
         if (tanh_mode) { if (M == 1) PFPN_WIDE_BWD(1, true); else if (M == 2) PFPN_WIDE_BWD(2, true); else PFPN_WIDE_BWD(4, true); }
         else { if (M == 1) PFPN_WIDE_BWD(1, false); else if (M == 2) PFPN_WIDE_BWD(2, false); else PFPN_WIDE_BWD(4, false); }
 #undef PFPN_WIDE_BWD
