@@ -745,8 +745,11 @@ static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
 }
 static int wide_c_env() { static const int v = getenv("PFPN_WIDE_C") ? atoi(getenv("PFPN_WIDE_C")) : 0; return v; }
 // waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
-static int wide_chunks(int B, int A) {
-    int C = (256 * 16 + A - 1) / A;
+static int wide_chunks(int B, int A, bool bwd = false) {
+    // measured on the 8192 x 128 x 256 stress shape: ~16 waves/CU (fwd) and ~12 waves/CU (bwd, which also
+    // streams 1 KiB stores per segment) keep about 8 MB of requests in flight chip-wide -- more in
+    // flight only lengthens the HBM queues (tools/bw_probe.hip)
+    int C = ((bwd ? 256 * 12 : 256 * 16) + A - 1) / A;
     if (C > 64) C = 64;
     if (wide_c_env() > 0) C = wide_c_env();
     if (C > (B + 3) / 4) C = (B + 3) / 4;      // at least U = 4 rows per wave
@@ -852,7 +855,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         return PFPN_OK;
     }
     if (wide_ok(A, N, logits, dlogits)) {
-        const int C = wide_chunks(B, A);
+        const int C = wide_chunks(B, A, true);
         if (workspace_bytes < (size_t)C * 2 * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
