@@ -165,10 +165,11 @@ int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply,
                              void* workspace, size_t workspace_bytes, void* stream);
 /* TF ApplyAdam on a flat buffer (epsilon outside the bias-corrected sqrt; NOT torch.optim.Adam).
  * beta_pow [2] = {beta1^t, beta2^t} device scalars, advanced when advance_beta_pow != 0.
- * norm_scale (optional) multiplies the gradient by norm_scale[1]; grad_mul by a host scalar. */
+ * norm_scale (optional) multiplies the gradient by norm_scale[1]; grad_mul by a host scalar.
+ * step_counter (optional device scalar): += 1 together with the beta powers (float(global_step)). */
 int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
                  float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
-                 float grad_mul, void* stream);
+                 float grad_mul, float* step_counter, void* stream);
 /* SAC loss head -- sac.py:123-139 (vf_target, q_target) and :160-173 (Q and policy losses).
  * q_pi, q_run, q_tgt are [2,B] (Q1 row then Q2 row): Q(s, a_pi), Q(s, action_hist), Q'(s', a').
  * Outputs dq_pi [2,B] (d policy_loss/dQ through tf.minimum), dq_run [2,B] (d value_loss/dQ),

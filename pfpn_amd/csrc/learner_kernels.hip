@@ -378,8 +378,12 @@ __global__ __launch_bounds__(256) void k_tf_adam(float* __restrict__ p, const fl
 }
 
 // beta powers advance after the applies (Adam/mul, Adam/mul_1 in the saved graph)
-__global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { beta_pow[0] *= b1; beta_pow[1] *= b2; }
+__global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2, float* __restrict__ step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        beta_pow[0] *= b1;
+        beta_pow[1] *= b2;
+        if (step) step[0] += 1.0f;          // float(global_step) used by the state-normaliser decay
+    }
 }
 
 // SAC soft target update (sac.py:67-73): t <- (1-tau)*t + tau*s
@@ -614,7 +618,7 @@ int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply,
 
 int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
                  float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
-                 float grad_mul, void* stream) {
+                 float grad_mul, float* step_counter, void* stream) {
     PFPN_BEGIN();
     if (!params || !grads || !m || !v || !beta_pow || n < 1) return PFPN_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
@@ -623,7 +627,7 @@ int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n
                        beta2, eps, beta_pow, norm_scale, grad_mul);
     PFPN_CHECK_LAUNCH();
     if (advance_beta_pow) {
-        hipLaunchKernelGGL(k_beta_pow_step, dim3(1), dim3(64), 0, st, beta_pow, beta1, beta2);
+        hipLaunchKernelGGL(k_beta_pow_step, dim3(1), dim3(64), 0, st, beta_pow, beta1, beta2, step_counter);
         PFPN_CHECK_LAUNCH();
     }
     return PFPN_OK;

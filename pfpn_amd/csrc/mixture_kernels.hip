@@ -633,27 +633,30 @@ __global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ lpseg
 }
 
 // Fixed-order reduction of per-block slabs: out[i] = sum_k partial[k*stride + i], i < n.
-// Also emits the loss scalars of the fused PPO kernel when `loss_out` is given:
-// loss_out = {loss, policy_loss, value_loss*coef}.  Grid: ceil((n+2)/64) blocks of 1024.
+// With `loss_out`, one extra block (the last) reduces the two loss columns behind the n data columns and
+// emits loss_out = {loss, policy_loss, value_loss*coef}.  Grid: ceil(n/64) (+1) blocks of 1024.
 __global__ __launch_bounds__(1024) void k_finalize(const float* __restrict__ partial, int nslab, int stride, int n,
                                                    float* __restrict__ out0, float* __restrict__ out1, int n0,
                                                    float* __restrict__ loss_out, float inv_B, float value_coef) {
     __shared__ float red[16][64];
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ncol = loss_out ? n + 2 : n;           // the two loss sums sit right behind the n columns
-    const float s = slab_reduce_1024<false>(partial, nslab, (size_t)stride, i, i < ncol, red);
-    if ((threadIdx.x >> 6) != 0 || i >= ncol) return;
-    if (i < n) {
-        if (i < n0) out0[i] = s; else out1[i - n0] = s;
-    } else if (i == n) {
-        loss_out[1] = -s * inv_B;                     // policy loss
-    } else {
-        loss_out[2] = s * inv_B * value_coef;         // value loss * coef
+    __shared__ float lsum[2];
+    const int cl = threadIdx.x & 63;
+    if (loss_out && blockIdx.x == gridDim.x - 1) {
+        const float s = slab_reduce_1024<false>(partial, nslab, (size_t)stride, n + (cl & 1), cl < 2, red);
+        if ((threadIdx.x >> 6) == 0 && cl < 2) lsum[cl] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float pl = -lsum[0] * inv_B, vl = lsum[1] * inv_B * value_coef;
+            loss_out[0] = pl + vl;
+            loss_out[1] = pl;
+            loss_out[2] = vl;
+        }
+        return;
     }
-}
-
-__global__ void k_loss_total(float* __restrict__ loss3) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) loss3[0] = loss3[1] + loss3[2];
+    const int i = blockIdx.x * 64 + cl;
+    const float s = slab_reduce_1024<false>(partial, nslab, (size_t)stride, i, i < n, red);
+    if ((threadIdx.x >> 6) != 0 || i >= n) return;
+    if (i < n0) out0[i] = s; else out1[i - n0] = s;
 }
 
 // adv_stats = {mean, 1/(sqrt(var)+1e-8)} with population variance (reference
@@ -922,10 +925,8 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     launch_packed<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
                             nullptr, partial, pa);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 2 + 63) / 64), dim3(1024), 0, st, partial, pl.grid, 2 * AN + 4,
+    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64 + 1), dim3(1024), 0, st, partial, pl.grid, 2 * AN + 4,
                        2 * AN, dloc, dlogstd, AN, loss3, pa.inv_B, value_coef);
-    PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_loss_total, dim3(1), dim3(64), 0, st, loss3);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -25,10 +25,11 @@ class GraphedLearnerStep(object):
                 optimizer.apply_device(net)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self.capture_stream = s
         for t, sv in zip(self._state_tensors(), saved):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=s):      # same stream as the warm-up: per-stream workspaces exist
             self.loss3 = net.compute_gradients(*self.inputs)
             optimizer.apply_device(net)
         # capture does not execute; state is untouched

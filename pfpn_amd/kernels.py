@@ -26,7 +26,9 @@ def _f32(t, *shape, name="tensor"):
 def workspace(nbytes, device):
     """Grow-only per-device scratch buffer (never reallocated inside a captured region if it was
     sized by a warm-up call first)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream): kernels on a side stream must not share slabs with the main stream
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
@@ -353,12 +355,13 @@ def clip_by_global_norm(grads_flat, clip_norm, norm_scale, apply=True):
 
 
 def tf_adam(params, grads, m, v, beta_pow, lr, beta1=0.9, beta2=0.999, eps=1e-8, advance=True, norm_scale=None,
-            grad_mul=1.0):
+            grad_mul=1.0, step_counter=None):
     lib = _lib.load()
     n = params.numel()
     _lib.check(lib.pfpn_tf_adam(_f32(params), _f32(grads), _f32(m), _f32(v), n, float(lr), float(beta1), float(beta2),
                                 float(eps), _f32(beta_pow, 2), int(advance),
-                                _f32(norm_scale, 2) if norm_scale is not None else None, float(grad_mul), _stream()),
+                                _f32(norm_scale, 2) if norm_scale is not None else None, float(grad_mul),
+                                _f32(step_counter, 1) if step_counter is not None else None, _stream()),
                "pfpn_tf_adam")
 
 

@@ -38,6 +38,7 @@ class SyncReplicasApplier(object):
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.world = int(world_size)
+        net.dp_world = self.world
         self.norm_scale = torch.zeros(2, dtype=torch.float32, device=st.device)
         self.groups = []
         for g in groups:
@@ -55,6 +56,7 @@ class SyncReplicasApplier(object):
         st = net.store
         W = self.world
         fused_scale = None
+        net.join_side_stream()
         if self.norm_clip:
             # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica
             kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=(W > 1))
@@ -62,12 +64,13 @@ class SyncReplicasApplier(object):
                 fused_scale = self.norm_scale          # folded into the Adam kernel
         if W > 1:
             self.reduce(net)
-        for g in self.groups:
+        for gi, g in enumerate(self.groups):
             sl = slice(g["off"], g["off"] + g["len"])
+            last = gi == len(self.groups) - 1
             kernels.tf_adam(st.flat[sl], st.grad[sl], st.m[sl], st.v[sl], g["beta_pow"], g["lr"], self.beta1,
-                            self.beta2, self.epsilon, advance=True, norm_scale=fused_scale, grad_mul=1.0 / W)
+                            self.beta2, self.epsilon, advance=True, norm_scale=fused_scale, grad_mul=1.0 / W,
+                            step_counter=net.step_dev if last else None)
         net.unpack_synced_stats(st.tail, 1.0 / W)
-        net.step_dev.add_(1.0)
 
     def reduce(self, net):
         """The exchange step: ONE all-reduce (sum) of the flat bucket [clipped grads | local statistics]

@@ -157,11 +157,13 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         kernels.bias_act(self.logits, self.policy_bias, relu6=False)
         return self.logits
 
-    def _forward(self, state):
-        """state [B,S] device tensor -> (policy distribution, actor hidden, critic hidden)."""
+    def _forward(self, state, x=None):
+        """state [B,S] device tensor -> (policy distribution, actor hidden, critic hidden).
+        `x`: the already normalised state (when the caller launched the normaliser itself)."""
         B = state.shape[0]
         self._ensure_buffers(B)
-        x = self._normalize(state)
+        if x is None:
+            x = self._normalize(state)
         ha, hc = self._trunks_forward(x)
         logits = self._policy_logits(ha)
         policy = MixtureGaussianDistribution(logits, self.loc, self.logstd, self.normalize_policy_output_)

@@ -92,6 +92,8 @@ class ActorCriticNetwork(object):
         self._init_weights()
         self.state_normalizer = OnlineNormalizer(self.S, self.device) if (self.normalize_state or self.clip_state) else None
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.device)   # float(global_step)
+        self.dp_world = 1                      # set by the optimiser (SyncReplicasApplier)
+        self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._B = None
         # names of the reference's placeholders/tensors, kept for workers that look them up
         self.state, self.action, self.action_hist = "state", "action", "action_hist"
@@ -218,11 +220,35 @@ class ActorCriticNetwork(object):
                 tail[off:off + n].copy_(t.view(-1))
 
     def unpack_synced_stats(self, tail, inv_world):
+        """after the all-reduce: statistics <- mean over replicas.  With one replica the state-normaliser
+        EMA was written in place (update_state_normalizer) and nothing is left to do."""
+        if inv_world == 1.0:
+            return
         for t, off, n, in_tail in self.stat_slots():
-            if inv_world != 1.0:
-                torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
-            elif in_tail:
-                t.view(-1).copy_(tail[off:off + n])
+            torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
+
+    def update_state_normalizer(self, state):
+        """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), on a side
+        stream so the five tiny launches overlap the MLP GEMMs.  One replica: in place (visible to the NEXT
+        step's forward, the deterministic choice of DESIGN.md section 5); W replicas: into the bucket tail that is
+        averaged by the all-reduce."""
+        if not (self.normalize_state and self.trainable):
+            return
+        nz, tail, S = self.state_normalizer, self.store.tail, self.S
+        main = torch.cuda.current_stream()
+        side = self.side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if self.dp_world == 1:
+                nz.updated(state, self.step_dev, nz.mean, nz.std)
+            else:
+                nz.updated(state, self.step_dev, tail[:S], tail[S:2 * S])
+        self._side_pending = True
+
+    def join_side_stream(self):
+        if getattr(self, "_side_pending", False):
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            self._side_pending = False
 
     def actor_param_names(self):
         return [n for n in self.store.names() if n.startswith("actor")]

@@ -66,14 +66,12 @@ def clip_ppo_network_wrapper(a2c_base_class):
             No host synchronisation: capturable in a hipGraph."""
             B = state.shape[0]
             st = self.store
-            policy, ha, hc = self._forward(state)
-            v = self._value(hc)
-            if self.normalize_state:
-                # UPDATE_OPS on the same minibatch (sync_model.py:123-138): EMA into the bucket tail,
-                # which is averaged over the data-parallel ranks before becoming the new statistics.
-                tail = st.tail
-                self.state_normalizer.updated(state, self.step_dev, tail[:self.S], tail[self.S:2 * self.S])
+            self._ensure_buffers(B)
+            x = self._normalize(state)
+            self.update_state_normalizer(state)        # side stream, joined in the optimiser
             kernels.adv_stats(advantage, self.normalize_advantage, out=self.adv_stats)
+            policy, ha, hc = self._forward(state, x)
+            v = self._value(hc)
             out = kernels.ppo_mixture_fwd_bwd(policy.logits, action, self.loc, self.logstd, log_prob, advantage, v,
                                               value, self.adv_stats, self.epsilon, self.value_loss_coef,
                                               out=self.train_out)

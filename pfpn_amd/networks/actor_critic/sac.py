@@ -207,8 +207,7 @@ def sac_network_wrapper(base_class):
             noise = noise or self.make_train_noise(B)
             x = self._normalize(state)
             x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
-            if self.normalize_state:
-                self.state_normalizer.updated(state, self.step_dev, st.tail[:S], st.tail[S:2 * S])
+            self.update_state_normalizer(state)        # side stream, joined in the optimiser
             # eval actor on s, shared actor on s' (sac.py:141-153)
             ha = self._actor_logits(x, 0, self.logits)
             self._actor_logits(x2, 1, self.logits2)
