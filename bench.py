@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true", help="skip PyTorch TunableOp GEMM selection")
     args = ap.parse_args()
 
     import torch
@@ -97,6 +98,15 @@ def main():
     from pfpn_amd.networks import ParticleFilteringClipPPONetwork
     from pfpn_amd import kernels, graphs
 
+    if not args.no_tune:
+        # let PyTorch pick the fastest rocBLAS/hipBLASLt solution per GEMM shape during the (untimed) warm-up
+        try:
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.set_max_tuning_duration(30)
+            torch.cuda.tunable.set_max_tuning_iterations(20)
+            torch.cuda.tunable.write_file_on_exit(False)
+        except Exception:
+            pass
     rank, world, local_rank = init_process_group("nccl" if args.gpus > 1 else None)
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
