@@ -213,8 +213,11 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         if (MODE == MODE_BWD) {
             if (active) my_g = dlogp_in[row0 + r];
         } else {
-            // publish: my segments of each touched row have arrived
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // publish: my segments of each touched row have arrived.  segbuf and cnt both live in LDS, and a
+            // wave's LDS operations are executed in issue order by the one LDS unit of the CU, so the ds_write
+            // of log p is visible to whoever observes the later ds_add: a compiler barrier is all that is needed.
+            // (A workgroup-scope fence would also drain vmcnt, i.e. wait for the NEXT tile's prefetch loads.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int rr_l = r_lo + lane;
             if (rr_l <= r_hi && rr_l < rows) {
                 const int n_r = min(min((rr_l + 1) * A, s_hi + 1), nact) - max(rr_l * A, s_lo);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                 while (__hip_atomic_load(&cnt[rr_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
                     __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            asm volatile("" ::: "memory");
             for (int rr = r_lo; rr <= r_hi && rr < rows; ++rr) {
                 float sacc = 0.f;
                 for (int i = lane; i < A; i += 64) sacc += sb[rr * A + i];
