@@ -36,6 +36,9 @@ extern "C" {
 
 /* library / ABI version, and a cheap "is the device code loadable" probe (no compute). */
 int pfpn_abi_version(void);
+/* diagnostic only: device buffer (16*64 uint64) receiving s_memtime phase stamps of block 0 of the packed
+ * mixture kernel; NULL (default) disables stamping. */
+int pfpn_debug_stamps(void* device_buffer);
 
 /* ---- mixture log-prob (K1/K2) ------------------------------------------------------------ */
 /* scratch needed by the mixture entry points for this shape */

@@ -80,6 +80,14 @@ __device__ __forceinline__ void put_slice(const Pref& pf, float* slice, int nv, 
     if (NV > 3 && lane + 192 < nv) s4[lane + 192] = pf.v3;
 }
 
+// Diagnostic phase stamps (s_memtime) of block 0: enabled only when pfpn_debug_stamps() installed a buffer.
+// Layout: [wave][slot], slot 0 = count; never read by the kernel itself.
+__device__ unsigned long long* g_stamps = nullptr;
+#define PFPN_STAMP(id_)                                                                              \
+    do {                                                                                             \
+        if (stamps && blockIdx.x == 0 && lane == 0) stamps[wave * 64 + (id_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 template <int N, int MODE>
 __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     const float* __restrict__ logits, const float* __restrict__ x,
@@ -120,6 +128,8 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
 
     for (int i = t; i < R; i += blockDim.x) cnt[i] = 0;
+    unsigned long long* stamps = g_stamps;
+    PFPN_STAMP(0);
 
     // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
     // as the reference graph computes them, pre-scaled to base 2:
@@ -147,8 +157,10 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     // my slice of tile `tid_` -> registers (clamped indices: every load is unconditional)
 #define PFPN_FETCH_SLICE(tid_)                                                                           \
     fetch_slice<NV>(pf, logits, (tid_) * R, min(R, B - (tid_) * R) * AN - s_lo * N, SLICE, AN, s_lo * N, lane)
+    PFPN_STAMP(1);
     if (vec_ok && (int)blockIdx.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE((int)blockIdx.x);
     __syncthreads();                                       // cnt zeroed
+    PFPN_STAMP(2);
 
     int it = 0;
     for (int tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x, ++it) {
@@ -167,6 +179,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         const bool active = seg_lane && sidx < nact;
         float xv = 0.f;
         if (active) xv = x[(size_t)row0 * A + sidx];
+        if (it < 4) PFPN_STAMP(3 + it * 6);
 
         // ---- forward on my quarter of the segment (wave-private LDS slice: no barrier) -------
         float ephi[NP];
@@ -208,6 +221,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
             }
         }
 
+        if (it < 4) PFPN_STAMP(4 + it * 6);
         // ---- row stage ------------------------------------------------------------------------
         float my_g = 0.f;                                   // d loss / d logp of my row
         if (MODE == MODE_BWD) {
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                     __builtin_amdgcn_s_sleep(1);
             }
             asm volatile("" ::: "memory");
+            if (it < 4) PFPN_STAMP(5 + it * 6);
             for (int rr = r_lo; rr <= r_hi && rr < rows; ++rr) {
                 float sacc = 0.f;
                 for (int i = lane; i < A; i += 64) sacc += sb[rr * A + i];
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
             }
         }
         if (MODE == MODE_FWD) continue;
+        if (it < 4) PFPN_STAMP(6 + it * 6);
 
         // ---- backward on my quarter (dlogits overwrite the LDS slot) ---------------------------
         if (active) {
@@ -286,6 +302,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                 }
             }
         }
+        if (it < 4) PFPN_STAMP(7 + it * 6);
         // my slice -> HBM (same wave wrote it: in-order LDS, no barrier)
         float* gdst = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;
         if (vec_ok) {
@@ -301,6 +318,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     }
 
     if (MODE == MODE_FWD) return;
+    PFPN_STAMP(40);
     // ---- block partials: dloc / dlogstd summed over the R segments that share an action dim,
     //      in row order; loss sums in wave order.  Slab layout [2*AN + 4] per block.
     float* slab = partial + (size_t)blockIdx.x * (2 * AN + 4);
@@ -332,6 +350,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         slab[2 * AN + 0] = 0.f;
         slab[2 * AN + 1] = 0.f;
     }
+    PFPN_STAMP(41);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -771,6 +790,12 @@ using namespace pfpn;
 // C ABI (declared in include/pfpn_hip.h)
 // =======================================================================================
 extern "C" {
+
+// diagnostic: install (or clear with NULL) a device buffer of 16*64 uint64 for the phase stamps of block 0
+int pfpn_debug_stamps(void* device_buffer) {
+    unsigned long long* p = (unsigned long long*)device_buffer;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? PFPN_OK : PFPN_ERR_LAUNCH;
+}
 
 size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
     // slabs: packed path <= 1024 blocks x (2AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]

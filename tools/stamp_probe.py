@@ -1,0 +1,37 @@
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from pfpn_amd import kernels, _lib
+lib = _lib.load()
+dev = torch.device("cuda:0")
+B, A, N = 4096, 36, 35
+g = torch.Generator(device=dev); g.manual_seed(0)
+logits = torch.randn(B, A*N, device=dev, generator=g)
+x = (torch.rand(B, A, device=dev, generator=g)*2.2-1.1)
+loc = torch.linspace(-1,1,N,device=dev).repeat(A,1).contiguous()
+logstd = torch.full((A,N), float(np.log(2/34)), device=dev)
+lp_old = kernels.logprob_fwd(logits, x, loc, logstd)
+adv = torch.randn(B, device=dev, generator=g); v = torch.randn(B, device=dev, generator=g); vo = torch.randn(B, device=dev, generator=g)
+st = kernels.adv_stats(adv)
+out = kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st)
+buf = torch.zeros(16*64, dtype=torch.int64, device=dev)
+for _ in range(3): kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st, out=out)
+torch.cuda.synchronize()
+assert lib.pfpn_debug_stamps(buf.data_ptr()) == 0
+kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st, out=out)
+torch.cuda.synchronize()
+lib.pfpn_debug_stamps(None)
+s = buf.cpu().numpy().reshape(16, 64)
+names = {0:"start",1:"bank done",2:"barrier0"}
+for it in range(4):
+    for k,nm in enumerate(["put+x","fwd done","wait done","row done","bwd done",""]):
+        names[3+it*6+k] = "t%d %s" % (it, nm)
+names[40]="loop end"; names[41]="slab done"
+t0 = s[:9,0].min()
+for w in (0, 4, 8):
+    print("wave", w)
+    prev = None
+    for k in sorted(names):
+        if s[w,k] == 0: continue
+        dt = (s[w,k]-t0)/100.0   # s_memtime: 100 MHz ticks? print raw delta
+        print("   %-14s %8d ticks  (+%d)" % (names[k], s[w,k]-t0, (s[w,k]-prev) if prev else 0))
+        prev = s[w,k]
