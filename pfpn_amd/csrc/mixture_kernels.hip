@@ -179,6 +179,16 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         const bool active = seg_lane && sidx < nact;
         float xv = 0.f;
         if (active) xv = x[(size_t)row0 * A + sidx];
+        // row scalars of the rows this wave touches: lane k fetches row r_lo + k now, the row stage reads
+        // them back with a lane broadcast after the forward (their latency hides behind it)
+        float rs_adv = 0.f, rs_lpo = 0.f, rs_val = 0.f, rs_vold = 0.f;
+        if (MODE == MODE_PPO) {
+            const int rr_l = r_lo + lane;
+            if (rr_l <= r_hi && rr_l < rows) {
+                const int b = row0 + rr_l;
+                rs_adv = ppo.adv[b]; rs_lpo = ppo.logp_old[b]; rs_val = ppo.value[b]; rs_vold = ppo.value_old[b];
+            }
+        }
         if (it < 4) PFPN_STAMP(3 + it * 6);
 
         // ---- forward on my quarter of the segment (wave-private LDS slice: no barrier) -------
@@ -250,9 +260,12 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                 const bool owner = (rr * A) / PACK_WSEG == wave;      // wave holding the row's first segment
                 float gval = 0.f;
                 if (MODE == MODE_PPO) {
-                    const float adv = ppo.adv[b];
+                    const int src = rr - r_lo;                         // lane that prefetched this row
+                    const float adv = __shfl(rs_adv, src, 64);
+                    const float lpo = __shfl(rs_lpo, src, 64);
+                    const float val_b = __shfl(rs_val, src, 64), vold_b = __shfl(rs_vold, src, 64);
                     const float nadv = (adv - adv_mean) * adv_rstd;
-                    const float ratio = expf(s - ppo.logp_old[b]);
+                    const float ratio = expf(s - lpo);
                     const float sur = ratio * nadv;
                     const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
                     const float csur = cr * nadv;
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
                     gval = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
                     if (owner && lane == 0) {
                         pol_sum += fminf(sur, csur);
-                        const float dvv = ppo.value[b] - (adv + ppo.value_old[b]);
+                        const float dvv = val_b - (adv + vold_b);
                         val_sum += dvv * dvv;
                         ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
                         if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
@@ -719,6 +732,12 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     int k = 12 / W0;
     if (k < 1) k = 1;
     int R = R0 * k;
+    // at <= 128 VGPRs a CU holds 16 waves: prefer ONE block that fills them (largest R with <= 16 waves)
+    // over two half-size blocks that cannot be co-resident (measured on the 4096 x 36 x 35 step)
+    {
+        const int rmax = (16 * PACK_WSEG) / A;
+        if (rmax >= 1 && (rmax * A + PACK_WSEG - 1) / PACK_WSEG <= 16 && rmax > R) R = rmax;
+    }
     static const int env_rows = getenv("PFPN_MIX_ROWS") ? atoi(getenv("PFPN_MIX_ROWS")) : 0;   // tuning knob
     if (env_rows > 0 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 16) R = env_rows;
     if (R > B) R = B;                                   // small batches: one partial tile
@@ -728,8 +747,8 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     pl.lds = (size_t)waves * PACK_WSEG * N * 4 + (size_t)(2 * R * A + R + 2 * waves + 8) * 4;
     pl.vec_ok = (AN % 4 == 0) && ((uintptr_t)logits % 16 == 0) && (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
     const int ntiles = (B + R - 1) / R;
-    // resident blocks per CU by wave slots (<= 96 VGPRs: 5 waves/SIMD = 20 waves/CU) and LDS
-    int per_cu = 20 / waves;
+    // resident blocks per CU by wave slots (128 VGPRs: 4 waves/SIMD = 16 waves/CU) and LDS
+    int per_cu = 16 / waves;
     const int by_lds = (int)((size_t)(150 * 1024) / (pl.lds ? pl.lds : 1));
     if (per_cu > by_lds) per_cu = by_lds;
     if (per_cu < 1) per_cu = 1;
