@@ -130,6 +130,15 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     for (int i = t; i < R; i += blockDim.x) cnt[i] = 0;
     unsigned long long* stamps = g_stamps;
     PFPN_STAMP(0);
+    const int ntiles = (B + R - 1) / R;
+    static_assert(NV <= 4, "slice prefetch holds at most 4 float4 per lane");
+    Pref pf;
+    pf.v0 = pf.v1 = pf.v2 = pf.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // my slice of tile `tid_` -> registers (clamped indices: every load is unconditional)
+#define PFPN_FETCH_SLICE(tid_)                                                                           \
+    fetch_slice<NV>(pf, logits, (tid_) * R, min(R, B - (tid_) * R) * AN - s_lo * N, SLICE, AN, s_lo * N, lane)
+    // first tile's HBM fetch goes out before anything else: its latency hides the bank set-up below
+    if (vec_ok && (int)blockIdx.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE((int)blockIdx.x);
 
     // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
     // as the reference graph computes them, pre-scaled to base 2:
@@ -150,15 +159,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     float adv_mean = 0.f, adv_rstd = 1.f;
     if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
 
-    const int ntiles = (B + R - 1) / R;
-    static_assert(NV <= 4, "slice prefetch holds at most 4 float4 per lane");
-    Pref pf;
-    pf.v0 = pf.v1 = pf.v2 = pf.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // my slice of tile `tid_` -> registers (clamped indices: every load is unconditional)
-#define PFPN_FETCH_SLICE(tid_)                                                                           \
-    fetch_slice<NV>(pf, logits, (tid_) * R, min(R, B - (tid_) * R) * AN - s_lo * N, SLICE, AN, s_lo * N, lane)
     PFPN_STAMP(1);
-    if (vec_ok && (int)blockIdx.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE((int)blockIdx.x);
     __syncthreads();                                       // cnt zeroed
     PFPN_STAMP(2);
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
             for (int rr = r_lo; rr <= r_hi && rr < rows; ++rr) {
                 float sacc = 0.f;
                 for (int i = lane; i < A; i += 64) sacc += sb[rr * A + i];
-                const float s = wave_sum(sacc);                       // same value in every touching wave
+                const float s = wave_sum_dpp(sacc);                   // same value in every touching wave
                 const int b = row0 + rr;
                 const bool owner = (rr * A) / PACK_WSEG == wave;      // wave holding the row's first segment
                 float gval = 0.f;
@@ -734,7 +735,8 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     int R = R0 * k;
     // at <= 128 VGPRs a CU holds 16 waves: prefer ONE block that fills them (largest R with <= 16 waves)
     // over two half-size blocks that cannot be co-resident (measured on the 4096 x 36 x 35 step)
-    {
+    static const int env_full = getenv("PFPN_MIX_FULL") ? atoi(getenv("PFPN_MIX_FULL")) : 1;
+    if (env_full) {
         const int rmax = (16 * PACK_WSEG) / A;
         if (rmax >= 1 && (rmax * A + PACK_WSEG - 1) / PACK_WSEG <= 16 && rmax > R) R = rmax;
     }
