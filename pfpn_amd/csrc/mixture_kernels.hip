@@ -735,7 +735,7 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     int R = R0 * k;
     // at <= 128 VGPRs a CU holds 16 waves: prefer ONE block that fills them (largest R with <= 16 waves)
     // over two half-size blocks that cannot be co-resident (measured on the 4096 x 36 x 35 step)
-    static const int env_full = getenv("PFPN_MIX_FULL") ? atoi(getenv("PFPN_MIX_FULL")) : 1;
+    static const int env_full = getenv("PFPN_MIX_FULL") ? atoi(getenv("PFPN_MIX_FULL")) : 0;
     if (env_full) {
         const int rmax = (16 * PACK_WSEG) / A;
         if (rmax >= 1 && (rmax * A + PACK_WSEG - 1) / PACK_WSEG <= 16 && rmax > R) R = rmax;
