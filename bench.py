@@ -191,9 +191,44 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / reps
         ab = algorithmic_bytes_fused(B)
         ach = ab / (us * 1e-6) / 1e9
+        traffic = None
+        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"]["k_mix_packed<35,PPO>"]["traffic_bytes"]
+        except Exception:
+            pass
         out["roofline"] = {"kernel": "k_mix_packed<35,PPO> (+k_finalize)", "bound": "hbm", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "algorithmic_bytes": ab, "us_per_launch": us}
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes": ab, "us_per_launch": us,
+                           "note": "42 MB per launch: latency/launch-bound at this size; see roofline_stress"}
+        # the same mixture math on the 1 GiB stress shape (BASELINE.json config 5, one GPU's shard)
+        try:
+            sB, sA, sN = 8192, 128, 256
+            g = torch.Generator(device=dev); g.manual_seed(1)
+            sl = torch.randn(sB, sA * sN, device=dev, generator=g)
+            sx = torch.rand(sB, sA, device=dev, generator=g) * 2.2 - 1.1
+            sloc = torch.linspace(-1, 1, sN, device=dev).repeat(sA, 1).contiguous()
+            sls = torch.full((sA, sN), float(np.log(2.0 / (sN - 1))), device=dev)
+            sg = torch.randn(sB, device=dev, generator=g)
+            L_, X_, V_, P_ = 4 * sB * sA * sN, 4 * sB * sA, 4 * sB, 8 * sA * sN
+            res = {}
+            for name, fn, nbytes in (("fwd", lambda: kernels.logprob_fwd(sl, sx, sloc, sls), L_ + X_ + V_ + P_),
+                                     ("bwd", lambda: kernels.logprob_bwd(sl, sx, sloc, sls, sg), 2 * L_ + X_ + 2 * V_ + 2 * P_)):
+                fn(); fn()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                u = e0.elapsed_time(e1) * 1e3 / 10
+                res[name] = {"kernel": "k_mix_wide<1,%s> (+reduce)" % name.upper(), "us_per_launch": u,
+                             "algorithmic_bytes": nbytes, "achieved": nbytes / u / 1e3, "unit": "GB/s",
+                             "peak": HBM_PEAK_GBS, "frac": nbytes / u / 1e3 / HBM_PEAK_GBS}
+            out["roofline_stress"] = {"shape": [sB, sA, sN], "bound": "hbm", **res}
+            del sl, sx, sg
+        except Exception as ex:      # never fail the headline line on the auxiliary measurement
+            out["roofline_stress"] = {"error": repr(ex)}
         # GEMM-only pass: forward + backward dense layers of one step
         def gemms():
             x = net.xn
