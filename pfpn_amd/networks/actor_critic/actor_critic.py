@@ -9,6 +9,8 @@ PyTorch-ROCm, everything else through the HIP kernels.  `sess` arguments are acc
 Out-of-scope options of the reference (value normaliser, conv/lstm layers, regularisers, a shared
 `common_net`) raise NotImplementedError instead of being silently ignored.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -94,6 +96,9 @@ class ActorCriticNetwork(object):
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.device)   # float(global_step)
         self.dp_world = 1                      # set by the optimiser (SyncReplicasApplier)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.dw_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "1") != "0"
+        self._dw_pending = False
         self._B = None
         # names of the reference's placeholders/tensors, kept for workers that look them up
         self.state, self.action, self.action_hist = "state", "action", "action_hist"
@@ -249,6 +254,9 @@ class ActorCriticNetwork(object):
         if getattr(self, "_side_pending", False):
             torch.cuda.current_stream().wait_stream(self.side_stream)
             self._side_pending = False
+        if self._dw_pending:
+            torch.cuda.current_stream().wait_stream(self.dw_stream)
+            self._dw_pending = False
 
     def actor_param_names(self):
         return [n for n in self.store.names() if n.startswith("actor")]

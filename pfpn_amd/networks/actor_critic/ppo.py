@@ -85,15 +85,24 @@ def clip_ppo_network_wrapper(a2c_base_class):
                 policy.entropy_backward(self.entropy_buf, dlogits)
             if self.fixed_sigma:
                 out["dlogstd"].zero_()
-            # fc_policy backward
-            torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
-            kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+            # fc_policy backward: the weight/bias gradients do not feed the dX chain -> second stream
+            dws = self.dw_stream if self.overlap_dw else None
+            if dws is not None:
+                main = torch.cuda.current_stream()
+                dws.wait_stream(main)
+                with torch.cuda.stream(dws):
+                    torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+                    kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+                self._dw_pending = True
+            else:
+                torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
             w3 = st["critic/fc3/weight"].view(-1)
             if self.trunk is not None:
                 torch.mm(dlogits, self.policy_weight.t(), out=self.dh[0])
                 kernels.value_head_bwd(hc, w3, out["dvalue"], self.dh[1], st.g("critic/fc3/weight").view(-1),
                                        st.g("critic/fc3/bias"), relu6=True)
-                self.trunk.backward(self.dh)
+                self.trunk.backward(self.dh, dw_stream=dws)
             else:
                 torch.mm(dlogits, self.policy_weight.t(), out=self.dh_a[0])
                 kernels.value_head_bwd(hc, w3, out["dvalue"], self.dh_c[0], st.g("critic/fc3/weight").view(-1),

@@ -163,11 +163,14 @@ class DenseStack:
             kernels.bias_act(out.view(self.G * B, -1), b, relu6=True, group_rows=B)
         return act[-1]
 
-    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None):
+    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output; masked in place.
-        Weight/bias gradients are written into the store's flat gradient buffer (need_dw)."""
+        Weight/bias gradients are written into the store's flat gradient buffer (need_dw).
+        `dw_stream`: run the weight-gradient GEMMs (independent of the dX chain) on that stream so they
+        overlap the next layer's dX GEMM; the caller joins the stream before using the gradients."""
         if B is None:
             B = dlast.shape[1]
+        main = torch.cuda.current_stream() if dw_stream is not None else None
         buf = self._bufs[(B, slot)]
         act, dact, x = buf["act"], buf["dact"], buf["x"]
         d = dlast
@@ -184,8 +187,14 @@ class DenseStack:
             if i == 0 and x.dim() == 2:
                 if need_dw:
                     xt = x.t()
-                    for g in range(self.G):
-                        torch.mm(xt, d[g], out=gw[g])
+                    if dw_stream is not None:
+                        dw_stream.wait_stream(main)
+                        with torch.cuda.stream(dw_stream):
+                            for g in range(self.G):
+                                torch.mm(xt, d[g], out=gw[g])
+                    else:
+                        for g in range(self.G):
+                            torch.mm(xt, d[g], out=gw[g])
                 if need_dx:
                     dx = torch.mm(d[0], w[0].t())
                     for g in range(1, self.G):
@@ -193,7 +202,12 @@ class DenseStack:
             else:
                 src = x if i == 0 else act[i - 1]
                 if need_dw:
-                    torch.bmm(src.transpose(1, 2), d, out=gw)
+                    if dw_stream is not None:
+                        dw_stream.wait_stream(main)
+                        with torch.cuda.stream(dw_stream):
+                            torch.bmm(src.transpose(1, 2), d, out=gw)
+                    else:
+                        torch.bmm(src.transpose(1, 2), d, out=gw)
                 if i > 0:
                     torch.bmm(d, w.transpose(1, 2), out=dact[i - 1])
                     d = dact[i - 1]
