@@ -162,6 +162,21 @@ int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B
 int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, int H, int relu6, float* dh,
                         float* dw, float* db, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- dense layers on the fp32 MFMA (v_mfma_f32_32x32x2_f32) with fused epilogues --------------------- */
+/* fc_layer forward -- ops.py:105-117: Y[g] = act(X[g] W[g] + b[g]).  X [rows,K] (leading dim ldx, shared by the G
+ * groups when x_gstride == 0), W [G,K,N], b [G,N], Y [G,rows,N].  K, N, ldx multiples of 4 (pad with zeros). */
+size_t pfpn_dense_workspace_bytes(int G, int K, int N);
+int pfpn_dense_fwd(const float* X, long long x_gstride, int ldx, const float* W, const float* bias, int G, int rows,
+                   int K, int N, int relu6, float* Y, void* stream);
+/* MatMul_grad (input side) fused with Relu6Grad of the layer below: dX[g] = (dY[g] W[g]^T) * [0 < Hin[g] < 6]
+ * (Hin NULL: no mask).  dY [G,rows,N], W [G,K,N], Hin/dX [G,rows,K]. */
+int pfpn_dense_dgrad(const float* dY, const float* W, const float* Hin, int G, int rows, int K, int N, float* dX,
+                     void* stream);
+/* MatMul_grad (weight side) fused with BiasAddGrad: dW[g] = X[g]^T dY[g] [K,N], db[g] = column sums of dY[g] [N]
+ * (db may be NULL).  Split over `rows` with fixed-order slab reduction (bitwise reproducible). */
+int pfpn_dense_wgrad(const float* X, long long x_gstride, int ldx, const float* dY, int G, int rows, int K, int N,
+                     float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* tf.clip_by_global_norm -- base_worker.py:97-102: norm_scale = {norm, clip*min(1/norm, 1/clip)};
  * apply != 0 scales grads in place (needed before a data-parallel all-reduce). */
 int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply, float* norm_scale,

@@ -19,7 +19,7 @@ _CT = {
     "int32_t*": ctypes.c_void_p, "const int64_t*": ctypes.c_void_p, "int64_t*": ctypes.c_void_p,
     "const uint8_t*": ctypes.c_void_p, "uint8_t*": ctypes.c_void_p,
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
-    "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
+    "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
     "void": None,
 }
 

@@ -1,0 +1,303 @@
+// fp32 MFMA GEMM with fused dense-layer epilogues for gfx950 (MI355X).
+//
+// Replaces fc_layer's MatMul + BiasAdd + Relu6 (reference networks/ops.py:105-117) and their TF gradients
+// (MatMul_grad, Relu6Grad, BiasAddGrad) with three kernels built on v_mfma_f32_32x32x2_f32 (exact fp32, the
+// reference computes in fp32 -- there is no TF32/bf16 shortcut):
+//   NN  Y  = act(X W + b)            X [M,K]  W [K,N]            epilogue: +bias, ReLU6
+//   NT  dX = (dY W^T) * relu6'(Hin)  dY [M,Kg] W [N,Kg]          epilogue: ReLU6 mask of the layer input
+//   TN  dW = X^T dY, db = 1^T dY     X [Kg,M] dY [Kg,N], split over Kg, fixed-order slab reduction
+// so the separate bias/activation/mask/bias-grad passes over the activations (~95 us of a 600 us learner step)
+// disappear into the GEMMs.
+//
+// Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 2x2 MFMA 32x32 tiles (64 accumulator
+// VGPRs); operands staged in LDS k-major (As[k][m], Bs[k][n]) so an MFMA fragment read is 2 runs of 32 consecutive
+// floats (conflict-free ds_read_b32); leading dims 129 (transposing store) / 132 (direct b128 store) keep the stores
+// conflict-free too.  The next k-tile is prefetched from HBM/L2 into registers while the current one is multiplied;
+// 4 co-resident blocks per CU (<= 128 VGPRs, 33 KiB LDS) hide the rest.
+#include "pfpn_common.h"
+
+namespace pfpn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int LD_T = 129;     // operand stored with a transposing (scalar) LDS write
+constexpr int LD_D = 132;     // operand stored with direct float4 LDS writes
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU6 = 2, EPI_MASK = 3 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias;          // [N]            (EPI_BIAS*)
+    const float* H;             // [M, ldh]       (EPI_MASK: activations of the layer input)
+    float* colsum;              // TN: [S][N] partial column sums of B (bias gradient), or null
+    int M, N, K;                // C is M x N, reduction length K
+    int lda, ldb, ldc, ldh;
+    long long sA, sB, sC, sBias, sH;    // batch strides (elements)
+    int ksplit;                 // TN: number of K chunks (grid.z = batch * ksplit)
+    int kchunk;                 // TN: K elements per chunk (multiple of GBK)
+};
+
+// ---- global -> register staging --------------------------------------------------------------------------------
+// "K-contiguous" operand (rows of the tile are rows of memory, k runs along the row): 128 rows x 32 k.
+// thread t: rows t/8 + 32 j (j < 4), k = 4 (t % 8).  A wave covers 8 rows x 128 B.
+__device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict__ P, int ld, int row0, int nrows,
+                                        int k0, int kend, int t) {
+    const int kq = (t & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = row0 + (t >> 3) + 32 * j;
+        const int k = k0 + kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows && k < kend) v = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);   // kend % 4 == 0
+        r[j] = v;
+    }
+}
+__device__ __forceinline__ void store_kc(float* __restrict__ S, const float4 (&r)[4], int t) {
+    const int kq = (t & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (t >> 3) + 32 * j;
+        S[(kq + 0) * LD_T + row] = r[j].x;
+        S[(kq + 1) * LD_T + row] = r[j].y;
+        S[(kq + 2) * LD_T + row] = r[j].z;
+        S[(kq + 3) * LD_T + row] = r[j].w;
+    }
+}
+// "tile-dim-contiguous" operand (k indexes memory rows, the tile dimension runs along the row): 32 k x 128 cols.
+// thread t: k = t/32 + 8 j (j < 4), col = 4 (t % 32).  A wave covers 2 k-rows x 512 B.
+__device__ __forceinline__ void load_tc(float4 (&r)[4], const float* __restrict__ P, int ld, int col0, int ncols,
+                                        int k0, int kend, int t) {
+    const int cq = (t & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + (t >> 5) + 8 * j;
+        const int col = col0 + cq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kend && col < ncols) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + col);   // ncols % 4 == 0
+        r[j] = v;
+    }
+}
+__device__ __forceinline__ void store_tc(float* __restrict__ S, const float4 (&r)[4], int t) {
+    const int cq = (t & 31) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = (t >> 5) + 8 * j;
+        *reinterpret_cast<float4*>(S + k * LD_D + cq) = r[j];
+    }
+}
+
+// AKC: A is K-contiguous (row-major [M][K]); else A is stored [K][M].  BKC: B is stored [N][K]; else row-major [K][N].
+template <bool AKC, bool BKC, int EPI, bool SPLITK>
+__global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
+    constexpr int LDA_S = AKC ? LD_T : LD_D;
+    constexpr int LDB_S = BKC ? LD_T : LD_D;
+    __shared__ __attribute__((aligned(16))) float As[GBK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * LDB_S];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;       // wave's 64x64 corner in the block tile
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    int batch = blockIdx.z, kc = 0;
+    if (SPLITK) { batch = blockIdx.z / g.ksplit; kc = blockIdx.z - batch * g.ksplit; }
+    const float* A = g.A + (size_t)batch * g.sA;
+    const float* B = g.B + (size_t)batch * g.sB;
+    const int kbeg = SPLITK ? kc * g.kchunk : 0;
+    const int kend = SPLITK ? min(g.K, kbeg + g.kchunk) : g.K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);              // TN: column sums of my B float4 column group
+
+    float4 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        if (AKC) load_kc(ra, A, g.lda, m0, g.M, k0, kend, t); else load_tc(ra, A, g.lda, m0, g.M, k0, kend, t);
+        if (BKC) load_kc(rb, B, g.ldb, n0, g.N, k0, kend, t); else load_tc(rb, B, g.ldb, n0, g.N, k0, kend, t);
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+        __syncthreads();                                   // previous tile's fragment reads are done
+        if (AKC) store_kc(As, ra, t); else store_tc(As, ra, t);
+        if (BKC) store_kc(Bs, rb, t); else store_tc(Bs, rb, t);
+        if (SPLITK && g.colsum && blockIdx.y == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { csum.x += rb[j].x; csum.y += rb[j].y; csum.z += rb[j].z; csum.w += rb[j].w; }
+        }
+        __syncthreads();
+        fetch(k0 + GBK);                                   // next tile in flight during the MFMAs (past the end: zeros)
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const int krow = kk + (lane >> 5);
+            const float a0 = As[krow * LDA_S + wm + (lane & 31)];
+            const float a1 = As[krow * LDA_S + wm + 32 + (lane & 31)];
+            const float b0 = Bs[krow * LDB_S + wn + (lane & 31)];
+            const float b1 = Bs[krow * LDB_S + wn + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----------------------
+    float* C = g.C + (size_t)batch * g.sC + (SPLITK ? (size_t)kc * g.M * g.ldc : 0);   // split-K: slab kc of this batch
+    const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU6) ? g.bias + (size_t)batch * g.sBias : nullptr;
+    const float* H = (EPI == EPI_MASK) ? g.H + (size_t)batch * g.sH : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + 32 * j + (lane & 31);
+        if (col >= g.N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_BIAS_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+                    if (EPI == EPI_MASK) {
+                        const float h = H[(size_t)row * g.ldh + col];
+                        v = (h > 0.f && h < 6.f) ? v : 0.f;
+                    }
+                    C[(size_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+    if (SPLITK && g.colsum && blockIdx.y == 0) {
+        // combine the 8 k-row lanes (t >> 5) that share a column group through LDS, fixed order
+        __syncthreads();
+        float4* red = reinterpret_cast<float4*>(As);       // 8 x 32 float4 = 4 KiB
+        red[(t >> 5) * 32 + (t & 31)] = csum;
+        __syncthreads();
+        if (t < 32) {
+            float4 s = red[t];
+            for (int q = 1; q < 8; ++q) { const float4 u = red[q * 32 + t]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+            const int col = n0 + 4 * t;
+            if (col < g.N)
+                *reinterpret_cast<float4*>(g.colsum + ((size_t)batch * g.ksplit + kc) * g.N + col) = s;
+        }
+    }
+}
+
+// out[b][i] = sum_s slab[b][s][i] in slab order (deterministic); n4 = elements/4 per slab
+__global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slab, int S, size_t n, float* __restrict__ out,
+                                                  long long out_stride) {
+    const size_t n4 = n >> 2;
+    const int b = blockIdx.y;
+    const float4* src = reinterpret_cast<const float4*>(slab + (size_t)b * S * n);
+    float4* dst = reinterpret_cast<float4*>(out + (size_t)b * out_stride);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = src[i];
+        for (int k = 1; k < S; ++k) { const float4 u = src[(size_t)k * n4 + i]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+        dst[i] = s;
+    }
+}
+
+template <bool AKC, bool BKC, int EPI, bool SPLITK>
+static void launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch * (SPLITK ? g.ksplit : 1));
+    hipLaunchKernelGGL((k_gemm<AKC, BKC, EPI, SPLITK>), grid, dim3(256), 0, st, g);
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace pfpn
+
+using namespace pfpn;
+
+extern "C" {
+
+// scratch for pfpn_dense_wgrad: split-K slabs of dW [G][S][K][N] and of the column sums [G][S][N]
+size_t pfpn_dense_workspace_bytes(int G, int K, int N) {
+    return ((size_t)G * 16 * ((size_t)K * N + N) + 64) * sizeof(float);
+}
+
+// Y[g] = act(X[g] W[g] + b[g]).  X: [rows, K] (shared by all groups when x_gstride == 0), ldx % 4 == 0, K % 4 == 0;
+// W [G, K, N] contiguous, N % 4 == 0; b [G, N]; Y [G, rows, N] contiguous.
+int pfpn_dense_fwd(const float* X, long long x_gstride, int ldx, const float* W, const float* bias, int G, int rows,
+                   int K, int N, int relu6, float* Y, void* stream) {
+    PFPN_BEGIN();
+    if (!X || !W || !bias || !Y || G < 1 || rows < 1 || K < 4 || N < 4) return PFPN_ERR_ARG;
+    if ((K & 3) || (N & 3) || (ldx & 3) || !aligned16(X) || !aligned16(W) || !aligned16(Y) || (x_gstride & 3))
+        return PFPN_ERR_ARG;
+    GemmArgs g{};
+    g.A = X; g.B = W; g.C = Y; g.bias = bias;
+    g.M = rows; g.N = N; g.K = K; g.lda = ldx; g.ldb = N; g.ldc = N;
+    g.sA = x_gstride; g.sB = (long long)K * N; g.sC = (long long)rows * N; g.sBias = N;
+    if (relu6) launch_gemm<true, false, EPI_BIAS_RELU6, false>(g, G, (hipStream_t)stream);
+    else launch_gemm<true, false, EPI_BIAS, false>(g, G, (hipStream_t)stream);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+// dX[g] = (dY[g] W[g]^T) * [0 < Hin[g] < 6] (mask optional: Hin may be NULL).  dY [G, rows, N], W [G, K, N],
+// Hin [G, rows, K] (the ReLU6 output that fed this layer), dX [G, rows, K].  K % 4 == 0, N % 4 == 0.
+int pfpn_dense_dgrad(const float* dY, const float* W, const float* Hin, int G, int rows, int K, int N, float* dX,
+                     void* stream) {
+    PFPN_BEGIN();
+    if (!dY || !W || !dX || G < 1 || rows < 1 || K < 4 || N < 4) return PFPN_ERR_ARG;
+    if ((K & 3) || (N & 3) || !aligned16(dY) || !aligned16(W) || !aligned16(dX)) return PFPN_ERR_ARG;
+    GemmArgs g{};
+    g.A = dY; g.B = W; g.C = dX; g.H = Hin;
+    g.M = rows; g.N = K; g.K = N;                  // output is rows x K, reduction over N
+    g.lda = N; g.ldb = N; g.ldc = K; g.ldh = K;
+    g.sA = (long long)rows * N; g.sB = (long long)K * N; g.sC = (long long)rows * K; g.sH = (long long)rows * K;
+    if (Hin) launch_gemm<true, true, EPI_MASK, false>(g, G, (hipStream_t)stream);
+    else launch_gemm<true, true, EPI_NONE, false>(g, G, (hipStream_t)stream);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+// dW[g] = X[g]^T dY[g]  [K, N]  and  db[g] = column sums of dY[g]  [N].  X [rows, K] (ldx, shared when x_gstride == 0),
+// dY [G, rows, N].  The reduction over `rows` is split into chunks whose partial products land in workspace slabs and
+// are summed in chunk order (bitwise reproducible).
+int pfpn_dense_wgrad(const float* X, long long x_gstride, int ldx, const float* dY, int G, int rows, int K, int N,
+                     float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
+    if (!X || !dY || !dW || G < 1 || rows < 1 || K < 4 || N < 4) return PFPN_ERR_ARG;
+    if ((K & 3) || (N & 3) || (ldx & 3) || !aligned16(X) || !aligned16(dY) || !aligned16(dW) || (x_gstride & 3))
+        return PFPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = ((K + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) * G;
+    int S = (1024 + tiles - 1) / tiles;            // ~4 blocks per CU
+    const int maxS = (rows + 4 * GBK - 1) / (4 * GBK);
+    if (S > maxS) S = maxS;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    int kchunk = ((rows + S - 1) / S + GBK - 1) / GBK * GBK;
+    S = (rows + kchunk - 1) / kchunk;
+    const size_t need = ((size_t)G * S * ((size_t)K * N + N)) * sizeof(float);
+    if (S > 1 || db) { if (!workspace || workspace_bytes < need) return PFPN_ERR_WORKSPACE; }
+    float* slab = (float*)workspace;
+    float* cs = slab ? slab + (size_t)G * S * K * N : nullptr;
+    GemmArgs g{};
+    g.A = X; g.B = dY; g.C = (S > 1) ? slab : dW; g.colsum = db ? cs : nullptr;
+    g.M = K; g.N = N; g.K = rows;                  // output K x N, reduction over rows
+    g.lda = ldx; g.ldb = N; g.ldc = N;
+    g.sA = x_gstride; g.sB = (long long)rows * N; g.sC = (S > 1) ? (long long)S * K * N : (long long)K * N;
+    g.ksplit = S; g.kchunk = kchunk;
+    launch_gemm<false, false, EPI_NONE, true>(g, G, st);
+    PFPN_CHECK_LAUNCH();
+    if (S > 1) {
+        const size_t n = (size_t)K * N;
+        int gx = (int)((n / 4 + 255) / 256);
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(k_slab_sum, dim3(gx, G), dim3(256), 0, st, slab, S, n, dW, (long long)n);
+        PFPN_CHECK_LAUNCH();
+    }
+    if (db) {
+        hipLaunchKernelGGL(k_slab_sum, dim3((N / 4 + 255) / 256, G), dim3(256), 0, st, cs, S, (size_t)N, db, (long long)N);
+        PFPN_CHECK_LAUNCH();
+    }
+    return PFPN_OK;
+}
+
+}  // extern "C"

@@ -382,3 +382,50 @@ def sac_loss(q_pi, q_run, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, 
                                  _f32(out["dq_pi"], 2, B), _f32(out["dq_run"], 2, B), _f32(out["dlogp"], B),
                                  _f32(out["dlog_alpha"]), _f32(out["loss3"], 3), _stream()), "pfpn_sac_loss")
     return out
+
+
+# --------------------------------------------------------------------------------------- #
+# dense layers on the hand-written fp32 MFMA GEMM (fused epilogues)                         #
+# --------------------------------------------------------------------------------------- #
+def _dense_ws(G, K, N, device):
+    lib = _lib.load()
+    buf = workspace(lib.pfpn_dense_workspace_bytes(G, K, N), device)
+    return buf.data_ptr(), buf.numel()
+
+
+def dense_fwd(x, w, bias, out, relu6=True):
+    """x [rows, ldx] shared by all groups (K = w.shape[1] <= ldx) or [G, rows, K]; w [G,K,N]; bias [G,N]; out [G,rows,N]."""
+    lib = _lib.load()
+    G, K, N = w.shape
+    if x.dim() == 2:
+        rows, ldx, gstride = x.shape[0], x.stride(0), 0
+    else:
+        rows, ldx, gstride = x.shape[1], x.stride(1), x.stride(0)
+    _lib.check(lib.pfpn_dense_fwd(x.data_ptr(), gstride, ldx, _f32(w, G, K, N), _f32(bias, G, N), G, rows, K, N,
+                                  int(relu6), _f32(out, G, rows, N), _stream()), "pfpn_dense_fwd")
+    return out
+
+
+def dense_dgrad(dy, w, hin, dx):
+    """dy [G,rows,N], w [G,K,N], hin [G,rows,K] or None, dx [G,rows,K]."""
+    lib = _lib.load()
+    G, K, N = w.shape
+    rows = dy.shape[1]
+    _lib.check(lib.pfpn_dense_dgrad(_f32(dy, G, rows, N), _f32(w, G, K, N),
+                                    _f32(hin, G, rows, K) if hin is not None else None, G, rows, K, N,
+                                    _f32(dx, G, rows, K), _stream()), "pfpn_dense_dgrad")
+    return dx
+
+
+def dense_wgrad(x, dy, dw, db):
+    """x [rows, ldx] shared or [G,rows,K]; dy [G,rows,N]; dw [G,K,N]; db [G,N] or None."""
+    lib = _lib.load()
+    G, K, N = dw.shape
+    if x.dim() == 2:
+        rows, ldx, gstride = x.shape[0], x.stride(0), 0
+    else:
+        rows, ldx, gstride = x.shape[1], x.stride(1), x.stride(0)
+    ws, wsn = _dense_ws(G, K, N, dy.device)
+    _lib.check(lib.pfpn_dense_wgrad(x.data_ptr(), gstride, ldx, _f32(dy, G, rows, N), G, rows, K, N, _f32(dw, G, K, N),
+                                    _f32(db, G, N) if db is not None else None, ws, wsn, _stream()), "pfpn_dense_wgrad")
+    return dw, db

@@ -97,7 +97,7 @@ class ActorCriticNetwork(object):
         self.dp_world = 1                      # set by the optimiser (SyncReplicasApplier)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.dw_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "1") != "0"
+        self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "0") != "0"   # measured slower on MI355X (concurrent GEMMs thrash): off
         self._dw_pending = False
         self._B = None
         # names of the reference's placeholders/tensors, kept for workers that look them up
