@@ -9,20 +9,21 @@
 // so the separate bias/activation/mask/bias-grad passes over the activations (~95 us of a 600 us learner step)
 // disappear into the GEMMs.
 //
-// Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 2x2 MFMA 32x32 tiles (64 accumulator
-// VGPRs); operands staged in LDS k-major (As[k][m], Bs[k][n]) so an MFMA fragment read is 2 runs of 32 consecutive
-// floats (conflict-free ds_read_b32); leading dims 129 (transposing store) / 132 (direct b128 store) keep the stores
-// conflict-free too.  The next k-tile is prefetched from HBM/L2 into registers while the current one is multiplied;
-// 4 co-resident blocks per CU (<= 128 VGPRs, 33 KiB LDS) hide the rest.
+// Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 4x4 MFMA 16x16x4 tiles (64 accumulator
+// VGPRs, 16 independent chains: the 40-cycle dependent latency never stalls the 32-cycle issue).  Operands are staged
+// in LDS k-major, As[k][m] / Bs[k][n], leading dim 144 (= 16 mod 32) so a fragment read -- 4 runs of 16 consecutive
+// floats for k..k+3 -- is conflict-free, and the column index is XOR-swizzled with ((k>>2)&7)<<2 so the TRANSPOSING
+// stores of a K-contiguous operand (lanes = 4 rows x 8 k-quads) are conflict-free too.  8 fragment reads feed 16 MFMAs.
+// The next k-tile is prefetched from HBM/L2 into registers while the current one is multiplied.
 #include "pfpn_common.h"
 
 namespace pfpn {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
-constexpr int LD_T = 129;     // operand stored with a transposing (scalar) LDS write
-constexpr int LD_D = 132;     // operand stored with direct float4 LDS writes
+constexpr int GLD = 144;      // LDS leading dim: 16 mod 32 (fragment reads), multiple of 4 (float4 stores)
+__device__ __forceinline__ int swz(int k) { return ((k >> 2) & 7) << 2; }
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU6 = 2, EPI_MASK = 3 };
 
@@ -58,10 +59,11 @@ __device__ __forceinline__ void store_kc(float* __restrict__ S, const float4 (&r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (t >> 3) + 32 * j;
-        S[(kq + 0) * LD_T + row] = r[j].x;
-        S[(kq + 1) * LD_T + row] = r[j].y;
-        S[(kq + 2) * LD_T + row] = r[j].z;
-        S[(kq + 3) * LD_T + row] = r[j].w;
+        const int c = row ^ swz(kq);               // same swizzle for the 4 k's of this quad
+        S[(kq + 0) * GLD + c] = r[j].x;
+        S[(kq + 1) * GLD + c] = r[j].y;
+        S[(kq + 2) * GLD + c] = r[j].z;
+        S[(kq + 3) * GLD + c] = r[j].w;
     }
 }
 // "tile-dim-contiguous" operand (k indexes memory rows, the tile dimension runs along the row): 32 k x 128 cols.
@@ -83,17 +85,15 @@ __device__ __forceinline__ void store_tc(float* __restrict__ S, const float4 (&r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = (t >> 5) + 8 * j;
-        *reinterpret_cast<float4*>(S + k * LD_D + cq) = r[j];
+        *reinterpret_cast<float4*>(S + k * GLD + (cq ^ swz(k))) = r[j];
     }
 }
 
 // AKC: A is K-contiguous (row-major [M][K]); else A is stored [K][M].  BKC: B is stored [N][K]; else row-major [K][N].
 template <bool AKC, bool BKC, int EPI, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
-    constexpr int LDA_S = AKC ? LD_T : LD_D;
-    constexpr int LDB_S = BKC ? LD_T : LD_D;
-    __shared__ __attribute__((aligned(16))) float As[GBK * LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[GBK * LDB_S];
+    __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -106,21 +106,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const int kbeg = SPLITK ? kc * g.kchunk : 0;
     const int kend = SPLITK ? min(g.K, kbeg + g.kchunk) : g.K;
 
-    f32x16 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);              // TN: column sums of my B float4 column group
 
     float4 ra[4], rb[4];
-    auto fetch = [&](int k0) {
-        if (AKC) load_kc(ra, A, g.lda, m0, g.M, k0, kend, t); else load_tc(ra, A, g.lda, m0, g.M, k0, kend, t);
-        if (BKC) load_kc(rb, B, g.ldb, n0, g.N, k0, kend, t); else load_tc(rb, B, g.ldb, n0, g.N, k0, kend, t);
-    };
-    fetch(kbeg);
+    if (AKC) load_kc(ra, A, g.lda, m0, g.M, kbeg, kend, t); else load_tc(ra, A, g.lda, m0, g.M, kbeg, kend, t);
+    if (BKC) load_kc(rb, B, g.ldb, n0, g.N, kbeg, kend, t); else load_tc(rb, B, g.ldb, n0, g.N, kbeg, kend, t);
+    const int frow = lane >> 4, fcol = lane & 15;           // fragment: k = kk + frow, m/n = base + fcol
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
         __syncthreads();                                   // previous tile's fragment reads are done
         if (AKC) store_kc(As, ra, t); else store_tc(As, ra, t);
@@ -130,35 +126,43 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             for (int j = 0; j < 4; ++j) { csum.x += rb[j].x; csum.y += rb[j].y; csum.z += rb[j].z; csum.w += rb[j].w; }
         }
         __syncthreads();
-        fetch(k0 + GBK);                                   // next tile in flight during the MFMAs (past the end: zeros)
+        // next tile in flight during the MFMAs (past the end: predicated off, zeros)
+        if (AKC) load_kc(ra, A, g.lda, m0, g.M, k0 + GBK, kend, t); else load_tc(ra, A, g.lda, m0, g.M, k0 + GBK, kend, t);
+        if (BKC) load_kc(rb, B, g.ldb, n0, g.N, k0 + GBK, kend, t); else load_tc(rb, B, g.ldb, n0, g.N, k0 + GBK, kend, t);
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 2) {
-            const int krow = kk + (lane >> 5);
-            const float a0 = As[krow * LDA_S + wm + (lane & 31)];
-            const float a1 = As[krow * LDA_S + wm + 32 + (lane & 31)];
-            const float b0 = Bs[krow * LDB_S + wn + (lane & 31)];
-            const float b1 = Bs[krow * LDB_S + wn + 32 + (lane & 31)];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kk = 0; kk < GBK; kk += 4) {
+            const int krow = kk + frow;
+            const int sw = swz(kk);                         // kk is a multiple of 4: one swizzle for k..k+3
+            const float* ar = As + krow * GLD;
+            const float* br = Bs + krow * GLD;
+            float af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = ar[(wm + 16 * i + fcol) ^ sw];
+                bf[i] = br[(wn + 16 * i + fcol) ^ sw];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
 
-    // ---- epilogue.  C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----------------------
+    // ---- epilogue.  16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + r ------------------------------------
     float* C = g.C + (size_t)batch * g.sC + (SPLITK ? (size_t)kc * g.M * g.ldc : 0);   // split-K: slab kc of this batch
     const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU6) ? g.bias + (size_t)batch * g.sBias : nullptr;
     const float* H = (EPI == EPI_MASK) ? g.H + (size_t)batch * g.sH : nullptr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn + 32 * j + (lane & 31);
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn + 16 * j + fcol;
         if (col >= g.N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + 16 * i + 4 * frow + r;
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
                     if (EPI == EPI_BIAS_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
