@@ -92,8 +92,13 @@ __device__ __forceinline__ void store_tc(float* __restrict__ S, const float4 (&r
 // AKC: A is K-contiguous (row-major [M][K]); else A is stored [K][M].  BKC: B is stored [N][K]; else row-major [K][N].
 template <bool AKC, bool BKC, int EPI, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GBK * GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GBK * GLD];
+    // double-buffered operand tiles: ONE barrier per k-step; the stores of tile k+1 and the HBM/L2 loads of
+    // tile k+2 are issued ahead of the 128 MFMAs of tile k, so a lone block on a CU keeps its matrix pipe busy
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As0 = lds;
+    float* Bs0 = lds + GBK * GLD;
+    float* As1 = lds + 2 * GBK * GLD;
+    float* Bs1 = lds + 3 * GBK * GLD;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const float* B = g.B + (size_t)batch * g.sB;
     const int kbeg = SPLITK ? kc * g.kchunk : 0;
     const int kend = SPLITK ? min(g.K, kbeg + g.kchunk) : g.K;
+    const bool do_csum = SPLITK && g.colsum && blockIdx.y == 0;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -114,27 +120,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);              // TN: column sums of my B float4 column group
 
     float4 ra[4], rb[4];
-    if (AKC) load_kc(ra, A, g.lda, m0, g.M, kbeg, kend, t); else load_tc(ra, A, g.lda, m0, g.M, kbeg, kend, t);
-    if (BKC) load_kc(rb, B, g.ldb, n0, g.N, kbeg, kend, t); else load_tc(rb, B, g.ldb, n0, g.N, kbeg, kend, t);
+#define GEMM_FETCH(k_)                                                                                          \
+    do {                                                                                                        \
+        if (AKC) load_kc(ra, A, g.lda, m0, g.M, (k_), kend, t); else load_tc(ra, A, g.lda, m0, g.M, (k_), kend, t); \
+        if (BKC) load_kc(rb, B, g.ldb, n0, g.N, (k_), kend, t); else load_tc(rb, B, g.ldb, n0, g.N, (k_), kend, t); \
+    } while (0)
+#define GEMM_STORE(As_, Bs_)                                                                                    \
+    do {                                                                                                        \
+        if (AKC) store_kc((As_), ra, t); else store_tc((As_), ra, t);                                           \
+        if (BKC) store_kc((Bs_), rb, t); else store_tc((Bs_), rb, t);                                           \
+        if (do_csum) {                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+                csum.x += rb[j].x; csum.y += rb[j].y; csum.z += rb[j].z; csum.w += rb[j].w;                     \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
     const int frow = lane >> 4, fcol = lane & 15;           // fragment: k = kk + frow, m/n = base + fcol
+    GEMM_FETCH(kbeg);
+    GEMM_STORE(As0, Bs0);
+    GEMM_FETCH(kbeg + GBK);
+    __syncthreads();
+    int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-        __syncthreads();                                   // previous tile's fragment reads are done
-        if (AKC) store_kc(As, ra, t); else store_tc(As, ra, t);
-        if (BKC) store_kc(Bs, rb, t); else store_tc(Bs, rb, t);
-        if (SPLITK && g.colsum && blockIdx.y == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { csum.x += rb[j].x; csum.y += rb[j].y; csum.z += rb[j].z; csum.w += rb[j].w; }
+        const float* Ac = buf ? As1 : As0;
+        const float* Bc = buf ? Bs1 : Bs0;
+        if (k0 + GBK < kend) {                              // tile k+1 (in registers) -> the other buffer
+            if (buf) GEMM_STORE(As0, Bs0); else GEMM_STORE(As1, Bs1);
+            GEMM_FETCH(k0 + 2 * GBK);                       // tile k+2 in flight during the MFMAs (past the end: zeros)
         }
-        __syncthreads();
-        // next tile in flight during the MFMAs (past the end: predicated off, zeros)
-        if (AKC) load_kc(ra, A, g.lda, m0, g.M, k0 + GBK, kend, t); else load_tc(ra, A, g.lda, m0, g.M, k0 + GBK, kend, t);
-        if (BKC) load_kc(rb, B, g.ldb, n0, g.N, k0 + GBK, kend, t); else load_tc(rb, B, g.ldb, n0, g.N, k0 + GBK, kend, t);
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 4) {
             const int krow = kk + frow;
             const int sw = swz(kk);                         // kk is a multiple of 4: one swizzle for k..k+3
-            const float* ar = As + krow * GLD;
-            const float* br = Bs + krow * GLD;
+            const float* ar = Ac + krow * GLD;
+            const float* br = Bc + krow * GLD;
             float af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -147,7 +166,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();                                    // tile k consumed by everyone, tile k+1 fully stored
+        buf ^= 1;
     }
+#undef GEMM_FETCH
+#undef GEMM_STORE
+    float* As = As0;
 
     // ---- epilogue.  16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + r ------------------------------------
     float* C = g.C + (size_t)batch * g.sC + (SPLITK ? (size_t)kc * g.M * g.ldc : 0);   // split-K: slab kc of this batch
@@ -208,7 +232,14 @@ __global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slab
 template <bool AKC, bool BKC, int EPI, bool SPLITK>
 static void launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch * (SPLITK ? g.ksplit : 1));
-    hipLaunchKernelGGL((k_gemm<AKC, BKC, EPI, SPLITK>), grid, dim3(256), 0, st, g);
+    constexpr size_t lds = (size_t)4 * GBK * GLD * sizeof(float);      // 72 KiB: two buffers of As + Bs
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, EPI, SPLITK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<AKC, BKC, EPI, SPLITK>), grid, dim3(256), lds, st, g);
 }
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
