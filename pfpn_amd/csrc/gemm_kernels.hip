@@ -148,24 +148,35 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             if (buf) GEMM_STORE(As0, Bs0); else GEMM_STORE(As1, Bs1);
             GEMM_FETCH(k0 + 2 * GBK);                       // tile k+2 in flight during the MFMAs (past the end: zeros)
         }
+        // software-pipelined fragments: the 8 ds_reads of k-quad q+1 are issued before the 16 MFMAs of quad q
+        // (sched_barrier keeps hipcc from sinking them next to their use, which exposed the LDS latency 4x per quad)
+        float af[2][4], bf[2][4];
+#define GEMM_FRAG(q_, kk_)                                                                  \
+    do {                                                                                    \
+        const float* ar_ = Ac + ((kk_) + frow) * GLD;                                       \
+        const float* br_ = Bc + ((kk_) + frow) * GLD;                                       \
+        const int sw_ = swz(kk_);                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                     \
+            af[q_][i] = ar_[(wm + 16 * i + fcol) ^ sw_];                                    \
+            bf[q_][i] = br_[(wn + 16 * i + fcol) ^ sw_];                                    \
+        }                                                                                   \
+    } while (0)
+        GEMM_FRAG(0, 0);
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 4) {
-            const int krow = kk + frow;
-            const int sw = swz(kk);                         // kk is a multiple of 4: one swizzle for k..k+3
-            const float* ar = Ac + krow * GLD;
-            const float* br = Bc + krow * GLD;
-            float af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = ar[(wm + 16 * i + fcol) ^ sw];
-                bf[i] = br[(wn + 16 * i + fcol) ^ sw];
+            const int cur = (kk >> 2) & 1;
+            if (kk + 4 < GBK) {
+                if (cur) GEMM_FRAG(0, kk + 4); else GEMM_FRAG(1, kk + 4);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef GEMM_FRAG
         __syncthreads();                                    // tile k consumed by everyone, tile k+1 fully stored
         buf ^= 1;
     }
