@@ -10,11 +10,17 @@
 // disappear into the GEMMs.
 //
 // Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 4x4 MFMA 16x16x4 tiles (64 accumulator
-// VGPRs, 16 independent chains: the 40-cycle dependent latency never stalls the 32-cycle issue).  Operands are staged
-// in LDS k-major, As[k][m] / Bs[k][n], leading dim 144 (= 16 mod 32) so a fragment read -- 4 runs of 16 consecutive
-// floats for k..k+3 -- is conflict-free, and the column index is XOR-swizzled with ((k>>2)&7)<<2 so the TRANSPOSING
-// stores of a K-contiguous operand (lanes = 4 rows x 8 k-quads) are conflict-free too.  8 fragment reads feed 16 MFMAs.
-// The next k-tile is prefetched from HBM/L2 into registers while the current one is multiplied.
+// VGPRs, 16 independent chains: the 40-cycle dependent latency never stalls the 32-cycle issue).
+// LDS staging keeps EVERY store a direct float4 (no transposes, no swizzle arithmetic) and every fragment address
+// a per-thread base + compile-time immediate:
+//   * K-contiguous operand (rows of memory = rows of the tile): LDS [128][40]; an MFMA k-quad q takes, on lane
+//     row f = lane>>4, k = 4f + q (q < 4) or 16 + 4f + (q-4): each lane's 8 k-values are two float4s, so a
+//     whole k-step needs 2 ds_read_b128 per 16-row block (conflict-free at leading dim 40).
+//   * tile-contiguous operand (k indexes memory rows): LDS [32][132]; same k mapping, one ds_read_b32 per quad
+//     (132 = 4 mod 8 puts rows k and k+4 sixteen banks apart: conflict-free).
+// Both operands of a product use the same k mapping, so the sum over k is unchanged (any bijection works).
+// LDS is double buffered (one barrier per k-step); the next k-tile is prefetched from HBM/L2 into registers and the
+// fragments of the next half k-step are read while the 64 MFMAs of the current half issue.
 #include "pfpn_common.h"
 
 namespace pfpn {
@@ -22,8 +28,9 @@ namespace pfpn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
-constexpr int GLD = 144;      // LDS leading dim: 16 mod 32 (fragment reads), multiple of 4 (float4 stores)
-__device__ __forceinline__ int swz(int k) { return ((k >> 2) & 7) << 2; }
+constexpr int LDKC = 40;      // K-contiguous operand: LDS [128][40]
+constexpr int LDTC = 132;     // tile-contiguous operand: LDS [32][132]
+constexpr int KC_FLOATS = 128 * LDKC, TC_FLOATS = GBK * LDTC;
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU6 = 2, EPI_MASK = 3 };
 
@@ -39,66 +46,82 @@ struct GemmArgs {
     int kchunk;                 // TN: K elements per chunk (multiple of GBK)
 };
 
-// ---- global -> register staging --------------------------------------------------------------------------------
-// "K-contiguous" operand (rows of the tile are rows of memory, k runs along the row): 128 rows x 32 k.
-// thread t: rows t/8 + 32 j (j < 4), k = 4 (t % 8).  A wave covers 8 rows x 128 B.
-__device__ __forceinline__ void load_kc(float4 (&r)[4], const float* __restrict__ P, int ld, int row0, int nrows,
-                                        int k0, int kend, int t) {
-    const int kq = (t & 7) * 4;
+// One operand of the product: global -> registers -> LDS -> MFMA fragments.
+//   KC = true : memory rows are tile rows, k runs along the row (X in X W, dY and W in dY W^T)
+//   KC = false: memory rows are k, the tile dimension runs along the row (W in X W, X and dY in X^T dY)
+template <bool KC>
+struct Operand {
+    unsigned goff[4];      // per-thread element offsets of my 4 float4 loads (relative to the k-step base)
+    bool gok[4];           // row / column in range
+    int kq;                // KC: my k offset inside the k-step (0,4,..,28) ; TC: my k row (0..7) + 8j
+    int sts[4];            // LDS float offsets of my 4 float4 stores
+    int frag;              // LDS float offset of my fragment base
+
+    __device__ __forceinline__ void init(int ld, int t0, int n_t, int t, int lane, int wbase) {
+        const int frow = lane >> 4, fcol = lane & 15;
+        if (KC) {
+            kq = (t & 7) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = row0 + (t >> 3) + 32 * j;
-        const int k = k0 + kq;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nrows && k < kend) v = *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);   // kend % 4 == 0
-        r[j] = v;
-    }
-}
-__device__ __forceinline__ void store_kc(float* __restrict__ S, const float4 (&r)[4], int t) {
-    const int kq = (t & 7) * 4;
+            for (int j = 0; j < 4; ++j) {
+                const int row = (t >> 3) + 32 * j;
+                gok[j] = (t0 + row) < n_t;
+                goff[j] = (unsigned)(t0 + row) * (unsigned)ld + (unsigned)kq;
+                sts[j] = row * LDKC + kq;
+            }
+            frag = (wbase + fcol) * LDKC + 4 * frow;
+        } else {
+            kq = t >> 5;
+            const int cq = (t & 31) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = (t >> 3) + 32 * j;
-        const int c = row ^ swz(kq);               // same swizzle for the 4 k's of this quad
-        S[(kq + 0) * GLD + c] = r[j].x;
-        S[(kq + 1) * GLD + c] = r[j].y;
-        S[(kq + 2) * GLD + c] = r[j].z;
-        S[(kq + 3) * GLD + c] = r[j].w;
+            for (int j = 0; j < 4; ++j) {
+                gok[j] = (t0 + cq) < n_t;
+                goff[j] = (unsigned)(kq + 8 * j) * (unsigned)ld + (unsigned)(t0 + cq);
+                sts[j] = (kq + 8 * j) * LDTC + cq;
+            }
+            frag = (4 * frow) * LDTC + wbase + fcol;
+        }
     }
-}
-// "tile-dim-contiguous" operand (k indexes memory rows, the tile dimension runs along the row): 32 k x 128 cols.
-// thread t: k = t/32 + 8 j (j < 4), col = 4 (t % 32).  A wave covers 2 k-rows x 512 B.
-__device__ __forceinline__ void load_tc(float4 (&r)[4], const float* __restrict__ P, int ld, int col0, int ncols,
-                                        int k0, int kend, int t) {
-    const int cq = (t & 31) * 4;
+    // P already points at the k-step: KC: P + k0 ; TC: P + k0 * ld
+    __device__ __forceinline__ void load(float4 (&r)[4], const float* __restrict__ P, int k0, int kend) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k0 + (t >> 5) + 8 * j;
-        const int col = col0 + cq;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kend && col < ncols) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + col);   // ncols % 4 == 0
-        r[j] = v;
+        for (int j = 0; j < 4; ++j) {
+            const bool kok = KC ? (k0 + kq < kend) : (k0 + kq + 8 * j < kend);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gok[j] && kok) v = *reinterpret_cast<const float4*>(P + goff[j]);
+            r[j] = v;
+        }
     }
-}
-__device__ __forceinline__ void store_tc(float* __restrict__ S, const float4 (&r)[4], int t) {
-    const int cq = (t & 31) * 4;
+    __device__ __forceinline__ void store(float* __restrict__ S, const float4 (&r)[4]) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = (t >> 5) + 8 * j;
-        *reinterpret_cast<float4*>(S + k * GLD + (cq ^ swz(k))) = r[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(S + sts[j]) = r[j];
     }
-}
+    // fragments of half h (k-quads 4h .. 4h+3) for the four 16-wide blocks: f[i][q]
+    __device__ __forceinline__ void frags(float (&f)[4][4], const float* __restrict__ S, int h) const {
+        if (KC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(S + frag + 16 * i * LDKC + 16 * h);
+                f[i][0] = v.x; f[i][1] = v.y; f[i][2] = v.z; f[i][3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[i][q] = S[frag + (16 * h + q) * LDTC + 16 * i];
+        }
+    }
+};
 
 // AKC: A is K-contiguous (row-major [M][K]); else A is stored [K][M].  BKC: B is stored [N][K]; else row-major [K][N].
 template <bool AKC, bool BKC, int EPI, bool SPLITK>
 __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
-    // double-buffered operand tiles: ONE barrier per k-step; the stores of tile k+1 and the HBM/L2 loads of
-    // tile k+2 are issued ahead of the 128 MFMAs of tile k, so a lone block on a CU keeps its matrix pipe busy
+    constexpr int AF = AKC ? KC_FLOATS : TC_FLOATS;
+    constexpr int BF = BKC ? KC_FLOATS : TC_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As0 = lds;
-    float* Bs0 = lds + GBK * GLD;
-    float* As1 = lds + 2 * GBK * GLD;
-    float* Bs1 = lds + 3 * GBK * GLD;
+    float* Bs0 = lds + AF;
+    float* As1 = lds + AF + BF;
+    float* Bs1 = lds + 2 * AF + BF;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -112,6 +135,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const int kend = SPLITK ? min(g.K, kbeg + g.kchunk) : g.K;
     const bool do_csum = SPLITK && g.colsum && blockIdx.y == 0;
 
+    Operand<AKC> opA;
+    Operand<BKC> opB;
+    opA.init(g.lda, m0, g.M, t, lane, wm);
+    opB.init(g.ldb, n0, g.N, t, lane, wn);
+
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -120,22 +148,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);              // TN: column sums of my B float4 column group
 
     float4 ra[4], rb[4];
-#define GEMM_FETCH(k_)                                                                                          \
-    do {                                                                                                        \
-        if (AKC) load_kc(ra, A, g.lda, m0, g.M, (k_), kend, t); else load_tc(ra, A, g.lda, m0, g.M, (k_), kend, t); \
-        if (BKC) load_kc(rb, B, g.ldb, n0, g.N, (k_), kend, t); else load_tc(rb, B, g.ldb, n0, g.N, (k_), kend, t); \
+#define GEMM_FETCH(k_)                                                                          \
+    do {                                                                                        \
+        opA.load(ra, AKC ? A + (k_) : A + (size_t)(k_) * g.lda, (k_), kend);                   \
+        opB.load(rb, BKC ? B + (k_) : B + (size_t)(k_) * g.ldb, (k_), kend);                   \
     } while (0)
-#define GEMM_STORE(As_, Bs_)                                                                                    \
-    do {                                                                                                        \
-        if (AKC) store_kc((As_), ra, t); else store_tc((As_), ra, t);                                           \
-        if (BKC) store_kc((Bs_), rb, t); else store_tc((Bs_), rb, t);                                           \
-        if (do_csum) {                                                                                          \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
-                csum.x += rb[j].x; csum.y += rb[j].y; csum.z += rb[j].z; csum.w += rb[j].w;                     \
-            }                                                                                                   \
-        }                                                                                                       \
+#define GEMM_STORE(As_, Bs_)                                                                    \
+    do {                                                                                        \
+        opA.store((As_), ra);                                                                   \
+        opB.store((Bs_), rb);                                                                   \
+        if (do_csum) {                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                     \
+                csum.x += rb[j].x; csum.y += rb[j].y; csum.z += rb[j].z; csum.w += rb[j].w;     \
+            }                                                                                   \
+        }                                                                                       \
     } while (0)
-    const int frow = lane >> 4, fcol = lane & 15;           // fragment: k = kk + frow, m/n = base + fcol
+    const int frow = lane >> 4, fcol = lane & 15;
     GEMM_FETCH(kbeg);
     GEMM_STORE(As0, Bs0);
     GEMM_FETCH(kbeg + GBK);
@@ -148,35 +176,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             if (buf) GEMM_STORE(As0, Bs0); else GEMM_STORE(As1, Bs1);
             GEMM_FETCH(k0 + 2 * GBK);                       // tile k+2 in flight during the MFMAs (past the end: zeros)
         }
-        // software-pipelined fragments: the 8 ds_reads of k-quad q+1 are issued before the 16 MFMAs of quad q
-        // (sched_barrier keeps hipcc from sinking them next to their use, which exposed the LDS latency 4x per quad)
-        float af[2][4], bf[2][4];
-#define GEMM_FRAG(q_, kk_)                                                                  \
-    do {                                                                                    \
-        const float* ar_ = Ac + ((kk_) + frow) * GLD;                                       \
-        const float* br_ = Bc + ((kk_) + frow) * GLD;                                       \
-        const int sw_ = swz(kk_);                                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                     \
-            af[q_][i] = ar_[(wm + 16 * i + fcol) ^ sw_];                                    \
-            bf[q_][i] = br_[(wn + 16 * i + fcol) ^ sw_];                                    \
-        }                                                                                   \
-    } while (0)
-        GEMM_FRAG(0, 0);
+        float fa[2][4][4], fb[2][4][4];
+        opA.frags(fa[0], Ac, 0);
+        opB.frags(fb[0], Bc, 0);
 #pragma unroll
-        for (int kk = 0; kk < GBK; kk += 4) {
-            const int cur = (kk >> 2) & 1;
-            if (kk + 4 < GBK) {
-                if (cur) GEMM_FRAG(0, kk + 4); else GEMM_FRAG(1, kk + 4);
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0) {                                   // fragments of the second half while the first half multiplies
+                opA.frags(fa[1], Ac, 1);
+                opB.frags(fb[1], Bc, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[h][i][q], fb[h][j][q], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-#undef GEMM_FRAG
         __syncthreads();                                    // tile k consumed by everyone, tile k+1 fully stored
         buf ^= 1;
     }
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slab
 template <bool AKC, bool BKC, int EPI, bool SPLITK>
 static void launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch * (SPLITK ? g.ksplit : 1));
-    constexpr size_t lds = (size_t)4 * GBK * GLD * sizeof(float);      // 72 KiB: two buffers of As + Bs
+    constexpr size_t lds = (size_t)2 * ((AKC ? KC_FLOATS : TC_FLOATS) + (BKC ? KC_FLOATS : TC_FLOATS)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, EPI, SPLITK>),
