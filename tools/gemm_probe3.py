@@ -11,7 +11,9 @@ def bench(f, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)*1e3/n
 R = 4096
-for name, G, K, N in (("L0", 2, 200, 1024), ("L1", 2, 1024, 512), ("head", 1, 512, 1260)):
+shapes = (("L0", 2, 200, 1024), ("L1", 2, 1024, 512), ("head", 1, 512, 1260))
+if os.environ.get("ONLY_L1"): shapes = shapes[1:2]
+for name, G, K, N in shapes:
     x = torch.randn(R, K, device=dev) if name == "L0" else torch.randn(G, R, K, device=dev)
     w = torch.randn(G, K, N, device=dev); b = torch.randn(G, N, device=dev)
     y = torch.empty(G, R, N, device=dev); dy = torch.randn(G, R, N, device=dev)
