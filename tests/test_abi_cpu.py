@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu(lib_path):
     lib = _lib.load()
     assert lib.pfpn_logprob_fwd(None, None, None, None, 4, 36, 35, 0, None, None, None, 0, None) == 1
     assert lib.pfpn_gae(None, None, None, 1, 0.95, 0.9, None, None) == 1
-    assert lib.pfpn_tf_adam(None, None, None, None, 10, 1e-4, 0.9, 0.999, 1e-8, None, 1, None, 1.0, None) == 1
+    assert lib.pfpn_tf_adam(None, None, None, None, 10, 1e-4, 0.9, 0.999, 1e-8, None, 1, None, 1.0, None, None) == 1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
