@@ -151,18 +151,31 @@ __global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ y, const f
                                                   int rows, int H, int group_rows, int relu6) {
     const int H4 = H >> 2;
     const size_t n4 = (size_t)rows * H4;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / H4);
-        const int c4 = (int)(i - (size_t)row * H4);
-        const int g = group_rows > 0 ? row / group_rows : 0;
-        float4 v = reinterpret_cast<float4*>(y)[i];
-        const float4 b = reinterpret_cast<const float4*>(bias + (size_t)g * H)[c4];
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        if (relu6) {
-            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
-            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // four independent float4 streams per thread so ~4 KiB per wave is in flight
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+        float4 v[4], bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = i0 + j * stride;
+            const size_t ic = i < n4 ? i : i0;
+            const int row = (int)(ic / H4);
+            const int c4 = (int)(ic - (size_t)row * H4);
+            const int g = group_rows > 0 ? row / group_rows : 0;
+            v[j] = reinterpret_cast<float4*>(y)[ic];
+            bb[j] = reinterpret_cast<const float4*>(bias + (size_t)g * H)[c4];
         }
-        reinterpret_cast<float4*>(y)[i] = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = i0 + j * stride;
+            float4 t = v[j];
+            t.x += bb[j].x; t.y += bb[j].y; t.z += bb[j].z; t.w += bb[j].w;
+            if (relu6) {
+                t.x = fminf(fmaxf(t.x, 0.f), 6.f); t.y = fminf(fmaxf(t.y, 0.f), 6.f);
+                t.z = fminf(fmaxf(t.z, 0.f), 6.f); t.w = fminf(fmaxf(t.w, 0.f), 6.f);
+            }
+            if (i < n4) reinterpret_cast<float4*>(y)[i] = t;
+        }
     }
 }
 
@@ -171,28 +184,44 @@ __global__ __launch_bounds__(256) void k_bias_act(float* __restrict__ y, const f
 // lanes (each wave streams whole 1 KiB row pieces); the 4 row lanes are combined through LDS in
 // lane order, so the result is deterministic.
 __global__ __launch_bounds__(256) void k_act_bwd_partial(const float* __restrict__ y, float* __restrict__ dy,
-                                                         int rows, int H, int chunk_len, int relu6,
+                                                         int grows, int H, int chunk_len, int relu6,
                                                          float* __restrict__ partial) {
     __shared__ float4 red[4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c4 = blockIdx.x * 64 + cl;
     const int H4 = H >> 2;
     const int ch = blockIdx.y;
-    const int b0 = ch * chunk_len, b1 = min(rows, b0 + chunk_len);
+    const size_t goff = (size_t)blockIdx.z * grows * H4;          // group g owns rows [g*grows, (g+1)*grows)
+    const int b0 = ch * chunk_len, b1 = min(grows, b0 + chunk_len);
+    const float4* y4 = reinterpret_cast<const float4*>(y) + goff;
+    float4* d4 = reinterpret_cast<float4*>(dy) + goff;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c4 < H4) {
-        for (int b = b0 + rl; b < b1; b += 4) {
-            const size_t i = (size_t)b * H4 + c4;
-            float4 g = reinterpret_cast<float4*>(dy)[i];
-            if (relu6) {
-                const float4 v = reinterpret_cast<const float4*>(y)[i];
-                g.x = (v.x > 0.f && v.x < 6.f) ? g.x : 0.f;
-                g.y = (v.y > 0.f && v.y < 6.f) ? g.y : 0.f;
-                g.z = (v.z > 0.f && v.z < 6.f) ? g.z : 0.f;
-                g.w = (v.w > 0.f && v.w < 6.f) ? g.w : 0.f;
-                reinterpret_cast<float4*>(dy)[i] = g;
+        // wave rl owns rows b0+rl, b0+rl+4, ...; four of them are loaded before any is consumed
+        for (int b = b0 + rl; b < b1; b += 16) {
+            float4 g[4], v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                const size_t i = (size_t)(r < b1 ? r : b) * H4 + c4;
+                g[j] = d4[i];
+                if (relu6) v[j] = y4[i];
             }
-            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                if (r < b1) {
+                    float4 t = g[j];
+                    if (relu6) {
+                        t.x = (v[j].x > 0.f && v[j].x < 6.f) ? t.x : 0.f;
+                        t.y = (v[j].y > 0.f && v[j].y < 6.f) ? t.y : 0.f;
+                        t.z = (v[j].z > 0.f && v[j].z < 6.f) ? t.z : 0.f;
+                        t.w = (v[j].w > 0.f && v[j].w < 6.f) ? t.w : 0.f;
+                        d4[(size_t)r * H4 + c4] = t;
+                    }
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                }
+            }
         }
     }
     red[rl][cl] = acc;
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial(const float* __restrict
     if (rl == 0 && c4 < H4) {
         float4 s = red[0][cl];
         for (int k = 1; k < 4; ++k) { const float4 t = red[k][cl]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-        reinterpret_cast<float4*>(partial + (size_t)ch * H)[c4] = s;
+        reinterpret_cast<float4*>(partial + ((size_t)blockIdx.z * gridDim.y + ch) * H)[c4] = s;
     }
 }
 
@@ -439,9 +468,12 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
     }
 }
 
+// Row-chunk count of the column-reduction kernels: 16-row chunks (4 rows per wave in flight),
+// at most PFPN_MAX_CHUNKS slabs in the workspace.
+#define PFPN_MAX_CHUNKS 1024
 static inline int row_chunks(int rows) {
-    int C = (rows + 31) / 32;
-    if (C > 128) C = 128;
+    int C = (rows + 15) / 16;
+    if (C > PFPN_MAX_CHUNKS) C = PFPN_MAX_CHUNKS;
     if (C < 1) C = 1;
     return C;
 }
@@ -493,8 +525,8 @@ int pfpn_state_norm(const float* s, const float* mean, const float* std, int B, 
 }
 
 size_t pfpn_learner_workspace_bytes(int rows, int H) {
-    // chunk slabs [128][H] + 2 column vectors + norm partials
-    return ((size_t)130 * (size_t)(H > 0 ? H : 1) + 4096) * sizeof(float) + (size_t)rows * 0;
+    // chunk slabs [PFPN_MAX_CHUNKS][H] + 2 column vectors + norm partials
+    return ((size_t)(PFPN_MAX_CHUNKS + 2) * (size_t)(H > 0 ? H : 1) + 4096) * sizeof(float) + (size_t)rows * 0;
 }
 
 int pfpn_state_norm_update(const float* s, int B, int S, const float* step, const float* mean_in, const float* std_in,
@@ -507,7 +539,7 @@ int pfpn_state_norm_update(const float* s, int B, int S, const float* step, cons
     const int C = row_chunks(B);
     const int len = (B + C - 1) / C;
     float* partial = (float*)workspace;
-    float* bmean = partial + (size_t)128 * S;
+    float* bmean = partial + (size_t)PFPN_MAX_CHUNKS * S;
     float* bvar = bmean + S;
     const dim3 g((S + 63) / 64, C);
     hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)nullptr, B, S, len, 0, partial);
@@ -544,24 +576,14 @@ int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group
     const int G = group_rows > 0 ? rows / group_rows : 1;
     const int grows = group_rows > 0 ? group_rows : rows;
     if (group_rows > 0 && rows % group_rows) return PFPN_ERR_ARG;
-    int cpg = row_chunks(grows);                 // chunks per group
-    while (cpg * G > 128) --cpg;
+    int cpg = row_chunks(grows);                 // chunks per group; chunks never straddle groups
+    if (cpg * G > PFPN_MAX_CHUNKS) cpg = PFPN_MAX_CHUNKS / G;
     if (cpg < 1) return PFPN_ERR_ARG;
-    int len = (grows + cpg - 1) / cpg;
-    // chunk boundaries must not straddle groups: chunk ch covers rows [g*grows + k*len, ...) of group g
+    const int len = (grows + cpg - 1) / cpg;
     float* partial = (float*)workspace;
-    if (G == 1) {
-        hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg), dim3(256), 0, st, y, dy, rows, H, len,
-                           relu6, partial);
-        PFPN_CHECK_LAUNCH();
-    } else {
-        for (int g = 0; g < G; ++g) {
-            const size_t off = (size_t)g * grows * H;
-            hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg), dim3(256), 0, st,
-                               y ? y + off : y, dy + off, grows, H, len, relu6, partial + (size_t)g * cpg * H);
-            PFPN_CHECK_LAUNCH();
-        }
-    }
+    hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy, grows, H, len,
+                       relu6, partial);
+    PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 63) / 64, G), dim3(1024), 0, st, partial, cpg, G, H, db);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;

@@ -153,8 +153,8 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
     # -- forward -----------------------------------------------------------------------------------
     def _policy_logits(self, ha):
         """fc_policy: logits [B, A*N] = h W + b (a2c.py:541-554)."""
-        torch.mm(ha, self.policy_weight, out=self.logits)
-        kernels.bias_act(self.logits, self.policy_bias, relu6=False)
+        # bias through the GEMM epilogue (hipBLASLt): no separate pass over the 20 MB of logits
+        torch.addmm(self.policy_bias, ha, self.policy_weight, out=self.logits)
         return self.logits
 
     def _forward(self, state, x=None):

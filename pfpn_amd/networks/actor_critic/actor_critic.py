@@ -149,8 +149,8 @@ class ActorCriticNetwork(object):
         out = {}
         for t in (self.trunk, self.actor_trunk, self.critic_trunk):
             if t is not None:
-                for ref, (name, g) in t.reference_names().items():
-                    out[ref] = self.store[name][g]
+                for ref, (name, sel) in t.reference_names().items():
+                    out[ref] = sel(self.store[name])
         for n in self.store.names():
             if "|" not in n:
                 out[n] = self.store[n]
@@ -160,8 +160,8 @@ class ActorCriticNetwork(object):
         out = {}
         for t in (self.trunk, self.actor_trunk, self.critic_trunk):
             if t is not None:
-                for ref, (name, g) in t.reference_names().items():
-                    out[ref] = self.store.g(name)[g]
+                for ref, (name, sel) in t.reference_names().items():
+                    out[ref] = sel(self.store.g(name))
         for n in self.store.names():
             if "|" not in n:
                 out[n] = self.store.g(n)

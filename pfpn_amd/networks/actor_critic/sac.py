@@ -78,13 +78,13 @@ def sac_network_wrapper(base_class):
 
         def variables(self):
             out = {}
-            for ref, (name, g) in self.q_stack.reference_names().items():
-                out[ref] = self.store[name][g]
+            for ref, (name, sel) in self.q_stack.reference_names().items():
+                out[ref] = sel(self.store[name])
             for g, q in enumerate(("q1", "q2")):
                 out["critic/%s/fc3/weight" % q] = self.q_w3[g]
                 out["critic/%s/fc3/bias" % q] = self.q_b3[g, :1]
-            for ref, (name, g) in self.actor_trunk.reference_names().items():
-                out[ref] = self.store[name][g]
+            for ref, (name, sel) in self.actor_trunk.reference_names().items():
+                out[ref] = sel(self.store[name])
             for n in ("actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
                       "alpha/log_alpha"):
                 out[n] = self.store[n]
@@ -93,13 +93,13 @@ def sac_network_wrapper(base_class):
         def gradients(self):
             st = self.store
             out = {}
-            for ref, (name, g) in self.q_stack.reference_names().items():
-                out[ref] = st.g(name)[g]
+            for ref, (name, sel) in self.q_stack.reference_names().items():
+                out[ref] = sel(st.g(name))
             for g, q in enumerate(("q1", "q2")):
                 out["critic/%s/fc3/weight" % q] = st.g("critic/q1+critic/q2|fc3/weight")[g]
                 out["critic/%s/fc3/bias" % q] = st.g("critic/q1+critic/q2|fc3/bias")[g, :1]
-            for ref, (name, g) in self.actor_trunk.reference_names().items():
-                out[ref] = st.g(name)[g]
+            for ref, (name, sel) in self.actor_trunk.reference_names().items():
+                out[ref] = sel(st.g(name))
             for n in ("actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
                       "alpha/log_alpha"):
                 out[n] = st.g(n)
@@ -108,8 +108,8 @@ def sac_network_wrapper(base_class):
         def target_variables(self):
             ts = self.target_store
             out = {}
-            for ref, (name, g) in self.q_stack.reference_names().items():
-                out[ref] = ts[name][g]
+            for ref, (name, sel) in self.q_stack.reference_names().items():
+                out[ref] = sel(ts[name])
             for g, q in enumerate(("q1", "q2")):
                 out["critic/%s/fc3/weight" % q] = ts["critic/q1+critic/q2|fc3/weight"][g]
                 out["critic/%s/fc3/bias" % q] = ts["critic/q1+critic/q2|fc3/bias"][g, :1]

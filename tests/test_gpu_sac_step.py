@@ -5,15 +5,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 F = np.float32
+from _parity import assert_close_mostly  # noqa: E402
 
-
-def assert_close_mostly(got, ref, rtol, atol, frac=3e-3, err_msg=""):
-    """allclose except for a tiny fraction of elements: a pre-activation that rounds to the other side of
-    a ReLU6 kink on the GPU flips one unit's mask for one row, which changes one column of dW."""
-    bad = np.abs(got - ref) > atol + rtol * np.abs(ref)
-    assert bad.sum() <= max(4, frac * bad.size), "%s: %d / %d elements off (max abs %.3g)" % (err_msg, bad.sum(), bad.size, np.abs(got - ref).max())
-    # and the tensors agree globally
-    assert np.linalg.norm(got - ref) <= 2e-2 * (np.linalg.norm(ref) + 1e-30), err_msg
 
 NET_OPTS = dict(common_net_shape=[], critic_net_shape=[1024, 512], actor_net_shape=[1024, 512],
                 value_loss_coef=0.5, gamma=0.95, normalize_state=True, clip_state=5.0,
