@@ -19,6 +19,24 @@ from ..ops import DenseStack, ParamStore
 from ..utils import OnlineNormalizer
 
 
+class _AuxScope:
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = None
+
+    def __enter__(self):
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class ActorCriticNetwork(object):
     def __init__(self, trainable, state_shape, action_shape,
                  common_net_shape, critic_net_shape, actor_net_shape,
@@ -96,8 +114,14 @@ class ActorCriticNetwork(object):
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.device)   # float(global_step)
         self.dp_world = 1                      # set by the optimiser (SyncReplicasApplier)
         self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # second helper stream: the latency-bound launches of the critic head / advantage statistics / logits
+        # bias gradient run beside the policy-head GEMMs (PFPN_OVERLAP_AUX=0: everything on one stream).
+        # Running the big weight-gradient GEMMs there too (PFPN_OVERLAP_DW=1) measured SLOWER on MI355X
+        # (concurrent GEMMs thrash the L2/MALL): off.
         self.dw_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "0") != "0"   # measured slower on MI355X (concurrent GEMMs thrash): off
+        self.overlap_aux = os.environ.get("PFPN_OVERLAP_AUX", "0") != "0"   # measured 5 % slower: off
+        self.overlap_ema = os.environ.get("PFPN_OVERLAP_EMA", "0") != "0"   # side stream for the state-norm EMA: measured 3 % slower
+        self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "0") != "0"
         self._dw_pending = False
         self._B = None
         # names of the reference's placeholders/tensors, kept for workers that look them up
@@ -241,14 +265,23 @@ class ActorCriticNetwork(object):
             return
         nz, tail, S = self.state_normalizer, self.store.tail, self.S
         main = torch.cuda.current_stream()
-        side = self.side_stream
+        side = self.side_stream if self.overlap_ema else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
             if self.dp_world == 1:
                 nz.updated(state, self.step_dev, nz.mean, nz.std)
             else:
                 nz.updated(state, self.step_dev, tail[:S], tail[S:2 * S])
-        self._side_pending = True
+        self._side_pending = self.overlap_ema
+
+    def aux(self):
+        """context manager: run the enclosed launches on the helper stream after everything queued so far
+        on the current stream (no-op context when overlap is off)."""
+        return _AuxScope(self.dw_stream if self.overlap_aux else None)
+
+    def aux_join(self):
+        if self.overlap_aux:
+            torch.cuda.current_stream().wait_stream(self.dw_stream)
 
     def join_side_stream(self):
         if getattr(self, "_side_pending", False):

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from ... import kernels
+from ..utils import MixtureGaussianDistribution
 from .a2c import ParticleFilteringA2CNetwork
 
 __all__ = ["ParticleFilteringClipPPONetwork"]
@@ -69,9 +70,14 @@ def clip_ppo_network_wrapper(a2c_base_class):
             self._ensure_buffers(B)
             x = self._normalize(state)
             self.update_state_normalizer(state)        # side stream, joined in the optimiser
-            kernels.adv_stats(advantage, self.normalize_advantage, out=self.adv_stats)
-            policy, ha, hc = self._forward(state, x)
-            v = self._value(hc)
+            with self.aux():                           # independent of the forward pass
+                kernels.adv_stats(advantage, self.normalize_advantage, out=self.adv_stats)
+            ha, hc = self._trunks_forward(x)
+            with self.aux():                           # critic head beside the policy-head GEMM
+                v = self._value(hc)
+            policy = MixtureGaussianDistribution(self._policy_logits(ha), self.loc, self.logstd,
+                                                 self.normalize_policy_output_)
+            self.aux_join()
             out = kernels.ppo_mixture_fwd_bwd(policy.logits, action, self.loc, self.logstd, log_prob, advantage, v,
                                               value, self.adv_stats, self.epsilon, self.value_loss_coef,
                                               out=self.train_out)
@@ -85,30 +91,24 @@ def clip_ppo_network_wrapper(a2c_base_class):
                 policy.entropy_backward(self.entropy_buf, dlogits)
             if self.fixed_sigma:
                 out["dlogstd"].zero_()
-            # fc_policy backward: the weight/bias gradients do not feed the dX chain -> second stream
-            dws = self.dw_stream if self.overlap_dw else None
-            if dws is not None:
-                main = torch.cuda.current_stream()
-                dws.wait_stream(main)
-                with torch.cuda.stream(dws):
-                    torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
-                    kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
-                self._dw_pending = True
-            else:
-                torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
-                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
             w3 = st["critic/fc3/weight"].view(-1)
-            if self.trunk is not None:
-                torch.mm(dlogits, self.policy_weight.t(), out=self.dh[0])
-                kernels.value_head_bwd(hc, w3, out["dvalue"], self.dh[1], st.g("critic/fc3/weight").view(-1),
+            dh_a, dh_c = (self.dh[0], self.dh[1]) if self.trunk is not None else (self.dh_a[0], self.dh_c[0])
+            # critic-head backward and the fc_policy bias gradient (column sums of dlogits) are short
+            # latency-bound launches: beside the two fc_policy GEMMs
+            with self.aux():
+                kernels.value_head_bwd(hc, w3, out["dvalue"], dh_c, st.g("critic/fc3/weight").view(-1),
                                        st.g("critic/fc3/bias"), relu6=True)
+                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+            dws = self.dw_stream if self.overlap_dw else None
+            torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+            torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
+            self.aux_join()
+            if self.trunk is not None:
                 self.trunk.backward(self.dh, dw_stream=dws)
             else:
-                torch.mm(dlogits, self.policy_weight.t(), out=self.dh_a[0])
-                kernels.value_head_bwd(hc, w3, out["dvalue"], self.dh_c[0], st.g("critic/fc3/weight").view(-1),
-                                       st.g("critic/fc3/bias"), relu6=True)
                 self.actor_trunk.backward(self.dh_a)
                 self.critic_trunk.backward(self.dh_c)
+            self._dw_pending = dws is not None
             return out["loss3"]
 
         def train_device(self, optimizer, state, action, value, log_prob, advantage):
