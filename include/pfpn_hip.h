@@ -67,6 +67,7 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
 /* Fused learner kernel: log_prob(action_hist) + clipped-PPO loss head + full backward in one pass
  * over the logits (reference ppo.py:31-54, actor_critic.py:132-184, utils.py:108-134).
  * Outputs: logp [B], dlogits [B,A*N], dloc/dlogstd [A,N], dvalue [B] (d loss / d value),
+ * dbias [A*N] (optional, may be NULL: column sums of dlogits = the fc_policy bias gradient, a2c.py:541-554),
  * loss3 = {loss, policy_loss, value_loss*coef}.  Returns PFPN_ERR_ARG for shapes the packed path
  * does not cover (N > 64 or no template instance): compose fwd + pfpn_ppo_loss + bwd instead. */
 int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const float* loc, const float* logstd,
@@ -74,7 +75,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
                              const float* value_old, const float* adv_stats,
                              int B, int A, int N, float clip_eps, float value_coef,
                              float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue,
-                             float* loss3, void* workspace, size_t workspace_bytes, void* stream);
+                             float* dbias, float* loss3, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Unfused PPO head on [B] vectors (same arithmetic as inside pfpn_ppo_mixture_fwd_bwd) --
  * reference ppo.py:31-54: dlogp [B], dvalue [B], loss3 = {loss, policy_loss, value_loss*coef}. */

@@ -100,47 +100,70 @@ __global__ __launch_bounds__(256) void k_state_norm(const float* __restrict__ s,
     }
 }
 
-// column sums over a contiguous chunk of rows: thread <-> column; mode 0: sum x, mode 1: sum (x-mean)^2
-__global__ __launch_bounds__(64) void k_col_partial(const float* __restrict__ s, const float* __restrict__ mean,
-                                                    int B, int S, int chunk_len, int mode,
-                                                    float* __restrict__ partial) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= S) return;
+// Batch moments for the state-normaliser EMA (utils.py:60-68), one pass: per 16-row chunk the column
+// sums of x and x^2 in float64 (mean and the biased variance of the batch are then exact to fp32
+// rounding; the reference's two-pass fp32 form agrees to ~1e-7).  256-thread block = 64 columns x
+// 4 row lanes, combined through LDS in lane order; partial[ch][0|1][S] doubles.
+__global__ __launch_bounds__(256) void k_col_moments(const float* __restrict__ s, int B, int S, int chunk_len,
+                                                     double* __restrict__ partial) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int ch = blockIdx.y;
     const int b0 = ch * chunk_len, b1 = min(B, b0 + chunk_len);
-    float acc = 0.f;
-    if (mode == 0) {
-        for (int b = b0; b < b1; ++b) acc += s[(size_t)b * S + c];
-    } else {
-        const float m = mean[c];
-        for (int b = b0; b < b1; ++b) { const float d = s[(size_t)b * S + c] - m; acc += d * d; }
+    double a1 = 0.0, a2 = 0.0;
+    if (c < S) {
+        for (int b = b0 + rl; b < b1; b += 16) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                v[j] = r < b1 ? s[(size_t)r * S + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; a1 += d; a2 += d * d; }
+        }
     }
-    partial[(size_t)ch * S + c] = acc;
+    red[0][rl][cl] = a1; red[1][rl][cl] = a2;
+    __syncthreads();
+    if (rl == 0 && c < S) {
+        double s1 = red[0][0][cl], s2 = red[1][0][cl];
+        for (int k = 1; k < 4; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        partial[((size_t)ch * 2 + 0) * S + c] = s1;
+        partial[((size_t)ch * 2 + 1) * S + c] = s2;
+    }
 }
 
-__global__ __launch_bounds__(1024) void k_col_mean(const float* __restrict__ partial, int C, int S, float inv_B,
-                                                   float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const float s = slab_reduce_1024<false>(partial, C, (size_t)S, c, c < S, red);
-    if ((threadIdx.x >> 6) == 0 && c < S) out[c] = s * inv_B;
-}
-
-// EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step))
-__global__ __launch_bounds__(256) void k_norm_ema(const float* __restrict__ bmean, const float* __restrict__ bvar,
-                                                  int S, const float* __restrict__ step_dev,
-                                                  const float* __restrict__ mean_in,
-                                                  const float* __restrict__ std_in, float* __restrict__ mean_out,
-                                                  float* __restrict__ std_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= S) return;
+// Chunk moments -> batch mean / variance -> EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step)).
+// 1024-thread block = 64 columns x 16 chunk lanes (fixed order: deterministic).
+__global__ __launch_bounds__(1024) void k_norm_ema(const double* __restrict__ partial, int C, int B, int S,
+                                                   const float* __restrict__ step_dev,
+                                                   const float* __restrict__ mean_in,
+                                                   const float* __restrict__ std_in, float* __restrict__ mean_out,
+                                                   float* __restrict__ std_out) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < S) {
+        for (int k = kl; k < C; k += 16) {
+            a1 += partial[((size_t)k * 2 + 0) * S + c];
+            a2 += partial[((size_t)k * 2 + 1) * S + c];
+        }
+    }
+    red[0][kl][cl] = a1; red[1][kl][cl] = a2;
+    __syncthreads();
+    if (kl != 0 || c >= S) return;
+    for (int j = 1; j < 16; ++j) { a1 += red[0][j][cl]; a2 += red[1][j][cl]; }
+    const double mu = a1 / (double)B;
+    double var = a2 / (double)B - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float bmean = (float)mu, bvar = (float)var;
     const float step = step_dev[0];                                // global_step as fp32 (device scalar)
     const float d = fminf(0.9999f, (1.f + step) / (10.f + step));
     const float omd = 1.f - d;
-    const float nm = d * mean_in[c] + omd * bmean[c];
-    const float ns = fmaxf(1e-6f, d * std_in[c] + omd * sqrtf(bvar[c]));
-    mean_out[c] = nm;
-    std_out[c] = ns;
+    mean_out[c] = d * mean_in[c] + omd * bmean;
+    std_out[c] = fmaxf(1e-6f, d * std_in[c] + omd * sqrtf(bvar));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -234,9 +257,19 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial(const float* __restrict
 }
 
 // db[g, c] = sum over the chunks of group g, fixed order.  Grid (ceil(H/64), G), block 1024.
+// With `vec` (value head): one extra block (blockIdx.x == gridDim.x-1) emits vec_out[0] = sum(vec[0..nvec)).
 __global__ __launch_bounds__(1024) void k_bias_grad_final(const float* __restrict__ partial, int chunks_per_group,
-                                                          int G, int H, float* __restrict__ db) {
+                                                          int G, int H, float* __restrict__ db,
+                                                          const float* __restrict__ vec = nullptr, int nvec = 0,
+                                                          float* __restrict__ vec_out = nullptr) {
     __shared__ float red[16][64];
+    if (vec && blockIdx.x == gridDim.x - 1) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < nvec; i += blockDim.x) s += vec[i];
+        s = block_sum(s, &red[0][0]);
+        if (threadIdx.x == 0) vec_out[0] = s;
+        return;
+    }
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int g = blockIdx.y;
     const float s = slab_reduce_1024<false>(partial + (size_t)g * chunks_per_group * H, chunks_per_group, (size_t)H,
@@ -299,14 +332,6 @@ __global__ __launch_bounds__(256) void k_value_head_bwd_partial(
         for (int k = 1; k < 4; ++k) { const float4 t = red[k][cl]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
         reinterpret_cast<float4*>(partial + (size_t)ch * H)[c4] = s;
     }
-}
-
-__global__ __launch_bounds__(1024) void k_vec_sum(const float* __restrict__ x, int n, float* __restrict__ out) {
-    __shared__ float red[16];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) out[0] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -536,22 +561,14 @@ int pfpn_state_norm_update(const float* s, int B, int S, const float* step, cons
     if (!s || !step || !mean_in || !std_in || !mean_out || !std_out || B < 1 || S < 1) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, S)) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int C = row_chunks(B);
+    int C = row_chunks(B);
+    if (C > 256) C = 256;                      // 2*C*S doubles fit the learner workspace
     const int len = (B + C - 1) / C;
-    float* partial = (float*)workspace;
-    float* bmean = partial + (size_t)PFPN_MAX_CHUNKS * S;
-    float* bvar = bmean + S;
-    const dim3 g((S + 63) / 64, C);
-    hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)nullptr, B, S, len, 0, partial);
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(k_col_moments, dim3((S + 63) / 64, C), dim3(256), 0, st, s, B, S, len, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_col_mean, dim3((S + 63) / 64), dim3(1024), 0, st, partial, C, S, 1.0f / (float)B, bmean);
-    PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_col_partial, g, dim3(64), 0, st, s, (const float*)bmean, B, S, len, 1, partial);
-    PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_col_mean, dim3((S + 63) / 64), dim3(1024), 0, st, partial, C, S, 1.0f / (float)B, bvar);
-    PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_norm_ema, dim3((S + 255) / 256), dim3(256), 0, st, bmean, bvar, S, step, mean_in, std_in,
-                       mean_out, std_out);
+    hipLaunchKernelGGL(k_norm_ema, dim3((S + 63) / 64), dim3(1024), 0, st, (const double*)partial, C, B, S, step,
+                       mean_in, std_in, mean_out, std_out);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
@@ -611,9 +628,8 @@ int pfpn_value_head_bwd(const float* h, const float* w, const float* dv, int B, 
     hipLaunchKernelGGL(k_value_head_bwd_partial, dim3(((H >> 2) + 63) / 64, C), dim3(256), 0, st, h, w, dv, B, H, len,
                        relu6, dh, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 63) / 64, 1), dim3(1024), 0, st, partial, C, 1, H, dw);
-    PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_vec_sum, dim3(1), dim3(1024), 0, st, dv, B, db);
+    hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 63) / 64 + 1, 1), dim3(1024), 0, st, partial, C, 1, H, dw, dv, B,
+                       db);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

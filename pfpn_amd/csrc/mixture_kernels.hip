@@ -36,6 +36,7 @@ struct PpoArgs {
     float value_coef;        // 0.5
     float* dvalue;           // [B] out
     float* ratio_out;        // [B] out (optional, may be null)
+    int want_db;             // also emit column sums of dlogits (fc_policy bias gradient) into the slab
 };
 
 constexpr int PACK_G = 4;                            // lanes per (row, action-dim) segment
@@ -88,8 +89,10 @@ __device__ unsigned long long* g_stamps = nullptr;
         if (stamps && blockIdx.x == 0 && lane == 0) stamps[wave * 64 + (id_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int N, int MODE>
-__global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
+// MAXT: launch bound.  640 threads (10 waves -> 3 waves/SIMD -> 168 VGPRs) covers the 9-wave tile of
+// A = 36; at the generic bound of 1024 (128 VGPRs) the PPO instance spills its accumulators.
+template <int N, int MODE, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_mix_packed(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ dlogp_in,      // MODE_BWD: [B]
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         b_isc[i] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
         b_ct[i] = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
     }
-    float acc_loc[NP], acc_ls[NP];
+    float acc_loc[NP], acc_ls[NP], acc_db[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { acc_loc[i] = 0.f; acc_ls[i] = 0.f; }
+    for (int i = 0; i < NP; ++i) { acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
     float pol_sum = 0.f, val_sum = 0.f;
     float adv_mean = 0.f, adv_rstd = 1.f;
     if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
@@ -299,7 +302,9 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
             for (int i = 0; i < NP; ++i) {
                 if (i < NP - 1 || last_ok) {
                     const float tt = qs * ephi[i];                          // q * w_n * phi_n
-                    seg[PACK_G * i] = fmaf(-seg[PACK_G * i], qp, tt);      // q * w_n * (phi_n - p)
+                    const float dlg = fmaf(-seg[PACK_G * i], qp, tt);       // q * w_n * (phi_n - p)
+                    seg[PACK_G * i] = dlg;
+                    if (MODE == MODE_PPO) acc_db[i] += dlg;                 // fc_policy bias gradient
                     const float zq = (xv - b_loc[i]) * b_isc[i];            // z / c
                     acc_loc[i] = fmaf(tt, zq, acc_loc[i]);                  // scaled by isc*c in the tail
                     acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);   // tt*(z^2 - 1)
@@ -334,15 +339,18 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
     if (MODE == MODE_FWD) return;
     PFPN_STAMP(40);
     // ---- block partials: dloc / dlogstd summed over the R segments that share an action dim,
-    //      in row order; loss sums in wave order.  Slab layout [2*AN + 4] per block.
-    float* slab = partial + (size_t)blockIdx.x * (2 * AN + 4);
-    for (int which = 0; which < 2; ++which) {
+    //      in row order; loss sums in wave order.  Slab layout [nq*AN + 4] per block, nq = 2 (+1 with
+    //      the dlogits column sums of the PPO mode).
+    const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
+    float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
+    for (int which = 0; which < nq; ++which) {
         __syncthreads();
         if (seg_lane) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
                 if (i < NP - 1 || last_ok)
-                    seg[PACK_G * i] = which ? acc_ls[i] : acc_loc[i] * (b_isc[i] * PFPN_2LN2);   // dloc *= c/scale
+                    seg[PACK_G * i] = which == 0 ? acc_loc[i] * (b_isc[i] * PFPN_2LN2)   // dloc *= c/scale
+                                    : which == 1 ? acc_ls[i] : acc_db[i];
         }
         __syncthreads();
         for (int i = t; i < AN; i += blockDim.x) {
@@ -357,12 +365,12 @@ __global__ __launch_bounds__(PACK_BLOCK) void k_mix_packed(
         if (t == 0) {
             float ps = 0.f, vs = 0.f;
             for (int i = 0; i < nwaves; ++i) { ps += lossbuf[i]; vs += lossbuf[nwaves + i]; }
-            slab[2 * AN + 0] = ps;
-            slab[2 * AN + 1] = vs;
+            slab[nq * AN + 0] = ps;
+            slab[nq * AN + 1] = vs;
         }
     } else if (t == 0) {
-        slab[2 * AN + 0] = 0.f;
-        slab[2 * AN + 1] = 0.f;
+        slab[nq * AN + 0] = 0.f;
+        slab[nq * AN + 1] = 0.f;
     }
     PFPN_STAMP(41);
 }
@@ -673,7 +681,8 @@ __global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ lpseg
 // emits loss_out = {loss, policy_loss, value_loss*coef}.  Grid: ceil(n/64) (+1) blocks of 1024.
 __global__ __launch_bounds__(1024) void k_finalize(const float* __restrict__ partial, int nslab, int stride, int n,
                                                    float* __restrict__ out0, float* __restrict__ out1, int n0,
-                                                   float* __restrict__ loss_out, float inv_B, float value_coef) {
+                                                   float* __restrict__ loss_out, float inv_B, float value_coef,
+                                                   float* __restrict__ out2 = nullptr) {
     __shared__ float red[16][64];
     __shared__ float lsum[2];
     const int cl = threadIdx.x & 63;
@@ -692,7 +701,9 @@ __global__ __launch_bounds__(1024) void k_finalize(const float* __restrict__ par
     const int i = blockIdx.x * 64 + cl;
     const float s = slab_reduce_1024<false>(partial, nslab, (size_t)stride, i, i < n, red);
     if ((threadIdx.x >> 6) != 0 || i >= n) return;
-    if (i < n0) out0[i] = s; else out1[i - n0] = s;
+    if (i < n0) out0[i] = s;
+    else if (i < 2 * n0) out1[i - n0] = s;
+    else out2[i - 2 * n0] = s;          // only reached with n = 3*n0
 }
 
 // adv_stats = {mean, 1/(sqrt(var)+1e-8)} with population variance (reference
@@ -767,10 +778,15 @@ template <int MODE>
 static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float* logits, const float* x,
                          const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
                          float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
-#define PFPN_LAUNCH_PACKED(NN)                                                                          \
-    hipLaunchKernelGGL((k_mix_packed<NN, MODE>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
-                       loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.vec_ok, logp, pmix, dlogits, dx,   \
+#define PFPN_LAUNCH_PACKED_T(NN, TT)                                                                        \
+    hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
+                       loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.vec_ok, logp, pmix, dlogits, dx,       \
                        partial, ppo)
+#define PFPN_LAUNCH_PACKED(NN)                                                  \
+    do {                                                                        \
+        if (pl.threads <= 640) PFPN_LAUNCH_PACKED_T(NN, 640);                   \
+        else PFPN_LAUNCH_PACKED_T(NN, PACK_BLOCK);                              \
+    } while (0)
     switch (N) {
         case 35: PFPN_LAUNCH_PACKED(35); break;
         case 50: PFPN_LAUNCH_PACKED(50); break;
@@ -779,6 +795,7 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
         default: return -1;
     }
 #undef PFPN_LAUNCH_PACKED
+#undef PFPN_LAUNCH_PACKED_T
     return 0;
 }
 
@@ -821,7 +838,7 @@ int pfpn_debug_stamps(void* device_buffer) {
 size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
     // slabs: packed path <= 1024 blocks x (2AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]
     const size_t AN = (size_t)A * N;
-    const size_t slabs = (N <= 64 ? (size_t)1024 : (size_t)64) * (2 * AN + 4);
+    const size_t slabs = (N <= 64 ? (size_t)1024 : (size_t)64) * (3 * AN + 4);
     return (slabs + (size_t)B * A + 64) * sizeof(float);
 }
 
@@ -955,7 +972,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
                              const float* value_old, const float* adv_stats,
                              int B, int A, int N, float clip_eps, float value_coef,
                              float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue,
-                             float* loss3, void* workspace, size_t workspace_bytes, void* stream) {
+                             float* dbias, float* loss3, void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
     if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats ||
         !logp || !dlogits || !dloc || !dlogstd || !dvalue || !loss3 || B < 1 || A < 1 || N < 1)
@@ -965,17 +982,18 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     const int AN = A * N;
     PackPlan pl = plan_packed(B, A, N, logits, dlogits);
     if (!(pl.ok && packed_has(N))) return PFPN_ERR_ARG;   // caller falls back to fwd + ppo_loss + bwd
-    if (workspace_bytes < (size_t)pl.grid * (2 * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
+    const int nq = dbias ? 3 : 2;
+    if (workspace_bytes < (size_t)pl.grid * (nq * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
     PpoArgs pa{};
     pa.logp_old = logp_old; pa.adv = adv; pa.value = value; pa.value_old = value_old; pa.adv_stats = adv_stats;
     pa.inv_B = 1.0f / (float)B; pa.clip_lo = 1.0f - clip_eps; pa.clip_hi = 1.0f + clip_eps;
-    pa.value_coef = value_coef; pa.dvalue = dvalue; pa.ratio_out = nullptr;
+    pa.value_coef = value_coef; pa.dvalue = dvalue; pa.ratio_out = nullptr; pa.want_db = dbias ? 1 : 0;
     float* partial = (float*)workspace;
     launch_packed<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
                             nullptr, partial, pa);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64 + 1), dim3(1024), 0, st, partial, pl.grid, 2 * AN + 4,
-                       2 * AN, dloc, dlogstd, AN, loss3, pa.inv_B, value_coef);
+    hipLaunchKernelGGL(k_finalize, dim3((nq * AN + 63) / 64 + 1), dim3(1024), 0, st, partial, pl.grid, nq * AN + 4,
+                       nq * AN, dloc, dlogstd, AN, loss3, pa.inv_B, value_coef, dbias);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

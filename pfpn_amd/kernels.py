@@ -91,8 +91,9 @@ def adv_stats(adv, normalize=True, out=None):
 
 
 def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value_old, stats,
-                        clip_eps=0.2, value_coef=0.5, out=None):
-    """Fused learner kernel.  Returns dict(logp, dlogits, dloc, dlogstd, dvalue, loss3)."""
+                        clip_eps=0.2, value_coef=0.5, out=None, dbias=None):
+    """Fused learner kernel.  Returns dict(logp, dlogits, dloc, dlogstd, dvalue, loss3).
+    `dbias` [A*N] (optional): receives the column sums of dlogits (fc_policy bias gradient)."""
     lib = _lib.load()
     A, N = loc.shape
     B = action.shape[0]
@@ -119,6 +120,7 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
                                             float(value_coef), out["logp"].data_ptr(),
                                             out["dlogits"].data_ptr(), out["dloc"].data_ptr(),
                                             out["dlogstd"].data_ptr(), out["dvalue"].data_ptr(),
+                                            _f32(dbias.view(-1), A * N, name="dbias") if dbias is not None else None,
                                             out["loss3"].data_ptr(), ws, wsn, _stream()),
                "pfpn_ppo_mixture_fwd_bwd")
     return out

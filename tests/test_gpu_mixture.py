@@ -105,8 +105,15 @@ def test_ppo_fused(oracle, dev, B):
     r_dl, r_dloc, r_dls, _ = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, dlogp)
     d = to_dev(dev, logits, x, loc, logstd, lp_old, adv, v, v_old)
     stats = kernels.adv_stats(d[5], normalize=B > 1)
-    out = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    dbias = torch.full((A * N,), float("nan"), device=dev)
+    out = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5, dbias=dbias)
     torch.cuda.synchronize()
+    # fc_policy bias gradient = column sums of dlogits (a2c.py:541-554 BiasAdd gradient)
+    r_db = r_dl.reshape(B, A * N).astype(np.float64).sum(0)
+    np.testing.assert_allclose(dbias.cpu().numpy(), r_db, rtol=2e-4, atol=2e-5 * (np.abs(r_db).max() + 1e-30))
+    out2 = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    for k in ("logp", "dlogits", "dloc", "dlogstd", "dvalue", "loss3"):          # dbias is optional
+        assert torch.equal(out[k], out2[k]), k
     np.testing.assert_allclose(out["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=1e-5)
     np.testing.assert_allclose(out["dvalue"].cpu().numpy(), dv, rtol=1e-5, atol=1e-9)
     got = out["loss3"].cpu().numpy()
