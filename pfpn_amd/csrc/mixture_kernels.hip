@@ -84,10 +84,14 @@ __device__ __forceinline__ void put_slice(const Pref& pf, float* slice, int nv, 
 // Diagnostic phase stamps (s_memtime) of block 0: enabled only when pfpn_debug_stamps() installed a buffer.
 // Layout: [wave][slot], slot 0 = count; never read by the kernel itself.
 __device__ unsigned long long* g_stamps = nullptr;
+#ifdef PFPN_ENABLE_STAMPS
 #define PFPN_STAMP(id_)                                                                              \
     do {                                                                                             \
         if (stamps && blockIdx.x == 0 && lane == 0) stamps[wave * 64 + (id_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define PFPN_STAMP(id_) do { } while (0)      /* build with -DPFPN_ENABLE_STAMPS for tools/stamp_probe.py */
+#endif
 
 // MAXT: launch bound.  640 threads (10 waves -> 3 waves/SIMD -> 168 VGPRs) covers the 9-wave tile of
 // A = 36; at the generic bound of 1024 (128 VGPRs) the PPO instance spills its accumulators.
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ dlogp_in,      // MODE_BWD: [B]
-    int B, int A, int R, int tanh_mode, int vec_ok,
+    int B, int A, int R, int tanh_mode, int flags,       // flags: bit 0 float4 slice path, bit 1 one-pass tail
     float* __restrict__ logp_out,            // [B]   (FWD, PPO)
     float* __restrict__ pmix_out,            // [B,A] optional
     float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
@@ -108,13 +112,16 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     constexpr int SLICE = PACK_WSEG * N;                  // floats per wave slice (16 segments)
     constexpr int NV = (SLICE / 4 + 63) / 64;             // float4 per lane per slice (3 for N=35)
     extern __shared__ float4 smem4[];
+    const int planes = (flags >> 1) & 3;                  // tile-sized LDS planes: 1, 2 (double buffer), 3 (+ one-pass tail)
     const int AN = A * N;
     const int nseg = R * A;                               // segments per full tile
     const int nwaves = blockDim.x >> 6;
-    float* tile = reinterpret_cast<float*>(smem4);        // [nwaves*SLICE] >= R*AN
-    float* segbuf = tile + nwaves * SLICE;                // [2][nseg]  per-segment log p (double buffered)
+    const int TS = nwaves * SLICE;                        // floats per plane (>= R*AN)
+    float* tile = reinterpret_cast<float*>(smem4);        // [planes][TS]
+    float* segbuf = tile + planes * TS;                   // [2][nseg]  per-segment log p (double buffered)
     int* cnt = reinterpret_cast<int*>(segbuf + 2 * nseg); // [R] row arrival counters
     float* lossbuf = reinterpret_cast<float*>(cnt + R);   // [2*nwaves]
+    const int dbuf = planes >= 2 ? 1 : 0;
 
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
@@ -123,25 +130,57 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     const bool seg_lane = sidx < nseg;
     const int r = seg_lane ? sidx / A : 0;
     const int a = seg_lane ? sidx - r * A : 0;
-    float* slice = tile + wave * SLICE;
-    float* seg = slice + q * N + g;                       // == tile + sidx*N + g
+    float* slice0 = tile + wave * SLICE;
+    float* seg0 = slice0 + q * N + g;                     // == tile + sidx*N + g
     const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
     // rows this wave touches
     const int s_lo = wave * PACK_WSEG, s_hi = min(nseg, s_lo + PACK_WSEG) - 1;     // inclusive
     const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
 
+    const int s_lo_c = min(s_lo, nseg - 1), r_lo_c = min(r_lo, R - 1);   // clamped copies for the prefetch addresses
     for (int i = t; i < R; i += blockDim.x) cnt[i] = 0;
+#ifdef PFPN_ENABLE_STAMPS
     unsigned long long* stamps = g_stamps;
+#endif
     PFPN_STAMP(0);
     const int ntiles = (B + R - 1) / R;
     static_assert(NV <= 4, "slice prefetch holds at most 4 float4 per lane");
+    // ---- one-tile-ahead register prefetch of EVERYTHING a tile reads from HBM: my logits slice, my
+    //      segment's action value, the row scalars of the rows whose loss head my 16-lane group runs
+    //      (PPO) or my row's incoming gradient (BWD).  The only vmcnt wait of the steady state is the
+    //      hand-off at the END of a tile, a full tile after the loads were issued.
     Pref pf;
     pf.v0 = pf.v1 = pf.v2 = pf.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // my slice of tile `tid_` -> registers (clamped indices: every load is unconditional)
-#define PFPN_FETCH_SLICE(tid_)                                                                           \
-    fetch_slice<NV>(pf, logits, (tid_) * R, min(R, B - (tid_) * R) * AN - s_lo * N, SLICE, AN, s_lo * N, lane)
+    float xn = 0.f, n_adv = 0.f, n_lpo = 0.f, n_val = 0.f, n_vold = 0.f, n_g = 0.f;
+#define PFPN_FETCH_GROUP(tid_)                                                                          \
+    do {                                                                                                \
+        /* every load is unconditional (indices clamped into the tile): a conditional load would make   \
+           the compiler wait for ALL outstanding loads -- the slice just requested -- at the join */    \
+        const int row0_ = (tid_) * R;                                                                   \
+        const int rows_ = min(R, B - row0_);                                                            \
+        const int nfl_f = rows_ * AN - s_lo_c * N;      /* <= 0: my slice lies beyond a ragged last tile */ \
+        fetch_slice<NV>(pf, logits, row0_, nfl_f, SLICE, AN, nfl_f > 0 ? s_lo_c * N : 0, lane);        \
+        xn = x[(size_t)row0_ * A + min(sidx, rows_ * A - 1)];                                           \
+        if (MODE == MODE_BWD) n_g = dlogp_in[row0_ + min(r, rows_ - 1)];                                \
+        if (MODE == MODE_PPO) {                                                                         \
+            /* 16-lane group k <-> k-th row this wave touches */                                        \
+            const int b_ = row0_ + min(r_lo_c + (lane >> 4), rows_ - 1);                                \
+            n_adv = ppo.adv[b_]; n_lpo = ppo.logp_old[b_]; n_val = ppo.value[b_];                       \
+            n_vold = ppo.value_old[b_];                                                                 \
+        }                                                                                               \
+    } while (0)
+    // logits slice of tile `tid_` (in the prefetch registers) -> LDS plane `pl_`
+#define PFPN_STAGE(tid_, pl_)                                                                           \
+    do {                                                                                                \
+        const int row0_ = (tid_) * R;                                                                   \
+        const int nfl_ = max(0, min(min(R, B - row0_) * AN - s_lo * N, SLICE));                         \
+        put_slice<NV>(pf, slice0 + (pl_) * TS, nfl_ >> 2, lane);                                        \
+    } while (0)
     // first tile's HBM fetch goes out before anything else: its latency hides the bank set-up below
-    if (vec_ok && (int)blockIdx.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE((int)blockIdx.x);
+    // (tile ids are clamped to the last tile instead of guarded: a redundant re-load at the very end is
+    // harmless, a conditional load is not -- see above)
+    const int tlast = ntiles - 1;
+    PFPN_FETCH_GROUP(min((int)blockIdx.x, tlast));
 
     // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
     // as the reference graph computes them, pre-scaled to base 2:
@@ -153,8 +192,11 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         const float sc = expf(logstd[a * N + n]);
         b_loc[i] = loc[a * N + n];
         b_isc[i] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
-        b_ct[i] = (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        // +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
+        // down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
+        b_ct[i] = 64.0f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
     }
+    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
     float acc_loc[NP], acc_ls[NP], acc_db[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) { acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
@@ -166,33 +208,21 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     __syncthreads();                                       // cnt zeroed
     PFPN_STAMP(2);
 
-    int it = 0;
+    // stage the first tile, take over its scalars, start the second tile's loads
+    float xv = 0.f, rs_adv = 0.f, rs_lpo = 0.f, rs_val = 0.f, rs_vold = 0.f, rs_g = 0.f;
+    PFPN_STAGE(min((int)blockIdx.x, tlast), 0);
+    xv = xn; rs_adv = n_adv; rs_lpo = n_lpo; rs_val = n_val; rs_vold = n_vold; rs_g = n_g;
+    PFPN_FETCH_GROUP(min((int)(blockIdx.x + gridDim.x), tlast));
+    int it = 0, cur = 0;
     for (int tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x, ++it) {
         const int row0 = tileid * R;
         const int rows = min(R, B - row0);
         const int nact = rows * A;                         // active segments in this tile
         const int nfl = max(0, min(nact * N - s_lo * N, SLICE));   // valid floats in my slice
         float* sb = segbuf + (it & 1) * nseg;
-        if (vec_ok) {
-            put_slice<NV>(pf, slice, nfl >> 2, lane);
-            if (tileid + (int)gridDim.x < ntiles && s_lo < nseg) PFPN_FETCH_SLICE(tileid + (int)gridDim.x);
-        } else {
-            const float* gsrc = logits + (size_t)row0 * AN + (size_t)s_lo * N;
-            for (int i = lane; i < nfl; i += 64) slice[i] = gsrc[i];
-        }
+        float* slice = slice0 + cur * TS;
+        float* seg = seg0 + cur * TS;
         const bool active = seg_lane && sidx < nact;
-        float xv = 0.f;
-        if (active) xv = x[(size_t)row0 * A + sidx];
-        // row scalars of the rows this wave touches: lane k fetches row r_lo + k now, the row stage reads
-        // them back with a lane broadcast after the forward (their latency hides behind it)
-        float rs_adv = 0.f, rs_lpo = 0.f, rs_val = 0.f, rs_vold = 0.f;
-        if (MODE == MODE_PPO) {
-            const int rr_l = r_lo + lane;
-            if (rr_l <= r_hi && rr_l < rows) {
-                const int b = row0 + rr_l;
-                rs_adv = ppo.adv[b]; rs_lpo = ppo.logp_old[b]; rs_val = ppo.value[b]; rs_vold = ppo.value_old[b];
-            }
-        }
         if (it < 4) PFPN_STAMP(3 + it * 6);
 
         // ---- forward on my quarter of the segment (wave-private LDS slice: no barrier) -------
@@ -203,32 +233,30 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
 #pragma unroll
             for (int i = 1; i < NP; ++i)
                 if (i < NP - 1 || last_ok) mx = fmaxf(mx, seg[PACK_G * i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+            mx = quad_max(mx);
             const float mxl = mx * PFPN_LOG2E;
             float sum = 0.f, num = 0.f;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 ephi[i] = 0.f;
                 if (i < NP - 1 || last_ok) {
-                    // softmax numerator: raw v_exp_f32 (tiny values may flush; they carry no mass)
-                    const float en = __builtin_amdgcn_exp2f(fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl));
+                    // raw v_exp_f32 twice: softmax numerator, and numerator * Normal.prob * 2^64 in one go
+                    const float le = fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl);
                     const float zq = (xv - b_loc[i]) * b_isc[i];
-                    const float ph = exp2f(fmaf(-zq, zq, -b_ct[i]));      // denormal-correct
+                    const float en = __builtin_amdgcn_exp2f(le);
+                    ephi[i] = __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
                     if (MODE != MODE_FWD) seg[PACK_G * i] = en;
-                    ephi[i] = en * ph;
                     sum += en;
                     num += ephi[i];
                 }
             }
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            num += __shfl_xor(num, 1, 64);
-            num += __shfl_xor(num, 2, 64);
-            inv_sum = 1.0f / sum;
-            p = num * inv_sum;
+            sum = quad_sum(sum);
+            num = quad_sum(num);
+            inv_sum = __builtin_amdgcn_rcpf(sum);
+            p = (num * two_m64) * inv_sum;
+            if (p < 1.401298464324817e-45f) p = 0.f;       // below the smallest fp32 denormal: the reference's p is 0
             if (g == 0) {
-                float lp = logf(p);
+                float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;      // v_log_f32 is log2
                 if (tanh_mode) lp -= tanh_log_det(xv);
                 if (pmix_out) pmix_out[(size_t)row0 * A + sidx] = p;
                 sb[sidx] = lp;
@@ -239,7 +267,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         // ---- row stage ------------------------------------------------------------------------
         float my_g = 0.f;                                   // d loss / d logp of my row
         if (MODE == MODE_BWD) {
-            if (active) my_g = dlogp_in[row0 + r];
+            if (active) my_g = rs_g;
         } else {
             // publish: my segments of each touched row have arrived.  segbuf and cnt both live in LDS, and a
             // wave's LDS operations are executed in issue order by the one LDS unit of the CU, so the ds_write
@@ -256,19 +284,31 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             }
             asm volatile("" ::: "memory");
             if (it < 4) PFPN_STAMP(5 + it * 6);
-            for (int rr = r_lo; rr <= r_hi && rr < rows; ++rr) {
+            // Row stage, up to 4 rows at once: 16-lane group k sums row base+k's A segment log-probs and runs
+            // its loss head; every wave touching a row forms the identical sum (same lanes, same order).
+            {
+                const int base = r_lo;                                 // a wave touches <= 4 rows (A >= 4, see plan_packed)
+                const int kq = lane >> 4, jl = lane & 15;
+                const int rk = base + kq;
+                const bool rk_ok = rk <= r_hi && rk < rows;
                 float sacc = 0.f;
-                for (int i = lane; i < A; i += 64) sacc += sb[rr * A + i];
-                const float s = wave_sum_dpp(sacc);                   // same value in every touching wave
-                const int b = row0 + rr;
-                const bool owner = (rr * A) / PACK_WSEG == wave;      // wave holding the row's first segment
+                if (rk_ok)
+                    for (int i = jl; i < A; i += 16) sacc += sb[rk * A + i];
+                sacc = quad_sum(sacc);
+                sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
+                sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
+                // the rotation steps associate differently per lane: every lane takes its group's lane 0
+                const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
+                const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
+                const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
+                const float t3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
+                const float s = kq == 0 ? t0 : kq == 1 ? t1 : kq == 2 ? t2 : t3;
+                const int b = row0 + rk;
+                const bool owner = rk_ok && jl == 0 && (rk * A) / PACK_WSEG == wave;   // wave holding the row's first segment
                 float gval = 0.f;
                 if (MODE == MODE_PPO) {
-                    const int src = rr - r_lo;                         // lane that prefetched this row
-                    const float adv = __shfl(rs_adv, src, 64);
-                    const float lpo = __shfl(rs_lpo, src, 64);
-                    const float val_b = __shfl(rs_val, src, 64), vold_b = __shfl(rs_vold, src, 64);
-                    const float nadv = (adv - adv_mean) * adv_rstd;
+                    const float adv = rs_adv, lpo = rs_lpo, val_b = rs_val, vold_b = rs_vold;
+                const float nadv = (adv - adv_mean) * adv_rstd;
                     const float ratio = expf(s - lpo);
                     const float sur = ratio * nadv;
                     const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
@@ -277,7 +317,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                     // clip_by_value passes where lo <= ratio <= hi.
                     const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
                     gval = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-                    if (owner && lane == 0) {
+                    if (owner) {
                         pol_sum += fminf(sur, csur);
                         const float dvv = val_b - (adv + vold_b);
                         val_sum += dvv * dvv;
@@ -285,23 +325,28 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                         if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
                     }
                 }
-                if (owner && lane == 0) logp_out[b] = s;
-                if (r == rr) my_g = gval;
+                if (owner) logp_out[b] = s;
+                const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 0));
+                const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 16));
+                const float g2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 32));
+                const float g3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 48));
+                const int rel = r - base;
+                if (rel >= 0 && rel < 4) my_g = rel == 0 ? g0 : rel == 1 ? g1 : rel == 2 ? g2 : g3;
             }
         }
-        if (MODE == MODE_FWD) continue;
         if (it < 4) PFPN_STAMP(6 + it * 6);
 
         // ---- backward on my quarter (dlogits overwrite the LDS slot) ---------------------------
-        if (active) {
-            const float q_ = guard_finite(my_g / p);
+        if (MODE != MODE_FWD && active) {
+            const float q_ = guard_finite(my_g * __builtin_amdgcn_rcpf(p));
             const float qs = q_ * inv_sum;
             const float qp = qs * p;
+            const float qs64 = qs * two_m64;
             float dxa = 0.f;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 if (i < NP - 1 || last_ok) {
-                    const float tt = qs * ephi[i];                          // q * w_n * phi_n
+                    const float tt = qs64 * ephi[i];                        // q * w_n * phi_n
                     const float dlg = fmaf(-seg[PACK_G * i], qp, tt);       // q * w_n * (phi_n - p)
                     seg[PACK_G * i] = dlg;
                     if (MODE == MODE_PPO) acc_db[i] += dlg;                 // fc_policy bias gradient
@@ -312,8 +357,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 }
             }
             if (dx_out) {
-                dxa += __shfl_xor(dxa, 1, 64);
-                dxa += __shfl_xor(dxa, 2, 64);
+                dxa = quad_sum(dxa);
                 if (g == 0) {
                     float d = -dxa;
                     if (tanh_mode) d += my_g * 2.f * tanhf(xv);
@@ -322,19 +366,31 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             }
         }
         if (it < 4) PFPN_STAMP(7 + it * 6);
-        // my slice -> HBM (same wave wrote it: in-order LDS, no barrier)
-        float* gdst = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;
-        if (vec_ok) {
-            const int nv = nfl >> 2;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = lane + 64 * j;
-                if (i < nv) reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(slice)[i];
-            }
-        } else {
-            for (int i = lane; i < nfl; i += 64) gdst[i] = slice[i];
-        }
+        // ---- hand-off: next tile registers -> the other LDS plane (the one vmcnt wait of the loop: those
+        //      loads are a tile old), its scalars -> live registers, the tile after that -> prefetch;
+        //      then my slice of dlogits -> HBM (same wave wrote it: in-order LDS, no barrier).  The stores
+        //      drain behind the next tile's compute.
+#define PFPN_STORE_SLICE()                                                                               \
+    do {                                                                                                \
+        float* gdst_ = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;                                  \
+        const int nv_ = nfl >> 2;                                                                       \
+        _Pragma("unroll") for (int j_ = 0; j_ < NV; ++j_) {                                             \
+            const int i_ = lane + 64 * j_;                                                              \
+            if (i_ < nv_) reinterpret_cast<float4*>(gdst_)[i_] = reinterpret_cast<const float4*>(slice)[i_]; \
+        }                                                                                               \
+    } while (0)
+        if (MODE != MODE_FWD && !dbuf) PFPN_STORE_SLICE(); // single plane: it must be read out first
+        const int nxt = tileid + (int)gridDim.x;
+        PFPN_STAGE(min(nxt, tlast), cur ^ dbuf);
+        if (it < 4) PFPN_STAMP(8 + it * 6);
+        xv = xn; rs_adv = n_adv; rs_lpo = n_lpo; rs_val = n_val; rs_vold = n_vold; rs_g = n_g;
+        PFPN_FETCH_GROUP(min(nxt + (int)gridDim.x, tlast));
+        if (MODE != MODE_FWD && dbuf) PFPN_STORE_SLICE();
+        cur ^= dbuf;
     }
+#undef PFPN_STORE_SLICE
+#undef PFPN_STAGE
+#undef PFPN_FETCH_GROUP
 
     if (MODE == MODE_FWD) return;
     PFPN_STAMP(40);
@@ -343,6 +399,36 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     //      the dlogits column sums of the PPO mode).
     const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
     float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
+    float* seg = seg0;                                     // plane 0
+    if (planes >= 3) {
+        // three tile-sized planes: all gradient sums staged in one pass
+        float* lsb = tile + TS;
+        __syncthreads();
+        if (seg_lane) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (i < NP - 1 || last_ok) {
+                    seg[PACK_G * i] = acc_loc[i] * (b_isc[i] * PFPN_2LN2);       // dloc *= c/scale
+                    lsb[sidx * N + g + PACK_G * i] = acc_ls[i];
+                    if (nq == 3) lsb[TS + sidx * N + g + PACK_G * i] = acc_db[i];
+                }
+        }
+        __syncthreads();
+        for (int idx = t; idx < nq * AN; idx += blockDim.x) {
+            const int which = idx >= 2 * AN ? 2 : idx >= AN ? 1 : 0;
+            const int i = idx - which * AN;
+            const float* src = which == 0 ? tile : lsb + (which - 1) * TS;
+            float s = 0.f;
+            int rr = 0;
+            for (; rr + 4 <= R; rr += 4) {                  // four loads in flight, summed in row order
+                const float v0 = src[rr * AN + i], v1 = src[(rr + 1) * AN + i];
+                const float v2 = src[(rr + 2) * AN + i], v3 = src[(rr + 3) * AN + i];
+                s = (((s + v0) + v1) + v2) + v3;
+            }
+            for (; rr < R; ++rr) s += src[rr * AN + i];
+            slab[idx] = s;
+        }
+    } else {
     for (int which = 0; which < nq; ++which) {
         __syncthreads();
         if (seg_lane) {
@@ -359,7 +445,10 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             slab[which * AN + i] = s;
         }
     }
+    }
     if (MODE == MODE_PPO) {
+        pol_sum = wave_sum_dpp(pol_sum);                  // held by the 4 group-leading lanes
+        val_sum = wave_sum_dpp(val_sum);
         if (lane == 0) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
         __syncthreads();
         if (t == 0) {
@@ -734,7 +823,9 @@ static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; 
 static PackPlan plan_packed(int B, int A, int N, const void* logits, const void* dlogits) {
     PackPlan pl{};
     pl.ok = false;
-    if (N > 64 || N < 1 || A < 1 || B < 1) return pl;
+    // A >= 4: the 16 consecutive segments of a wave then span at most 4 rows (one 16-lane group per row
+    // in the row stage); narrower action spaces take the wave kernel
+    if (N > 64 || N < 1 || A < 4 || B < 1) return pl;
     const int AN = A * N;
     // rows per tile: the smallest R0 with R0*A a multiple of 16 segments (full waves), repeated while the
     // block stays <= 12 waves (A=36: R=4, 9 waves, every lane busy)
@@ -757,8 +848,17 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     const int waves = (R * A + PACK_WSEG - 1) / PACK_WSEG;
     pl.R = R;
     pl.threads = waves * 64;
-    pl.lds = (size_t)waves * PACK_WSEG * N * 4 + (size_t)(2 * R * A + R + 2 * waves + 8) * 4;
-    pl.vec_ok = (AN % 4 == 0) && ((uintptr_t)logits % 16 == 0) && (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
+    // LDS: tile-sized planes + small arrays.  1 plane is the minimum; 2 double-buffer the tile (the next
+    // tile is staged while the current one is still being stored); 3 also give the backward tail room to
+    // stage all three gradient sums in one pass.
+    const size_t plane = (size_t)waves * PACK_WSEG * N * 4;
+    const size_t small = (size_t)(2 * R * A + R + 2 * waves + 8) * 4;
+    int planes = 1;
+    if (2 * plane + small <= 64 * 1024) planes = 2;
+    if (dlogits && 3 * plane + small <= 64 * 1024) planes = 3;
+    pl.lds = planes * plane + small;
+    pl.vec_ok = ((AN % 4 == 0) && ((uintptr_t)logits % 16 == 0) && (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0)) ? 1 : 0;
+    pl.vec_ok |= planes << 1;                           // kernel `flags`: bit 0 float4 path, bits 1-2 plane count
     const int ntiles = (B + R - 1) / R;
     // resident blocks per CU by wave slots (128 VGPRs: 4 waves/SIMD = 16 waves/CU) and LDS
     int per_cu = 16 / waves;
@@ -770,7 +870,8 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     if (env_pcu > 0) per_cu = env_pcu;
     const int cap = 256 * per_cu;
     pl.grid = ntiles < cap ? ntiles : cap;
-    pl.ok = pl.lds <= 64 * 1024 && waves <= 16;
+    // the packed kernel streams float4 slices only; unaligned shapes take the wave kernel
+    pl.ok = pl.lds <= 64 * 1024 && waves <= 16 && (pl.vec_ok & 1);
     return pl;
 }
 

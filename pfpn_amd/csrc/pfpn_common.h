@@ -78,6 +78,18 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Reductions over the 4 lanes of a quad (lanes 4k..4k+3): two quad_perm DPP steps, result in all 4 lanes.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_shift<0xB1, 0xf>(v, 0.f);       // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_shift<0x4E, 0xf>(v, 0.f);       // quad_perm [2,3,0,1]  (xor 2)
+    return v;
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, dpp_shift<0xB1, 0xf>(v, v));
+    v = fmaxf(v, dpp_shift<0x4E, 0xf>(v, v));
+    return v;
+}
+
 // Four independent wave reductions for the price of ~one: a transposing butterfly.  Lanes first trade
 // rows (xor 1, xor 2: afterwards lane class (lane & 3) = {0,1,2,3} carries a 4-lane partial of row
 // {0,2,1,3}), then ONE value per lane is combined over the remaining 16 lane groups (row_ror 4/8 inside

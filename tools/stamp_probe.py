@@ -23,7 +23,7 @@ lib.pfpn_debug_stamps(None)
 s = buf.cpu().numpy().reshape(16, 64)
 names = {0:"start",1:"bank done",2:"barrier0"}
 for it in range(4):
-    for k,nm in enumerate(["put+x","fwd done","wait done","row done","bwd done",""]):
+    for k,nm in enumerate(["top","fwd done","wait done","row done","bwd done","staged next"]):
         names[3+it*6+k] = "t%d %s" % (it, nm)
 names[40]="loop end"; names[41]="slab done"
 t0 = s[:9,0].min()
