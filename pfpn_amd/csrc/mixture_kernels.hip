@@ -42,43 +42,124 @@ struct PpoArgs {
 constexpr int PACK_G = 4;                            // lanes per (row, action-dim) segment
 constexpr int PACK_BLOCK = 1024;                     // launch bound; actual block = waves*64
 constexpr int PACK_WSEG = 64 / PACK_G;               // 16 segments per wave
+constexpr size_t PACK_MAX_LDS = 150 * 1024;         // dynamic LDS the packed kernel may ask for (160 KB per CU)
 
 // ---------------------------------------------------------------------------------------
-// packed path ("wave-sliced")
+// packed path ("wave-sliced", loader/consumer ring)
 //
-// A tile is Rt whole batch rows = Rt*A segments, laid out in LDS exactly as in HBM.  Wave w owns
-// the 16 consecutive segments [16w, 16w+16) of the tile -- a contiguous 64*N-byte slice that the
-// wave itself loads (float4, prefetched one tile ahead into registers), transforms in place and
-// stores back: NO block barrier in steady state.  4 lanes share a segment (particles g, g+4, ...),
-// their softmax/mixture reductions are two DPP shuffles.  The particle bank of a lane's (a, n) set
-// is constant across tiles (same slot -> same action dim), so it lives in REGISTERS.
-// The only cross-wave dependency is the row log-prob (a row's A segments span 2-4 waves): waves
-// publish per-segment log p to LDS and bump a per-row arrival counter (monotonic, never reset);
-// a wave waits only for the rows it touches.
+// A tile is Rt whole batch rows = Rt*A segments, laid out in an LDS plane exactly as in HBM.
+//
+// * LOADER waves (PACK_NL of them, no arithmetic) move tiles HBM -> LDS with LDS-DMA
+//   (`global_load_lds_dwordx4`: 1 KiB per wave-instruction, no VGPR destination), several tiles
+//   ahead, into a ring of P planes; with them ride the tile's action values and per-row scalars.
+//   A loader's instruction stream is nothing but DMAs, so its `s_waitcnt vmcnt(n)` can be counted
+//   exactly: it keeps up to 63 DMAs in flight and bumps the plane's `ready` counter when the OLDEST
+//   tile has landed.  This is what fills the memory pipeline: the bytes in flight per CU are no longer
+//   limited by the VGPRs of the computing waves (one tile ahead = 20 KB per CU measured ~2.6 TB/s
+//   chip-wide; by Little's law 6 TB/s at ~3 us loaded latency needs ~70 KB per CU in flight).
+// * COMPUTE wave w owns the 16 consecutive segments [16w, 16w+16) of every tile -- a contiguous
+//   64*N-byte slice of the plane that it transforms in place (logits -> softmax numerators -> dlogits)
+//   and stores back itself: no block barrier in steady state, and NO global load (hence no vmcnt wait)
+//   anywhere in its loop.  4 lanes share a segment (particles g, g+4, ...); their softmax/mixture
+//   reductions are two quad-permute DPP steps.  The particle bank of a lane's (a, n) set is constant
+//   across tiles (same slot -> same action dim), so it lives in registers.
+// * The only cross-wave dependency is the row log-prob (a row's A segments span 2-4 waves): waves
+//   publish per-segment log p to LDS and bump a per-row arrival counter (monotonic, never reset).
+//   The loop is software-pipelined -- forward(t+1) | row stage(t) | backward(t) | store(t) -- so a wave
+//   asks for a row's log-prob a whole forward pass after it published its own part.
+// * When a compute wave has read its dlogits slice back out of the plane it bumps the plane's `freed`
+//   counter; the loaders reuse a plane once all compute waves have.
 // ---------------------------------------------------------------------------------------
-// Prefetch registers as NAMED float4s (an indexed array that is conditionally written across loop
-// iterations gets demoted to scratch by hipcc).
-struct Pref { float4 v0, v1, v2, v3; };
+constexpr int PACK_NL = 2;                           // loader waves per block
+#ifndef PACK_DEPTH
+#define PACK_DEPTH 2                                 // tiles a loader keeps in flight
+#endif
 
-template <int NV>
-__device__ __forceinline__ void fetch_slice(Pref& pf, const float* __restrict__ logits, int row0, int nfl,
-                                            int slice, int AN, int soff, int lane) {
-    const int nv = max(0, min(nfl, slice)) >> 2;
-    const int last = nv > 0 ? nv - 1 : 0;
-    const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN + (size_t)soff);
-    pf.v0 = g4[min(lane, last)];
-    if (NV > 1) pf.v1 = g4[min(lane + 64, last)];
-    if (NV > 2) pf.v2 = g4[min(lane + 128, last)];
-    if (NV > 3) pf.v3 = g4[min(lane + 192, last)];
+// LDS-DMA of one wave-instruction: lane i's 16 (or 4) bytes at `gsrc` land at lds_byte + 16*i (4*i).
+// M0 carries the wave-uniform LDS base and is compiler-reserved: saved/restored inside the statement.
+// hipcc does not see these loads: their completion is counted by hand (wait_vmcnt below).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [0, 63] (the immediate must be a literal)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+        case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+        case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+        case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+        case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+        case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+        case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+        case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+        case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+        case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+        case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+        case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+        case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+        case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+        case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+        case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+        case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+        case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+        case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+        case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+        case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+        case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
+        case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+        case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
+        case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+        case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
+        case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
 }
 
-template <int NV>
-__device__ __forceinline__ void put_slice(const Pref& pf, float* slice, int nv, int lane) {
-    float4* s4 = reinterpret_cast<float4*>(slice);
-    if (lane < nv) s4[lane] = pf.v0;
-    if (NV > 1 && lane + 64 < nv) s4[lane + 64] = pf.v1;
-    if (NV > 2 && lane + 128 < nv) s4[lane + 128] = pf.v2;
-    if (NV > 3 && lane + 192 < nv) s4[lane + 192] = pf.v3;
+__device__ __forceinline__ int lds_counter(const int* c) {
+    return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // Diagnostic phase stamps (s_memtime) of block 0: enabled only when pfpn_debug_stamps() installed a buffer.
@@ -93,41 +174,52 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define PFPN_STAMP(id_) do { } while (0)      /* build with -DPFPN_ENABLE_STAMPS for tools/stamp_probe.py */
 #endif
 
-// MAXT: launch bound.  640 threads (10 waves -> 3 waves/SIMD -> 168 VGPRs) covers the 9-wave tile of
-// A = 36; at the generic bound of 1024 (128 VGPRs) the PPO instance spills its accumulators.
+// MAXT: launch bound.  704 threads (9 compute + 2 loader waves -> 3 waves/SIMD -> 168 VGPRs) covers the tile
+// of A = 36; the generic bound of 1024 caps the allocation at 128 VGPRs.
 template <int N, int MODE, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_mix_packed(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ dlogp_in,      // MODE_BWD: [B]
-    int B, int A, int R, int tanh_mode, int flags,       // flags: bit 0 float4 slice path, bit 1 one-pass tail
+    int B, int A, int R, int tanh_mode, int P,           // P: LDS planes in the ring
     float* __restrict__ logp_out,            // [B]   (FWD, PPO)
     float* __restrict__ pmix_out,            // [B,A] optional
     float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
     float* __restrict__ dx_out,              // [B,A] optional (BWD)
-    float* __restrict__ partial,             // [grid][2*A*N + 4] (BWD, PPO)
+    float* __restrict__ partial,             // [grid][nq*A*N + 4] (BWD, PPO)
     PpoArgs ppo)
 {
     constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
     constexpr int SLICE = PACK_WSEG * N;                  // floats per wave slice (16 segments)
     constexpr int NV = (SLICE / 4 + 63) / 64;             // float4 per lane per slice (3 for N=35)
     extern __shared__ float4 smem4[];
-    const int planes = (flags >> 1) & 3;                  // tile-sized LDS planes: 1, 2 (double buffer), 3 (+ one-pass tail)
     const int AN = A * N;
     const int nseg = R * A;                               // segments per full tile
-    const int nwaves = blockDim.x >> 6;
+    const int nwaves = (blockDim.x >> 6) - PACK_NL;       // compute waves
     const int TS = nwaves * SLICE;                        // floats per plane (>= R*AN)
-    float* tile = reinterpret_cast<float*>(smem4);        // [planes][TS]
-    float* segbuf = tile + planes * TS;                   // [2][nseg]  per-segment log p (double buffered)
-    int* cnt = reinterpret_cast<int*>(segbuf + 2 * nseg); // [R] row arrival counters
-    float* lossbuf = reinterpret_cast<float*>(cnt + R);   // [2*nwaves]
-    const int dbuf = planes >= 2 ? 1 : 0;
+    const int XS = (nseg + 63) & ~63;                     // floats per action-value plane
+    // LDS map (floats):  [P][TS] tiles | [P][XS] action values | [P][64] row scalars | [4][nseg] segment log p
+    //                    | [2][R] row counters | [P] ready | [P] freed | [1] bank_done | [2*nwaves] loss partials
+    //                    | [3][AN] particle bank
+    float* tile = reinterpret_cast<float*>(smem4);
+    float* xpl = tile + (size_t)P * TS;
+    float* rpl = xpl + P * XS;                            // [P][4][16]: adv, logp_old, value, value_old (PPO) | dlogp (BWD)
+    float* segbuf = rpl + P * 64;
+    int* cnt = reinterpret_cast<int*>(segbuf + 4 * nseg);
+    int* ready = cnt + 2 * R;
+    int* freed = ready + P;
+    int* bank_done = freed + P;                           // compute waves that have written their share of the bank
+    float* lossbuf = reinterpret_cast<float*>(bank_done + 1);
+    float* bank = lossbuf + 2 * nwaves;                   // [3][AN]: loc | isc2 | 64 - ct2   (see below)
 
     const int t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
+    // counters first, so the loaders are released before the compute waves' index arithmetic
+    for (int i = t; i < 2 * R + 2 * P + 1; i += blockDim.x) cnt[i] = 0;   // cnt, ready, freed, bank_done are contiguous
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave index as a scalar: uniform control flow
     const int q = lane >> 2, g = lane & 3;
-    const int sidx = wave * PACK_WSEG + q;                // segment slot in the tile
-    const bool seg_lane = sidx < nseg;
+    const int sidx = wave * PACK_WSEG + q;                // segment slot in the tile (compute waves)
+    const bool seg_lane = wave < nwaves && sidx < nseg;
     const int r = seg_lane ? sidx / A : 0;
     const int a = seg_lane ? sidx - r * A : 0;
     float* slice0 = tile + wave * SLICE;
@@ -137,159 +229,268 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     const int s_lo = wave * PACK_WSEG, s_hi = min(nseg, s_lo + PACK_WSEG) - 1;     // inclusive
     const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
 
-    const int s_lo_c = min(s_lo, nseg - 1), r_lo_c = min(r_lo, R - 1);   // clamped copies for the prefetch addresses
-    for (int i = t; i < R; i += blockDim.x) cnt[i] = 0;
 #ifdef PFPN_ENABLE_STAMPS
     unsigned long long* stamps = g_stamps;
 #endif
     PFPN_STAMP(0);
     const int ntiles = (B + R - 1) / R;
-    static_assert(NV <= 4, "slice prefetch holds at most 4 float4 per lane");
-    // ---- one-tile-ahead register prefetch of EVERYTHING a tile reads from HBM: my logits slice, my
-    //      segment's action value, the row scalars of the rows whose loss head my 16-lane group runs
-    //      (PPO) or my row's incoming gradient (BWD).  The only vmcnt wait of the steady state is the
-    //      hand-off at the END of a tile, a full tile after the loads were issued.
-    Pref pf;
-    pf.v0 = pf.v1 = pf.v2 = pf.v3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float xn = 0.f, n_adv = 0.f, n_lpo = 0.f, n_val = 0.f, n_vold = 0.f, n_g = 0.f;
-#define PFPN_FETCH_GROUP(tid_)                                                                          \
-    do {                                                                                                \
-        /* every load is unconditional (indices clamped into the tile): a conditional load would make   \
-           the compiler wait for ALL outstanding loads -- the slice just requested -- at the join */    \
-        const int row0_ = (tid_) * R;                                                                   \
-        const int rows_ = min(R, B - row0_);                                                            \
-        const int nfl_f = rows_ * AN - s_lo_c * N;      /* <= 0: my slice lies beyond a ragged last tile */ \
-        fetch_slice<NV>(pf, logits, row0_, nfl_f, SLICE, AN, nfl_f > 0 ? s_lo_c * N : 0, lane);        \
-        xn = x[(size_t)row0_ * A + min(sidx, rows_ * A - 1)];                                           \
-        if (MODE == MODE_BWD) n_g = dlogp_in[row0_ + min(r, rows_ - 1)];                                \
-        if (MODE == MODE_PPO) {                                                                         \
-            /* 16-lane group k <-> k-th row this wave touches */                                        \
-            const int b_ = row0_ + min(r_lo_c + (lane >> 4), rows_ - 1);                                \
-            n_adv = ppo.adv[b_]; n_lpo = ppo.logp_old[b_]; n_val = ppo.value[b_];                       \
-            n_vold = ppo.value_old[b_];                                                                 \
-        }                                                                                               \
-    } while (0)
-    // logits slice of tile `tid_` (in the prefetch registers) -> LDS plane `pl_`
-#define PFPN_STAGE(tid_, pl_)                                                                           \
-    do {                                                                                                \
-        const int row0_ = (tid_) * R;                                                                   \
-        const int nfl_ = max(0, min(min(R, B - row0_) * AN - s_lo * N, SLICE));                         \
-        put_slice<NV>(pf, slice0 + (pl_) * TS, nfl_ >> 2, lane);                                        \
-    } while (0)
-    // first tile's HBM fetch goes out before anything else: its latency hides the bank set-up below
-    // (tile ids are clamped to the last tile instead of guarded: a redundant re-load at the very end is
-    // harmless, a conditional load is not -- see above)
-    const int tlast = ntiles - 1;
-    PFPN_FETCH_GROUP(min((int)blockIdx.x, tlast));
+    const int gs = (int)gridDim.x;
+    const int T = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + gs - 1) / gs : 0;   // my tiles
 
+    // =========================== loader waves ================================================
+    if (wave >= nwaves) {
+        const int l = wave - nwaves;
+        PFPN_STAMP(1);
+        // per-tile DMA items: tile chunks of 64 float4 | action-value chunks of 64 floats | one row-scalar piece
+        const int cap4 = TS >> 2;                          // float4 capacity of a plane
+        const int nct = (R * AN / 4 + 63) >> 6;            // tile chunks (R*AN % 4 == 0 on this path)
+        const int ncx = (nseg + 63) >> 6;
+        const int nrs = (MODE == MODE_FWD) ? 0 : 1;
+        const int M = nct + ncx + nrs;
+        const int Q = (M - l + PACK_NL - 1) / PACK_NL;     // my DMAs per tile (constant: short tiles clamp, never skip)
+        // tiles I keep in flight: two.  A compute pass over a tile takes about twice as long as the memory system
+        // needs to deliver one, so more only queues requests in front of the tile that is needed next (the first
+        // tile of a cold start lands ~1000 + 120 ticks per KB requested per CU); vmcnt immediate <= 63 caps it too.
+        const int dmax = Q > 0 ? max(1, min(PACK_DEPTH, 63 / Q + 1)) : 1;
+        const unsigned tile_b = (unsigned)(uintptr_t)tile, xpl_b = (unsigned)(uintptr_t)xpl,
+                       rpl_b = (unsigned)(uintptr_t)rpl;
+        int issued = 0, signalled = 0;
+        int slot_i = 0, wrap_i = 0, slot_s = 0;            // issued % P, issued / P, signalled % P without dividing
+        while (signalled < T) {
+            bool can = issued < T && issued - signalled < dmax;
+            if (can && wrap_i > 0)                         // plane still being read by the compute waves?
+                can = lds_counter(&freed[slot_i]) >= nwaves * wrap_i;
+            if (can) {
+                const int tid = (int)blockIdx.x + issued * gs;
+                const int row0 = tid * R, rows = min(R, B - row0);
+                const int slot = slot_i;
+                const int nv4 = rows * AN / 4;             // valid float4 of this tile
+                const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN);
+                // item i (tile chunks, then action-value chunks, then the row scalars) belongs to loader i % NL.
+                // A wave issues at most one instruction per ~4 cycles, so the full-tile path below keeps the
+                // per-DMA overhead to a pointer bump (measured: 250 -> ~50 cycles per DMA).
+                if (rows == R) {
+                    const char* gp = reinterpret_cast<const char*>(g4) + (size_t)(l * 64 + lane) * 16;
+                    unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + l * 1024));
+                    int c = l;
+                    for (; c < nct - 1; c += PACK_NL) {
+                        dma16(gp, lb);
+                        gp += PACK_NL * 1024;
+                        lb += PACK_NL * 1024;
+                    }
+                    if (c == nct - 1 && c * 64 + lane < nv4) dma16(gp, lb);        // last chunk: partial (never empty)
+                    int cx = ((l - nct) % PACK_NL + PACK_NL) % PACK_NL;
+                    for (; cx < ncx; cx += PACK_NL) {
+                        const int i = cx * 64 + lane;
+                        dma4(x + (size_t)row0 * A + min(i, nseg - 1),
+                             __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + cx * 64) * 4)));
+                    }
+                } else {
+                    for (int it_ = l; it_ < nct + ncx; it_ += PACK_NL) {
+                        if (it_ < nct) {
+                            const int i4 = it_ * 64 + lane;
+                            if (i4 < cap4)                 // never past the plane; short tiles re-read their last float4
+                                dma16(g4 + min(i4, nv4 - 1),
+                                      __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + it_ * 1024)));
+                        } else {
+                            const int c = it_ - nct;
+                            const int i = c * 64 + lane;
+                            dma4(x + (size_t)row0 * A + min(i, rows * A - 1),
+                                 __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + c * 64) * 4)));
+                        }
+                    }
+                }
+                if (nrs && (nct + ncx) % PACK_NL == l) {
+                    // lane j -> array j/16, row j%16 (R <= 16)
+                    const int arr = lane >> 4, rw = min(lane & 15, rows - 1);
+                    const float* src;
+                    if (MODE == MODE_PPO)
+                        src = (arr == 0 ? ppo.adv : arr == 1 ? ppo.logp_old : arr == 2 ? ppo.value : ppo.value_old) +
+                              row0 + rw;
+                    else
+                        src = dlogp_in + row0 + rw;
+                    dma4(src, __builtin_amdgcn_readfirstlane(rpl_b + (unsigned)(slot * 64 * 4)));
+                }
+                ++issued;
+                if (++slot_i == P) { slot_i = 0; ++wrap_i; }
+                if (issued <= 4) PFPN_STAMP(3 + (issued - 1) * 6);
+            } else if (issued > signalled) {
+                // oldest unsignalled tile: everything issued after it may stay in flight
+                wait_vmcnt(Q * (issued - signalled - 1));
+                if (lane == 0) atomicAdd(&ready[slot_s], 1);
+                ++signalled;
+                if (++slot_s == P) slot_s = 0;
+                if (signalled <= 4) PFPN_STAMP(4 + (signalled - 1) * 6);
+            } else {
+                __builtin_amdgcn_s_sleep(2);               // ring full and nothing of mine in flight
+            }
+        }
+    }
+
+    // =========================== compute waves ===============================================
     // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
     // as the reference graph computes them, pre-scaled to base 2:
     //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale, ct2 = cterm*log2 e
     float b_loc[NP], b_isc[NP], b_ct[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int n = min(g + PACK_G * i, N - 1);
-        const float sc = expf(logstd[a * N + n]);
-        b_loc[i] = loc[a * N + n];
-        b_isc[i] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
-        // +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
-        // down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
-        b_ct[i] = 64.0f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
-    }
-    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
     float acc_loc[NP], acc_ls[NP], acc_db[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) { acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
+    for (int i = 0; i < NP; ++i) { b_loc[i] = 0.f; b_isc[i] = 0.f; b_ct[i] = 0.f; acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
+    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
     float pol_sum = 0.f, val_sum = 0.f;
-    float adv_mean = 0.f, adv_rstd = 1.f;
-    if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
-
-    PFPN_STAMP(1);
-    __syncthreads();                                       // cnt zeroed
-    PFPN_STAMP(2);
-
-    // stage the first tile, take over its scalars, start the second tile's loads
-    float xv = 0.f, rs_adv = 0.f, rs_lpo = 0.f, rs_val = 0.f, rs_vold = 0.f, rs_g = 0.f;
-    PFPN_STAGE(min((int)blockIdx.x, tlast), 0);
-    xv = xn; rs_adv = n_adv; rs_lpo = n_lpo; rs_val = n_val; rs_vold = n_vold; rs_g = n_g;
-    PFPN_FETCH_GROUP(min((int)(blockIdx.x + gridDim.x), tlast));
-    int it = 0, cur = 0;
-    for (int tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x, ++it) {
-        const int row0 = tileid * R;
-        const int rows = min(R, B - row0);
-        const int nact = rows * A;                         // active segments in this tile
-        const int nfl = max(0, min(nact * N - s_lo * N, SLICE));   // valid floats in my slice
-        float* sb = segbuf + (it & 1) * nseg;
-        float* slice = slice0 + cur * TS;
-        float* seg = seg0 + cur * TS;
-        const bool active = seg_lane && sidx < nact;
-        if (it < 4) PFPN_STAMP(3 + it * 6);
-
-        // ---- forward on my quarter of the segment (wave-private LDS slice: no barrier) -------
-        float ephi[NP];
-        float inv_sum = 0.f, p = 0.f;
-        if (active) {
-            float mx = seg[0];
+    if (wave < nwaves) {
+        // The [A,N] tables are tiny, but read per lane they are ~20 scattered lines per wave-instruction x 18
+        // instructions x every wave of every CU, all on the same few L2 lines: measured ~3 us of queueing in
+        // front of the first tile's loads.  So: each element is transformed ONCE per block (coalesced loads,
+        // a quarter of the exp/log work) into LDS, and the lanes pick their (a, n) set from there.
+        //   scale = exp(logstd), cterm = 0.5log(2pi)+log(scale) as the reference graph computes them, pre-scaled
+        //   to base 2:  z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale
+        //   +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
+        //   down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
+        for (int i0 = t; i0 < AN; i0 += 4 * nwaves * 64) {
+            float ls[4], lc[4];
 #pragma unroll
-            for (int i = 1; i < NP; ++i)
-                if (i < NP - 1 || last_ok) mx = fmaxf(mx, seg[PACK_G * i]);
-            mx = quad_max(mx);
-            const float mxl = mx * PFPN_LOG2E;
-            float sum = 0.f, num = 0.f;
+            for (int u = 0; u < 4; ++u) {                  // one round trip for up to four elements per thread
+                const int i = min(i0 + u * nwaves * 64, AN - 1);
+                ls[u] = logstd[i];
+                lc[u] = loc[i];
+            }
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                ephi[i] = 0.f;
-                if (i < NP - 1 || last_ok) {
-                    // raw v_exp_f32 twice: softmax numerator, and numerator * Normal.prob * 2^64 in one go
-                    const float le = fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl);
-                    const float zq = (xv - b_loc[i]) * b_isc[i];
-                    const float en = __builtin_amdgcn_exp2f(le);
-                    ephi[i] = __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
-                    if (MODE != MODE_FWD) seg[PACK_G * i] = en;
-                    sum += en;
-                    num += ephi[i];
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nwaves * 64;
+                if (i < AN) {
+                    const float sc = expf(ls[u]);
+                    bank[i] = lc[u];
+                    bank[AN + i] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
+                    bank[2 * AN + i] = 64.0f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
                 }
             }
-            sum = quad_sum(sum);
-            num = quad_sum(num);
-            inv_sum = __builtin_amdgcn_rcpf(sum);
-            p = (num * two_m64) * inv_sum;
-            if (p < 1.401298464324817e-45f) p = 0.f;       // below the smallest fp32 denormal: the reference's p is 0
-            if (g == 0) {
-                float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;      // v_log_f32 is log2
-                if (tanh_mode) lp -= tanh_log_det(xv);
-                if (pmix_out) pmix_out[(size_t)row0 * A + sidx] = p;
-                sb[sidx] = lp;
-            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) atomicAdd(bank_done, 1);
+        while (lds_counter(bank_done) < nwaves) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int n = min(g + PACK_G * i, N - 1);
+            b_loc[i] = bank[a * N + n];
+            b_isc[i] = bank[AN + a * N + n];
+            b_ct[i] = bank[2 * AN + a * N + n];
+        }
+        float adv_mean = 0.f, adv_rstd = 1.f;
+        if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
+        PFPN_STAMP(1);
 
-        if (it < 4) PFPN_STAMP(4 + it * 6);
-        // ---- row stage ------------------------------------------------------------------------
-        float my_g = 0.f;                                   // d loss / d logp of my row
-        if (MODE == MODE_BWD) {
-            if (active) my_g = rs_g;
-        } else {
-            // publish: my segments of each touched row have arrived.  segbuf and cnt both live in LDS, and a
-            // wave's LDS operations are executed in issue order by the one LDS unit of the CU, so the ds_write
-            // of log p is visible to whoever observes the later ds_add: a compiler barrier is all that is needed.
-            // (A workgroup-scope fence would also drain vmcnt, i.e. wait for the NEXT tile's prefetch loads.)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int rr_l = r_lo + lane;
-            if (rr_l <= r_hi && rr_l < rows) {
-                const int n_r = min(min((rr_l + 1) * A, s_hi + 1), nact) - max(rr_l * A, s_lo);
-                if (n_r > 0) atomicAdd(&cnt[rr_l], n_r);
-                const int target = A * (it + 1);
-                while (__hip_atomic_load(&cnt[rr_l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target)
-                    __builtin_amdgcn_s_sleep(1);
-            }
+        // tile k of this block lives in plane k % P; wait until both loaders have landed their part
+        auto wait_ready = [&](int k) __attribute__((always_inline)) {
+            const int target = PACK_NL * (k / P + 1);
+            while (lds_counter(&ready[k % P]) < target) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            if (it < 4) PFPN_STAMP(5 + it * 6);
-            // Row stage, up to 4 rows at once: 16-lane group k sums row base+k's A segment log-probs and runs
-            // its loss head; every wave touching a row forms the identical sum (same lanes, same order).
-            {
-                const int base = r_lo;                                 // a wave touches <= 4 rows (A >= 4, see plan_packed)
+        };
+        // forward of tile k: softmax numerators stay in the plane, per-segment log p is published to
+        // segbuf[k mod 4] and the row arrival counters of that parity are bumped.
+        auto forward = [&](int k, float& p_o, float& inv_o) __attribute__((always_inline)) {
+            const int tid = (int)blockIdx.x + k * gs;
+            const int row0 = tid * R;
+            const int rows = min(R, B - row0);
+            const int nact = rows * A;                     // active segments in this tile
+            const bool active = seg_lane && sidx < nact;
+            const int slot = k % P;
+            float* seg = seg0 + slot * TS;
+            // four log-p buffers: a wave that has run ahead writes tile k+2's (and, one iteration later, k+3's)
+            // values while a neighbour may still be summing tile k's; it cannot reach k+4 before that neighbour
+            // has published k+2, which in the neighbour's program order follows its reads of tile k
+            float* sb = segbuf + (k & 3) * nseg;
+            float inv_sum = 0.f, p = 0.f;
+            if (active) {
+                const float xval = xpl[slot * XS + sidx];
+                float mx = seg[0];
+#pragma unroll
+                for (int i = 1; i < NP; ++i)
+                    if (i < NP - 1 || last_ok) mx = fmaxf(mx, seg[PACK_G * i]);
+                mx = quad_max(mx);
+                const float mxl = mx * PFPN_LOG2E;
+                float sum = 0.f, num = 0.f;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    if (i < NP - 1 || last_ok) {
+                        // raw v_exp_f32 twice: softmax numerator, and numerator * Normal.prob * 2^64 in one go
+                        const float le = fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl);
+                        const float zq = (xval - b_loc[i]) * b_isc[i];
+                        const float en = __builtin_amdgcn_exp2f(le);
+                        if (MODE != MODE_FWD) seg[PACK_G * i] = en;
+                        sum += en;
+                        num += __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
+                    }
+                }
+                sum = quad_sum(sum);
+                num = quad_sum(num);
+                inv_sum = __builtin_amdgcn_rcpf(sum);
+                p = (num * two_m64) * inv_sum;
+                if (p < 1.401298464324817e-45f) p = 0.f;   // below the smallest fp32 denormal: the reference's p is 0
+                if (g == 0) {
+                    float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;      // v_log_f32 is log2
+                    if (tanh_mode) lp -= tanh_log_det(xval);
+                    if (pmix_out) pmix_out[(size_t)row0 * A + sidx] = p;
+                    sb[sidx] = lp;
+                }
+            }
+            p_o = p; inv_o = inv_sum;
+            if (MODE != MODE_BWD) {
+                // publish: my segments of each touched row have arrived.  segbuf and cnt both live in LDS, and a
+                // wave's LDS operations are executed in issue order by the one LDS unit of the CU, so the ds_write
+                // of log p is visible to whoever observes the later ds_add: a compiler barrier is all that is needed.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const int rr_l = r_lo + lane;
+                if (rr_l <= r_hi && rr_l < rows) {
+                    const int n_r = min(min((rr_l + 1) * A, s_hi + 1), nact) - max(rr_l * A, s_lo);
+                    if (n_r > 0) atomicAdd(&cnt[(k & 1) * R + rr_l], n_r);
+                }
+            }
+            if (MODE == MODE_FWD) {
+                // forward mode never stores the plane: it is free as soon as my reads of it are done
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(&freed[slot], 1);
+            }
+        };
+
+        float p = 0.f, inv_sum = 0.f, p1 = 0.f, inv1 = 0.f;
+        if (T > 0) { wait_ready(0); forward(0, p, inv_sum); }
+        PFPN_STAMP(2);
+
+        for (int k = 0; k < T; ++k) {
+            const int tileid = (int)blockIdx.x + k * gs;
+            const int row0 = tileid * R;
+            const int rows = min(R, B - row0);
+            const int nact = rows * A;                     // active segments in this tile
+            const int nfl = max(0, min(nact * N - s_lo * N, SLICE));   // valid floats in my slice
+            const int slot = k % P;
+            float* sb = segbuf + (k & 3) * nseg;
+            float* slice = slice0 + slot * TS;
+            float* seg = seg0 + slot * TS;
+            const bool active = seg_lane && sidx < nact;
+            if (k < 4) PFPN_STAMP(3 + k * 6);
+
+            // ---- forward of the next tile --------------------------------------------------------
+            if (k + 1 < T) { wait_ready(k + 1); forward(k + 1, p1, inv1); }
+            if (k < 4) PFPN_STAMP(4 + k * 6);
+
+            // ---- row stage of this tile ----------------------------------------------------------
+            float my_g = 0.f;                               // d loss / d logp of my row
+            if (MODE == MODE_BWD) {
+                if (active) my_g = rpl[slot * 64 + r];
+            } else {
+                const int rr_l = r_lo + lane;
+                if (rr_l <= r_hi && rr_l < rows) {
+                    const int target = A * ((k >> 1) + 1);
+                    while (lds_counter(&cnt[(k & 1) * R + rr_l]) < target) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                if (k < 4) PFPN_STAMP(5 + k * 6);
+                // 16-lane group j sums row r_lo+j's A segment log-probs and runs its loss head; every wave
+                // touching a row forms the identical sum (same lanes, same order).  A wave touches <= 4 rows
+                // (A >= 4, see plan_packed).
                 const int kq = lane >> 4, jl = lane & 15;
-                const int rk = base + kq;
+                const int rk = r_lo + kq;
                 const bool rk_ok = rk <= r_hi && rk < rows;
                 float sacc = 0.f;
                 if (rk_ok)
@@ -298,17 +499,19 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
                 sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
                 // the rotation steps associate differently per lane: every lane takes its group's lane 0
-                const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
-                const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
-                const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
-                const float t3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
-                const float s = kq == 0 ? t0 : kq == 1 ? t1 : kq == 2 ? t2 : t3;
+                const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
+                const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
+                const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
+                const float u3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
+                const float s = kq == 0 ? u0 : kq == 1 ? u1 : kq == 2 ? u2 : u3;
                 const int b = row0 + rk;
                 const bool owner = rk_ok && jl == 0 && (rk * A) / PACK_WSEG == wave;   // wave holding the row's first segment
                 float gval = 0.f;
                 if (MODE == MODE_PPO) {
-                    const float adv = rs_adv, lpo = rs_lpo, val_b = rs_val, vold_b = rs_vold;
-                const float nadv = (adv - adv_mean) * adv_rstd;
+                    const int rkc = min(rk, R - 1);
+                    const float* rs = rpl + slot * 64;
+                    const float adv = rs[rkc], lpo = rs[16 + rkc], val_b = rs[32 + rkc], vold_b = rs[48 + rkc];
+                    const float nadv = (adv - adv_mean) * adv_rstd;
                     const float ratio = expf(s - lpo);
                     const float sur = ratio * nadv;
                     const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
@@ -330,85 +533,78 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 16));
                 const float g2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 32));
                 const float g3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 48));
-                const int rel = r - base;
-                if (rel >= 0 && rel < 4) my_g = rel == 0 ? g0 : rel == 1 ? g1 : rel == 2 ? g2 : g3;
+                const int rel = r - r_lo;
+                my_g = rel == 0 ? g0 : rel == 1 ? g1 : rel == 2 ? g2 : g3;
             }
-        }
-        if (it < 4) PFPN_STAMP(6 + it * 6);
+            if (k < 4) PFPN_STAMP(6 + k * 6);
 
-        // ---- backward on my quarter (dlogits overwrite the LDS slot) ---------------------------
-        if (MODE != MODE_FWD && active) {
-            const float q_ = guard_finite(my_g * __builtin_amdgcn_rcpf(p));
-            const float qs = q_ * inv_sum;
-            const float qp = qs * p;
-            const float qs64 = qs * two_m64;
-            float dxa = 0.f;
+            if (MODE != MODE_FWD) {
+                // ---- backward on my quarter (dlogits overwrite the LDS slot) -----------------------
+                if (active) {
+                    const float xv = xpl[slot * XS + sidx];
+                    const float q_ = guard_finite(my_g * __builtin_amdgcn_rcpf(p));
+                    const float qs = q_ * inv_sum;
+                    const float qp = qs * p;
+                    const float qs64 = qs * two_m64;
+                    float dxa = 0.f;
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                if (i < NP - 1 || last_ok) {
-                    const float tt = qs64 * ephi[i];                        // q * w_n * phi_n
-                    const float dlg = fmaf(-seg[PACK_G * i], qp, tt);       // q * w_n * (phi_n - p)
-                    seg[PACK_G * i] = dlg;
-                    if (MODE == MODE_PPO) acc_db[i] += dlg;                 // fc_policy bias gradient
-                    const float zq = (xv - b_loc[i]) * b_isc[i];            // z / c
-                    acc_loc[i] = fmaf(tt, zq, acc_loc[i]);                  // scaled by isc*c in the tail
-                    acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);   // tt*(z^2 - 1)
-                    if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);        // isc*c = isc2*2ln2
+                    for (int i = 0; i < NP; ++i) {
+                        if (i < NP - 1 || last_ok) {
+                            // e*phi is re-formed from the numerator kept in LDS (one v_exp) instead of being held
+                            // in registers across the next tile's forward and the row stage
+                            const float en = seg[PACK_G * i];
+                            const float zq = (xv - b_loc[i]) * b_isc[i];            // z / c
+                            const float tt = qs64 * (en * __builtin_amdgcn_exp2f(fmaf(-zq, zq, b_ct[i])));   // q * w_n * phi_n
+                            const float dlg = fmaf(-en, qp, tt);                    // q * w_n * (phi_n - p)
+                            seg[PACK_G * i] = dlg;
+                            if (MODE == MODE_PPO) acc_db[i] += dlg;                 // fc_policy bias gradient
+                            acc_loc[i] = fmaf(tt, zq, acc_loc[i]);                  // scaled by isc*c in the tail
+                            acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);   // tt*(z^2 - 1)
+                            if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);        // isc*c = isc2*2ln2
+                        }
+                    }
+                    if (dx_out) {
+                        dxa = quad_sum(dxa);
+                        if (g == 0) {
+                            float d = -dxa;
+                            if (tanh_mode) d += my_g * 2.f * tanhf(xv);
+                            dx_out[(size_t)row0 * A + sidx] = d;
+                        }
+                    }
                 }
-            }
-            if (dx_out) {
-                dxa = quad_sum(dxa);
-                if (g == 0) {
-                    float d = -dxa;
-                    if (tanh_mode) d += my_g * 2.f * tanhf(xv);
-                    dx_out[(size_t)row0 * A + sidx] = d;
+                if (k < 4) PFPN_STAMP(7 + k * 6);
+                // ---- my slice of dlogits -> HBM (same wave wrote it: in-order LDS, no barrier), then the plane
+                //      is the loaders' again.  The stores are never waited for inside the loop.
+                float* gdst = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;
+                const int nv = nfl >> 2;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < nv) reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(slice)[i];
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my ds_reads of the plane have returned
+                if (lane == 0) atomicAdd(&freed[slot], 1);
+                if (k < 4) PFPN_STAMP(8 + k * 6);
             }
+            p = p1; inv_sum = inv1;
         }
-        if (it < 4) PFPN_STAMP(7 + it * 6);
-        // ---- hand-off: next tile registers -> the other LDS plane (the one vmcnt wait of the loop: those
-        //      loads are a tile old), its scalars -> live registers, the tile after that -> prefetch;
-        //      then my slice of dlogits -> HBM (same wave wrote it: in-order LDS, no barrier).  The stores
-        //      drain behind the next tile's compute.
-#define PFPN_STORE_SLICE()                                                                               \
-    do {                                                                                                \
-        float* gdst_ = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;                                  \
-        const int nv_ = nfl >> 2;                                                                       \
-        _Pragma("unroll") for (int j_ = 0; j_ < NV; ++j_) {                                             \
-            const int i_ = lane + 64 * j_;                                                              \
-            if (i_ < nv_) reinterpret_cast<float4*>(gdst_)[i_] = reinterpret_cast<const float4*>(slice)[i_]; \
-        }                                                                                               \
-    } while (0)
-        if (MODE != MODE_FWD && !dbuf) PFPN_STORE_SLICE(); // single plane: it must be read out first
-        const int nxt = tileid + (int)gridDim.x;
-        PFPN_STAGE(min(nxt, tlast), cur ^ dbuf);
-        if (it < 4) PFPN_STAMP(8 + it * 6);
-        xv = xn; rs_adv = n_adv; rs_lpo = n_lpo; rs_val = n_val; rs_vold = n_vold; rs_g = n_g;
-        PFPN_FETCH_GROUP(min(nxt + (int)gridDim.x, tlast));
-        if (MODE != MODE_FWD && dbuf) PFPN_STORE_SLICE();
-        cur ^= dbuf;
     }
-#undef PFPN_STORE_SLICE
-#undef PFPN_STAGE
-#undef PFPN_FETCH_GROUP
 
     if (MODE == MODE_FWD) return;
     PFPN_STAMP(40);
-    // ---- block partials: dloc / dlogstd summed over the R segments that share an action dim,
-    //      in row order; loss sums in wave order.  Slab layout [nq*AN + 4] per block, nq = 2 (+1 with
-    //      the dlogits column sums of the PPO mode).
+    // ---- block partials: dloc / dlogstd (/ dlogits column sums) summed over the R segments that share an
+    //      action dim, in row order; loss sums in wave order.  Slab layout [nq*AN + 4] per block.
+    //      The ring's first three planes are free now: all sums are staged in one pass.
     const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
     float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
-    float* seg = seg0;                                     // plane 0
-    if (planes >= 3) {
-        // three tile-sized planes: all gradient sums staged in one pass
+    {
         float* lsb = tile + TS;
         __syncthreads();
         if (seg_lane) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
                 if (i < NP - 1 || last_ok) {
-                    seg[PACK_G * i] = acc_loc[i] * (b_isc[i] * PFPN_2LN2);       // dloc *= c/scale
+                    seg0[PACK_G * i] = acc_loc[i] * (b_isc[i] * PFPN_2LN2);      // dloc *= c/scale
                     lsb[sidx * N + g + PACK_G * i] = acc_ls[i];
                     if (nq == 3) lsb[TS + sidx * N + g + PACK_G * i] = acc_db[i];
                 }
@@ -428,28 +624,11 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             for (; rr < R; ++rr) s += src[rr * AN + i];
             slab[idx] = s;
         }
-    } else {
-    for (int which = 0; which < nq; ++which) {
-        __syncthreads();
-        if (seg_lane) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i)
-                if (i < NP - 1 || last_ok)
-                    seg[PACK_G * i] = which == 0 ? acc_loc[i] * (b_isc[i] * PFPN_2LN2)   // dloc *= c/scale
-                                    : which == 1 ? acc_ls[i] : acc_db[i];
-        }
-        __syncthreads();
-        for (int i = t; i < AN; i += blockDim.x) {
-            float s = 0.f;
-            for (int rr = 0; rr < R; ++rr) s += tile[rr * AN + i];
-            slab[which * AN + i] = s;
-        }
-    }
     }
     if (MODE == MODE_PPO) {
         pol_sum = wave_sum_dpp(pol_sum);                  // held by the 4 group-leading lanes
         val_sum = wave_sum_dpp(val_sum);
-        if (lane == 0) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
+        if (lane == 0 && wave < nwaves) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
         __syncthreads();
         if (t == 0) {
             float ps = 0.f, vs = 0.f;
@@ -816,7 +995,7 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // ---------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------
-struct PackPlan { int R; int grid; int threads; size_t lds; int vec_ok; bool ok; };
+struct PackPlan { int R; int grid; int threads; size_t lds; int P; bool ok; };
 
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
@@ -827,51 +1006,43 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     // in the row stage); narrower action spaces take the wave kernel
     if (N > 64 || N < 1 || A < 4 || B < 1) return pl;
     const int AN = A * N;
+    // the kernel streams float4 slices / 1 KiB DMA pieces only; unaligned shapes take the wave kernel
+    if ((AN % 4) || ((uintptr_t)logits % 16) || (dlogits && (uintptr_t)dlogits % 16)) return pl;
     // rows per tile: the smallest R0 with R0*A a multiple of 16 segments (full waves), repeated while the
-    // block stays <= 12 waves (A=36: R=4, 9 waves, every lane busy)
+    // block stays <= 12 compute waves and <= 16 rows (A=36: R=4, 9 waves, every lane busy)
     const int R0 = PACK_WSEG / gcd_i(A, PACK_WSEG);
     const int W0 = R0 * A / PACK_WSEG;
-    if (W0 > 16) return pl;
+    if (W0 > 14 || R0 > 16) return pl;
     int k = 12 / W0;
     if (k < 1) k = 1;
+    while (k > 1 && R0 * k > 16) --k;
     int R = R0 * k;
-    // at <= 128 VGPRs a CU holds 16 waves: prefer ONE block that fills them (largest R with <= 16 waves)
-    // over two half-size blocks that cannot be co-resident (measured on the 4096 x 36 x 35 step)
-    static const int env_full = getenv("PFPN_MIX_FULL") ? atoi(getenv("PFPN_MIX_FULL")) : 0;
-    if (env_full) {
-        const int rmax = (16 * PACK_WSEG) / A;
-        if (rmax >= 1 && (rmax * A + PACK_WSEG - 1) / PACK_WSEG <= 16 && rmax > R) R = rmax;
-    }
     static const int env_rows = getenv("PFPN_MIX_ROWS") ? atoi(getenv("PFPN_MIX_ROWS")) : 0;   // tuning knob
-    if (env_rows > 0 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 16) R = env_rows;
+    if (env_rows > 0 && env_rows <= 16 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 14) R = env_rows;
     if (R > B) R = B;                                   // small batches: one partial tile
-    const int waves = (R * A + PACK_WSEG - 1) / PACK_WSEG;
+    const int waves = (R * A + PACK_WSEG - 1) / PACK_WSEG;      // compute waves
     pl.R = R;
-    pl.threads = waves * 64;
-    // LDS: tile-sized planes + small arrays.  1 plane is the minimum; 2 double-buffer the tile (the next
-    // tile is staged while the current one is still being stored); 3 also give the backward tail room to
-    // stage all three gradient sums in one pass.
-    const size_t plane = (size_t)waves * PACK_WSEG * N * 4;
-    const size_t small = (size_t)(2 * R * A + R + 2 * waves + 8) * 4;
-    int planes = 1;
-    if (2 * plane + small <= 64 * 1024) planes = 2;
-    if (dlogits && 3 * plane + small <= 64 * 1024) planes = 3;
-    pl.lds = planes * plane + small;
-    pl.vec_ok = ((AN % 4 == 0) && ((uintptr_t)logits % 16 == 0) && (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0)) ? 1 : 0;
-    pl.vec_ok |= planes << 1;                           // kernel `flags`: bit 0 float4 path, bits 1-2 plane count
+    pl.threads = (waves + PACK_NL) * 64;
+    // LDS ring: P planes of (tile + action values + row scalars), then the small arrays (see the kernel's map)
+    const size_t plane = (size_t)waves * PACK_WSEG * N * 4 + (size_t)(((R * A + 63) & ~63) + 64) * 4;
+    const int pmin = dlogits ? 3 : 2;
+    int P = 4;
+    static const int env_p = getenv("PFPN_MIX_PLANES") ? atoi(getenv("PFPN_MIX_PLANES")) : 0;     // tuning knob
+    if (env_p >= pmin && env_p <= 8) P = env_p;
+    size_t small = 0;
+    for (;; --P) {
+        small = (size_t)(4 * R * A + 2 * R + 2 * P + 2 * waves + 16 + 3 * AN) * 4;
+        if (P * plane + small <= PACK_MAX_LDS || P <= pmin) break;
+    }
+    pl.P = P;
+    pl.lds = P * plane + small;
     const int ntiles = (B + R - 1) / R;
-    // resident blocks per CU by wave slots (128 VGPRs: 4 waves/SIMD = 16 waves/CU) and LDS
-    int per_cu = 16 / waves;
-    const int by_lds = (int)((size_t)(150 * 1024) / (pl.lds ? pl.lds : 1));
-    if (per_cu > by_lds) per_cu = by_lds;
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
+    int per_cu = 1;                                     // one block (compute + loader waves) per CU
     static const int env_pcu = getenv("PFPN_MIX_PER_CU") ? atoi(getenv("PFPN_MIX_PER_CU")) : 0;   // tuning knob
     if (env_pcu > 0) per_cu = env_pcu;
     const int cap = 256 * per_cu;
     pl.grid = ntiles < cap ? ntiles : cap;
-    // the packed kernel streams float4 slices only; unaligned shapes take the wave kernel
-    pl.ok = pl.lds <= 64 * 1024 && waves <= 16 && (pl.vec_ok & 1);
+    pl.ok = pl.lds <= PACK_MAX_LDS && waves <= 14 && R <= 16;
     return pl;
 }
 
@@ -880,12 +1051,20 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
                          const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
                          float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
 #define PFPN_LAUNCH_PACKED_T(NN, TT)                                                                        \
-    hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
-                       loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.vec_ok, logp, pmix, dlogits, dx,       \
-                       partial, ppo)
+    do {                                                                                                    \
+        static bool big_lds_ok = false;          /* > 64 KB of dynamic LDS needs a one-time opt-in */         \
+        if (pl.lds > 64 * 1024 && !big_lds_ok) {                                                            \
+            (void)hipFuncSetAttribute((const void*)&k_mix_packed<NN, MODE, TT>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PACK_MAX_LDS);        \
+            big_lds_ok = true;                                                                              \
+        }                                                                                                   \
+        hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
+                           loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.P, logp, pmix, dlogits, dx,        \
+                           partial, ppo);                                                                   \
+    } while (0)
 #define PFPN_LAUNCH_PACKED(NN)                                                  \
     do {                                                                        \
-        if (pl.threads <= 640) PFPN_LAUNCH_PACKED_T(NN, 640);                   \
+        if (pl.threads <= 704) PFPN_LAUNCH_PACKED_T(NN, 704);                   \
         else PFPN_LAUNCH_PACKED_T(NN, PACK_BLOCK);                              \
     } while (0)
     switch (N) {

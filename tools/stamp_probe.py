@@ -35,3 +35,18 @@ for w in (0, 4, 8):
         dt = (s[w,k]-t0)/100.0   # s_memtime: 100 MHz ticks? print raw delta
         print("   %-14s %8d ticks  (+%d)" % (names[k], s[w,k]-t0, (s[w,k]-prev) if prev else 0))
         prev = s[w,k]
+
+print("\nper-wave timeline (ticks since block start): top | fwd done | wait done | bwd done | staged next")
+for it in range(4):
+    print("tile", it)
+    for w in range(9):
+        base = 3 + it * 6
+        print("   w%d  top %6d  fwd %6d  wait %6d  row %6d  bwd %6d  staged %6d" % (
+            w, s[w, base] - t0, s[w, base + 1] - t0, s[w, base + 2] - t0, s[w, base + 3] - t0, s[w, base + 4] - t0,
+            (s[w, base + 5] - t0) if s[w, base + 5] else -1))
+
+print("loader waves: tile k issued / landed (ticks)")
+for w in (9, 10):
+    print("   w%d " % w + "  ".join("t%d issued %6d landed %6d" % (k, s[w, 3 + k * 6] - t0, s[w, 4 + k * 6] - t0) for k in range(4)))
+
+print("starts: " + "  ".join("w%d s0 %d s1 %d s2 %d" % (w, s[w,0]-t0, s[w,1]-t0, (s[w,2]-t0) if s[w,2] else -1) for w in (0,4,8,9,10)))
