@@ -142,6 +142,21 @@ size_t pfpn_learner_workspace_bytes(int rows, int H);
 int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, int E, float gamma,
              double gae_gamma, float* adv, void* stream);
 
+/* V-trace targets -- reference networks/actor_critic/vtrace.py:101-180.  E episodes of T steps, all [E*T]
+ * vectors flat in episode-major order (index e*T + t: vtrace.py:16-37); seq_len [E] (optional, int32) marks
+ * zero-padded episodes.  fp32, the reverse tf.scan's operation order; rho_clip / pg_rho_clip <= 0 = None.
+ * Outputs (flat, same order): vs = value target, pg_adv = policy-gradient advantage, mask (optional) =
+ * valid_data_mask as 0/1 floats. */
+int pfpn_vtrace(const float* logp_target, const float* logp_behavior, const float* value, const float* reward,
+                const float* not_terminal, const int32_t* seq_len, int E, int T, float gamma, float rho_clip,
+                float pg_rho_clip, float* vs, float* pg_adv, float* mask, void* stream);
+/* Policy-gradient loss head of the A2C / A3C / IMPALA networks -- reference a2c.py:53-65, actor_critic.py:132-184:
+ * policy_loss = -mean_valid(logp*adv_n), value_loss = coef*mean_valid((v - value_target)^2); mask optional
+ * (valid_data_mask, 0/1).  Outputs dlogp [B], dvalue [B], loss4 = {loss, policy_loss, value_loss*coef, n_valid}. */
+int pfpn_a2c_loss(const float* logp, const float* adv, const float* value, const float* value_target,
+                  const float* adv_stats, const float* mask, int B, float value_coef, float* dlogp, float* dvalue,
+                  float* loss4, void* stream);
+
 /* x = clip((s-mean)/std, +-clip) -- actor_critic.py:223-244 (clip <= 0: no clipping). */
 int pfpn_state_norm(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
                     void* stream);

@@ -714,3 +714,120 @@ def sac_learner_step(st, batch, noise, lr_c=1e-4, lr_a=1e-4, clip_norm=1.0, tau=
     if st.train_flag >= st.resample_interval:
         st.max_active[:] = 0; st.sum_active[:] = 0; st.train_flag = 0
     return losses, aux
+
+
+# --------------------------------------------------------------------------------------- #
+# V-trace / A2C (A3C, IMPALA) learner -- SURVEY 8(f)-2                                    #
+# --------------------------------------------------------------------------------------- #
+def vtrace(logp_target, logp_behavior, value, reward, not_terminal, E, gamma, rho_clip=1.0, pg_rho_clip=1.0,
+           seq_len=None):
+    """reference networks/actor_critic/vtrace.py:101-180.  Inputs flat [E*T] in episode-major order
+    (to_batches :56-61 reshapes to [E,T] and transposes to time-major [T,E]); fp32 throughout, the reverse
+    tf.scan (:143-153) restated as a loop.  Returns (vs, pg_adv, mask), flat in the input order (to_flat)."""
+    tb = lambda a: np.asarray(a, F).reshape(E, -1).T.copy()          # [T, E]
+    lt, lb, v, r, nt = tb(logp_target), tb(logp_behavior), tb(value), tb(reward), tb(not_terminal)
+    T = v.shape[0]
+    rho = np.exp((lt - lb).astype(F)).astype(F)                                   # :117-119
+    v_rho = rho if rho_clip is None else np.minimum(F(rho_clip), rho)             # :121-126
+    c = np.minimum(F(1.0), rho)                                                   # :134
+    disc = (F(gamma) * nt).astype(F)                                              # :113-115
+    end_mask = np.zeros((T, E), bool)
+    if seq_len is not None:                                                       # :68-76 batched_episodic_end_mask
+        for e in range(E):
+            end_mask[int(seq_len[e]) - 1, e] = True
+
+    def concat_bootstrap(x, val):                                                 # :91-97
+        x1 = np.concatenate((x[1:], val[-1:]), axis=0)
+        return np.where(end_mask, val, x1) if seq_len is not None else x1
+
+    v_t1 = concat_bootstrap(v, v)                                                 # :127-128
+    td = (v_rho * ((r + (disc * v_t1).astype(F)).astype(F) - v).astype(F)).astype(F)     # :129-132
+    dsc = np.where(end_mask, F(0), disc).astype(F) if seq_len is not None else disc      # :136-141
+    a = np.zeros(E, F)
+    vmv = np.zeros((T, E), F)
+    for t in range(T - 1, -1, -1):                                                # :143-153 reverse scan
+        a = (td[t] + ((dsc[t] * c[t]).astype(F) * a).astype(F)).astype(F)
+        vmv[t] = a
+    vs = (vmv + v).astype(F)                                                      # :154
+    pg_rho = rho if pg_rho_clip is None else np.minimum(F(pg_rho_clip), rho)      # :165-171
+    vs_t1 = concat_bootstrap(vs, v)                                               # :172-173
+    pg = (pg_rho * ((r + (disc * vs_t1).astype(F)).astype(F) - v).astype(F)).astype(F)   # :174-178
+    mask = np.ones((T, E), F)
+    if seq_len is not None:                                                       # :77-78 sequence_mask
+        mask = (np.arange(T)[:, None] < np.asarray(seq_len)[None, :]).astype(F)
+    flat = lambda x: np.ascontiguousarray(x.T).reshape(-1)                        # to_flat :63-64
+    return flat(vs), flat(pg), flat(mask)
+
+
+def a2c_loss(logp, adv, v, v_target, value_loss_coef=0.5, mask=None, normalize_adv=False):
+    """reference a2c.py:53-65 + actor_critic.py:132-184: policy_loss = -mean(valid(logp*adv_n)),
+    value_loss = coef*mean(valid((v - vt)^2)).  Returns (loss, policy_loss, value_loss*coef, dlogp, dv)."""
+    m = np.ones_like(logp, F) if mask is None else np.asarray(mask, F)
+    n = F(m.sum())
+    adv = np.asarray(adv, F)
+    if normalize_adv:
+        va = adv[m > 0]
+        adv = ((adv - va.mean(dtype=F)) / (np.sqrt(va.var(dtype=F)) + F(1e-8))).astype(F)
+    pl = -F((m * (logp * adv)).sum(dtype=F) / n)
+    d = (v - v_target).astype(F)
+    vl = F((m * d * d).sum(dtype=F) / n) * F(value_loss_coef)
+    dlogp = (-(adv * m) / n).astype(F)
+    dv = (F(2.0 * value_loss_coef) * (d * m) / n).astype(F)
+    return F(pl + vl), pl, vl, dlogp, dv
+
+
+def a2c_grads(P, norm_mean, norm_std, batch, A, N, value_loss_coef=0.5, entropy_beta=0.0, vtrace_opts=None):
+    """Forward + backward of the A2C loss (A3C: batch has value_target/advantage; IMPALA: vtrace_opts =
+    dict(E, gamma, rho_clip, pg_rho_clip, seq_len) and batch has reward/log_prob/not_terminal -- the targets
+    come from V-trace on the CURRENT value and target log-prob, stop-gradient: vtrace.py:101-180)."""
+    x = state_normalize(batch["state"], norm_mean, norm_std, 5.0)
+    logits, (h1, h2) = actor_forward(P, x, A, N)
+    v, (c1, c2) = critic_forward(P, x)
+    logp, _ = mixture_log_prob(logits, batch["action"], P["actor/samples"], P["actor/samples_std"])
+    mask = None
+    if vtrace_opts is not None:
+        vt, adv, mask = vtrace(logp, batch["log_prob"], v, batch["reward"], batch["not_terminal"], vtrace_opts["E"],
+                               vtrace_opts["gamma"], vtrace_opts.get("rho_clip", 1.0),
+                               vtrace_opts.get("pg_rho_clip", 1.0), vtrace_opts.get("seq_len"))
+        if vtrace_opts.get("seq_len") is None:
+            mask = None
+    else:
+        vt, adv = batch["value_target"], batch["advantage"]
+    loss, pl, vl, dlogp, dv = a2c_loss(logp, adv, v, vt, value_loss_coef, mask)
+    dlogits, dloc, dlogstd, _ = mixture_log_prob_bwd(logits, batch["action"], P["actor/samples"],
+                                                     P["actor/samples_std"], dlogp)
+    ent = None
+    if entropy_beta:
+        m = np.ones(len(x), F) if mask is None else mask
+        n = F(m.sum())
+        H = categorical_entropy(logits)                               # [B,A]  (a2c.py:62-65: sum over A, mean over valid)
+        ent = F((m * H.sum(1, dtype=F)).sum(dtype=F) / n)
+        pl = F(pl - F(entropy_beta) * ent)
+        loss = F(loss - F(entropy_beta) * ent)
+        dH = np.broadcast_to((-(F(entropy_beta)) * m / n)[:, None], H.shape).astype(F)
+        dlogits = (dlogits + categorical_entropy_bwd(logits, dH)).astype(F)
+    G = {"actor/samples": dloc, "actor/samples_std": dlogstd}
+    dl = dlogits.reshape(len(x), A * N)
+    dh2, G["actor/fc_policy/weight"], G["actor/fc_policy/bias"] = _fc_bwd(h2, P["actor/fc_policy/weight"], None, dl, False)
+    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True)
+    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True)
+    dc2, G["critic/fc3/weight"], G["critic/fc3/bias"] = _fc_bwd(c2, P["critic/fc3/weight"], None, dv[:, None], False)
+    dc1, G["critic/fc2/weight"], G["critic/fc2/bias"] = _fc_bwd(c1, P["critic/fc2/weight"], c2, dc2, True)
+    _, G["critic/fc1/weight"], G["critic/fc1/bias"] = _fc_bwd(x, P["critic/fc1/weight"], c1, dc1, True)
+    return (loss, ent, pl, vl), G, {"logp": logp, "value": v, "value_target": vt, "advantage": adv, "mask": mask}
+
+
+def a2c_learner_step(st, batch, lr=1e-4, clip_norm=0.5, value_loss_coef=0.5, entropy_beta=0.00025, vtrace_opts=None):
+    """One single-replica learner step of the A3C / IMPALA PFPN settings (deepmimic_a3c_base.py,
+    deepmimic_impala_base.py: norm_clip 0.5, entropy_beta 0.00025; state-norm EMA as in the DPPO step)."""
+    lm, ls = state_norm_update(batch["state"], st.norm_mean, st.norm_std, st.global_step)
+    losses, G, aux = a2c_grads(st.P, st.norm_mean, st.norm_std, batch, st.A, st.N, value_loss_coef, entropy_beta,
+                               vtrace_opts)
+    clipped, _ = clip_by_global_norm([G[n] for n in PARAM_ORDER], clip_norm)
+    st.norm_mean, st.norm_std = lm, ls
+    for n, g in zip(PARAM_ORDER, clipped):
+        st.P[n], st.m[n], st.v[n] = tf_adam(st.P[n], g.astype(F), st.m[n], st.v[n], st.b1p, st.b2p, lr)
+    st.b1p, st.b2p = F(st.b1p * F(0.9)), F(st.b2p * F(0.999))
+    st.global_step += 1
+    st.train_flag += 1
+    return losses, aux

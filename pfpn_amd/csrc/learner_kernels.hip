@@ -86,6 +86,88 @@ __global__ __launch_bounds__(1024) void k_ppo_loss(
 }
 
 // ---------------------------------------------------------------------------------------
+// V-trace (reference networks/actor_critic/vtrace.py:101-180).  E episodes of T steps, data flat in
+// episode-major order (index e*T + t, the order the workers feed: vtrace.py:16-37).  One thread per
+// episode walks its T steps backwards exactly as the reference's reverse tf.scan does, in fp32 and in
+// the graph's operation order:
+//   rho = exp(lp_target - lp_behaviour); v_rho = min(rho_clip, rho); c = min(1, rho); disc = gamma*not_terminal
+//   value_t1[t] = value[t+1], and value[t] itself at the last step / at t = seq_len-1 (concat_bootstrap_value)
+//   a[t] = v_rho*((r + disc*value_t1) - value) + (disc'*c)*a[t+1],  disc' = 0 at t = seq_len-1;  vs = a + value
+//   pg_adv[t] = pg_rho*((r + disc*vs_t1) - value), vs_t1 = vs[t+1] (value[t] at the last step / episode end)
+// Clips <= 0 mean "None" (no clipping).  mask[t] = t < seq_len (all ones without seq_len).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_vtrace(const float* __restrict__ lp_t, const float* __restrict__ lp_b,
+                                               const float* __restrict__ value, const float* __restrict__ reward,
+                                               const float* __restrict__ not_terminal,
+                                               const int* __restrict__ seq_len, int E, int T, float gamma,
+                                               float rho_clip, float pg_rho_clip, float* __restrict__ vs,
+                                               float* __restrict__ pg_adv, float* __restrict__ mask) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int end = seq_len ? seq_len[e] - 1 : -1;           // episodic_end_idx within the episode
+    const size_t base = (size_t)e * T;
+    float a_next = 0.f, vs_next = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t i = base + t;
+        const float v = value[i], r = reward[i];
+        const float rho = expf(lp_t[i] - lp_b[i]);
+        const float v_rho = rho_clip > 0.f ? fminf(rho_clip, rho) : rho;
+        const float pg_rho = pg_rho_clip > 0.f ? fminf(pg_rho_clip, rho) : rho;
+        const float c = fminf(1.0f, rho);
+        const float disc = gamma * not_terminal[i];
+        const bool boot = (t == T - 1) || (t == end);
+        const float v_t1 = boot ? v : value[i + 1];
+        const float td = v_rho * ((r + disc * v_t1) - v);
+        const float dsc = (t == end) ? 0.f : disc;
+        const float a = td + (dsc * c) * a_next;
+        const float vs_t = a + v;
+        const float vs_t1 = boot ? v : vs_next;
+        vs[i] = vs_t;
+        pg_adv[i] = pg_rho * ((r + disc * vs_t1) - v);
+        if (mask) mask[i] = (!seq_len || t <= end) ? 1.f : 0.f;
+        a_next = a;
+        vs_next = vs_t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Policy-gradient (A2C / A3C / IMPALA) loss head on [B] vectors -- reference a2c.py:53-65,
+// actor_critic.py:132-184:  policy_loss = -mean_valid(logp * adv_n),  value_loss = coef * mean_valid((v - vt)^2),
+// adv_n = (adv - mean)*rstd (stats = {0,1}: off).  mask (optional, 0/1) is valid_data_mask; means run over the
+// valid rows.  dlogp = -adv_n*mask/n, dvalue = 2*coef*(v - vt)*mask/n.  One block, fixed order.
+// loss3 = {loss, policy_loss, value_loss*coef}; n_valid is returned in loss3[3].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_a2c_loss(const float* __restrict__ logp, const float* __restrict__ adv,
+                                                   const float* __restrict__ value,
+                                                   const float* __restrict__ value_target,
+                                                   const float* __restrict__ stats, const float* __restrict__ mask,
+                                                   int B, float value_coef, float* __restrict__ dlogp,
+                                                   float* __restrict__ dvalue, float* __restrict__ loss4) {
+    __shared__ float red[16];
+    float nv = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) nv += mask ? mask[b] : 1.f;
+    nv = block_sum(nv, red);
+    const float inv_n = 1.0f / nv;
+    const float mean = stats[0], rstd = stats[1];
+    float ps = 0.f, vs = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float m = mask ? mask[b] : 1.f;
+        const float nadv = (adv[b] - mean) * rstd;
+        ps += m * (logp[b] * nadv);
+        const float d = value[b] - value_target[b];
+        vs += m * (d * d);
+        dlogp[b] = -(nadv * m) * inv_n;
+        dvalue[b] = (2.f * value_coef) * (d * m) * inv_n;
+    }
+    ps = block_sum(ps, red);
+    vs = block_sum(vs, red);
+    if (threadIdx.x == 0) {
+        const float pl = -ps * inv_n, vl = vs * inv_n * value_coef;
+        loss4[0] = pl + vl; loss4[1] = pl; loss4[2] = vl; loss4[3] = nv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // K8: state normaliser
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_state_norm(const float* __restrict__ s, const float* __restrict__ mean,
@@ -534,6 +616,32 @@ int pfpn_ppo_loss(const float* logp, const float* logp_old, const float* adv, co
         return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, logp_old, adv, value,
                        value_old, adv_stats, B, 1.0f - clip_eps, 1.0f + clip_eps, value_coef, dlogp, dvalue, loss3);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_vtrace(const float* logp_target, const float* logp_behavior, const float* value, const float* reward,
+                const float* not_terminal, const int32_t* seq_len, int E, int T, float gamma, float rho_clip,
+                float pg_rho_clip, float* vs, float* pg_adv, float* mask, void* stream) {
+    PFPN_BEGIN();
+    if (!logp_target || !logp_behavior || !value || !reward || !not_terminal || !vs || !pg_adv || E < 0 || T < 1)
+        return PFPN_ERR_ARG;
+    if (E == 0) return PFPN_OK;
+    hipLaunchKernelGGL(k_vtrace, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, logp_target, logp_behavior,
+                       value, reward, not_terminal, (const int*)seq_len, E, T, gamma, rho_clip, pg_rho_clip, vs,
+                       pg_adv, mask);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_a2c_loss(const float* logp, const float* adv, const float* value, const float* value_target,
+                  const float* adv_stats, const float* mask, int B, float value_coef, float* dlogp, float* dvalue,
+                  float* loss4, void* stream) {
+    PFPN_BEGIN();
+    if (!logp || !adv || !value || !value_target || !adv_stats || !dlogp || !dvalue || !loss4 || B < 1)
+        return PFPN_ERR_ARG;
+    hipLaunchKernelGGL(k_a2c_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, logp, adv, value, value_target,
+                       adv_stats, mask, B, value_coef, dlogp, dvalue, loss4);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -167,6 +167,42 @@ def ppo_loss(logp, logp_old, adv, value, value_old, stats, clip_eps=0.2, value_c
     return dlogp, dvalue, loss3
 
 
+def vtrace(logp_target, logp_behavior, value, reward, not_terminal, E, gamma, rho_clip=1.0, pg_rho_clip=1.0,
+           seq_len=None, want_mask=False):
+    """V-trace value targets and policy-gradient advantages; all inputs flat [E*T] episode-major.
+    -> vs, pg_adv (, mask)."""
+    lib = _lib.load()
+    n = logp_target.shape[0]
+    if E < 1 or n % E:
+        raise ValueError("V-trace: %d rows do not split into %d episodes" % (n, E))
+    T = n // E
+    dev = logp_target.device
+    vs = torch.empty(n, dtype=torch.float32, device=dev)
+    pg = torch.empty(n, dtype=torch.float32, device=dev)
+    mask = torch.empty(n, dtype=torch.float32, device=dev) if want_mask else None
+    _lib.check(lib.pfpn_vtrace(_f32(logp_target, n), _f32(logp_behavior, n), _f32(value, n), _f32(reward, n),
+                               _f32(not_terminal, n),
+                               _typed(seq_len, torch.int32, E, name="seq_len") if seq_len is not None else None,
+                               E, T, float(gamma), float(rho_clip or 0.0), float(pg_rho_clip or 0.0),
+                               vs.data_ptr(), pg.data_ptr(), mask.data_ptr() if want_mask else None, _stream()),
+               "pfpn_vtrace")
+    return (vs, pg, mask) if want_mask else (vs, pg)
+
+
+def a2c_loss(logp, adv, value, value_target, stats, value_coef=0.5, mask=None):
+    """-> dlogp [B], dvalue [B], loss4 = {loss, policy_loss, value_loss*coef, n_valid}."""
+    lib = _lib.load()
+    B = logp.shape[0]
+    dev = logp.device
+    dlogp = torch.empty(B, dtype=torch.float32, device=dev)
+    dvalue = torch.empty(B, dtype=torch.float32, device=dev)
+    loss4 = torch.empty(4, dtype=torch.float32, device=dev)
+    _lib.check(lib.pfpn_a2c_loss(_f32(logp, B), _f32(adv, B), _f32(value, B), _f32(value_target, B), _f32(stats, 2),
+                                 _f32(mask, B) if mask is not None else None, B, float(value_coef),
+                                 dlogp.data_ptr(), dvalue.data_ptr(), loss4.data_ptr(), _stream()), "pfpn_a2c_loss")
+    return dlogp, dvalue, loss4
+
+
 def sample(logits, loc, logstd, u_cat, eps_sel, max_active=None, sum_active=None, want_logp=True):
     """-> k [B,A] int32, action [B,A], logp [B] (or None); updates max/sum_active in place if given."""
     lib = _lib.load()

@@ -33,9 +33,9 @@ class AbstractDistributedWorker(object):
         self.batch_size = batch_size
         self.unroll_length = unroll_length
         self.opt_epochs = opt_epochs
+        # episodic training: the learner is fed whole (zero-padded) rollout segments plus their lengths --
+        # what the V-trace network needs (reference distributed_model.py:166-189, :293-310, :354-370)
         self.episodic_training = episodic_training
-        if episodic_training:
-            raise NotImplementedError("episodic (LSTM) training is not part of the PFPN path")
         self.logger = None
         self.request_stop = False
         self.global_step = 0
@@ -74,8 +74,14 @@ class AbstractDistributedWorker(object):
                 action, *_ = self.sample_action(sess, state)
                 state, _, terminal, info = self.interact_with_env(sess, state, action)
                 if self.target_net.trainable:
-                    if self.need_train(sess, terminal, state, info):
-                        self.flat_train(sess)
+                    need_train = self.need_train(sess, terminal, state, info)
+                    if self.sequence_length is not None and (terminal or self.episodic_terminal):
+                        self._close_segment(terminal)
+                    if need_train:
+                        if self.sequence_length is not None:
+                            self.episodic_train(sess)
+                        else:
+                            self.flat_train(sess)
                         self.after_train(sess)
                 if max_iterations is not None and self.global_step >= max_iterations:
                     self.request_stop = True
@@ -93,9 +99,53 @@ class AbstractDistributedWorker(object):
         if self.on_policy and self.exp_buffers is not None:
             for _, v in self.exp.items():
                 v.clear()
+            if self.sequence_length is not None:
+                self.sequence_length.clear()
+                self.sequence_terminal.clear()
         self.sample_counter = 0
 
+    # -- rollout segments for episodic training ---------------------------------------------------
+    def _open_rows(self):
+        """rows collected since the last closed segment."""
+        closed = len(self.sequence_length) * (self.unroll_length if self.unroll_length is not None else 0)
+        if self.unroll_length is None:
+            closed = sum(self.sequence_length)
+        return len(self.exp["state"]) - closed
+
+    def _close_segment(self, terminal):
+        """A segment ends at an episode end or when `unroll_length` rows are in: record its length; with a
+        fixed unroll length it is zero-padded to that length at once (reference :166-176)."""
+        n = self._open_rows()
+        if self.unroll_length is not None:
+            for buf in self.exp.values():
+                buf.extend(np.zeros_like(buf[0]) for _ in range(self.unroll_length - n))
+        self.sequence_length.append(n)
+        self.sequence_terminal.append(terminal)
+
+    def _pack_segments(self):
+        """Variable-length segments -> equal length: zero rows behind every shorter one (reference :178-187)."""
+        if self.unroll_length is not None or not self.sequence_length:
+            return
+        T = max(self.sequence_length)
+        for k, buf in self.exp.items():
+            packed, pos = [], 0
+            for n in self.sequence_length:
+                seg = buf[pos:pos + n]
+                packed.extend(seg)
+                packed.extend(np.zeros_like(buf[0]) for _ in range(T - n))
+                pos += n
+            buf[:] = packed
+
+    def episodic_train(self, sess):
+        """reference :354-370 without the recurrent training state (no PFPN setting has one)."""
+        assert self.on_policy
+        self._pack_segments()
+        for _ in range(self.opt_epochs):
+            self.train(sess)
+
     def before_work(self, sess):
+        self.sequence_length = [] if self.episodic_training else None
+        self.sequence_terminal = []
         self.evaluator_counter = 0
         self.sample_counter = 0
         self.setup_buffers()
@@ -149,12 +199,19 @@ class AbstractDistributedWorker(object):
         return state_, reward, terminal, info
 
     def need_train(self, sess, terminal, last_state, info):
+        if self.episodic_training:         # train once `batch_size` segments are in (reference :293-297)
+            if terminal or self.episodic_terminal:
+                return len(self.sequence_length) + 1 >= self.batch_size
+            return False
         if self.unroll_length is None:
             return terminal
         return self.sample_counter >= self.unroll_length
 
     @property
     def episodic_terminal(self):
+        """the open segment has reached `unroll_length` rows (reference :302-308)."""
+        if self.sequence_length is not None and self.unroll_length is not None:
+            return self._open_rows() >= self.unroll_length
         return False
 
     def after_train(self, sess):

@@ -1,3 +1,5 @@
 from .ppo import *
 from .ddpg import *
 from .sac import *
+from .a2c import *
+from .vtrace import *

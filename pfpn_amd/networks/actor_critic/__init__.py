@@ -1,3 +1,4 @@
 from .a2c import *
 from .ppo import *
 from .sac import *
+from .vtrace import *

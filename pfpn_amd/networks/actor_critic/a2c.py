@@ -139,8 +139,26 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             self.local_update_variables = ["state_normalizer/mean", "state_normalizer/std"] + self.local_update_variables
 
     def _alloc_policy_buffers(self, B):
-        AN = self.n_actions * self.particles
-        self.logits = torch.empty(B, AN, dtype=torch.float32, device=self.device)
+        dev, AN = self.device, self.n_actions * self.particles
+        self.logits = torch.empty(B, AN, dtype=torch.float32, device=dev)
+        if not self.trainable:
+            return
+        hc = self.critic_net_shape[-1]
+        self.train_out = {
+            "logp": torch.empty(B, dtype=torch.float32, device=dev),
+            "dlogits": torch.empty(B, AN, dtype=torch.float32, device=dev),
+            "dloc": self.store.g("actor/samples"),
+            "dlogstd": self.store.g("actor/samples_std"),
+            "dvalue": torch.empty(B, dtype=torch.float32, device=dev),
+            "loss3": torch.empty(3, dtype=torch.float32, device=dev),
+        }
+        self.adv_stats = torch.empty(2, dtype=torch.float32, device=dev)
+        if self.trunk is not None:
+            self.dh = torch.empty(2, B, hc, dtype=torch.float32, device=dev)
+        else:
+            self.dh_a = torch.empty(1, B, self.actor_net_shape[-1], dtype=torch.float32, device=dev)
+            self.dh_c = torch.empty(1, B, hc, dtype=torch.float32, device=dev)
+        self.entropy_buf = None
 
     def stat_slots(self):
         slots = super().stat_slots()
@@ -172,6 +190,105 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
     def _value(self, hc):
         return kernels.value_head_fwd(hc, self.store["critic/fc3/weight"].view(-1), self.store["critic/fc3/bias"],
                                       out=self.value_buf)
+
+    # -- learner step pieces shared by the PPO / A2C / V-trace heads -----------------------------------
+    def _entropy_term(self, policy, dlogits, B, mask=None, n_valid=None):
+        """policy_loss -= beta * mean_valid(sum_a H)  (actor_critic.py:172-176, a2c.py:62-65): adds the
+        entropy gradient into dlogits; keeps the per-row entropies for the loss report."""
+        if mask is None:
+            if self.entropy_buf is None or self.entropy_buf.shape[0] != B:
+                self.entropy_buf = torch.full((B, self.n_actions), -float(self.entropy_beta) / B,
+                                              dtype=torch.float32, device=self.device)
+            dH = self.entropy_buf
+        else:
+            dH = ((-float(self.entropy_beta)) * mask / n_valid).view(B, 1).expand(B, self.n_actions).contiguous()
+        self.last_entropy = policy.entropy()
+        self.last_entropy_mask = mask
+        policy.entropy_backward(dH, dlogits)
+
+    def _entropy_value(self):
+        H = self.last_entropy.sum(1)
+        if self.last_entropy_mask is None:
+            return float(H.mean().item())
+        m = self.last_entropy_mask
+        return float(((H * m).sum() / m.sum()).item())
+
+    def _backward_heads(self, ha, hc, dlogits, dvalue, fused_db):
+        """fc_policy and critic-head backward, then the trunks; gradients land in the flat gradient buffer."""
+        st = self.store
+        w3 = st["critic/fc3/weight"].view(-1)
+        dh_a, dh_c = (self.dh[0], self.dh[1]) if self.trunk is not None else (self.dh_a[0], self.dh_c[0])
+        # critic-head backward and the fc_policy bias gradient (column sums of dlogits) are short
+        # latency-bound launches (optionally beside the two fc_policy GEMMs: PFPN_OVERLAP_AUX)
+        with self.aux():
+            kernels.value_head_bwd(hc, w3, dvalue, dh_c, st.g("critic/fc3/weight").view(-1),
+                                   st.g("critic/fc3/bias"), relu6=True)
+            if not fused_db:
+                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+        dws = self.dw_stream if self.overlap_dw else None
+        torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+        torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
+        self.aux_join()
+        if self.trunk is not None:
+            self.trunk.backward(self.dh, dw_stream=dws)
+        else:
+            self.actor_trunk.backward(self.dh_a)
+            self.critic_trunk.backward(self.dh_c)
+        self._dw_pending = dws is not None
+
+    def _pg_gradients(self, state, action, targets):
+        """Policy-gradient (A2C) loss: forward, `targets(logp, value) -> (value_target, advantage, mask)`,
+        loss head, backward.  Returns loss4 (device): {loss, policy_loss, value_loss*coef, n_valid}."""
+        B = state.shape[0]
+        self._ensure_buffers(B)
+        x = self._normalize(state)
+        self.update_state_normalizer(state)
+        ha, hc = self._trunks_forward(x)
+        v = self._value(hc)
+        policy = MixtureGaussianDistribution(self._policy_logits(ha), self.loc, self.logstd,
+                                             self.normalize_policy_output_)
+        logp = policy.log_prob(action)
+        value_target, advantage, mask = targets(logp, v)
+        if mask is not None and self.normalize_advantage:
+            raise NotImplementedError("normalize_advantage over a valid_data_mask is not built "
+                                      "(no shipped V-trace setting uses it)")
+        kernels.adv_stats(advantage, self.normalize_advantage, out=self.adv_stats)
+        dlogp, dvalue, loss4 = kernels.a2c_loss(logp, advantage, v, value_target, self.adv_stats,
+                                                self.value_loss_coef, mask)
+        dlogits, dloc, dlogstd = policy.log_prob_backward(action, dlogp)
+        dlogits = dlogits.view(B, -1)
+        self.store.g("actor/samples").copy_(dloc)
+        self.store.g("actor/samples_std").copy_(dlogstd)
+        if self.entropy_beta:
+            self._entropy_term(policy, dlogits, B, mask, loss4[3] if mask is not None else None)
+        if self.fixed_sigma:
+            self.store.g("actor/samples_std").zero_()
+        self._backward_heads(ha, hc, dlogits, dvalue, fused_db=False)
+        self.last_targets = (value_target, advantage, mask, logp, v)
+        return loss4
+
+    def _report(self, loss4, ops):
+        loss4 = loss4.cpu().numpy()
+        ent = None
+        if self.entropy_beta:
+            ent = self._entropy_value()
+            loss4 = loss4.copy()
+            loss4[1] -= self.entropy_beta * ent
+            loss4[0] -= self.entropy_beta * ent
+        loss = (float(loss4[0]), ent, float(loss4[1]), float(loss4[2]))
+        extra = []
+        for o in (ops if hasattr(ops, "__len__") else ([ops] if ops else [])):
+            extra.append(self.global_step if o in ("global_step", "step") else (o() if callable(o) else None))
+        return loss, extra
+
+    def train(self, sess, optimizer, ops, state, action, value_target, advantage):
+        """reference a2c.py:80-88 (A2C / A3C): policy-gradient loss on host-computed targets.
+        Returns ((loss, entropy-or-None, policy_loss, value_loss), extra_fetches)."""
+        st, ac, vt, adv = [self._to_dev(a) for a in (state, action, value_target, advantage)]
+        loss4 = self._pg_gradients(st.view(-1, self.S), ac.view(-1, self.n_actions),
+                                   lambda logp, v: (vt.view(-1), adv.view(-1), None))
+        optimizer.apply(self)
+        return self._report(loss4, ops)
 
     def denormalize_action(self, a):
         """reference a2c.py:246-261 scales only when `self.normalize_policy_output` is set, and the

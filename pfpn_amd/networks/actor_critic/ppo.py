@@ -27,27 +27,6 @@ def clip_ppo_network_wrapper(a2c_base_class):
             self.running_log_prob = "pi_running"
             self.running_value = "value_running"
 
-        def _alloc_policy_buffers(self, B):
-            super()._alloc_policy_buffers(B)
-            dev, AN = self.device, self.n_actions * self.particles
-            hc = self.critic_net_shape[-1]
-            G = 2 if self.trunk is not None else 1
-            self.train_out = {
-                "logp": torch.empty(B, dtype=torch.float32, device=dev),
-                "dlogits": torch.empty(B, AN, dtype=torch.float32, device=dev),
-                "dloc": self.store.g("actor/samples"),
-                "dlogstd": self.store.g("actor/samples_std"),
-                "dvalue": torch.empty(B, dtype=torch.float32, device=dev),
-                "loss3": torch.empty(3, dtype=torch.float32, device=dev),
-            }
-            self.adv_stats = torch.empty(2, dtype=torch.float32, device=dev)
-            if self.trunk is not None:
-                self.dh = torch.empty(2, B, hc, dtype=torch.float32, device=dev)
-            else:
-                self.dh_a = torch.empty(1, B, self.actor_net_shape[-1], dtype=torch.float32, device=dev)
-                self.dh_c = torch.empty(1, B, hc, dtype=torch.float32, device=dev)
-            self.entropy_buf = None
-
         # -- rollout ---------------------------------------------------------------------------
         def run(self, sess, state, ops=None):
             """reference ppo.py:56-62: [action, action_log_prob, value] for one state (row 0)."""
@@ -87,33 +66,10 @@ def clip_ppo_network_wrapper(a2c_base_class):
                                               dbias=st.g("actor/fc_policy/bias") if fused_db else None)
             dlogits = out["dlogits"]
             if self.entropy_beta:
-                # policy_loss -= beta * mean_b sum_a H  (actor_critic.py:172-176, a2c.py:62-65)
-                if self.entropy_buf is None or self.entropy_buf.shape[0] != B:
-                    self.entropy_buf = torch.full((B, self.n_actions), -float(self.entropy_beta) / B,
-                                                  dtype=torch.float32, device=self.device)
-                self.last_entropy = policy.entropy()
-                policy.entropy_backward(self.entropy_buf, dlogits)
+                self._entropy_term(policy, dlogits, B)
             if self.fixed_sigma:
                 out["dlogstd"].zero_()
-            w3 = st["critic/fc3/weight"].view(-1)
-            dh_a, dh_c = (self.dh[0], self.dh[1]) if self.trunk is not None else (self.dh_a[0], self.dh_c[0])
-            # critic-head backward and the fc_policy bias gradient (column sums of dlogits) are short
-            # latency-bound launches: beside the two fc_policy GEMMs
-            with self.aux():
-                kernels.value_head_bwd(hc, w3, out["dvalue"], dh_c, st.g("critic/fc3/weight").view(-1),
-                                       st.g("critic/fc3/bias"), relu6=True)
-                if not fused_db:
-                    kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
-            dws = self.dw_stream if self.overlap_dw else None
-            torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
-            torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
-            self.aux_join()
-            if self.trunk is not None:
-                self.trunk.backward(self.dh, dw_stream=dws)
-            else:
-                self.actor_trunk.backward(self.dh_a)
-                self.critic_trunk.backward(self.dh_c)
-            self._dw_pending = dws is not None
+            self._backward_heads(ha, hc, dlogits, out["dvalue"], fused_db)
             return out["loss3"]
 
         def train_device(self, optimizer, state, action, value, log_prob, advantage):
@@ -128,18 +84,8 @@ def clip_ppo_network_wrapper(a2c_base_class):
             args = [self._to_dev(a) for a in (state, action, value, log_prob, advantage)]
             args[0] = args[0].view(-1, self.S)
             args[1] = args[1].view(-1, self.n_actions)
-            loss3 = self.train_device(optimizer, *args).cpu().numpy()
-            ent = None
-            if self.entropy_beta:
-                ent = float(self.last_entropy.sum(1).mean().item())
-                loss3 = loss3.copy()
-                loss3[1] -= self.entropy_beta * ent
-                loss3[0] -= self.entropy_beta * ent
-            loss = (float(loss3[0]), ent, float(loss3[1]), float(loss3[2]))
-            extra = []
-            for o in (ops if hasattr(ops, "__len__") else ([ops] if ops else [])):
-                extra.append(self.global_step if o in ("global_step", "step") else (o() if callable(o) else None))
-            return loss, extra
+            loss3 = self.train_device(optimizer, *args)
+            return self._report(loss3, ops)
 
     return ClipPPONetwork
 

@@ -164,3 +164,72 @@ def test_out_of_scope_options_raise():
         ParticleFilteringClipPPONetwork(resample=3, **base)
     with pytest.raises(NotImplementedError):
         ParticleFilteringClipPPONetwork(**dict(base, common_net_shape=[16]))
+
+
+# --- A2C / V-trace workers: segment bookkeeping -------------------------------------------------
+class StubA2CNet(StubNet):
+    def run(self, sess, state, ops=None):
+        a = self.rng.uniform(-1.5, 1.5, 36).astype(np.float32)
+        return [a, float(np.sum(state[:3]))]                      # a2c.py:67-73: [action, value]
+
+
+class StubVTraceNet(StubNet):
+    def run(self, sess, state, ops=None):
+        a = self.rng.uniform(-1.5, 1.5, 36).astype(np.float32)
+        return [a, float(self.rng.normal())]                      # vtrace.py:184-192: [action, log_prob]
+
+
+def test_a2c_worker_targets(oracle):
+    from pfpn_amd.models import SyncA2CWorker
+    net = StubA2CNet(oracle)
+    w = make_worker(SyncA2CWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=0.5, opt_epochs=1, batch_size=32,
+                    unroll_length=32)
+    w.work(None, max_iterations=3)
+    assert len(net.trained) == 3
+    state, action, value_target, adv = net.trained[0]
+    assert state.shape == (32, 197) and action.shape == (32, 36) and value_target.shape == (32,) and adv.shape == (32,)
+    # value_target = value + advantage (a2c.py:42-49); value = sum(state[:3]) by the stub; rows are shuffled together
+    np.testing.assert_allclose(value_target - adv, state[:, :3].sum(1), rtol=1e-5, atol=1e-5)
+
+
+def test_vtrace_worker_segments(oracle):
+    from pfpn_amd.models import SyncVTraceWorker, IMPALAWorker
+    assert IMPALAWorker is SyncVTraceWorker
+    net = StubVTraceNet(oracle)
+    # episodes are 50 steps, unroll 64 > 50: every segment ends at an episode end and is zero-padded to 64
+    w = make_worker(SyncVTraceWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=0.5, opt_epochs=1, batch_size=4,
+                    unroll_length=64)
+    w.work(None, max_iterations=2)
+    assert len(net.trained) == 2
+    state, action, reward, log_prob, not_terminal, seq_len = net.trained[0]
+    assert list(seq_len) == [50, 50, 50, 50]
+    assert state.shape == (4 * 64, 197) and log_prob.shape == (256,) and not_terminal.shape == (256,)
+    s = state.reshape(4, 64, 197)
+    assert np.all(s[:, 50:] == 0) and np.all(np.abs(s[:, :50]).sum(-1) > 0)          # padding behind every segment
+    # the synthetic env ends by time limit: not terminal for the bootstrap (vtrace.py:48-51)
+    assert np.all(not_terminal.reshape(4, 64)[:, :50] == 1.0)
+    # shorter unroll: segments of exactly `unroll_length` rows, cut mid-episode
+    net2 = StubVTraceNet(oracle)
+    w2 = make_worker(SyncVTraceWorker, net2, lr_critic=1e-4, lr_actor=1e-4, norm_clip=0.5, opt_epochs=1, batch_size=3,
+                     unroll_length=20)
+    w2.work(None, max_iterations=1)
+    st2, _, _, _, _, sl2 = net2.trained[0]
+    assert list(sl2) == [20, 20, 10] and st2.shape == (60, 197)      # 20 + 20 + the 10 rows left of the 50-step episode
+    assert np.all(st2.reshape(3, 20, 197)[2, 10:] == 0)
+
+
+def test_variable_length_packing(oracle):
+    from pfpn_amd.models import SyncVTraceWorker
+    net = StubVTraceNet(oracle)
+    w = make_worker(SyncVTraceWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=0.5, opt_epochs=1, batch_size=2,
+                    unroll_length=None)
+    w.before_work(None)
+    for n in (3, 5):
+        for i in range(n):
+            for k in w.exp:
+                w.exp[k].append(np.full(2, 10 * n + i, np.float32) if k == "state" else np.float32(10 * n + i))
+        w._close_segment(True)
+    w._pack_segments()
+    assert w.sequence_length == [3, 5]
+    st = np.asarray(w.exp["state"])
+    assert st.shape == (10, 2) and list(st[:, 0]) == [30, 31, 32, 0, 0, 50, 51, 52, 53, 54]
