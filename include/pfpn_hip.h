@@ -133,6 +133,12 @@ int pfpn_resample(float* loc, float* logstd, float* bias, float* weight, int H,
                   const float* u_noise, int A, int N, float threshold, int tanh_mode,
                   int32_t* dead_out, int32_t* src_out, void* stream);
 
+/* ---- host utility ------------------------------------------------------------------------- */
+/* CRC-32C (Castagnoli) of a HOST buffer, chained through `crc` (0 for the first call): the per-tensor and
+ * per-block checksum of TensorFlow's tensor_bundle checkpoint files, which the reference writes through
+ * tf.train.Saver (models/distributed_model.py:436-496).  Used by pfpn_amd/checkpoint.py. */
+uint32_t pfpn_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* ---- learner utilities (K6, K8, K9, dense epilogues) ------------------------------------- */
 size_t pfpn_learner_workspace_bytes(int rows, int H);
 

@@ -20,6 +20,7 @@ _CT = {
     "const uint8_t*": ctypes.c_void_p, "uint8_t*": ctypes.c_void_p,
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
     "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,
+    "uint32_t": ctypes.c_uint32,
     "void": None,
 }
 
@@ -30,7 +31,7 @@ def parse_header(path=HEADER_PATH):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     protos = {}
-    for m in re.finditer(r"\b(int|size_t|void)\s+(pfpn_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int|size_t|void|uint32_t)\s+(pfpn_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes, argnames = [], []
         if args and args != "void":

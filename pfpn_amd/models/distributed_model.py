@@ -326,7 +326,42 @@ class DistributedModel(object):
         worker.init()
         return worker
 
+    # -- checkpoints: TensorFlow tensor_bundle files under the reference's names (pfpn_amd/checkpoint.py),
+    #    so runs can be resumed / evaluated across the two code bases (reference :436-496, :608-619) -------
+    def restore(self, worker):
+        from .. import checkpoint
+        prefix = checkpoint.latest_checkpoint(self.checkpoint_dir) if self.checkpoint_dir else None
+        if prefix is None or not os.path.exists(prefix + ".data-00000-of-00001"):
+            return None
+        checkpoint.restore(prefix, worker.global_net, getattr(worker, "opt_op", None)
+                           if hasattr(getattr(worker, "opt_op", None), "groups") else None)
+        worker.global_step = worker.global_net.global_step
+        print("[RESTORE] {} (global step {})".format(prefix, worker.global_step))
+        return prefix
+
+    def save(self, worker):
+        from .. import checkpoint
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        prefix = os.path.join(self.checkpoint_dir, "model.ckpt-%d" % worker.global_net.global_step)
+        opt = getattr(worker, "opt_op", None)
+        checkpoint.save(prefix, worker.global_net, opt if hasattr(opt, "groups") else None,
+                        total_samples=worker.total_samples)
+        return prefix
+
     def start(self, distributions=None):
         worker = self.build_worker(evaluator=distributions is None)
+        self.restore(worker)
+        if self.checkpoint_dir and worker.is_chief and not worker.is_evaluator and self.save_checkpoint_interval:
+            every, state = int(self.save_checkpoint_interval), {"last": worker.global_step}
+            after = worker.after_train
+
+            def after_train_and_save(sess):
+                after(sess)
+                if worker.global_step - state["last"] >= every:
+                    state["last"] = worker.global_step
+                    self.save(worker)
+            worker.after_train = after_train_and_save
         worker.work(None, max_iterations=self.max_iterations)
+        if self.checkpoint_dir and worker.is_chief and not worker.is_evaluator and worker.global_step > 0:
+            self.save(worker)
         return worker

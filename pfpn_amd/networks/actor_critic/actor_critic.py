@@ -168,16 +168,18 @@ class ActorCriticNetwork(object):
         raise NotImplementedError
 
     # reference-named parameter access (checkpoint / tests) ---------------------------------------
-    def variables(self):
-        """{reference variable name: tensor view} for the trainables of the saved graph."""
+    def variables(self, views=None):
+        """{reference variable name: tensor view} for the trainables of the saved graph.
+        `views`: named views of another flat buffer of the same layout (`store.views_of(store.m)`: Adam slots)."""
+        src = self.store if views is None else views
         out = {}
         for t in (self.trunk, self.actor_trunk, self.critic_trunk):
             if t is not None:
                 for ref, (name, sel) in t.reference_names().items():
-                    out[ref] = sel(self.store[name])
+                    out[ref] = sel(src[name])
         for n in self.store.names():
             if "|" not in n:
-                out[n] = self.store[n]
+                out[n] = src[n]
         return out
 
     def gradients(self):
@@ -191,8 +193,8 @@ class ActorCriticNetwork(object):
                 out[n] = self.store.g(n)
         return out
 
-    def load_variables(self, values):
-        v = self.variables()
+    def load_variables(self, values, views=None):
+        v = self.variables(views)
         with torch.no_grad():
             for k, arr in values.items():
                 v[k].copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(self.device).view(v[k].shape))

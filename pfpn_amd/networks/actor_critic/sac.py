@@ -76,18 +76,19 @@ def sac_network_wrapper(base_class):
         def actor_param_names(self):
             return [n for n in self.store.names() if "critic" not in n]
 
-        def variables(self):
+        def variables(self, views=None):
+            src = self.store if views is None else views
             out = {}
             for ref, (name, sel) in self.q_stack.reference_names().items():
-                out[ref] = sel(self.store[name])
+                out[ref] = sel(src[name])
             for g, q in enumerate(("q1", "q2")):
-                out["critic/%s/fc3/weight" % q] = self.q_w3[g]
-                out["critic/%s/fc3/bias" % q] = self.q_b3[g, :1]
+                out["critic/%s/fc3/weight" % q] = src["critic/q1+critic/q2|fc3/weight"][g]
+                out["critic/%s/fc3/bias" % q] = src["critic/q1+critic/q2|fc3/bias"][g, :1]
             for ref, (name, sel) in self.actor_trunk.reference_names().items():
-                out[ref] = sel(self.store[name])
+                out[ref] = sel(src[name])
             for n in ("actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias",
                       "alpha/log_alpha"):
-                out[n] = self.store[n]
+                out[n] = src[n]
             return out
 
         def gradients(self):

@@ -65,6 +65,17 @@ class ParamStore:
     def __getitem__(self, name):
         return self._views[name]
 
+    def views_of(self, flat):
+        """named views of ANOTHER flat buffer with this store's layout (Adam m / v, a target network)."""
+        class _Views(dict):
+            def g(self, name):
+                return self[name]
+        out = _Views()
+        for name, shape, off in self.specs:
+            n = int(math.prod(shape)) if len(shape) else 1
+            out[name] = flat[off:off + n].view(shape)
+        return out
+
     def g(self, name):
         return self._gviews[name]
 
