@@ -6,15 +6,16 @@
 // plus the clipped-PPO loss head (reference networks/actor_critic/ppo.py:31-54,
 // actor_critic.py:151-156).
 //
-// Two data paths:
-//  * "packed" (N <= 64, templated on N; the shipped N=35 / default N=50): a 256-thread block
-//    stages R whole batch rows (R*A*N contiguous floats, float4-coalesced) in LDS, one THREAD owns
-//    one (row, action-dim) segment and walks its N particles out of LDS with everything in
-//    registers; the particle bank {loc, 1/scale, 0.5log2pi+log scale} is LDS-resident as float4
-//    (conflict-free b128 reads at stride 35).  Because a block owns complete rows, the row-level
-//    log-prob, the PPO ratio/clip and the backward run in ONE pass: logits are read from HBM
-//    once and dlogits written once (2L traffic instead of 3L).
-//  * "wave" (any N): one 64-lane wavefront owns one segment, lanes stride the particles; a
+// Three data paths (chosen by shape in the C entry points at the end of this file):
+//  * "packed" (4 <= A, N <= 64, A*N % 4 == 0; templated on N: the shipped N=35, the default N=50, 16, 8):
+//    a loader/consumer ring -- LDS-DMA loader waves stream 4-row tiles into LDS planes, compute waves
+//    own 16-segment slices (4 lanes per segment) and run forward, row stage, loss head and backward
+//    out of LDS and registers.  Because a block owns complete rows, the row-level log-prob, the PPO
+//    ratio/clip and the backward run in ONE pass: logits are read from HBM once and dlogits written
+//    once (2L traffic instead of 3L).  See the block comment above k_mix_packed.
+//  * "wide" (N >= 64, N % 4 == 0: the 128 x 256 stress shape): one wavefront per segment, float4 per
+//    lane straight from HBM, 4 rows reduced together by a transposing DPP butterfly.
+//  * "wave" (any shape): one 64-lane wavefront owns one segment, lanes stride the particles; a
 //    wave keeps a fixed action dim so dloc/dlogstd accumulate in registers.
 // Reductions over the batch (dloc, dlogstd, loss sums) go through per-block partial slabs and
 // a fixed-order finalize kernel: results are bitwise reproducible (no float atomics).
@@ -40,7 +41,7 @@ struct PpoArgs {
 };
 
 constexpr int PACK_G = 4;                            // lanes per (row, action-dim) segment
-constexpr int PACK_BLOCK = 1024;                     // launch bound; actual block = waves*64
+constexpr int PACK_BLOCK = 1024;                     // generic launch bound; actual block = (compute + loader waves)*64
 constexpr int PACK_WSEG = 64 / PACK_G;               // 16 segments per wave
 constexpr size_t PACK_MAX_LDS = 150 * 1024;         // dynamic LDS the packed kernel may ask for (160 KB per CU)
 
