@@ -338,6 +338,17 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             kernels.active_stats(self.logits, self.max_active, self.sum_active)
         return float(self._value(hc)[0].item())
 
+    def evaluate_batch(self, states):
+        """V(states [n,S]) as a device tensor: the bootstrap values of all rollout segments that end in one
+        batched critic call (the per-state `evaluate` above, batched; same statistics side effect)."""
+        st = self._to_dev(np.asarray(states, dtype=np.float32)).view(-1, self.S)
+        if st.shape[0] == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.device)
+        _, _, hc = self._forward(st)
+        if self.trainable and self.max_active is not None:
+            kernels.active_stats(self.logits, self.max_active, self.sum_active)
+        return self._value(hc).clone()
+
     # -- resample ----------------------------------------------------------------------------------
     def resample_tick(self):
         """train op run after every optimiser apply (a2c.py:367-383)."""

@@ -1,0 +1,91 @@
+"""CPU: the host environment pool (processes + shared memory) and the batched PPO rollout bookkeeping."""
+import numpy as np
+import torch
+
+from pfpn_amd.env_pool import BatchedPPORollout, EnvPool
+from pfpn_amd.envs import SyntheticDeepMimicEnv
+
+
+def make_fns(E, length=23):
+    return [(lambda i=i: SyntheticDeepMimicEnv(episode_length=length, seed=100 + i)) for i in range(E)]
+
+
+def test_pool_matches_sequential_envs():
+    E, steps = 5, 60
+    pool = EnvPool(make_fns(E), processes=2)
+    try:
+        ref = [fn() for fn in make_fns(E)]
+        s_ref = np.stack([e.reset() for e in ref])
+        s = pool.reset()
+        assert np.array_equal(s, s_ref)
+        rng = np.random.default_rng(0)
+        for _ in range(steps):
+            a = rng.uniform(-1.5, 1.5, (E, 36)).astype(np.float32)
+            s, r, d, tr, last = pool.step(a)
+            for i, e in enumerate(ref):
+                si, ri, di, info = e.step(np.clip(a[i], -1, 1))          # the env sees the clipped action
+                assert np.array_equal(last[i], si) and r[i] == np.float32(ri) and d[i] == di
+                assert tr[i] == bool(info.get("TimeLimit.truncated", False))
+                if di:
+                    si = e.reset()                                       # auto-reset: next state of the new episode
+                assert np.array_equal(s[i], si)
+        assert d.sum() >= 0
+    finally:
+        pool.close()
+
+
+class StubNet(object):
+    """value = sum of the first three state entries; gae through the oracle (checker)."""
+    device = torch.device("cpu")
+
+    def __init__(self, oracle):
+        self.oracle = oracle
+        self.rng = np.random.default_rng(1)
+        self.calls = 0
+
+    def run_batch(self, states):
+        st = torch.as_tensor(np.asarray(states, np.float32))
+        self.calls += 1
+        a = torch.from_numpy(self.rng.uniform(-1.5, 1.5, (st.shape[0], 36)).astype(np.float32))
+        return a, torch.full((st.shape[0],), -40.0), st[:, :3].sum(1)
+
+    def evaluate_batch(self, states):
+        return torch.as_tensor(np.asarray(states, np.float32)).view(-1, 197)[:, :3].sum(1)
+
+    def gae_batch(self, reward, value, offsets):
+        r, v, off = reward.numpy(), value.numpy(), offsets.numpy()
+        out = [self.oracle.gae(r[off[e]:off[e + 1]], v[off[e] + e:off[e + 1] + e + 1], 0.95, 0.95 * 0.95)
+               for e in range(len(off) - 1)]
+        return torch.from_numpy(np.concatenate(out).astype(np.float32))
+
+
+def test_batched_rollout_buffers(oracle):
+    E, T = 4, 40                                  # episodes of 23 steps: every env crosses one time limit
+    pool = EnvPool(make_fns(E), processes=2)
+    try:
+        net = StubNet(oracle)
+        ro = BatchedPPORollout(net, pool, T)
+        buf = ro.collect()
+        assert net.calls == T                     # ONE policy call per step for all environments
+        n = E * T
+        assert buf["state"].shape == (n, 197) and buf["action"].shape == (n, 36) and buf["advantage"].shape == (n,)
+        assert ro.total_samples == n
+        assert buf["action"].abs().max() > 1.0    # the unclipped action is stored
+        # value buffer is V(state) of the stored state, environment-major segments
+        np.testing.assert_allclose(buf["value"].numpy(), buf["state"].numpy()[:, :3].sum(1), rtol=1e-6)
+        # replay env 0 by hand: segments [0,23) (time limit -> bootstrap V(last)), [23,40) (unroll boundary)
+        st0 = buf["state"].numpy()[:T]
+        v0 = st0[:, :3].sum(1)
+        e0 = make_fns(1)[0]()
+        s = e0.reset()
+        rewards, lasts = [], []
+        for t in range(T):
+            assert np.array_equal(st0[t], s)
+            s2, r, d, info = e0.step(np.clip(buf["action"].numpy()[t], -1, 1))
+            rewards.append(r); lasts.append(s2)
+            s = e0.reset() if d else s2
+        adv_a = oracle.gae(np.array(rewards[:23], np.float32), np.append(v0[:23], lasts[22][:3].sum()), 0.95, 0.95 ** 2)
+        adv_b = oracle.gae(np.array(rewards[23:], np.float32), np.append(v0[23:], s[:3].sum()), 0.95, 0.95 ** 2)
+        np.testing.assert_allclose(buf["advantage"].numpy()[:T], np.concatenate([adv_a, adv_b]), rtol=1e-5, atol=1e-6)
+    finally:
+        pool.close()

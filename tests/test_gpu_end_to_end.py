@@ -45,3 +45,29 @@ def test_sac_launcher_end_to_end(dev):
     d = (ev["critic/q1/fc1/weight"] - tg["critic/q1/fc1/weight"]).abs().max().item()
     assert 0 < d < 1e-2
     assert all(np.isfinite(v.detach().cpu().numpy()).all() for v in ev.values())
+
+
+def test_batched_rollout_feeds_learner(dev):
+    """E environments in host processes, one batched policy call per step, PPO buffers, one step."""
+    import numpy as np
+    import torch
+    from pfpn_amd.env_pool import BatchedPPORollout, EnvPool
+    from pfpn_amd.envs import SyntheticDeepMimicEnv
+    from pfpn_amd.models import SyncReplicasApplier
+    from test_gpu_dppo_step import make_net
+    net = make_net(dev, seed=3)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    pool = EnvPool([(lambda i=i: SyntheticDeepMimicEnv(episode_length=50, seed=i)) for i in range(8)], processes=2)
+    try:
+        ro = BatchedPPORollout(net, pool, unroll_length=64)
+        buf = ro.collect()
+        assert buf["state"].shape == (512, 197) and torch.isfinite(buf["advantage"]).all()
+        # log_prob stored at sampling time == log-prob of that action under the (unchanged) policy
+        policy, _, _ = net._forward(buf["state"])
+        lp = policy.log_prob(buf["action"])
+        assert torch.allclose(lp, buf["log_prob"], rtol=1e-4, atol=1e-3)
+        assert net.sum_active.sum().item() > 0                      # rollout updated the activation statistics
+        loss, _ = net.train(None, opt, [], buf["state"], buf["action"], buf["value"], buf["log_prob"], buf["advantage"])
+        assert np.isfinite(loss[0]) and net.global_step == 1
+    finally:
+        pool.close()
