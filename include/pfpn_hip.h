@@ -148,6 +148,15 @@ size_t pfpn_learner_workspace_bytes(int rows, int H);
 int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, int E, float gamma,
              double gae_gamma, float* adv, void* stream);
 
+/* The learner step's prologue in one launch: x = clip((s-mean)/std) as pfpn_state_norm, plus (want_moments) the
+ * float64 column moments of s for pfpn_state_norm_ema, plus (adv_stats != NULL) pfpn_adv_stats' {mean, 1/(std+1e-8)}
+ * of the advantages.  pfpn_state_norm_ema turns the moments into the EMA update of pfpn_state_norm_update. */
+int pfpn_state_prologue(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
+                        int want_moments, const float* adv, int normalize_adv, float* adv_stats,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int pfpn_state_norm_ema(const void* workspace, int B, int S, const float* step, const float* mean_in,
+                        const float* std_in, float* mean_out, float* std_out, void* stream);
+
 /* V-trace targets -- reference networks/actor_critic/vtrace.py:101-180.  E episodes of T steps, all [E*T]
  * vectors flat in episode-major order (index e*T + t: vtrace.py:16-37); seq_len [E] (optional, int32) marks
  * zero-padded episodes.  fp32, the reverse tf.scan's operation order; rho_clip / pg_rho_clip <= 0 = None.
@@ -210,6 +219,15 @@ int pfpn_clip_by_global_norm(float* grads, size_t n, float clip_norm, int apply,
 int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n, float lr, float beta1,
                  float beta2, float eps, float* beta_pow, int advance_beta_pow, const float* norm_scale,
                  float grad_mul, float* step_counter, void* stream);
+/* One-replica optimiser step in two launches: tf.clip_by_global_norm over the whole gradient buffer folded into
+ * TF ApplyAdam for up to 4 parameter groups (contiguous, 4-aligned ranges with their own learning rate: the critic /
+ * actor optimisers of base_worker.py:33-45).  beta_pow is [n_groups][4] = {b1^t, b2^t as TF's beta*_power variables
+ * hold them, and the pair this apply used}; group_* are HOST arrays.  Also writes norm_scale = {norm, scale} and
+ * bumps step_counter (device scalar, optional).  Same arithmetic as pfpn_clip_by_global_norm + pfpn_tf_adam. */
+int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                   const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                   float beta2, float eps, float* beta_pow, float clip_norm, float* norm_scale, float* step_counter,
+                   void* workspace, size_t workspace_bytes, void* stream);
 /* SAC loss head -- sac.py:123-139 (vf_target, q_target) and :160-173 (Q and policy losses).
  * q_pi, q_run, q_tgt are [2,B] (Q1 row then Q2 row): Q(s, a_pi), Q(s, action_hist), Q'(s', a').
  * Outputs dq_pi [2,B] (d policy_loss/dQ through tf.minimum), dq_run [2,B] (d value_loss/dQ),

@@ -216,6 +216,70 @@ __global__ __launch_bounds__(256) void k_col_moments(const float* __restrict__ s
     }
 }
 
+// Step prologue in ONE launch (the learner's first four launches were latency-bound ~5 us each):
+//   blocks (x, ch < C): x = clip((s - mean)/std) for a 16-row chunk of 64 columns (k_state_norm's arithmetic) AND
+//                       that chunk's float64 column moments (k_col_moments' arithmetic and layout);
+//   block  (0, C)     : advantage moments {mean, 1/(std + 1e-8)} (k_adv_stats' arithmetic, 256 threads), optional.
+__global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict__ s, const float* __restrict__ mean,
+                                                        const float* __restrict__ std, int B, int S, int chunk_len,
+                                                        int C, float clip, float* __restrict__ x,
+                                                        double* __restrict__ partial, const float* __restrict__ adv,
+                                                        int normalize_adv, float* __restrict__ adv_stats) {
+    __shared__ double red[2][4][64];
+    if ((int)blockIdx.y == C) {                            // the advantage block
+        if (blockIdx.x != 0 || !adv_stats) return;
+        float* fred = reinterpret_cast<float*>(&red[0][0][0]);
+        if (!normalize_adv) {
+            if (threadIdx.x == 0) { adv_stats[0] = 0.f; adv_stats[1] = 1.f; }
+            return;
+        }
+        float sm = 0.f;
+        for (int i = threadIdx.x; i < B; i += blockDim.x) sm += adv[i];
+        const float mu = block_sum(sm, fred) / (float)B;
+        float vv = 0.f;
+        for (int i = threadIdx.x; i < B; i += blockDim.x) { const float d = adv[i] - mu; vv = fmaf(d, d, vv); }
+        const float var = block_sum(vv, fred) / (float)B;
+        if (threadIdx.x == 0) { adv_stats[0] = mu; adv_stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
+        return;
+    }
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int ch = blockIdx.y;
+    const int b0 = ch * chunk_len, b1 = min(B, b0 + chunk_len);
+    double a1 = 0.0, a2 = 0.0;
+    if (c < S) {
+        const float mc = mean[c], sc = std[c];
+        for (int b = b0 + rl; b < b1; b += 16) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                v[j] = r < b1 ? s[(size_t)r * S + c] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                const double d = (double)v[j];
+                a1 += d; a2 += d * d;                                  // zero rows beyond the chunk add nothing
+                if (r < b1) {
+                    float xn = (v[j] - mc) / sc;                       // actor_critic.py:229-232
+                    if (clip > 0.f) xn = fmaxf(fminf(xn, clip), -clip);
+                    x[(size_t)r * S + c] = xn;
+                }
+            }
+        }
+    }
+    if (!partial) return;
+    red[0][rl][cl] = a1; red[1][rl][cl] = a2;
+    __syncthreads();
+    if (rl == 0 && c < S) {
+        double s1 = red[0][0][cl], s2 = red[1][0][cl];
+        for (int k = 1; k < 4; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+        partial[((size_t)ch * 2 + 0) * S + c] = s1;
+        partial[((size_t)ch * 2 + 1) * S + c] = s2;
+    }
+}
+
 // Chunk moments -> batch mean / variance -> EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step)).
 // 1024-thread block = 64 columns x 16 chunk lanes (fixed order: deterministic).
 __global__ __launch_bounds__(1024) void k_norm_ema(const double* __restrict__ partial, int C, int B, int S,
@@ -513,6 +577,82 @@ __global__ __launch_bounds__(256) void k_tf_adam(float* __restrict__ p, const fl
     }
 }
 
+// ---- one-replica optimiser step in TWO launches (clip folded into Adam) ---------------------------------------
+// beta_pow[g] = {b1^t, b2^t for the NEXT apply ("next": the value of TF's beta*_power variables), and the pair the
+// CURRENT apply uses ("used")}.  Launch 1 (k_sqsum_partial_rot) rotates used <- next, next <- next*beta in block 0
+// -- nobody else touches the powers in that launch -- so launch 2 can read `used` from every block without racing
+// the advance (one kernel doing both would).
+struct AdamGroups {
+    int n;                       // <= 4
+    long long off[4], len[4];    // ranges of the flat buffers (floats, 4-aligned)
+    float lr[4];
+};
+
+__global__ __launch_bounds__(256) void k_sqsum_partial_rot(const float* __restrict__ g, size_t n,
+                                                           float* __restrict__ partial, float* __restrict__ beta_pow,
+                                                           int n_groups, float b1, float b2) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = s;
+        if (blockIdx.x == 0)
+            for (int k = 0; k < n_groups; ++k) {
+                float* bp = beta_pow + 4 * k;
+                bp[2] = bp[0]; bp[3] = bp[1];
+                bp[0] *= b1; bp[1] *= b2;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, AdamGroups gr,
+                                                   float b1, float b2, float eps, const float* __restrict__ beta_pow,
+                                                   const float* __restrict__ partial, int nblk, float clip_norm,
+                                                   float* __restrict__ norm_scale, float* __restrict__ step) {
+    __shared__ float red[4];
+    // every block forms the same scale from the same partial sums, in k_clip_scale's order
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) sq += partial[i];
+    sq = block_sum(sq, red);
+    const float norm = sqrtf(2.f * (0.5f * sq));
+    float gs = 1.0f;
+    if (clip_norm > 0.f) {
+        gs = clip_norm * fminf(1.0f / norm, 1.0f / clip_norm);
+        if (!isfinite(norm)) gs = NAN;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        norm_scale[0] = norm; norm_scale[1] = gs;
+        if (step) step[0] += 1.0f;          // float(global_step) of the state-normaliser decay; no reader in this launch
+    }
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (int k = 0; k < gr.n; ++k) {
+        const float alpha = gr.lr[k] * sqrtf(1.f - beta_pow[4 * k + 3]) / (1.f - beta_pow[4 * k + 2]);
+        const size_t o4 = (size_t)gr.off[k] >> 2, n4 = (size_t)gr.len[k] >> 2;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            float4 pp = reinterpret_cast<float4*>(p)[o4 + i];
+            float4 gg = reinterpret_cast<const float4*>(g)[o4 + i];
+            float4 mm = reinterpret_cast<float4*>(m)[o4 + i];
+            float4 vv = reinterpret_cast<float4*>(v)[o4 + i];
+            gg.x *= gs; gg.y *= gs; gg.z *= gs; gg.w *= gs;
+            adam1(pp.x, gg.x, mm.x, vv.x, alpha, omb1, omb2, eps);
+            adam1(pp.y, gg.y, mm.y, vv.y, alpha, omb1, omb2, eps);
+            adam1(pp.z, gg.z, mm.z, vv.z, alpha, omb1, omb2, eps);
+            adam1(pp.w, gg.w, mm.w, vv.w, alpha, omb1, omb2, eps);
+            reinterpret_cast<float4*>(p)[o4 + i] = pp;
+            reinterpret_cast<float4*>(m)[o4 + i] = mm;
+            reinterpret_cast<float4*>(v)[o4 + i] = vv;
+        }
+    }
+}
+
 // beta powers advance after the applies (Adam/mul, Adam/mul_1 in the saved graph)
 __global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2, float* __restrict__ step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -681,6 +821,34 @@ int pfpn_state_norm_update(const float* s, int B, int S, const float* step, cons
     return PFPN_OK;
 }
 
+int pfpn_state_prologue(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
+                        int want_moments, const float* adv, int normalize_adv, float* adv_stats,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
+    if (!s || !mean || !std || !x || B < 1 || S < 1 || (adv_stats && !adv)) return PFPN_ERR_ARG;
+    if (want_moments && (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, S))) return PFPN_ERR_WORKSPACE;
+    int C = row_chunks(B);
+    if (C > 256) C = 256;
+    const int len = (B + C - 1) / C;
+    hipLaunchKernelGGL(k_state_prologue, dim3((S + 63) / 64, C + 1), dim3(256), 0, (hipStream_t)stream, s, mean, std, B,
+                       S, len, C, clip, x, want_moments ? (double*)workspace : (double*)nullptr, adv, normalize_adv,
+                       adv_stats);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_state_norm_ema(const void* workspace, int B, int S, const float* step, const float* mean_in,
+                        const float* std_in, float* mean_out, float* std_out, void* stream) {
+    PFPN_BEGIN();
+    if (!workspace || !step || !mean_in || !std_in || !mean_out || !std_out || B < 1 || S < 1) return PFPN_ERR_ARG;
+    int C = row_chunks(B);
+    if (C > 256) C = 256;
+    hipLaunchKernelGGL(k_norm_ema, dim3((S + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const double*)workspace, C,
+                       B, S, step, mean_in, std_in, mean_out, std_out);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
 int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, int relu6, void* stream) {
     PFPN_BEGIN();
     if (!y || !bias || rows < 0 || H < 4 || (H & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15))
@@ -776,6 +944,40 @@ int pfpn_tf_adam(float* params, const float* grads, float* m, float* v, size_t n
         hipLaunchKernelGGL(k_beta_pow_step, dim3(1), dim3(64), 0, st, beta_pow, beta1, beta2, step_counter);
         PFPN_CHECK_LAUNCH();
     }
+    return PFPN_OK;
+}
+
+int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                   const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                   float beta2, float eps, float* beta_pow, float clip_norm, float* norm_scale, float* step_counter,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
+    if (!params || !grads || !m || !v || !beta_pow || !norm_scale || !group_off || !group_len || !group_lr ||
+        n < 1 || n_groups < 1 || n_groups > 4)
+        return PFPN_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < 256 * sizeof(float)) return PFPN_ERR_WORKSPACE;
+    AdamGroups gr{};
+    gr.n = n_groups;
+    size_t longest = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (group_off[k] < 0 || group_len[k] < 0 || (group_off[k] & 3) || (group_len[k] & 3) ||
+            (size_t)(group_off[k] + group_len[k]) > n)
+            return PFPN_ERR_ARG;
+        gr.off[k] = group_off[k]; gr.len[k] = group_len[k]; gr.lr[k] = group_lr[k];
+        if ((size_t)group_len[k] > longest) longest = (size_t)group_len[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = stream_grid(n >> 2);
+    if (nblk > 256) nblk = 256;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(k_sqsum_partial_rot, dim3(nblk), dim3(256), 0, st, grads, n, partial, beta_pow, n_groups, beta1,
+                       beta2);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, st, params, grads, m, v, gr, beta1,
+                       beta2, eps, (const float*)beta_pow, (const float*)partial, nblk, clip_norm, norm_scale,
+                       step_counter);
+    PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
 

@@ -4,6 +4,8 @@ PyTorch is plumbing here: device memory + the current HIP stream.  Every functio
 shapes/dtypes on the host before launching (a faulting kernel can take the whole node down) and
 launches on torch's current stream, so calls can be captured in a torch.cuda.CUDAGraph.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -357,6 +359,27 @@ def state_norm_update(s, step, mean, std, mean_out=None, std_out=None):
     return mean_out, std_out
 
 
+def state_prologue(s, mean, std, clip, out_x, want_moments=True, adv=None, normalize_adv=False, adv_stats=None):
+    """x = clip((s-mean)/std) + float64 column moments of s (for state_norm_ema) + advantage moments, one launch."""
+    lib = _lib.load()
+    B, S = s.shape
+    ws, wsn = _learn_ws(B, S, s.device)
+    _lib.check(lib.pfpn_state_prologue(_f32(s, B, S), _f32(mean, S), _f32(std, S), B, S, float(clip or 0.0),
+                                       _f32(out_x, B, S), int(want_moments),
+                                       _f32(adv, B) if adv_stats is not None else None, int(normalize_adv),
+                                       _f32(adv_stats, 2) if adv_stats is not None else None, ws, wsn, _stream()),
+               "pfpn_state_prologue")
+    return out_x
+
+
+def state_norm_ema(B, S, step, mean, std, mean_out, std_out):
+    """EMA update from the moments state_prologue left in the learner workspace of this stream (call it next)."""
+    lib = _lib.load()
+    ws, _ = _learn_ws(B, S, mean.device)
+    _lib.check(lib.pfpn_state_norm_ema(ws, B, S, _f32(step, 1), _f32(mean, S), _f32(std, S), _f32(mean_out, S),
+                                       _f32(std_out, S), _stream()), "pfpn_state_norm_ema")
+
+
 def bias_act(y, bias, relu6=True, group_rows=0):
     lib = _lib.load()
     rows, H = y.shape
@@ -412,6 +435,21 @@ def tf_adam(params, grads, m, v, beta_pow, lr, beta1=0.9, beta2=0.999, eps=1e-8,
                                 _f32(norm_scale, 2) if norm_scale is not None else None, float(grad_mul),
                                 _f32(step_counter, 1) if step_counter is not None else None, _stream()),
                "pfpn_tf_adam")
+
+
+def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, clip_norm, norm_scale, beta1=0.9,
+              beta2=0.999, eps=1e-8, step_counter=None):
+    """One-replica optimiser step in two launches (global-norm clip folded into TF-Adam).  group_* are ctypes
+    arrays (host); beta_pow is [G,4] (see include/pfpn_hip.h)."""
+    lib = _lib.load()
+    n = params.numel()
+    G = len(group_lr)
+    ws, wsn = _learn_ws(1, 1, params.device)
+    _lib.check(lib.pfpn_clip_adam(_f32(params), _f32(grads), _f32(m), _f32(v), n, G, ctypes.addressof(group_off),
+                                  ctypes.addressof(group_len), ctypes.addressof(group_lr), float(beta1), float(beta2),
+                                  float(eps), _f32(beta_pow, G, 4), float(clip_norm), _f32(norm_scale, 2),
+                                  _f32(step_counter, 1) if step_counter is not None else None, ws, wsn, _stream()),
+               "pfpn_clip_adam")
 
 
 def soft_update(target, source, tau):

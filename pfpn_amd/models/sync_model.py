@@ -12,6 +12,8 @@ single `torch.distributed.all_reduce` (backend "nccl" == RCCL) and divided by W 
 (`grad_mul`); every rank then applies the identical TF-Adam update and resample tick, so replicas stay
 bit-identical and no pull step is needed.  There is no parameter server and no gRPC.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -40,16 +42,23 @@ class SyncReplicasApplier(object):
         self.world = int(world_size)
         net.dp_world = self.world
         self.norm_scale = torch.zeros(2, dtype=torch.float32, device=st.device)
+        # beta powers of all groups in one [G,4] tensor: {b1^t, b2^t as TF's beta*_power hold them | the pair the
+        # last fused apply used}; a group's "beta_pow" is the view of the first pair
+        self.beta_pow = torch.tensor([[beta1, beta2, beta1, beta2]] * len(groups), dtype=torch.float32,
+                                     device=st.device)
         self.groups = []
-        for g in groups:
+        for gi, g in enumerate(groups):
             if g.get("names") is None:
                 off, ln = 0, st.size
             else:
                 off, ln = st.span(g["names"])
-            self.groups.append({
-                "off": off, "len": ln, "lr": float(g["lr"]),
-                "beta_pow": torch.tensor([beta1, beta2], dtype=torch.float32, device=st.device),
-            })
+            self.groups.append({"off": off, "len": ln, "lr": float(g["lr"]), "beta_pow": self.beta_pow[gi, :2]})
+        import ctypes
+        G = len(self.groups)
+        self._g_off = (ctypes.c_longlong * G)(*[g["off"] for g in self.groups])
+        self._g_len = (ctypes.c_longlong * G)(*[g["len"] for g in self.groups])
+        self._g_lr = (ctypes.c_float * G)(*[g["lr"] for g in self.groups])
+        self.fused = os.environ.get("PFPN_FUSED_OPT", "1") != "0"
 
     # -- device part (no host sync; capturable when world == 1) -------------------------------------
     def apply_device(self, net):
@@ -57,6 +66,13 @@ class SyncReplicasApplier(object):
         W = self.world
         fused_scale = None
         net.join_side_stream()
+        if W == 1 and self.norm_clip and self.fused and len(self.groups) <= 4:
+            # one replica: clip + every group's Adam + power / step-counter advance in two launches
+            kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
+                              self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
+                              step_counter=net.step_dev)
+            net.unpack_synced_stats(st.tail, 1.0)
+            return
         if self.norm_clip:
             # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica
             kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=(W > 1))

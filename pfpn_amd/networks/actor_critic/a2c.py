@@ -241,8 +241,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         loss head, backward.  Returns loss4 (device): {loss, policy_loss, value_loss*coef, n_valid}."""
         B = state.shape[0]
         self._ensure_buffers(B)
-        x = self._normalize(state)
-        self.update_state_normalizer(state)
+        x = self.prologue(state)
         ha, hc = self._trunks_forward(x)
         v = self._value(hc)
         policy = MixtureGaussianDistribution(self._policy_logits(ha), self.loc, self.logstd,

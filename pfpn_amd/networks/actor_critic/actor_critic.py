@@ -14,6 +14,7 @@ import os
 import numpy as np
 import torch
 
+from ... import kernels
 from .. import ops
 from ..ops import DenseStack, ParamStore
 from ..utils import OnlineNormalizer
@@ -257,6 +258,29 @@ class ActorCriticNetwork(object):
             return
         for t, off, n, in_tail in self.stat_slots():
             torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
+
+    def prologue(self, state, advantage=None):
+        """First launches of a learner step: x = normalised state, the state-normaliser EMA on this minibatch
+        (UPDATE_OPS, reference sync_model.py:123-138) and -- when `advantage` is given -- its normalisation
+        moments into self.adv_stats.  With the normaliser on this is two launches (fused prologue + EMA
+        finalisation) instead of four or more."""
+        fusable = self.state_normalizer is not None and self.normalize_state and self.trainable and \
+            not self.overlap_ema and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+        if not fusable:
+            x = self._normalize(state)
+            self.update_state_normalizer(state)
+            if advantage is not None:
+                kernels.adv_stats(advantage, self.normalize_advantage, out=self.adv_stats)
+            return x
+        nz, tail, S = self.state_normalizer, self.store.tail, self.S
+        B = state.shape[0]
+        kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
+                               self.normalize_advantage, self.adv_stats if advantage is not None else None)
+        if self.dp_world == 1:          # in place: visible to the NEXT step's forward (x above used the old moments)
+            kernels.state_norm_ema(B, S, self.step_dev, nz.mean, nz.std, nz.mean, nz.std)
+        else:                           # into the bucket tail that the all-reduce averages
+            kernels.state_norm_ema(B, S, self.step_dev, nz.mean, nz.std, tail[:S], tail[S:2 * S])
+        return self.xn
 
     def update_state_normalizer(self, state):
         """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), on a side

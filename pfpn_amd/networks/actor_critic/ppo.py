@@ -47,10 +47,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
             B = state.shape[0]
             st = self.store
             self._ensure_buffers(B)
-            x = self._normalize(state)
-            self.update_state_normalizer(state)        # side stream, joined in the optimiser
-            with self.aux():                           # independent of the forward pass
-                kernels.adv_stats(advantage, self.normalize_advantage, out=self.adv_stats)
+            x = self.prologue(state, advantage)         # normalised state, state-norm EMA, advantage moments
             ha, hc = self._trunks_forward(x)
             with self.aux():                           # critic head beside the policy-head GEMM
                 v = self._value(hc)

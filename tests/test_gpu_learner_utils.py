@@ -160,3 +160,63 @@ def test_ppo_loss_unfused(oracle, dev):
     np.testing.assert_allclose(l3.cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=5e-6)
     np.testing.assert_allclose(g_lp.cpu().numpy(), dlogp, rtol=2e-5, atol=1e-9)
     np.testing.assert_allclose(g_v.cpu().numpy(), dv, rtol=1e-5, atol=1e-10)
+
+
+def test_fused_prologue_matches_separate_launches(dev):
+    """pfpn_state_prologue + pfpn_state_norm_ema == pfpn_state_norm + pfpn_state_norm_update + pfpn_adv_stats."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(5)
+    for B, S in ((4096, 197), (33, 7), (1, 197)):
+        s = torch.from_numpy((rng.normal(0, 1, (B, S)) * 3 + 0.5).astype(np.float32)).to(dev)
+        mean = torch.from_numpy(rng.normal(0, 0.3, S).astype(np.float32)).to(dev)
+        std = torch.from_numpy(rng.uniform(0.5, 2, S).astype(np.float32)).to(dev)
+        adv = torch.from_numpy(rng.normal(0.2, 1.5, B).astype(np.float32)).to(dev)
+        step = torch.tensor([3.0], device=dev)
+        x_ref = kernels.state_norm(s, mean, std, 5.0)
+        m_ref, sd_ref = kernels.state_norm_update(s, step, mean, std)
+        st_ref = kernels.adv_stats(adv, normalize=B > 1)
+        x = torch.empty_like(s)
+        st = torch.empty(2, device=dev)
+        kernels.state_prologue(s, mean, std, 5.0, x, True, adv, B > 1, st)
+        m, sd = torch.empty_like(mean), torch.empty_like(std)
+        kernels.state_norm_ema(B, S, step, mean, std, m, sd)
+        assert torch.equal(x, x_ref)                                   # same arithmetic
+        assert torch.equal(m, m_ref) and torch.equal(sd, sd_ref)       # same float64 moments, same order
+        np.testing.assert_allclose(st.cpu().numpy(), st_ref.cpu().numpy(), rtol=2e-6)   # 256- vs 1024-thread sums
+        # without the optional parts
+        x2 = torch.empty_like(s)
+        kernels.state_prologue(s, mean, std, 0.0, x2, False)
+        assert torch.equal(x2, kernels.state_norm(s, mean, std, 0.0))
+
+
+def test_clip_adam_matches_clip_then_adam(dev):
+    """pfpn_clip_adam (2 launches) == pfpn_clip_by_global_norm + pfpn_tf_adam per group + power advance, bit for bit."""
+    import ctypes
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(6)
+    n = 40000
+    cuts = [(0, 12000, 1e-4), (12000, 28000, 3e-4)]
+    base = [torch.from_numpy(rng.normal(0, s, n).astype(np.float32)).to(dev) for s in (1.0, 0.05, 0.01)]
+    vabs = torch.from_numpy(np.abs(rng.normal(0, 0.01, n)).astype(np.float32)).to(dev)
+    for clip in (1.0, 1e6):
+        p1, g, m1 = [t.clone() for t in base]
+        v1 = vabs.clone()
+        p2, m2, v2 = p1.clone(), m1.clone(), v1.clone()
+        bp1 = [torch.tensor([0.9 ** 3, 0.999 ** 3], device=dev) for _ in cuts]
+        bp2 = torch.tensor([[0.9 ** 3, 0.999 ** 3, 0, 0]] * len(cuts), device=dev)
+        step1, step2 = torch.tensor([7.0], device=dev), torch.tensor([7.0], device=dev)
+        ns1, ns2 = torch.zeros(2, device=dev), torch.zeros(2, device=dev)
+        kernels.clip_by_global_norm(g, clip, ns1, apply=False)
+        for gi, (off, ln, lr) in enumerate(cuts):
+            sl = slice(off, off + ln)
+            kernels.tf_adam(p1[sl], g[sl], m1[sl], v1[sl], bp1[gi], lr, advance=True, norm_scale=ns1,
+                            step_counter=step1 if gi == len(cuts) - 1 else None)
+        G = len(cuts)
+        kernels.clip_adam(p2, g, m2, v2, (ctypes.c_longlong * G)(*[c[0] for c in cuts]),
+                          (ctypes.c_longlong * G)(*[c[1] for c in cuts]), (ctypes.c_float * G)(*[c[2] for c in cuts]),
+                          bp2, clip, ns2, step_counter=step2)
+        assert torch.equal(ns1, ns2) and torch.equal(step1, step2)
+        assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+        for gi in range(G):
+            assert torch.equal(bp2[gi, :2], bp1[gi])                   # TF's beta*_power after the step
+            assert torch.allclose(bp2[gi, 2:], torch.tensor([0.9 ** 3, 0.999 ** 3], device=dev))
