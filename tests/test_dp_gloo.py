@@ -101,6 +101,10 @@ def _rank_main(rank, world, port, q):
         mx = np.maximum(shards[0]["max_active"], shards[1]["max_active"]).reshape(-1)
         ok &= not np.allclose(net.max_active.numpy(), mx)
         q.put((rank, bool(ok), float(net.store.bucket.sum())))
+    except Exception as e:                 # report instead of leaving the parent waiting for its timeout
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False, repr(e)))
     finally:
         dist.destroy_process_group()
 
@@ -113,7 +117,7 @@ def test_bucket_allreduce_world2_gloo():
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(60)
     assert all(r[1] for r in res), res
