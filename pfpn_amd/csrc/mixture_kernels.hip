@@ -26,6 +26,8 @@ namespace pfpn {
 
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_PPO = 2 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));     // packed-fp32 operand (v_pk_*_f32)
+
 struct PpoArgs {
     const float* logp_old;   // [B]
     const float* adv;        // [B]
@@ -768,65 +770,78 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     // e*phi = exp2(l*log2e - max*log2e - z'^2 + ct64) * 2^-64 in ONE v_exp_f32: the +64 keeps every
     // product that matters far above the flush-to-zero threshold of the raw instruction.
     bool ok[M];
-    float4 b_loc[M], b_isc[M], b_ct[M];
+    v2f b_loc2[M][2], b_isc2[M][2], b_ct2[M][2];            // float2 halves (xy | zw) of each lane's float4
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int qi = lane + 64 * j;
         ok[j] = FULLN || qi < nq;                            // FULLN: N == 256*M, every lane owns particles
         const int o = a * N + 4 * (ok[j] ? qi : 0);
         const float4 lo = ld4(loc + o), ls = ld4(logstd + o);
-        b_loc[j] = lo;
-        float sc;
-#define PFPN_BANK(c_)                                                                       \
-    sc = expf(ls.c_);                                                                       \
-    b_isc[j].c_ = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;                                        \
-    b_ct[j].c_ = 64.f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
-        PFPN_BANK(x) PFPN_BANK(y) PFPN_BANK(z) PFPN_BANK(w)
-#undef PFPN_BANK
-    }
-    float4 acc_loc[M], acc_ls[M];
+        const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, ls_[4] = {ls.x, ls.y, ls.z, ls.w};
 #pragma unroll
-    for (int j = 0; j < M; ++j) { acc_loc[j] = make_float4(0.f, 0.f, 0.f, 0.f); acc_ls[j] = acc_loc[j]; }
+        for (int k = 0; k < 4; ++k) {
+            const float sc = expf(ls_[k]);
+            b_loc2[j][k >> 1][k & 1] = lo_[k];
+            b_isc2[j][k >> 1][k & 1] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
+            b_ct2[j][k >> 1][k & 1] = 64.f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        }
+    }
+    v2f acc_loc2[M][2], acc_ls2[M][2];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+        for (int h = 0; h < 2; ++h) { acc_loc2[j][h] = (v2f){0.f, 0.f}; acc_ls2[j][h] = (v2f){0.f, 0.f}; }
     const float two_m64 = 5.421010862427522e-20f;           // 2^-64
 
     // One group of U rows.  FULL = every row of the group exists: the body is then BRANCH-FREE straight-line
     // code (stores unconditional), so hipcc's waitcnt pass can count the stores younger than the prefetch
     // loads and emit s_waitcnt vmcnt(k) instead of vmcnt(0) -- otherwise every iteration would also wait for
     // its own stores to be acknowledged (~1 us exposed per iteration; CDNA4 vmcnt counts stores).
+    // The per-particle arithmetic runs on float2 halves of each float4 (v_pk_mul/add/fma_f32: two fp32 results per
+    // issue slot) -- at 128 x 256 this kernel is VALU-issue bound, not HBM bound: 17 VALU slots per particle
+    // before, ~10 now, 8 of them the two quarter-rate v_exp_f32.  The row maximum is taken on l*log2(e) (a product:
+    // no canonicalisation instructions in front of v_max3_f32, unlike on raw loads).
     auto group = [&](int b0, const float4 (&l)[U][M], const float (&xv)[U], const float (&gv)[U], auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
+        v2f lp[U][M][2];                                      // l * log2(e)
         float mx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             mx[u] = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < M; ++j)
-                if (ok[j]) mx[u] = fmaxf(mx[u], fmaxf(fmaxf(l[u][j].x, l[u][j].y), fmaxf(l[u][j].z, l[u][j].w)));
+            for (int j = 0; j < M; ++j) {
+                lp[u][j][0] = (v2f){l[u][j].x, l[u][j].y} * PFPN_LOG2E;
+                lp[u][j][1] = (v2f){l[u][j].z, l[u][j].w} * PFPN_LOG2E;
+                if (ok[j]) {                                  // two v_max3_f32 per float4
+                    mx[u] = fmaxf(fmaxf(lp[u][j][0].x, lp[u][j][0].y), mx[u]);
+                    mx[u] = fmaxf(fmaxf(lp[u][j][1].x, lp[u][j][1].y), mx[u]);
+                }
+            }
         }
         wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
-        float4 e[U][M], ef[U][M], zq[U][M];
+        v2f e[U][M][2], ef[U][M][2], zq[U][M][2];
         float sum[U], num[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const float mxl = mx[u] * PFPN_LOG2E;
-            sum[u] = 0.f; num[u] = 0.f;
+            v2f s2 = {0.f, 0.f}, n2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                e[u][j] = ef[u][j] = zq[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[j]) {
-#define PFPN_EL(c_)                                                                              \
-    {                                                                                            \
-        const float le = fmaf(l[u][j].c_, PFPN_LOG2E, -mxl);                                     \
-        zq[u][j].c_ = (xv[u] - b_loc[j].c_) * b_isc[j].c_;                                       \
-        e[u][j].c_ = __builtin_amdgcn_exp2f(le);                                                 \
-        ef[u][j].c_ = __builtin_amdgcn_exp2f(le + fmaf(-zq[u][j].c_, zq[u][j].c_, b_ct[j].c_));  \
-    }
-                    PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
-#undef PFPN_EL
-                    sum[u] += (e[u][j].x + e[u][j].y) + (e[u][j].z + e[u][j].w);
-                    num[u] += (ef[u][j].x + ef[u][j].y) + (ef[u][j].z + ef[u][j].w);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    e[u][j][h] = ef[u][j][h] = zq[u][j][h] = (v2f){0.f, 0.f};
+                    if (ok[j]) {
+                        const v2f le = lp[u][j][h] - mx[u];
+                        const v2f z = (xv[u] - b_loc2[j][h]) * b_isc2[j][h];
+                        const v2f arg = le + __builtin_elementwise_fma(-z, z, b_ct2[j][h]);
+                        zq[u][j][h] = z;
+                        e[u][j][h] = (v2f){__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
+                        ef[u][j][h] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                        s2 += e[u][j][h];
+                        n2 += ef[u][j][h];
+                    }
                 }
             }
+            sum[u] = s2.x + s2.y;
+            num[u] = n2.x + n2.y;
         }
         wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
         wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
@@ -840,11 +855,11 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             if (p < 1.401298464324817e-45f) p = 0.f;         // below the smallest fp32 denormal: the reference's p is 0
             dxa[u] = 0.f;
             if (MODE == MODE_FWD) {
-                float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;     // v_log_f32 is log2
-                if (TANH) lp -= tanh_log_det(xv[u]);
+                float lpr = __builtin_amdgcn_logf(p) * 0.6931471805599453f;     // v_log_f32 is log2
+                if (TANH) lpr -= tanh_log_det(xv[u]);
                 // every lane stores the same value to the same address (one transaction, no branch)
                 if (live) {
-                    lpseg_out[(size_t)b * A + a] = lp;
+                    lpseg_out[(size_t)b * A + a] = lpr;
                     if (pmix_out) pmix_out[(size_t)b * A + a] = p;
                 }
             } else {
@@ -853,24 +868,27 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 const float qp = qs * p;
                 const float qs64 = qs * two_m64;
                 float* drow = dlogits + (size_t)b * AN + (size_t)a * N;
+                v2f dx2 = {0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     if (ok[j]) {
-                        float4 d;
-#define PFPN_EL(c_)                                                                              \
-    {                                                                                            \
-        const float tt = qs64 * ef[u][j].c_;                                                     \
-        const float z_ = zq[u][j].c_;                                                            \
-        d.c_ = fmaf(-e[u][j].c_, qp, tt);                                                        \
-        acc_loc[j].c_ = fmaf(tt, z_, acc_loc[j].c_);                                             \
-        acc_ls[j].c_ = fmaf(tt, fmaf(z_ * z_, PFPN_2LN2, -1.f), acc_ls[j].c_);                   \
-        if (dx_out) dxa[u] = fmaf(tt * z_, b_isc[j].c_ * PFPN_2LN2, dxa[u]);                     \
-    }
-                        PFPN_EL(x) PFPN_EL(y) PFPN_EL(z) PFPN_EL(w)
-#undef PFPN_EL
-                        if (live) *reinterpret_cast<float4*>(drow + 4 * (lane + 64 * j)) = d;
+                        v2f d[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const v2f tt = ef[u][j][h] * qs64;
+                            const v2f z = zq[u][j][h];
+                            d[h] = __builtin_elementwise_fma(-e[u][j][h], (v2f){qp, qp}, tt);
+                            acc_loc2[j][h] = __builtin_elementwise_fma(tt, z, acc_loc2[j][h]);
+                            acc_ls2[j][h] = __builtin_elementwise_fma(
+                                tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}),
+                                acc_ls2[j][h]);
+                            if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, b_isc2[j][h] * PFPN_2LN2, dx2);
+                        }
+                        if (live)
+                            *reinterpret_cast<float4*>(drow + 4 * (lane + 64 * j)) = make_float4(d[0].x, d[0].y, d[1].x, d[1].y);
                     }
                 }
+                dxa[u] = dx2.x + dx2.y;
             }
         }
         if (MODE == MODE_BWD && dx_out) {
@@ -922,11 +940,10 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             if (ok[j]) {
-                float4 dl;
-                dl.x = acc_loc[j].x * (b_isc[j].x * PFPN_2LN2); dl.y = acc_loc[j].y * (b_isc[j].y * PFPN_2LN2);
-                dl.z = acc_loc[j].z * (b_isc[j].z * PFPN_2LN2); dl.w = acc_loc[j].w * (b_isc[j].w * PFPN_2LN2);
-                *reinterpret_cast<float4*>(slab + 4 * (lane + 64 * j)) = dl;
-                *reinterpret_cast<float4*>(slab + AN + 4 * (lane + 64 * j)) = acc_ls[j];
+                const v2f d0 = acc_loc2[j][0] * (b_isc2[j][0] * PFPN_2LN2), d1 = acc_loc2[j][1] * (b_isc2[j][1] * PFPN_2LN2);
+                *reinterpret_cast<float4*>(slab + 4 * (lane + 64 * j)) = make_float4(d0.x, d0.y, d1.x, d1.y);
+                *reinterpret_cast<float4*>(slab + AN + 4 * (lane + 64 * j)) =
+                    make_float4(acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
             }
         }
     }
@@ -1090,10 +1107,11 @@ static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
 static int wide_c_env() { static const int v = getenv("PFPN_WIDE_C") ? atoi(getenv("PFPN_WIDE_C")) : 0; return v; }
 // waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
 static int wide_chunks(int B, int A, bool bwd = false) {
-    // measured on the 8192 x 128 x 256 stress shape: ~16 waves/CU (fwd) and ~12 waves/CU (bwd, which also
-    // streams 1 KiB stores per segment) keep about 8 MB of requests in flight chip-wide -- more in
-    // flight only lengthens the HBM queues (tools/bw_probe.hip)
-    int C = ((bwd ? 256 * 12 : 256 * 16) + A - 1) / A;
+    // measured on the 8192 x 128 x 256 stress shape (sweeps of PFPN_WIDE_C, +-3 % run to run): ~20 waves/CU
+    // forward (C = 38..48: 199-207 us; 32: 209-213; 24: 245; 64: 232) and ~12 waves/CU backward, which also
+    // streams 1 KiB stores per segment (C = 22..24: 419-433 us; 32: 484; 48: 467).  More in flight only lengthens
+    // the HBM queues (tools/bw_probe.hip), and power-of-two row strides between a wave's rows alias HBM channels.
+    int C = ((bwd ? 256 * 12 : 256 * 20) + A - 1) / A;
     if (C > 64) C = 64;
     if (wide_c_env() > 0) C = wide_c_env();
     if (C > (B + 3) / 4) C = (B + 3) / 4;      // at least U = 4 rows per wave
