@@ -220,18 +220,6 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     for (int i = t; i < 2 * R + 2 * P + 1; i += blockDim.x) cnt[i] = 0;   // cnt, ready, freed, bank_done are contiguous
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave index as a scalar: uniform control flow
-    const int q = lane >> 2, g = lane & 3;
-    const int sidx = wave * PACK_WSEG + q;                // segment slot in the tile (compute waves)
-    const bool seg_lane = wave < nwaves && sidx < nseg;
-    const int r = seg_lane ? sidx / A : 0;
-    const int a = seg_lane ? sidx - r * A : 0;
-    float* slice0 = tile + wave * SLICE;
-    float* seg0 = slice0 + q * N + g;                     // == tile + sidx*N + g
-    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
-    // rows this wave touches
-    const int s_lo = wave * PACK_WSEG, s_hi = min(nseg, s_lo + PACK_WSEG) - 1;     // inclusive
-    const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
-
 #ifdef PFPN_ENABLE_STAMPS
     unsigned long long* stamps = g_stamps;
 #endif
@@ -254,7 +242,8 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         // tiles I keep in flight: two.  A compute pass over a tile takes about twice as long as the memory system
         // needs to deliver one, so more only queues requests in front of the tile that is needed next (the first
         // tile of a cold start lands ~1000 + 120 ticks per KB requested per CU); vmcnt immediate <= 63 caps it too.
-        const int dmax = Q > 0 ? max(1, min(PACK_DEPTH, 63 / Q + 1)) : 1;
+        int dmax = PACK_DEPTH;
+        while (dmax > 1 && (dmax - 1) * Q > 63) --dmax;
         const unsigned tile_b = (unsigned)(uintptr_t)tile, xpl_b = (unsigned)(uintptr_t)xpl,
                        rpl_b = (unsigned)(uintptr_t)rpl;
         int issued = 0, signalled = 0;
@@ -329,6 +318,19 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             }
         }
     }
+
+    // (index arithmetic of the compute waves: after the loader branch, so the loaders do not execute it)
+    const int q = lane >> 2, g = lane & 3;
+    const int sidx = wave * PACK_WSEG + q;                // segment slot in the tile (compute waves)
+    const bool seg_lane = wave < nwaves && sidx < nseg;
+    const int r = seg_lane ? sidx / A : 0;
+    const int a = seg_lane ? sidx - r * A : 0;
+    float* slice0 = tile + wave * SLICE;
+    float* seg0 = slice0 + q * N + g;                     // == tile + sidx*N + g
+    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
+    // rows this wave touches
+    const int s_lo = wave * PACK_WSEG, s_hi = min(nseg, s_lo + PACK_WSEG) - 1;     // inclusive
+    const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
 
     // =========================== compute waves ===============================================
     // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
