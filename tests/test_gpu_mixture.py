@@ -24,7 +24,9 @@ def to_dev(dev, *arrs):
 
 SHAPES = [(1, 36, 35), (5, 36, 35), (7, 36, 35), (8, 36, 35), (64, 36, 35), (257, 36, 35), (4096, 36, 35),
           (33, 6, 50), (19, 36, 16), (40, 3, 8), (9, 5, 35), (3, 1, 35),
-          (17, 36, 23), (6, 4, 100), (5, 3, 256), (4, 7, 64), (3, 2, 2)]
+          (17, 36, 23), (6, 4, 100), (5, 3, 256), (4, 7, 64), (3, 2, 2),
+          # more tiles per block than LDS planes (the loader ring wraps), ragged last tiles
+          (6001, 36, 35), (20003, 8, 16), (9001, 12, 8), (5000, 4, 50), (1030, 20, 35)]
 
 
 @pytest.mark.parametrize("B,A,N", SHAPES)
@@ -56,7 +58,8 @@ def test_logprob_bwd(oracle, dev, B, A, N, tanh_mode):
     o_dl, o_dloc, o_dls, o_dx = kernels.logprob_bwd(dl, dx, dloc, dls, dg, tanh_mode, want_dx=True)
     torch.cuda.synchronize()
     sc = np.abs(r_dl).max() + 1e-30
-    np.testing.assert_allclose(o_dl.cpu().numpy(), r_dl, rtol=1e-4, atol=1e-6 * sc)
+    # dlogit = q*w*(phi - p): a difference of two terms of the size of `sc`, each good to a few 1e-7 relative
+    np.testing.assert_allclose(o_dl.cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * sc)
     np.testing.assert_allclose(o_dx.cpu().numpy(), r_dx, rtol=1e-4, atol=1e-5 * (np.abs(r_dx).max() + 1e-30))
     # sums over B of fp32 terms: tolerance scales with the summed magnitude
     for got, ref in ((o_dloc, r_dloc), (o_dls, r_dls)):
@@ -89,7 +92,7 @@ def test_logprob_underflow_guard(oracle, dev):
     assert np.all(np.isfinite(o_dloc.cpu().numpy())) and np.all(np.isfinite(o_dls.cpu().numpy()))
 
 
-@pytest.mark.parametrize("B", [1, 7, 100, 4096])
+@pytest.mark.parametrize("B", [1, 7, 100, 4096, 6001])
 def test_ppo_fused(oracle, dev, B):
     """Fused fwd + PPO loss + bwd kernel == oracle log_prob -> ppo_loss -> log_prob_bwd."""
     from pfpn_amd import kernels
