@@ -73,7 +73,10 @@ constexpr size_t PACK_MAX_LDS = 150 * 1024;         // dynamic LDS the packed ke
 // * When a compute wave has read its dlogits slice back out of the plane it bumps the plane's `freed`
 //   counter; the loaders reuse a plane once all compute waves have.
 // ---------------------------------------------------------------------------------------
-constexpr int PACK_NL = 2;                           // loader waves per block
+#ifndef PACK_NLOAD
+#define PACK_NLOAD 2
+#endif
+constexpr int PACK_NL = PACK_NLOAD;                  // loader waves per block
 #ifndef PACK_DEPTH
 #define PACK_DEPTH 2                                 // tiles a loader keeps in flight
 #endif
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     PpoArgs ppo)
 {
     constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
+    constexpr int NPK = (NP - 1) / 2;                     // particle pairs that always exist (packed fp32 math)
     constexpr int SLICE = PACK_WSEG * N;                  // floats per wave slice (16 segments)
     constexpr int NV = (SLICE / 4 + 63) / 64;             // float4 per lane per slice (3 for N=35)
     extern __shared__ float4 smem4[];
@@ -408,18 +412,43 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             float inv_sum = 0.f, p = 0.f;
             if (active) {
                 const float xval = xpl[slot * XS + sidx];
-                float mx = seg[0];
+                // particles in pairs (2k, 2k+1): v_pk_mul/add/fma_f32 give two results per issue slot (this loop is
+                // VALU-issue bound on the SIMD that hosts three of the nine waves); the last one or two particles
+                // -- the only ones that may not exist -- stay scalar.  The maximum is taken on l*log2(e).
+                v2f lp2[NPK > 0 ? NPK : 1];
+                float lpt[NP - 2 * NPK];
+                float mx = -INFINITY;
 #pragma unroll
-                for (int i = 1; i < NP; ++i)
-                    if (i < NP - 1 || last_ok) mx = fmaxf(mx, seg[PACK_G * i]);
-                mx = quad_max(mx);
-                const float mxl = mx * PFPN_LOG2E;
-                float sum = 0.f, num = 0.f;
+                for (int k = 0; k < NPK; ++k) {
+                    lp2[k] = (v2f){seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]} * PFPN_LOG2E;
+                    mx = fmaxf(fmaxf(lp2[k].x, lp2[k].y), mx);
+                }
 #pragma unroll
-                for (int i = 0; i < NP; ++i) {
+                for (int i = 2 * NPK; i < NP; ++i) {
+                    lpt[i - 2 * NPK] = 0.f;
                     if (i < NP - 1 || last_ok) {
-                        // raw v_exp_f32 twice: softmax numerator, and numerator * Normal.prob * 2^64 in one go
-                        const float le = fmaf(seg[PACK_G * i], PFPN_LOG2E, -mxl);
+                        lpt[i - 2 * NPK] = seg[PACK_G * i] * PFPN_LOG2E;
+                        mx = fmaxf(mx, lpt[i - 2 * NPK]);
+                    }
+                }
+                mx = quad_max(mx);
+                v2f s2 = {0.f, 0.f}, n2 = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < NPK; ++k) {
+                    // raw v_exp_f32 twice per particle: softmax numerator, and numerator * Normal.prob * 2^64 in one go
+                    const v2f le = lp2[k] - mx;
+                    const v2f z = (xval - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * (v2f){b_isc[2 * k], b_isc[2 * k + 1]};
+                    const v2f arg = le + __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
+                    const v2f en = {__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
+                    if (MODE != MODE_FWD) { seg[PACK_G * 2 * k] = en.x; seg[PACK_G * (2 * k + 1)] = en.y; }
+                    s2 += en;
+                    n2 += (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                }
+                float sum = s2.x + s2.y, num = n2.x + n2.y;
+#pragma unroll
+                for (int i = 2 * NPK; i < NP; ++i) {
+                    if (i < NP - 1 || last_ok) {
+                        const float le = lpt[i - 2 * NPK] - mx;
                         const float zq = (xval - b_loc[i]) * b_isc[i];
                         const float en = __builtin_amdgcn_exp2f(le);
                         if (MODE != MODE_FWD) seg[PACK_G * i] = en;
@@ -552,22 +581,42 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                     const float qp = qs * p;
                     const float qs64 = qs * two_m64;
                     float dxa = 0.f;
+                    v2f dx2 = {0.f, 0.f};
+                    // e*phi is re-formed from the numerator kept in LDS (one v_exp) instead of being held in registers
+                    // across the next tile's forward and the row stage.  Pairs of particles, as in the forward.
 #pragma unroll
-                    for (int i = 0; i < NP; ++i) {
+                    for (int k = 0; k < NPK; ++k) {
+                        const v2f en = {seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]};
+                        const v2f isc = {b_isc[2 * k], b_isc[2 * k + 1]};
+                        const v2f z = (xv - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * isc;            // z / c
+                        const v2f g2 = __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
+                        const v2f tt = (en * (v2f){__builtin_amdgcn_exp2f(g2.x), __builtin_amdgcn_exp2f(g2.y)}) * qs64;   // q * w_n * phi_n
+                        const v2f dlg = __builtin_elementwise_fma(-en, (v2f){qp, qp}, tt);            // q * w_n * (phi_n - p)
+                        seg[PACK_G * 2 * k] = dlg.x; seg[PACK_G * (2 * k + 1)] = dlg.y;
+                        if (MODE == MODE_PPO) { acc_db[2 * k] += dlg.x; acc_db[2 * k + 1] += dlg.y; }   // fc_policy bias gradient
+                        const v2f al = __builtin_elementwise_fma(tt, z, (v2f){acc_loc[2 * k], acc_loc[2 * k + 1]});     // scaled by isc*c in the tail
+                        acc_loc[2 * k] = al.x; acc_loc[2 * k + 1] = al.y;
+                        const v2f as = __builtin_elementwise_fma(
+                            tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}),
+                            (v2f){acc_ls[2 * k], acc_ls[2 * k + 1]});                                 // tt*(z^2 - 1)
+                        acc_ls[2 * k] = as.x; acc_ls[2 * k + 1] = as.y;
+                        if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, isc * PFPN_2LN2, dx2);     // isc*c = isc2*2ln2
+                    }
+#pragma unroll
+                    for (int i = 2 * NPK; i < NP; ++i) {
                         if (i < NP - 1 || last_ok) {
-                            // e*phi is re-formed from the numerator kept in LDS (one v_exp) instead of being held
-                            // in registers across the next tile's forward and the row stage
                             const float en = seg[PACK_G * i];
-                            const float zq = (xv - b_loc[i]) * b_isc[i];            // z / c
-                            const float tt = qs64 * (en * __builtin_amdgcn_exp2f(fmaf(-zq, zq, b_ct[i])));   // q * w_n * phi_n
-                            const float dlg = fmaf(-en, qp, tt);                    // q * w_n * (phi_n - p)
+                            const float zq = (xv - b_loc[i]) * b_isc[i];
+                            const float tt = qs64 * (en * __builtin_amdgcn_exp2f(fmaf(-zq, zq, b_ct[i])));
+                            const float dlg = fmaf(-en, qp, tt);
                             seg[PACK_G * i] = dlg;
-                            if (MODE == MODE_PPO) acc_db[i] += dlg;                 // fc_policy bias gradient
-                            acc_loc[i] = fmaf(tt, zq, acc_loc[i]);                  // scaled by isc*c in the tail
-                            acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);   // tt*(z^2 - 1)
-                            if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);        // isc*c = isc2*2ln2
+                            if (MODE == MODE_PPO) acc_db[i] += dlg;
+                            acc_loc[i] = fmaf(tt, zq, acc_loc[i]);
+                            acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);
+                            if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);
                         }
                     }
+                    dxa += dx2.x + dx2.y;
                     if (dx_out) {
                         dxa = quad_sum(dxa);
                         if (g == 0) {
