@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_rsample_fwd(
 
 // backward of the custom gradients `mask`/`mask2` (utils.py:165-183) through softmax(logits+g)
 // and p = loc + scale*eps.  Per segment: dlogits row, and the (k, d p_k) pair for the parameter
-// scatter done by k_rsample_param_grad.
+// scatter done by k_rsample_param_partial / k_param_grad_final.
 __global__ __launch_bounds__(256) void k_rsample_bwd(
     const float* __restrict__ logits, const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ gumbel, const float* __restrict__ eps,
@@ -264,20 +264,165 @@ __global__ __launch_bounds__(256) void k_rsample_bwd(
     gs_tmp[s] = gp * sck * er[k];                           // d L / d logstd_k
 }
 
-// dloc[a,n] (+)= sum_b [k[b,a]==n] gp[b,a]; dlogstd likewise.  Thread <-> (a,n), rows in order.
-__global__ __launch_bounds__(256) void k_rsample_param_grad(
-    const int* __restrict__ k_tmp, const float* __restrict__ gp_tmp, const float* __restrict__ gs_tmp,
-    int B, int A, int N, int accumulate, float* __restrict__ dloc, float* __restrict__ dlogstd)
-{
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= A * N) return;
-    const int a = col / N, n = col - a * N;
-    float sl = 0.f, ss = 0.f;
-    for (int b = 0; b < B; ++b) {
-        if (k_tmp[b * A + a] == n) { sl += gp_tmp[b * A + a]; ss += gs_tmp[b * A + a]; }
+// ---------------------------------------------------------------------------------------
+// Quad forms of the two kernels above for N <= 64 (every shipped setting): 4 lanes per (row, action-dim)
+// segment -- lane g owns particles g, g+4, ... in registers -- so a wave covers 16 consecutive segments
+// (one contiguous 64*N-byte span of logits / gumbel / eps: coalesced, unlike one thread per 140-byte row),
+// every exp/tanh is evaluated once, and max / argmax / sums are two quad-permute DPP steps.
+// The argmax keeps the serial rule: the FIRST maximum wins (ties -> lowest particle index).
+// ---------------------------------------------------------------------------------------
+constexpr int RS_G = 4;
+constexpr int RS_NP = 16;                               // particles per lane, N <= 64
+
+__device__ __forceinline__ void quad_argmax(float& v, int& i) {
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        const float ov = __shfl_xor(v, m, 64);
+        const int oi = __shfl_xor(i, m, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
     }
-    dloc[col] = accumulate ? dloc[col] + sl : sl;
-    dlogstd[col] = accumulate ? dlogstd[col] + ss : ss;
+}
+
+__global__ __launch_bounds__(256) void k_rsample_fwd_quad(
+    const float* __restrict__ logits, const float* __restrict__ loc, const float* __restrict__ logstd,
+    const float* __restrict__ gumbel, const float* __restrict__ eps, int B, int A, int N,
+    int* __restrict__ k_out, float* __restrict__ a_out, float* __restrict__ s_out)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = B * A;
+    const int s = min(tid >> 2, S - 1), g = tid & 3;       // clamped: whole quads stay alive for the shuffles
+    const bool live = (tid >> 2) < S;
+    const int a = s % A;
+    const float* row = logits + (size_t)s * N;
+    const float* gr = gumbel + (size_t)s * N;
+    float mx = -INFINITY;
+    int k = 0x7fffffff;
+    for (int n = g; n < N; n += RS_G) {
+        const float y = row[n] + gr[n];
+        if (y > mx) { mx = y; k = n; }
+    }
+    quad_argmax(mx, k);
+    if (live && g == 0) {
+        const float pk = loc[a * N + k] + expf(logstd[a * N + k]) * eps[(size_t)s * N + k];
+        k_out[s] = k;
+        s_out[s] = pk;
+        a_out[s] = tanhf(pk);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rsample_bwd_quad(
+    const float* __restrict__ logits, const float* __restrict__ loc, const float* __restrict__ logstd,
+    const float* __restrict__ gumbel, const float* __restrict__ eps,
+    const float* __restrict__ da, const float* __restrict__ ds, int B, int A, int N, int accumulate,
+    float* __restrict__ dlogits, int* __restrict__ k_tmp, float* __restrict__ gp_tmp,
+    float* __restrict__ gs_tmp)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = B * A;
+    const int s = min(tid >> 2, S - 1), g = tid & 3;
+    const bool live = (tid >> 2) < S;
+    const int a = s % A;
+    const float* row = logits + (size_t)s * N;
+    const float* gr = gumbel + (size_t)s * N;
+    const float* er = eps + (size_t)s * N;
+    const float* locr = loc + a * N;
+    const float* lsr = logstd + a * N;
+    float y[RS_NP], th[RS_NP];
+    float mx = -INFINITY;
+    int k = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < RS_NP; ++i) {
+        const int n = g + RS_G * i;
+        y[i] = -INFINITY; th[i] = 0.f;
+        if (n < N) {
+            y[i] = row[n] + gr[n];
+            th[i] = tanhf(locr[n] + expf(lsr[n]) * er[n]);       // tanh of every particle's candidate sample
+            if (y[i] > mx) { mx = y[i]; k = n; }
+        }
+    }
+    quad_argmax(mx, k);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < RS_NP; ++i) {
+        y[i] = (g + RS_G * i < N) ? expf(y[i] - mx) : 0.f;        // y <- softmax numerator
+        sum += y[i];
+    }
+    sum = quad_sum(sum);
+    const float inv = 1.0f / sum;
+    const float sck = expf(lsr[k]);
+    const float tk = tanhf(locr[k] + sck * er[k]);
+    const float one_m = 1.f - tk * tk;
+    const float gda = da[s], gds = ds[s];
+    const float cs = gds / fmaxf(1e-6f, one_m);
+    float dot = 0.f;                                        // sum_n gw_n w_n
+#pragma unroll
+    for (int i = 0; i < RS_NP; ++i) {
+        const float gap = th[i] - tk;
+        th[i] = gap * gda + gap * cs;                       // th <- gw_n
+        y[i] *= inv;                                        // y <- w_n
+        dot += th[i] * y[i];
+    }
+    dot = quad_sum(dot);
+    if (!live) return;
+    float* drow = dlogits + (size_t)s * N;
+#pragma unroll
+    for (int i = 0; i < RS_NP; ++i) {
+        const int n = g + RS_G * i;
+        if (n < N) {
+            const float d = y[i] * (th[i] - dot);
+            drow[n] = accumulate ? drow[n] + d : d;
+        }
+    }
+    if (g == 0) {
+        const float gp = gda * one_m + gds;                 // d L / d p_k
+        k_tmp[s] = k;
+        gp_tmp[s] = gp;
+        gs_tmp[s] = gp * sck * er[k];                       // d L / d logstd_k
+    }
+}
+
+// Parameter scatter, deterministic and parallel: wave (chunk c, dim a) walks its rows IN ORDER, 64 at a time
+// (one coalesced load of the (k, dp, dlogstd) triples, then a 64-step register loop: lane n adds row j's pair
+// when k_j == n), and leaves a slab of per-particle partial sums; k_param_grad_final adds the slabs in chunk order.
+__global__ __launch_bounds__(256) void k_rsample_param_partial(
+    const int* __restrict__ k_tmp, const float* __restrict__ gp_tmp, const float* __restrict__ gs_tmp,
+    int B, int A, int N, int C, int chunk_len, float* __restrict__ partial)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= C * A) return;
+    const int a = w % A, c = w / A;
+    const int b0 = c * chunk_len, b1 = min(B, b0 + chunk_len);
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        float sl = 0.f, ss = 0.f;
+        for (int b = b0; b < b1; b += 64) {
+            const int bj = min(b + lane, b1 - 1);
+            const int kj = k_tmp[bj * A + a];
+            const float gpj = gp_tmp[bj * A + a], gsj = gs_tmp[bj * A + a];
+            const int cnt = min(64, b1 - b);
+            for (int j = 0; j < cnt; ++j) {
+                const int kk = __shfl(kj, j, 64);
+                const float p_ = __shfl(gpj, j, 64), s_ = __shfl(gsj, j, 64);
+                if (kk == n) { sl += p_; ss += s_; }
+            }
+        }
+        if (n < N) {
+            partial[((size_t)c * 2 + 0) * A * N + a * N + n] = sl;
+            partial[((size_t)c * 2 + 1) * A * N + a * N + n] = ss;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_param_grad_final(const float* __restrict__ partial, int C, int AN,
+                                                           int accumulate, float* __restrict__ dloc,
+                                                           float* __restrict__ dlogstd) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);      // column of the [2*AN] slab
+    const float s = slab_reduce_1024<false>(partial, C, (size_t)2 * AN, col, col < 2 * AN, red);
+    if ((threadIdx.x >> 6) != 0 || col >= 2 * AN) return;
+    float* dst = col < AN ? dloc + col : dlogstd + (col - AN);
+    *dst = accumulate ? *dst + s : s;
 }
 
 static inline int stats_chunks(int B) {
@@ -294,8 +439,8 @@ using namespace pfpn;
 extern "C" {
 
 size_t pfpn_rollout_workspace_bytes(int B, int A, int N) {
-    // lpseg, smax, sinv, gp, gs [B*A] floats + k [B*A] ints + stats partial [64][2][AN]
-    return ((size_t)B * A * 6 + (size_t)64 * 2 * A * N + 64) * sizeof(float);
+    // lpseg, smax, sinv, gp, gs [B*A] floats + k [B*A] ints + partial slabs [<=256][2][AN]
+    return ((size_t)B * A * 6 + (size_t)256 * 2 * A * N + 64) * sizeof(float);
 }
 
 static int stats_launch(const float* logits, const float* smax, const float* sinv, int B, int A, int N,
@@ -396,8 +541,12 @@ int pfpn_rsample_fwd(const float* logits, const float* loc, const float* logstd,
         return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     const int S = B * A;
-    hipLaunchKernelGGL(k_rsample_fwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, loc,
-                       logstd, gumbel, eps, B, A, N, (int*)k, a_out, s_out);
+    if (N <= RS_G * RS_NP)
+        hipLaunchKernelGGL(k_rsample_fwd_quad, dim3((S * RS_G + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits,
+                           loc, logstd, gumbel, eps, B, A, N, (int*)k, a_out, s_out);
+    else
+        hipLaunchKernelGGL(k_rsample_fwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, loc,
+                           logstd, gumbel, eps, B, A, N, (int*)k, a_out, s_out);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
@@ -417,10 +566,23 @@ int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd,
     float* gs = gp + (size_t)B * A;
     int* kt = (int*)(gs + (size_t)B * A);
     const int S = B * A;
-    hipLaunchKernelGGL(k_rsample_bwd, dim3((S + 255) / 256), dim3(256), 0, st, logits, loc, logstd, gumbel, eps,
-                       da, ds, B, A, N, accumulate, dlogits, kt, gp, gs);
+    if (N <= RS_G * RS_NP)
+        hipLaunchKernelGGL(k_rsample_bwd_quad, dim3((S * RS_G + 255) / 256), dim3(256), 0, st, logits, loc, logstd,
+                           gumbel, eps, da, ds, B, A, N, accumulate, dlogits, kt, gp, gs);
+    else
+        hipLaunchKernelGGL(k_rsample_bwd, dim3((S + 255) / 256), dim3(256), 0, st, logits, loc, logstd, gumbel, eps,
+                           da, ds, B, A, N, accumulate, dlogits, kt, gp, gs);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_rsample_param_grad, dim3((A * N + 255) / 256), dim3(256), 0, st, kt, gp, gs, B, A, N,
+    // parameter scatter: <= 256 row chunks (multiples of 64 rows) x A waves, then a fixed-order slab sum
+    int C = (B + 63) / 64;
+    if (C > 256) C = 256;
+    const int len = (((B + C - 1) / C) + 63) / 64 * 64;
+    C = (B + len - 1) / len;
+    float* partial = (float*)workspace + (size_t)B * A * 6;
+    hipLaunchKernelGGL(k_rsample_param_partial, dim3((C * A * 64 + 255) / 256), dim3(256), 0, st, kt, gp, gs, B, A, N,
+                       C, len, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_param_grad_final, dim3((2 * A * N + 63) / 64), dim3(1024), 0, st, partial, C, A * N,
                        accumulate, dloc, dlogstd);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
