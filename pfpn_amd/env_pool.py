@@ -132,10 +132,17 @@ class BatchedPPORollout(object):
     UNCLIPPED action is stored, a true terminal bootstraps with 0 and a time limit / unroll boundary with
     V(last state), GAE runs per environment segment (device scan over ragged sequences)."""
 
-    def __init__(self, net, pool, unroll_length):
+    def __init__(self, net, pool, unroll_length, graph=None):
         self.net, self.pool, self.T = net, pool, int(unroll_length)
         self.state = pool.reset()
         self.total_samples = 0
+        # on a GPU the per-step policy call is one hipGraph replay (pfpn_amd/graphs.py: GraphedRollout)
+        if graph is None:
+            graph = getattr(net, "device", None) is not None and getattr(net.device, "type", "cpu") == "cuda"
+        self._infer = net.run_batch
+        if graph:
+            from .graphs import GraphedRollout
+            self._infer = GraphedRollout(net, pool.E)
 
     def collect(self):
         import torch
@@ -151,7 +158,7 @@ class BatchedPPORollout(object):
         boot_state = np.zeros((T, E, S), np.float32)      # ... and bootstraps with V(this state) unless terminal
         boot_zero = np.zeros((T, E), bool)
         for t in range(T):
-            a, lp, v = net.run_batch(self.state)
+            a, lp, v = self._infer(self.state)
             states[t] = self.state
             actions[t], logps[t], values[t] = a, lp, v
             nxt, r, done, trunc, last = self.pool.step(a.cpu().numpy())

@@ -14,6 +14,7 @@ class GraphedLearnerStep(object):
         assert optimizer.world == 1, "graph capture covers the single-GPU step (RCCL runs eagerly)"
         self.net, self.opt = net, optimizer
         self.inputs = (state, action, value, log_prob, advantage)
+        net._ensure_buffers(state.shape[0], pin=True)        # the graph keeps pointing at this size's buffers
         st = net.store
         # warm up on a side stream (lazy hipBLASLt/workspace init), then restore every piece of state
         saved = [t.clone() for t in self._state_tensors()]
@@ -50,3 +51,50 @@ class GraphedLearnerStep(object):
         self.graph.replay()
         self.opt.apply_host(self.net)
         return self.loss3
+
+
+class GraphedRollout(object):
+    """`net.run_batch` for a fixed number E of environments as ONE hipGraph replay per environment step.
+
+    The rollout inference is ~15 short launches (normalise, 3 GEMMs + epilogues, sample, row sum, statistics,
+    critic head): ~200 us of host dispatch per call whatever E is.  Captured once, a step costs one H2D copy of
+    the states, two RNG fills (the draws stay OUTSIDE the graph, from the network's generator) and one replay.
+    Returns the same (action, log_prob, value) device tensors on every call (overwritten by the next one)."""
+
+    def __init__(self, net, E, warmup=2):
+        self.net, self.E = net, int(E)
+        dev = net.device
+        self.states = torch.zeros(self.E, net.S, dtype=torch.float32, device=dev)
+        net._ensure_buffers(self.E, pin=True)
+        policy, _, _ = net._forward(self.states)
+        self.noise = policy.make_noise(net.rng)              # static buffers of the right shapes / dtypes
+        stats = [t for t in (getattr(net, "max_active", None), getattr(net, "sum_active", None)) if t is not None]
+        saved = [t.clone() for t in stats]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                net.run_batch(self.states, noise=self.noise)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, sv in zip(stats, saved):
+            t.copy_(sv)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=s):
+            self.out = net.run_batch(self.states, noise=self.noise)
+        self.policy = net.policy
+
+    def __call__(self, states):
+        net = self.net
+        self.states.copy_(torch.as_tensor(states, dtype=torch.float32).view(self.E, net.S), non_blocking=True)
+        for k, t in self.noise.items():                      # fresh draws, same distributions as make_noise
+            if k in ("u_cat",):
+                t.uniform_(generator=net.rng)
+            elif k == "gumbel":
+                t.uniform_(generator=net.rng).clamp_(min=float(torch.finfo(torch.float32).tiny))
+                torch.log(t, out=t); t.neg_(); torch.log(t, out=t); t.neg_()
+            else:
+                t.normal_(generator=net.rng)
+        self.graph.replay()
+        net.policy = self.policy
+        return self.out

@@ -5,6 +5,8 @@ run/evaluate :67-78), the sampler/log-prob plumbing of `ContinuousA2CNetwork` (:
 `ParticleFilteringA2CNetwork` (:310-559: particle grid :476-534, fc_policy :541-558, activation
 statistics :346-365, resample tick :367-383, resample ops :385-474).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -320,9 +322,22 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         value = self._value(hc) if self.trainable else None
         return action, logp, value
 
+    def run_one(self, state):
+        """run_batch on ONE state, the reference worker's per-environment-step call.  After a few eager calls the
+        launch sequence is captured once and replayed (pfpn_amd/graphs.py: GraphedRollout, ~95 vs ~200 us per call;
+        bit-identical results); PFPN_GRAPH_RUN=0 keeps it eager."""
+        st = np.asarray(state, dtype=np.float32)[None]
+        g = getattr(self, "_run_graph", None)
+        if g is None:
+            self._run_calls = getattr(self, "_run_calls", 0) + 1
+            if self._run_calls > 3 and self.device.type == "cuda" and os.environ.get("PFPN_GRAPH_RUN", "1") != "0":
+                from ...graphs import GraphedRollout
+                g = self._run_graph = GraphedRollout(self, 1)
+        return g(st) if g is not None else self.run_batch(st)
+
     def run(self, sess, state, ops=None):
         """reference a2c.py:67-73 / actor_critic.py:368-380: one state -> [action, value]."""
-        action, _, value = self.run_batch(np.asarray(state, dtype=np.float32)[None])
+        action, _, value = self.run_one(state)
         out = [action[0].cpu().numpy()]
         if self.trainable:
             out.append(float(value[0].item()))

@@ -125,6 +125,7 @@ class ActorCriticNetwork(object):
         self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "0") != "0"
         self._dw_pending = False
         self._B = None
+        self._buf_cache, self._buf_pinned = {}, set()
         # names of the reference's placeholders/tensors, kept for workers that look them up
         self.state, self.action, self.action_hist = "state", "action", "action_hist"
         self.advantage, self.value = "advantage", "value"
@@ -201,13 +202,32 @@ class ActorCriticNetwork(object):
                 v[k].copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(self.device).view(v[k].shape))
 
     # forward pieces -------------------------------------------------------------------------------
-    def _ensure_buffers(self, B):
+    def _ensure_buffers(self, B, pin=False):
+        """Activation / gradient buffers for a batch of B rows.  A worker alternates between sizes (B = 1 or E in
+        the rollout, the minibatch size in the learner), so each size's buffers are kept: nothing is allocated
+        in steady state, and a captured hipGraph (`pin=True`) keeps pointing at live memory."""
         if self._B == B:
+            if pin:
+                self._buf_pinned.add(B)
             return
-        dev = self.device
-        self.xn = torch.empty(B, self.S, dtype=torch.float32, device=dev)
-        self.value_buf = torch.empty(B, dtype=torch.float32, device=dev)
-        self._alloc_policy_buffers(B)
+        cache = self._buf_cache
+        if B in cache:
+            self.__dict__.update(cache[B])
+        else:
+            before = dict(self.__dict__)
+            dev = self.device
+            self.xn = torch.empty(B, self.S, dtype=torch.float32, device=dev)
+            self.value_buf = torch.empty(B, dtype=torch.float32, device=dev)
+            self._alloc_policy_buffers(B)
+            cache[B] = {k: v for k, v in self.__dict__.items()
+                        if k not in ("_B", "_buf_cache", "_buf_pinned") and (k not in before or before[k] is not v)}
+            if len(cache) > 8:                       # bounded: drop the oldest size no graph depends on
+                for old in list(cache):
+                    if old != B and old not in self._buf_pinned:
+                        del cache[old]
+                        break
+        if pin:
+            self._buf_pinned.add(B)
         self._B = B
 
     def _alloc_policy_buffers(self, B):

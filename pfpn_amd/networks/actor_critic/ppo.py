@@ -30,7 +30,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
         # -- rollout ---------------------------------------------------------------------------
         def run(self, sess, state, ops=None):
             """reference ppo.py:56-62: [action, action_log_prob, value] for one state (row 0)."""
-            action, logp, value = self.run_batch(np.asarray(state, dtype=np.float32)[None])
+            action, logp, value = self.run_one(state)
             if not self.trainable:
                 return [action[0].cpu().numpy()]
             if logp is None:       # deterministic action: log-prob of the mean action

@@ -28,7 +28,7 @@ def v_trace_network_wrapper(base_a2c_class):
 
         def run(self, sess, state, ops=None):
             """reference vtrace.py:184-192: [action, action_log_prob] for one state."""
-            action, logp, _ = self.run_batch(np.asarray(state, dtype=np.float32)[None])
+            action, logp, _ = self.run_one(state)
             if not self.trainable:
                 return [action[0].cpu().numpy()]
             if logp is None:

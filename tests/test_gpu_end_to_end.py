@@ -71,3 +71,33 @@ def test_batched_rollout_feeds_learner(dev):
         assert np.isfinite(loss[0]) and net.global_step == 1
     finally:
         pool.close()
+
+
+def test_graphed_rollout_matches_eager(dev):
+    """One hipGraph replay per environment step gives what run_batch gives on the same states and draws, keeps
+    the activation statistics going, and survives the learner using other batch sizes in between."""
+    import numpy as np
+    import torch
+    from pfpn_amd.graphs import GraphedRollout
+    from pfpn_amd.models import SyncReplicasApplier
+    from test_gpu_dppo_step import make_net, make_batch
+    net = make_net(dev, seed=4)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    E = 16
+    gr = GraphedRollout(net, E)
+    rng = np.random.default_rng(0)
+    for it in range(3):
+        st = rng.normal(0, 1, (E, 197)).astype(np.float32)
+        before = net.sum_active.clone()
+        a, lp, v = [t.clone() for t in gr(st)]
+        noise = {k: t.clone() for k, t in gr.noise.items()}
+        after_graph = net.sum_active.clone()
+        net.sum_active.copy_(before)
+        a2, lp2, v2 = net.run_batch(st, noise=noise)
+        assert torch.equal(a, a2) and torch.equal(lp, lp2) and torch.equal(v, v2)
+        assert torch.equal(after_graph, net.sum_active) and not torch.equal(before, after_graph)
+        # a learner step with another batch size in between must not disturb the captured buffers
+        b = make_batch(rng, 64)
+        b["log_prob"] = np.full(64, -40.0, np.float32)
+        net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+        net.run(None, st[0])

@@ -23,6 +23,15 @@ for E in (1, 8, 32, 128, 512):
     for _ in range(100): net.run_batch(st)[0].cpu()          # the action must reach the host every step
     t = (time.perf_counter() - t0) / 100
     print("run_batch(E=%3d)          : %7.1f us per call  -> %8.0f env steps/s" % (E, t * 1e6, E / t))
+from pfpn_amd.graphs import GraphedRollout
+for E in (1, 8, 128, 512):
+    st = rng.normal(0, 1, (E, 197)).astype(np.float32)
+    gr = GraphedRollout(net, E)
+    for _ in range(10): gr(st)[0].cpu()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100): gr(st)[0].cpu()
+    t = (time.perf_counter() - t0) / 100
+    print("GraphedRollout(E=%3d)     : %7.1f us per call  -> %8.0f env steps/s" % (E, t * 1e6, E / t))
 for E, P in ((8, 4), (32, 8)):
     pool = EnvPool([(lambda i=i: SyntheticDeepMimicEnv(seed=i)) for i in range(E)], processes=P)
     ro = BatchedPPORollout(net, pool, 64)
