@@ -9,20 +9,42 @@ the graph: the resample kernels run eagerly between replays.
 import torch
 
 
+def refill_noise(noise, generator):
+    """fresh draws into static noise buffers, same distributions as MixtureGaussianDistribution.make_noise /
+    the SAC network's make_train_noise (u_cat: U[0,1) float64; gumbel*: -log(-log U(tiny,1)); others: N(0,1))."""
+    for k, t in noise.items():
+        if k == "u_cat":
+            t.uniform_(generator=generator)
+        elif k.startswith("gumbel"):
+            t.uniform_(generator=generator).clamp_(min=float(torch.finfo(torch.float32).tiny))
+            torch.log(t, out=t); t.neg_(); torch.log(t, out=t); t.neg_()
+        else:
+            t.normal_(generator=generator)
+
+
 class GraphedLearnerStep(object):
-    def __init__(self, net, optimizer, state, action, value, log_prob, advantage, warmup=3):
+    """`net.compute_gradients(*inputs[, noise])` + the optimiser's device part as one hipGraph.
+    `inputs` are static device tensors (a call with `batch` copies into them); `noise` (SAC: the
+    reparameterisation draws) is a dict of static tensors refilled from the network's generator before every
+    replay -- random draws stay outside the graph."""
+
+    def __init__(self, net, optimizer, *inputs, warmup=3, noise=None):
         assert optimizer.world == 1, "graph capture covers the single-GPU step (RCCL runs eagerly)"
         self.net, self.opt = net, optimizer
-        self.inputs = (state, action, value, log_prob, advantage)
-        net._ensure_buffers(state.shape[0], pin=True)        # the graph keeps pointing at this size's buffers
+        self.inputs = tuple(inputs)
+        self.noise = noise
+        args = self.inputs if noise is None else self.inputs + (noise,)
+        net._ensure_buffers(inputs[0].shape[0], pin=True)    # the graph keeps pointing at this size's buffers
         st = net.store
+        if hasattr(net, "sync_target_net_hard"):
+            net.sync_target_net_hard()                       # SAC: the init op must not happen inside the warm-up
         # warm up on a side stream (lazy hipBLASLt/workspace init), then restore every piece of state
         saved = [t.clone() for t in self._state_tensors()]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                net.compute_gradients(*self.inputs)
+                net.compute_gradients(*args)
                 optimizer.apply_device(net)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -31,16 +53,18 @@ class GraphedLearnerStep(object):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s):      # same stream as the warm-up: per-stream workspaces exist
-            self.loss3 = net.compute_gradients(*self.inputs)
+            self.loss3 = net.compute_gradients(*args)
             optimizer.apply_device(net)
         # capture does not execute; state is untouched
 
     def _state_tensors(self):
         net, opt, st = self.net, self.opt, self.net.store
-        ts = [st.flat, st.m, st.v, st.bucket, net.step_dev] + [g["beta_pow"] for g in opt.groups]
+        ts = [st.flat, st.m, st.v, st.bucket, net.step_dev, opt.beta_pow]
+        if getattr(net, "target_store", None) is not None:
+            ts.append(net.target_store.flat)
         if net.state_normalizer is not None:
             ts += [net.state_normalizer.mean, net.state_normalizer.std]
-        if net.max_active is not None:
+        if getattr(net, "max_active", None) is not None:
             ts += [net.max_active, net.sum_active]
         return ts
 
@@ -48,6 +72,8 @@ class GraphedLearnerStep(object):
         if batch is not None:
             for dst, src in zip(self.inputs, batch):
                 dst.copy_(src, non_blocking=True)
+        if self.noise is not None:
+            refill_noise(self.noise, self.net.rng)
         self.graph.replay()
         self.opt.apply_host(self.net)
         return self.loss3
@@ -87,14 +113,7 @@ class GraphedRollout(object):
     def __call__(self, states):
         net = self.net
         self.states.copy_(torch.as_tensor(states, dtype=torch.float32).view(self.E, net.S), non_blocking=True)
-        for k, t in self.noise.items():                      # fresh draws, same distributions as make_noise
-            if k in ("u_cat",):
-                t.uniform_(generator=net.rng)
-            elif k == "gumbel":
-                t.uniform_(generator=net.rng).clamp_(min=float(torch.finfo(torch.float32).tiny))
-                torch.log(t, out=t); t.neg_(); torch.log(t, out=t); t.neg_()
-            else:
-                t.normal_(generator=net.rng)
+        refill_noise(self.noise, net.rng)                    # fresh draws, same distributions as make_noise
         self.graph.replay()
         net.policy = self.policy
         return self.out

@@ -126,6 +126,7 @@ class ActorCriticNetwork(object):
         self._dw_pending = False
         self._B = None
         self._buf_cache, self._buf_pinned = {}, set()
+        self._train_graphs, self._train_calls = {}, {}
         # names of the reference's placeholders/tensors, kept for workers that look them up
         self.state, self.action, self.action_hist = "state", "action", "action_hist"
         self.advantage, self.value = "advantage", "value"
@@ -278,6 +279,28 @@ class ActorCriticNetwork(object):
             return
         for t, off, n, in_tail in self.stat_slots():
             torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
+
+    def graphed_train(self, optimizer, args, make_noise=None):
+        """One learner step on the device tensors `args` (-> loss3, device).  A worker trains on a fixed minibatch
+        size (32 rows in the DPPO setting: ~40 launches of almost no work each), so after a few eager steps at
+        one size the step is captured into a hipGraph (pfpn_amd/graphs.py) and replayed: identical results,
+        a third of the time.  Data-parallel runs (the RCCL all-reduce stays eager) and PFPN_GRAPH_TRAIN=0 keep the
+        eager path."""
+        B = args[0].shape[0]
+        key = (B, id(optimizer))
+        g = self._train_graphs.get(key)
+        if g is None:
+            n = self._train_calls[key] = self._train_calls.get(key, 0) + 1
+            if n > 4 and optimizer.world == 1 and self.device.type == "cuda" and len(self._train_graphs) < 4 and \
+                    os.environ.get("PFPN_GRAPH_TRAIN", "1") != "0":
+                from ...graphs import GraphedLearnerStep
+                g = self._train_graphs[key] = GraphedLearnerStep(
+                    self, optimizer, *[a.clone() for a in args], noise=make_noise() if make_noise else None)
+        if g is not None:
+            return g(batch=args)
+        loss3 = self.compute_gradients(*args) if make_noise is None else self.compute_gradients(*args, make_noise())
+        optimizer.apply(self)
+        return loss3
 
     def prologue(self, state, advantage=None):
         """First launches of a learner step: x = normalised state, the state-normaliser EMA on this minibatch

@@ -81,7 +81,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
             args = [self._to_dev(a) for a in (state, action, value, log_prob, advantage)]
             args[0] = args[0].view(-1, self.S)
             args[1] = args[1].view(-1, self.n_actions)
-            loss3 = self.train_device(optimizer, *args)
+            loss3 = self.graphed_train(optimizer, args)
             return self._report(loss3, ops)
 
     return ClipPPONetwork

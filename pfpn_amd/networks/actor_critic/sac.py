@@ -263,7 +263,8 @@ def sac_network_wrapper(base_class):
             args[0] = args[0].view(-1, self.S)
             args[1] = args[1].view(-1, self.n_actions)
             args[4] = args[4].view(-1, self.S)
-            loss3 = self.train_device(optimizer, *args).cpu().numpy()
+            B = args[0].shape[0]
+            loss3 = self.graphed_train(optimizer, args, lambda: self.make_train_noise(B)).cpu().numpy()
             loss = (float(loss3[0]), None, float(loss3[1]), float(loss3[2]))
             extra = []
             for o in (ops if hasattr(ops, "__len__") else ([ops] if ops else [])):

@@ -122,3 +122,24 @@ def test_deterministic_evaluator(dev):
     # deterministic action = loc[a, argmax logits]: a grid point of the (untrained) particle grid
     grid = -1 + 2 * np.arange(35) / 34
     assert np.all(np.abs(out1[0][:, None] - grid[None]).min(1) < 1e-6)
+
+
+def test_train_captures_itself_and_matches_eager(dev, monkeypatch):
+    """train() switches to a hipGraph replay after a few steps at one minibatch size: same bits as the eager path."""
+    from pfpn_amd.models import SyncReplicasApplier
+    nets = [make_net(dev, seed=21, resample_interval=5) for _ in range(2)]
+    opts = [SyncReplicasApplier(n, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1) for n in nets]
+    rng = np.random.default_rng(2)
+    for it in range(9):
+        b = make_batch(rng, 32)
+        b["log_prob"] = np.full(32, -40.0, F)
+        losses = []
+        for i, (net, opt) in enumerate(zip(nets, opts)):
+            monkeypatch.setenv("PFPN_GRAPH_TRAIN", "1" if i == 0 else "0")
+            losses.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
+                                    b["advantage"]))
+        assert losses[0] == losses[1], it
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat), it
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+    assert len(nets[0]._train_graphs) == 1 and len(nets[1]._train_graphs) == 0
+    assert nets[0].global_step == 9 and nets[0].train_flag == nets[1].train_flag      # resample ticks ran on both

@@ -95,3 +95,34 @@ def test_sac_api_surface(dev):
     a1 = ev.run(None, np.zeros(197, F))[0]
     a2 = ev.run(None, np.zeros(197, F))[0]
     assert np.array_equal(a1, a2) and np.all(np.abs(a1) < 1)
+
+
+def test_sac_step_as_graph_matches_eager(dev):
+    """The captured SAC learner step (draws refilled outside the graph) == the eager step on the same draws."""
+    from pfpn_amd.graphs import GraphedLearnerStep
+    from pfpn_amd.models import SyncReplicasApplier
+    rng = np.random.default_rng(3)
+    B = 64
+    nets, opts = [], []
+    for _ in range(2):
+        net = make_net(dev)
+        nets.append(net)
+        opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                              {"names": net.actor_param_names(), "lr": 1e-4}],
+                                        norm_clip=1.0, world_size=1))
+    assert torch.equal(nets[0].store.flat, nets[1].store.flat)
+    batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                   rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                   rng.normal(0.5, 0.3, B).astype(F),
+                                                   (rng.uniform(size=B) > 0.05).astype(F),
+                                                   (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
+    g = GraphedLearnerStep(nets[0], opts[0], *[t.clone() for t in batch], noise=nets[0].make_train_noise(B))
+    for it in range(3):
+        l_g = g().clone()
+        noise = {k: t.clone() for k, t in g.noise.items()}
+        l_e = nets[1].compute_gradients(*batch, noise).clone()
+        opts[1].apply(nets[1])
+        assert torch.equal(l_g, l_e), it
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
+        assert torch.equal(nets[0].target_store.flat, nets[1].target_store.flat)
+        assert nets[0].global_step == nets[1].global_step == it + 1

@@ -24,3 +24,21 @@ for B in (256, 1024, 4096):
     for _ in range(n): step()
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / n
     print("SAC-PFPN learner step, replay batch %4d: %.3f ms/step -> %.0f steps/s" % (B, t * 1e3, 1 / t))
+
+from pfpn_amd.graphs import GraphedLearnerStep
+for B in (256, 1024, 4096):
+    net = make_net(dev)
+    opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4}, {"names": net.actor_param_names(), "lr": 1e-4}],
+                              norm_clip=1.0, world_size=1)
+    b = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(np.float32),
+                                               rng.uniform(-0.9, 0.9, (B, 36)).astype(np.float32),
+                                               rng.normal(0.5, 0.3, B).astype(np.float32),
+                                               (rng.uniform(size=B) > 0.02).astype(np.float32),
+                                               (rng.normal(0, 1, (B, 197)) * 2).astype(np.float32))]
+    step = GraphedLearnerStep(net, opt, *b, noise=net.make_train_noise(B))
+    for _ in range(10): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100): step()
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 100
+    print("SAC-PFPN learner step as one hipGraph, replay batch %4d: %.3f ms/step -> %.0f steps/s (loss %s)" % (
+        B, t * 1e3, 1 / t, step.loss3.cpu().numpy()))
