@@ -533,6 +533,31 @@ __global__ __launch_bounds__(256) void k_scale_inplace(float* __restrict__ g, si
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] *= sc;
 }
 
+// clip scale from the partial sums (k_clip_scale's arithmetic, in every block) + g *= scale, one launch
+__global__ __launch_bounds__(256) void k_clip_scale_inplace(float* __restrict__ g, size_t n,
+                                                            const float* __restrict__ partial, int nblk,
+                                                            float clip_norm, float* __restrict__ norm_scale) {
+    __shared__ float red[4];
+    float sq = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) sq += partial[i];
+    sq = block_sum(sq, red);
+    const float norm = sqrtf(2.f * (0.5f * sq));
+    float sc = 1.0f;
+    if (clip_norm > 0.f) {
+        sc = clip_norm * fminf(1.0f / norm, 1.0f / clip_norm);
+        if (!isfinite(norm)) sc = NAN;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { norm_scale[0] = norm; norm_scale[1] = sc; }
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = reinterpret_cast<float4*>(g)[i];
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        reinterpret_cast<float4*>(g)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) g[i] *= sc;
+}
+
 // TF ApplyAdam (CPU kernel form): alpha = lr*sqrt(1-b2^t)/(1-b1^t); m += (g-m)(1-b1);
 // v += (g*g-v)(1-b2); p -= m*alpha/(sqrt(v)+eps).  g is first multiplied by the optional device
 // scalar norm_scale[1] (clip) and by grad_mul (1/W after an all-reduce sum).
@@ -616,22 +641,25 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, AdamGroups gr,
                                                    float b1, float b2, float eps, const float* __restrict__ beta_pow,
                                                    const float* __restrict__ partial, int nblk, float clip_norm,
-                                                   float* __restrict__ norm_scale, float* __restrict__ step) {
+                                                   float grad_mul, float* __restrict__ norm_scale,
+                                                   float* __restrict__ step) {
     __shared__ float red[4];
-    // every block forms the same scale from the same partial sums, in k_clip_scale's order
-    float sq = 0.f;
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) sq += partial[i];
-    sq = block_sum(sq, red);
-    const float norm = sqrtf(2.f * (0.5f * sq));
     float gs = 1.0f;
-    if (clip_norm > 0.f) {
-        gs = clip_norm * fminf(1.0f / norm, 1.0f / clip_norm);
-        if (!isfinite(norm)) gs = NAN;
+    if (nblk > 0) {
+        // every block forms the same scale from the same partial sums, in k_clip_scale's order
+        float sq = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += blockDim.x) sq += partial[i];
+        sq = block_sum(sq, red);
+        const float norm = sqrtf(2.f * (0.5f * sq));
+        if (clip_norm > 0.f) {
+            gs = clip_norm * fminf(1.0f / norm, 1.0f / clip_norm);
+            if (!isfinite(norm)) gs = NAN;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && norm_scale) { norm_scale[0] = norm; norm_scale[1] = gs; }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        norm_scale[0] = norm; norm_scale[1] = gs;
-        if (step) step[0] += 1.0f;          // float(global_step) of the state-normaliser decay; no reader in this launch
-    }
+    if (grad_mul != 1.f) gs *= grad_mul;        // 1/W after an all-reduce sum
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step)
+        step[0] += 1.0f;                        // float(global_step) of the state-normaliser decay; no reader in this launch
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     for (int k = 0; k < gr.n; ++k) {
         const float alpha = gr.lr[k] * sqrtf(1.f - beta_pow[4 * k + 3]) / (1.f - beta_pow[4 * k + 2]);
@@ -975,7 +1003,55 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
                        beta2);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, st, params, grads, m, v, gr, beta1,
-                       beta2, eps, (const float*)beta_pow, (const float*)partial, nblk, clip_norm, norm_scale,
+                       beta2, eps, (const float*)beta_pow, (const float*)partial, nblk, clip_norm, 1.0f, norm_scale,
+                       step_counter);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+// ---- data-parallel optimiser step around the all-reduce: clip per replica (2 launches), Adam on the sum (1) ----
+int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm_scale, float* beta_pow, int n_groups,
+                            float beta1, float beta2, void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
+    if (!grads || !norm_scale || n < 1 || ((uintptr_t)grads & 15) || (beta_pow && (n_groups < 1 || n_groups > 4)))
+        return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < 256 * sizeof(float)) return PFPN_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nblk = stream_grid(n >> 2);
+    if (nblk > 256) nblk = 256;
+    float* partial = (float*)workspace;
+    if (beta_pow)
+        hipLaunchKernelGGL(k_sqsum_partial_rot, dim3(nblk), dim3(256), 0, st, (const float*)grads, n, partial, beta_pow,
+                           n_groups, beta1, beta2);
+    else
+        hipLaunchKernelGGL(k_sqsum_partial, dim3(nblk), dim3(256), 0, st, (const float*)grads, n, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_clip_scale_inplace, dim3(stream_grid(n >> 2)), dim3(256), 0, st, grads, n,
+                       (const float*)partial, nblk, clip_norm, norm_scale);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                     const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                     float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter, void* stream) {
+    PFPN_BEGIN();
+    if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || n < 1 || n_groups < 1 ||
+        n_groups > 4)
+        return PFPN_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
+    AdamGroups gr{};
+    gr.n = n_groups;
+    size_t longest = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (group_off[k] < 0 || group_len[k] < 0 || (group_off[k] & 3) || (group_len[k] & 3) ||
+            (size_t)(group_off[k] + group_len[k]) > n)
+            return PFPN_ERR_ARG;
+        gr.off[k] = group_off[k]; gr.len[k] = group_len[k]; gr.lr[k] = group_lr[k];
+        if ((size_t)group_len[k] > longest) longest = (size_t)group_len[k];
+    }
+    hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
+                       v, gr, beta1, beta2, eps, beta_pow, (const float*)nullptr, 0, 0.f, grad_mul, (float*)nullptr,
                        step_counter);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;

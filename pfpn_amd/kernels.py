@@ -452,6 +452,28 @@ def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, cli
                "pfpn_clip_adam")
 
 
+def clip_scale_inplace(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0.9, beta2=0.999):
+    """per-replica global-norm clip applied in place (2 launches); rotates the [G,4] Adam powers when given."""
+    lib = _lib.load()
+    ws, wsn = _learn_ws(1, 1, grads_flat.device)
+    G = beta_pow.shape[0] if beta_pow is not None else 0
+    _lib.check(lib.pfpn_clip_scale_inplace(_f32(grads_flat), grads_flat.numel(), float(clip_norm), _f32(norm_scale, 2),
+                                           _f32(beta_pow, G, 4) if beta_pow is not None else None, G, float(beta1),
+                                           float(beta2), ws, wsn, _stream()), "pfpn_clip_scale_inplace")
+
+
+def adam_groups(params, grads, m, v, group_off, group_len, group_lr, beta_pow, grad_mul=1.0, beta1=0.9, beta2=0.999,
+                eps=1e-8, step_counter=None):
+    """TF-Adam of every parameter group in one launch, on the powers pfpn_clip_scale_inplace / pfpn_clip_adam rotated."""
+    lib = _lib.load()
+    G = len(group_lr)
+    _lib.check(lib.pfpn_adam_groups(_f32(params), _f32(grads), _f32(m), _f32(v), params.numel(), G,
+                                    ctypes.addressof(group_off), ctypes.addressof(group_len), ctypes.addressof(group_lr),
+                                    float(beta1), float(beta2), float(eps), _f32(beta_pow, G, 4), float(grad_mul),
+                                    _f32(step_counter, 1) if step_counter is not None else None, _stream()),
+               "pfpn_adam_groups")
+
+
 def soft_update(target, source, tau):
     lib = _lib.load()
     _lib.check(lib.pfpn_soft_update(_f32(target), _f32(source), target.numel(), float(tau), _stream()),

@@ -59,6 +59,8 @@ class SyncReplicasApplier(object):
         self._g_len = (ctypes.c_longlong * G)(*[g["len"] for g in self.groups])
         self._g_lr = (ctypes.c_float * G)(*[g["lr"] for g in self.groups])
         self.fused = os.environ.get("PFPN_FUSED_OPT", "1") != "0"
+        if self.world > 1 and hasattr(net, "adopt_tail_statistics"):
+            net.adopt_tail_statistics()        # replicated statistics live in the all-reduce bucket from now on
 
     # -- device part (no host sync; capturable when world == 1) -------------------------------------
     def apply_device(self, net):
@@ -72,6 +74,15 @@ class SyncReplicasApplier(object):
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
                               step_counter=net.step_dev)
             net.unpack_synced_stats(st.tail, 1.0)
+            return
+        if W > 1 and self.norm_clip and self.fused and len(self.groups) <= 4:
+            # data parallel: clip in place (2 launches), ONE all-reduce of [clipped grads | statistics], Adam on the
+            # sum with 1/W folded in (1 launch), statistics <- mean (1 launch)
+            kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2)
+            self.reduce(net)
+            kernels.adam_groups(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
+                                1.0 / W, self.beta1, self.beta2, self.epsilon, step_counter=net.step_dev)
+            net.unpack_synced_stats(st.tail, 1.0 / W)
             return
         if self.norm_clip:
             # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica

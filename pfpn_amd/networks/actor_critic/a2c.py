@@ -170,6 +170,12 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             slots += [(self.max_active, base, AN, False), (self.sum_active, base + AN, AN, False)]
         return slots
 
+    def _stat_attrs(self):
+        attrs = super()._stat_attrs()
+        if self.max_active is not None:
+            attrs += [(self, "max_active"), (self, "sum_active")]
+        return attrs
+
     # -- forward -----------------------------------------------------------------------------------
     def _policy_logits(self, ha):
         """fc_policy: logits [B, A*N] = h W + b (a2c.py:541-554)."""

@@ -267,7 +267,25 @@ class ActorCriticNetwork(object):
             slots += [(nz.mean, 0, self.S, True), (nz.std, self.S, self.S, True)]
         return slots
 
+    def _stat_attrs(self):
+        """(owner, attribute name) of every tensor of stat_slots(), same order."""
+        return [(self.state_normalizer, "mean"), (self.state_normalizer, "std")] \
+            if (self.normalize_state and self.trainable) else []
+
+    def adopt_tail_statistics(self):
+        """Data-parallel runs: the replicated statistics LIVE in the all-reduce bucket's tail (the attributes become
+        views of it), so nothing is packed before the all-reduce and one scale by 1/W afterwards turns the sums
+        into the replica mean for all of them."""
+        tail = self.store.tail
+        for (t, off, n, _), (owner, attr) in zip(self.stat_slots(), self._stat_attrs()):
+            view = tail[off:off + n].view(t.shape)
+            view.copy_(t)
+            setattr(owner, attr, view)
+        self._stats_in_tail = True
+
     def pack_local_stats(self, tail):
+        if getattr(self, "_stats_in_tail", False):
+            return
         for t, off, n, in_tail in self.stat_slots():
             if not in_tail:
                 tail[off:off + n].copy_(t.view(-1))
@@ -276,6 +294,9 @@ class ActorCriticNetwork(object):
         """after the all-reduce: statistics <- mean over replicas.  With one replica the state-normaliser
         EMA was written in place (update_state_normalizer) and nothing is left to do."""
         if inv_world == 1.0:
+            return
+        if getattr(self, "_stats_in_tail", False):
+            tail.mul_(inv_world)
             return
         for t, off, n, in_tail in self.stat_slots():
             torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
@@ -319,7 +340,9 @@ class ActorCriticNetwork(object):
         B = state.shape[0]
         kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
                                self.normalize_advantage, self.adv_stats if advantage is not None else None)
-        if self.dp_world == 1:          # in place: visible to the NEXT step's forward (x above used the old moments)
+        if self.dp_world == 1 or getattr(self, "_stats_in_tail", False):
+            # in place: visible to the NEXT step's forward (x above used the old moments); with the statistics
+            # resident in the bucket tail this IS the write into the tail
             kernels.state_norm_ema(B, S, self.step_dev, nz.mean, nz.std, nz.mean, nz.std)
         else:                           # into the bucket tail that the all-reduce averages
             kernels.state_norm_ema(B, S, self.step_dev, nz.mean, nz.std, tail[:S], tail[S:2 * S])
@@ -337,7 +360,7 @@ class ActorCriticNetwork(object):
         side = self.side_stream if self.overlap_ema else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            if self.dp_world == 1:
+            if self.dp_world == 1 or getattr(self, "_stats_in_tail", False):
                 nz.updated(state, self.step_dev, nz.mean, nz.std)
             else:
                 nz.updated(state, self.step_dev, tail[:S], tail[S:2 * S])

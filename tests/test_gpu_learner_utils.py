@@ -220,3 +220,31 @@ def test_clip_adam_matches_clip_then_adam(dev):
         for gi in range(G):
             assert torch.equal(bp2[gi, :2], bp1[gi])                   # TF's beta*_power after the step
             assert torch.allclose(bp2[gi, 2:], torch.tensor([0.9 ** 3, 0.999 ** 3], device=dev))
+
+
+def test_dp_split_step_matches_separate_kernels(dev):
+    """pfpn_clip_scale_inplace + pfpn_adam_groups (the data-parallel split of the optimiser step) ==
+    pfpn_clip_by_global_norm(apply) + pfpn_tf_adam(grad_mul) + power advance, bit for bit."""
+    import ctypes
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(8)
+    n, W = 30000, 4
+    cuts = [(0, 30000, 1e-4)]
+    p0 = torch.from_numpy(rng.normal(0, 1, n).astype(np.float32)).to(dev)
+    g0 = torch.from_numpy(rng.normal(0, 0.05, n).astype(np.float32)).to(dev)
+    p1, g1, m1, v1 = p0.clone(), g0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    p2, g2, m2, v2 = p0.clone(), g0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    ns1, ns2 = torch.zeros(2, device=dev), torch.zeros(2, device=dev)
+    bp1 = torch.tensor([0.9, 0.999], device=dev)
+    bp2 = torch.tensor([[0.9, 0.999, 0, 0]], device=dev)
+    s1, s2 = torch.tensor([0.0], device=dev), torch.tensor([0.0], device=dev)
+    kernels.clip_by_global_norm(g1, 1.0, ns1, apply=True)
+    kernels.clip_scale_inplace(g2, 1.0, ns2, bp2)
+    assert torch.equal(g1, g2) and torch.equal(ns1, ns2)
+    g1.mul_(W); g2.mul_(W)                                    # stands in for the all-reduce sum of W equal replicas
+    kernels.tf_adam(p1, g1, m1, v1, bp1, 1e-4, advance=True, grad_mul=1.0 / W, step_counter=s1)
+    G = 1
+    kernels.adam_groups(p2, g2, m2, v2, (ctypes.c_longlong * G)(0), (ctypes.c_longlong * G)(n), (ctypes.c_float * G)(1e-4),
+                        bp2, 1.0 / W, step_counter=s2)
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(s1, s2)
+    assert torch.equal(bp2[0, :2], bp1)
