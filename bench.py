@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="skip PyTorch TunableOp GEMM selection")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); "
+                                                      "`gloo` + --one-device smoke-tests the multi-rank path on one GPU")
+    ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (control-flow smoke test only)")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +110,9 @@ def main():
             torch.cuda.tunable.write_file_on_exit(False)
         except Exception:
             pass
-    rank, world, local_rank = init_process_group("nccl" if args.gpus > 1 else None)
+    if args.one_device:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local_rank = init_process_group(args.backend if args.gpus > 1 else None)
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
