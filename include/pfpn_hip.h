@@ -68,7 +68,9 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
  * over the logits (reference ppo.py:31-54, actor_critic.py:132-184, utils.py:108-134).
  * Outputs: logp [B], dlogits [B,A*N], dloc/dlogstd [A,N], dvalue [B] (d loss / d value),
  * dbias [A*N] (optional, may be NULL: column sums of dlogits = the fc_policy bias gradient, a2c.py:541-554),
- * loss3 = {loss, policy_loss, value_loss*coef}.  Returns PFPN_ERR_ARG for shapes the packed path
+ * loss3 = {loss, policy_loss, value_loss*coef} (NULL: the per-block partial sums are left unreduced in the workspace --
+ * dloc/dlogstd/dbias/loss3 are then NOT written; used by bench.py to time the main kernel alone).
+ * Returns PFPN_ERR_ARG for shapes the packed path
  * does not cover (N > 64 or no template instance): compose fwd + pfpn_ppo_loss + bwd instead. */
 int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const float* loc, const float* logstd,
                              const float* logp_old, const float* adv, const float* value,

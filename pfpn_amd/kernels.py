@@ -93,7 +93,7 @@ def adv_stats(adv, normalize=True, out=None):
 
 
 def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value_old, stats,
-                        clip_eps=0.2, value_coef=0.5, out=None, dbias=None):
+                        clip_eps=0.2, value_coef=0.5, out=None, dbias=None, finalize=True):
     """Fused learner kernel.  Returns dict(logp, dlogits, dloc, dlogstd, dvalue, loss3).
     `dbias` [A*N] (optional): receives the column sums of dlogits (fc_policy bias gradient)."""
     lib = _lib.load()
@@ -123,7 +123,7 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
                                       out["dlogits"].data_ptr(), out["dloc"].data_ptr(),
                                       out["dlogstd"].data_ptr(), out["dvalue"].data_ptr(),
                                       _f32(dbias.view(-1), A * N, name="dbias") if dbias is not None else None,
-                                      out["loss3"].data_ptr(), ws, wsn, _stream())
+                                      out["loss3"].data_ptr() if finalize else None, ws, wsn, _stream())
     if rc == 1 and B >= 1:
         # shape outside the fused kernel's coverage (N > 64, no template instance, A*N % 4 != 0): the
         # documented composition of the three HIP entry points (include/pfpn_hip.h)
