@@ -1,59 +1,56 @@
-"""PPO worker: which buffers, when to train, the GAE call.
+"""PPO worker: what is buffered per environment step, when a rollout round ends, how advantages are formed.
 
-Host-side mirror of reference models/workers/ppo.py: `PPOWorker` (:11-82) -- exp buffers (:18-21),
-train_args order [state, action, value, log_prob, advantage] (:23-30), `sample_action` storing
-log_prob/value (:43-48), `need_train` with bootstrap value and GAE over [buffer_stamp:] (:50-73).
+Behaviour of reference models/workers/ppo.py (`PPOWorker`, :11-82): the learner receives
+[state, action, value, log_prob, advantage] (:23-30); `run()` returns (action, log-prob, value) and the last two
+are buffered with the step (:43-48); when an episode ends, the unroll is full or a segment closes, the open
+segment [buffer_stamp:] gets its GAE advantages, bootstrapped with 0 after a true terminal and with V(last state)
+after a time limit or an unroll boundary (:50-73).
 """
 from .base_worker import SyncActorCriticWorker
 
 __all__ = ["SyncPPOWorker", "DPPOWorker"]
 
 
-def ppo_worker_wrapper(base_actor_critic_worker):
-    class PPOWorker(base_actor_critic_worker):
-        def __init__(self, **kwargs):
-            kwargs["_on_policy"] = True
-            super().__init__(**kwargs)
+class SyncPPOWorker(SyncActorCriticWorker):
+    BUFFERS = ("state", "action", "reward", "value", "advantage", "log_prob")
+    LEARNER_INPUT = ("state", "action", "value", "log_prob", "advantage")
 
-        @property
-        def exp_buffers(self):
-            return ["state", "action", "reward", "value", "advantage", "log_prob"]
+    def __init__(self, **kwargs):
+        super().__init__(**dict(kwargs, _on_policy=True))
+        self.buffer_stamp = 0                       # first row of the segment whose advantages are still open
 
-        @property
-        def train_args(self):
-            return [self.exp["state"], self.exp["action"], self.exp["value"], self.exp["log_prob"],
-                    self.exp["advantage"]]
+    exp_buffers = property(lambda self: list(self.BUFFERS))
+    train_args = property(lambda self: [self.exp[k] for k in self.LEARNER_INPUT])
 
-        def sample_action(self, sess, state):
-            result = super().sample_action(sess, state)
-            if self.target_net.trainable:
-                self.exp["log_prob"].append(result[1])
-                self.exp["value"].append(result[2])
-            return result
+    def sample_action(self, sess, state):
+        fetched = super().sample_action(sess, state)
+        if self.target_net.trainable:
+            _, log_prob, value = fetched[:3]
+            self.exp["log_prob"].append(log_prob)
+            self.exp["value"].append(value)
+        return fetched
 
-        def need_train(self, sess, terminal, last_state, info):
-            need_train = super().need_train(sess, terminal, last_state, info)
-            if terminal or need_train or self.episodic_terminal:
-                if terminal and not self.overtime(info):
-                    boostrap_value = 0.0
-                else:
-                    boostrap_value = self.local_net.evaluate(sess, last_state)
-                self.exp["value"].append(boostrap_value)
-                self.exp["advantage"].extend(self.local_net.generalized_advantage_estimate(
-                    self.exp["reward"][self.buffer_stamp:], self.exp["value"][self.buffer_stamp:]))
-                self.exp["value"].pop()
-                self.buffer_stamp = len(self.exp["value"])
-            return need_train
+    def _close_advantages(self, sess, terminal, last_state, info):
+        true_end = terminal and not self.overtime(info)
+        bootstrap = 0.0 if true_end else self.local_net.evaluate(sess, last_state)
+        lo = self.buffer_stamp
+        values = self.exp["value"][lo:] + [bootstrap]
+        self.exp["advantage"] += list(self.local_net.generalized_advantage_estimate(self.exp["reward"][lo:], values))
+        self.buffer_stamp = len(self.exp["value"])
 
-        def setup_buffers(self):
-            self.buffer_stamp = 0
-            return super().setup_buffers()
+    def need_train(self, sess, terminal, last_state, info):
+        train_now = super().need_train(sess, terminal, last_state, info)
+        if terminal or train_now or self.episodic_terminal:
+            self._close_advantages(sess, terminal, last_state, info)
+        return train_now
 
-        def clear_buffers(self):
-            super().clear_buffers()
-            self.buffer_stamp = 0
+    def setup_buffers(self):
+        self.buffer_stamp = 0
+        return super().setup_buffers()
 
-    return PPOWorker
+    def clear_buffers(self):
+        super().clear_buffers()
+        self.buffer_stamp = 0
 
 
-SyncPPOWorker = DPPOWorker = ppo_worker_wrapper(SyncActorCriticWorker)
+DPPOWorker = SyncPPOWorker

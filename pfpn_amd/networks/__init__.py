@@ -1,1 +1,3 @@
-from .actor_critic import *
+"""Policy networks of the PFPN path (names as main.py resolves them: reference networks/__init__.py)."""
+from .actor_critic import (ParticleFilteringA2CNetwork, ParticleFilteringClipPPONetwork, ParticleFilteringSACNetwork,
+                           ParticleFilteringVTraceNetwork, particle_grid, v_trace_network_wrapper)

@@ -1,4 +1,5 @@
-from .a2c import *
-from .ppo import *
-from .sac import *
-from .vtrace import *
+"""Actor-critic networks (reference networks/actor_critic/__init__.py exports the same class names)."""
+from .a2c import ParticleFilteringA2CNetwork, particle_grid
+from .ppo import ParticleFilteringClipPPONetwork
+from .sac import ParticleFilteringSACNetwork
+from .vtrace import ParticleFilteringVTraceNetwork, v_trace_network_wrapper
