@@ -189,6 +189,49 @@ int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, 
 /* Relu6Grad + BiasAddGrad: dy <- dy*[0<y<6] in place (relu6), db [G,H] = column sums of dy per group. */
 int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group_rows, int relu6, float* db,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Last trunk layer's epilogue with the critic head folded in (ops.py:105-117 + actor_critic.py:206-210):
+ * y <- act(y + bias) on all rows, and v[b] = y[value_group rows][b,:] . value_w + value_b[0].  group_rows % 4 == 0. */
+int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_rows, int relu6, int value_group,
+                        const float* value_w, const float* value_b, float* v, void* stream);
+/* Relu6Grad + per-chunk BiasAddGrad partials only: like pfpn_act_bwd_bias_grad but the column sums stay as
+ * partial[G][chunks_per_group][H] (chunks_per_group is returned) for pfpn_reduce_jobs.  With value_w != NULL the critic
+ * head's backward is folded in: on group value_group, dy is FORMED as dvalue[b]*value_w[c] (not read), masked and
+ * written, and value_partial[chunks_per_group][H] receives the partials of dW_fc3 = sum_b y[b,:]*dvalue[b]. */
+int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_rows, int relu6, int value_group,
+                         const float* value_w, const float* dvalue, float* value_partial, float* partial,
+                         size_t partial_floats, int* chunks_per_group, void* stream);
+
+/* Deferred fixed-order reductions, one launch for up to PFPN_MAX_REDUCE_JOBS jobs (the gradients the reference gets
+ * from tf.gradients' BiasAddGrad / Sum nodes, sync_model.py:110-121, and the UPDATE_OPS EMA, utils.py:60-68):
+ *   PFPN_JOB_COLSUM   out[i] = sum_{k<nslab} src[k*stride + i], i < n           (float slabs)
+ *   PFPN_JOB_VECSUM   out[0] = sum_{i<n} src[i]                                  (nslab = 1)
+ *   PFPN_JOB_PPO_LOSS src -> the two loss columns of pfpn_ppo_mixture_fwd_bwd's slabs; out = loss3; p0 = 1/B,
+ *                     p1 = value_coef; n = 2
+ *   PFPN_JOB_NORM_EMA src = float64 moments of pfpn_state_prologue (nslab = pfpn_state_moment_chunks(B) chunks),
+ *                     n = S, stride = B; in0 = step, in1 = mean_in, in2 = std_in; out = mean_out, out2 = std_out */
+#define PFPN_MAX_REDUCE_JOBS 16
+#define PFPN_JOB_COLSUM 0
+#define PFPN_JOB_VECSUM 1
+#define PFPN_JOB_PPO_LOSS 2
+#define PFPN_JOB_NORM_EMA 3
+typedef struct PfpnReduceJob {
+    int kind, nslab, stride, n;
+    const void* src;
+    float* out;
+    float* out2;
+    const float* in0;
+    const float* in1;
+    const float* in2;
+    float p0, p1;
+} PfpnReduceJob;
+int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream);
+int pfpn_state_moment_chunks(int B);
+/* Slab geometry of pfpn_ppo_mixture_fwd_bwd called with loss3 = NULL (same arguments): nslab slabs of `stride`
+ * floats laid out [dloc A*N | dlogstd A*N | (dbias A*N) | policy-loss, value-loss, pad, pad].  PFPN_ERR_ARG when the
+ * packed path does not cover the shape. */
+int pfpn_ppo_mixture_slabs(int B, int A, int N, int want_dbias, const float* logits, const float* dlogits,
+                           int* nslab, int* stride);
+
 /* critic fc3 (H -> 1, squeeze) -- actor_critic.py:206-210: v[b] = h[b,:].w + bias[0]; backward gives
  * dh = dv (x) w masked by the ReLU6 of h, dw [H], db [1]. */
 int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B, int H, float* v, void* stream);

@@ -27,16 +27,18 @@
 // Both operands of a product use the same k mapping, so the sum over k is unchanged (any bijection works).
 // LDS is double buffered (one barrier per k-step); the next k-tile is prefetched from HBM/L2 into registers and the
 // fragments of the next half k-step are read while the 64 MFMAs of the current half issue.
+#include <cstdlib>
 #include "pfpn_common.h"
 #include <stdlib.h>
 
 namespace pfpn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int GBM = 128, GBN = 128, GBK = 32;
-constexpr int LDKC = 40;      // K-contiguous operand: LDS [128][40]
-constexpr int LDTC = 132;     // tile-contiguous operand: LDS [32][132]
+constexpr int LDKC = 36;      // K-contiguous operand: LDS [128][36]  (16 consecutive rows -> 16 disjoint 4-bank groups)
+constexpr int LDTC = 136;     // tile-contiguous operand: LDS [32][136] (rows k and k+4 are 32 banks apart)
 constexpr int KC_FLOATS = 128 * LDKC, TC_FLOATS = GBK * LDTC;
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU6 = 2, EPI_MASK = 3 };
@@ -51,6 +53,7 @@ struct GemmArgs {
     long long sA, sB, sC, sBias, sH;    // batch strides (elements)
     int ksplit;                 // TN: number of K chunks (grid.z = batch * ksplit)
     int kchunk;                 // TN: K elements per chunk (multiple of GBK)
+    int xcd_remap;              // re-deal tiles so each XCD works a contiguous tile range
 };
 
 // One operand of the product: global -> registers -> LDS -> MFMA fragments.
@@ -65,7 +68,7 @@ struct Operand {
     int frag;              // LDS float offset of my fragment base
 
     __device__ __forceinline__ void init(int ld, int t0, int n_t, int t, int lane, int wbase) {
-        const int frow = lane >> 4, fcol = lane & 15;
+        const int fhalf = lane >> 5, fcol = lane & 31;     // 32x32x2: lane half h supplies k = 4h + q of a chunk
         if (KC) {
             kq = (t & 7) * 4;
 #pragma unroll
@@ -75,7 +78,7 @@ struct Operand {
                 goff[j] = (unsigned)(t0 + row) * (unsigned)ld + (unsigned)kq;
                 sts[j] = row * LDKC + kq;
             }
-            frag = (wbase + fcol) * LDKC + 4 * frow;
+            frag = (wbase + fcol) * LDKC + 4 * fhalf;
         } else {
             kq = t >> 5;
             const int cq = (t & 31) * 4;
@@ -85,7 +88,7 @@ struct Operand {
                 goff[j] = (unsigned)(kq + 8 * j) * (unsigned)ld + (unsigned)(t0 + cq);
                 sts[j] = (kq + 8 * j) * LDTC + cq;
             }
-            frag = (4 * frow) * LDTC + wbase + fcol;
+            frag = (4 * fhalf) * LDTC + wbase + fcol;
         }
     }
     // P already points at the k-step: KC: P + k0 ; TC: P + k0 * ld
@@ -102,19 +105,21 @@ struct Operand {
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(S + sts[j]) = r[j];
     }
-    // fragments of half h (k-quads 4h .. 4h+3) for the four 16-wide blocks: f[i][q]
-    __device__ __forceinline__ void frags(float (&f)[4][4], const float* __restrict__ S, int h) const {
+    // fragments of k-chunk c (k = 8c .. 8c+7) for the two 32-wide blocks: f[i][q], q = MFMA k-step inside the chunk.
+    // On lane half h the step q multiplies k = 8c + 4h + q: both operands use this mapping, so a chunk still
+    // covers its 8 k-values exactly once (the sum over k is order independent up to rounding).
+    __device__ __forceinline__ void frags(float (&f)[2][4], const float* __restrict__ S, int c) const {
         if (KC) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(S + frag + 16 * i * LDKC + 16 * h);
+            for (int i = 0; i < 2; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(S + frag + 32 * i * LDKC + 8 * c);
                 f[i][0] = v.x; f[i][1] = v.y; f[i][2] = v.z; f[i][3] = v.w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f[i][q] = S[frag + (16 * h + q) * LDTC + 16 * i];
+                for (int q = 0; q < 4; ++q) f[i][q] = S[frag + (8 * c + q) * LDTC + 32 * i];
         }
     }
 };
@@ -133,25 +138,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;       // wave's 64x64 corner in the block tile
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-    int batch = blockIdx.z, kc = 0;
-    if (SPLITK) { batch = blockIdx.z / g.ksplit; kc = blockIdx.z - batch * g.ksplit; }
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by linear id, so neighbouring ids (the
+    // column tiles of one row tile, which share the A panel) would land in 8 different L2s.  Re-deal: XCD x works the
+    // contiguous id range [x T/8, (x+1) T/8), so a row panel is fetched into one L2 once.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (g.xcd_remap && (total & 7u) == 0) {
+            const unsigned lid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            unsigned nid = (lid & 7u) * (total >> 3) + (lid >> 3);
+            bx = nid % gridDim.x; nid /= gridDim.x;
+            by = nid % gridDim.y; bz = nid / gridDim.y;
+        }
+    }
+    const int m0 = by * GBM, n0 = bx * GBN;
+    int batch = bz, kc = 0;
+    if (SPLITK) { batch = bz / g.ksplit; kc = bz - batch * g.ksplit; }
     const float* A = g.A + (size_t)batch * g.sA;
     const float* B = g.B + (size_t)batch * g.sB;
     const int kbeg = SPLITK ? kc * g.kchunk : 0;
     const int kend = SPLITK ? min(g.K, kbeg + g.kchunk) : g.K;
-    const bool do_csum = SPLITK && g.colsum && blockIdx.y == 0;
+    const bool do_csum = SPLITK && g.colsum && by == 0;
 
     Operand<AKC> opA;
     Operand<BKC> opB;
     opA.init(g.lda, m0, g.M, t, lane, wm);
     opB.init(g.ldb, n0, g.N, t, lane, wn);
 
-    f32x4 acc[4][4];
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);              // TN: column sums of my B float4 column group
 
     float4 ra[4], rb[4];
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             }                                                                                   \
         }                                                                                       \
     } while (0)
-    const int frow = lane >> 4, fcol = lane & 15;
+    const int fhalf = lane >> 5, fcol = lane & 31;
     GEMM_FETCH(kbeg);
     GEMM_STORE(As0, Bs0);
     GEMM_FETCH(kbeg + GBK);
@@ -179,50 +199,54 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
         const float* Ac = buf ? As1 : As0;
         const float* Bc = buf ? Bs1 : Bs0;
-        if (k0 + GBK < kend) {                              // tile k+1 (in registers) -> the other buffer
+#ifndef GEMM_EXP
+#define GEMM_EXP 0
+#endif
+        if (!(GEMM_EXP & 1) && k0 + GBK < kend) {           // tile k+1 (in registers) -> the other buffer
             if (buf) GEMM_STORE(As0, Bs0); else GEMM_STORE(As1, Bs1);
             GEMM_FETCH(k0 + 2 * GBK);                       // tile k+2 in flight during the MFMAs (past the end: zeros)
         }
-        float fa[2][4][4], fb[2][4][4];
+        // four k-chunks of 8: the fragments of chunk c+1 are read while the 16 MFMAs (64 cycles each) of chunk c issue
+        float fa[2][2][4], fb[2][2][4];
         opA.frags(fa[0], Ac, 0);
         opB.frags(fb[0], Bc, 0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h == 0) {                                   // fragments of the second half while the first half multiplies
-                opA.frags(fa[1], Ac, 1);
-                opB.frags(fb[1], Bc, 1);
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3 && !(GEMM_EXP & 4)) {
+                opA.frags(fa[(c + 1) & 1], Ac, c + 1);
+                opB.frags(fb[(c + 1) & 1], Bc, c + 1);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[h][i][q], fb[h][j][q], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][i][q], fb[c & 1][j][q], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                    // tile k consumed by everyone, tile k+1 fully stored
+        if (!(GEMM_EXP & 2)) __syncthreads();               // tile k consumed by everyone, tile k+1 fully stored
         buf ^= 1;
     }
 #undef GEMM_FETCH
 #undef GEMM_STORE
     float* As = As0;
 
-    // ---- epilogue.  16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + r ------------------------------------
+    // ---- epilogue.  32x32 C/D map: col = lane & 31, row = 8 (r >> 2) + 4 (lane >> 5) + (r & 3) -----------------------
     float* C = g.C + (size_t)batch * g.sC + (SPLITK ? (size_t)kc * g.M * g.ldc : 0);   // split-K: slab kc of this batch
     const float* bias = (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU6) ? g.bias + (size_t)batch * g.sBias : nullptr;
     const float* H = (EPI == EPI_MASK) ? g.H + (size_t)batch * g.sH : nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn + 16 * j + fcol;
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn + 32 * j + fcol;
         if (col >= g.N) continue;
         const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm + 16 * i + 4 * frow + r;
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * fhalf + (r & 3);
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
                     if (EPI == EPI_BIAS_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
@@ -235,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
             }
         }
     }
-    if (SPLITK && g.colsum && blockIdx.y == 0) {
+    if (SPLITK && g.colsum && by == 0) {
         // combine the 8 k-row lanes (t >> 5) that share a column group through LDS, fixed order
         __syncthreads();
         float4* red = reinterpret_cast<float4*>(As);       // 8 x 32 float4 = 4 KiB
@@ -267,9 +291,13 @@ __global__ __launch_bounds__(256) void k_slab_sum(const float* __restrict__ slab
 
 template <bool AKC, bool BKC, int EPI, bool SPLITK>
 static void launch_gemm(const GemmArgs& g_in, int batch, hipStream_t st) {
-    const GemmArgs& g = g_in;
+    GemmArgs g = g_in;
+    static const int remap = getenv("PFPN_GEMM_XCD_REMAP") ? atoi(getenv("PFPN_GEMM_XCD_REMAP")) : 1;
+    g.xcd_remap = remap;
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch * (SPLITK ? g.ksplit : 1));
-    constexpr size_t lds = (size_t)2 * ((AKC ? KC_FLOATS : TC_FLOATS) + (BKC ? KC_FLOATS : TC_FLOATS)) * sizeof(float);
+    constexpr size_t lds_need = (size_t)2 * ((AKC ? KC_FLOATS : TC_FLOATS) + (BKC ? KC_FLOATS : TC_FLOATS)) * sizeof(float);
+    static const size_t lds_pad = getenv("PFPN_GEMM_LDS_PAD") ? (size_t)atoi(getenv("PFPN_GEMM_LDS_PAD")) : 0;
+    const size_t lds = lds_need + lds_pad;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, EPI, SPLITK>),

@@ -4,6 +4,7 @@
 // soft target update.  All HBM-bound streaming kernels: float4 where rows allow, column
 // reductions through fixed-order chunk slabs (bitwise reproducible).
 #include "pfpn_common.h"
+#include "pfpn_hip.h"     // PfpnReduceJob; also checks every definition below against its declaration
 
 namespace pfpn {
 
@@ -743,6 +744,198 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
     }
 }
 
+
+// Last trunk layer: y <- act(y + bias) AND the scalar critic head v[b] = y[b,:] . w + vb on the rows of group
+// `vgroup` (critic fc3, actor_critic.py:206-210) in the same pass -- the head's own launch re-read 8 MB to do
+// 2 flops per element.  One wave per row, four rows in flight; the dot product is accumulated exactly like
+// k_value_head_fwd (lane partial over i = lane, lane+64, ..; wave_sum), so both paths agree bit for bit.
+__global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, const float* __restrict__ bias, int rows,
+                                                        int H, int group_rows, int relu6, int vgroup,
+                                                        const float* __restrict__ vw, const float* __restrict__ vb,
+                                                        float* __restrict__ v) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int r0 = wave * 4;
+    if (r0 >= rows) return;
+    const int H4 = H >> 2;
+    const int g = group_rows > 0 ? r0 / group_rows : 0;          // group_rows % 4 == 0: the four rows share a group
+    const bool head = g == vgroup;
+    const float4* b4 = reinterpret_cast<const float4*>(bias + (size_t)g * H);
+    const float4* w4 = reinterpret_cast<const float4*>(vw);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < H4; i += 64) {
+        float4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j < rows ? r0 + j : r0;
+            t[j] = reinterpret_cast<const float4*>(y)[(size_t)r * H4 + i];
+        }
+        const float4 bb = b4[i];
+        float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (head) ww = w4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 u = t[j];
+            u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
+            if (relu6) {
+                u.x = fminf(fmaxf(u.x, 0.f), 6.f); u.y = fminf(fmaxf(u.y, 0.f), 6.f);
+                u.z = fminf(fmaxf(u.z, 0.f), 6.f); u.w = fminf(fmaxf(u.w, 0.f), 6.f);
+            }
+            if (r0 + j < rows) reinterpret_cast<float4*>(y)[(size_t)(r0 + j) * H4 + i] = u;
+            acc[j] += u.x * ww.x + u.y * ww.y + u.z * ww.z + u.w * ww.w;
+        }
+    }
+    if (!head) return;
+    const float b0 = vb[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sacc = wave_sum(acc[j]);
+        const int r = r0 + j;
+        if (lane == 0 && r < rows) v[r - vgroup * group_rows] = sacc + b0;
+    }
+}
+
+// k_act_bwd_partial with the critic head's backward folded in: on group `vgroup` the incoming gradient is not read
+// but formed as dv[b] * w[c] (k_value_head_bwd_partial's arithmetic), masked and written like any other row, and a
+// second accumulator collects the head's weight-gradient partials sum_b y[b,c] dv[b] into vpartial[chunk][H].
+__global__ __launch_bounds__(256) void k_act_bwd_partial_value(const float* __restrict__ y, float* __restrict__ dy,
+                                                               int grows, int H, int chunk_len,
+                                                               float* __restrict__ partial, int vgroup,
+                                                               const float* __restrict__ vw,
+                                                               const float* __restrict__ dv,
+                                                               float* __restrict__ vpartial) {
+    __shared__ float4 red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + cl;
+    const int H4 = H >> 2;
+    const int ch = blockIdx.y;
+    const bool head = (int)blockIdx.z == vgroup;
+    const size_t goff = (size_t)blockIdx.z * grows * H4;
+    const int b0 = ch * chunk_len, b1 = min(grows, b0 + chunk_len);
+    const float4* y4 = reinterpret_cast<const float4*>(y) + goff;
+    float4* d4 = reinterpret_cast<float4*>(dy) + goff;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < H4) {
+        float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (head) wv = reinterpret_cast<const float4*>(vw)[c4];
+        for (int b = b0 + rl; b < b1; b += 16) {
+            float4 g[4], v[4];
+            float gs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                const int rc = r < b1 ? r : b;
+                const size_t i = (size_t)rc * H4 + c4;
+                v[j] = y4[i];
+                if (head) {
+                    gs[j] = dv[rc];
+                    g[j] = make_float4(gs[j] * wv.x, gs[j] * wv.y, gs[j] * wv.z, gs[j] * wv.w);
+                } else {
+                    gs[j] = 0.f;
+                    g[j] = d4[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = b + 4 * j;
+                if (r < b1) {
+                    float4 t = g[j];
+                    t.x = (v[j].x > 0.f && v[j].x < 6.f) ? t.x : 0.f;
+                    t.y = (v[j].y > 0.f && v[j].y < 6.f) ? t.y : 0.f;
+                    t.z = (v[j].z > 0.f && v[j].z < 6.f) ? t.z : 0.f;
+                    t.w = (v[j].w > 0.f && v[j].w < 6.f) ? t.w : 0.f;
+                    d4[(size_t)r * H4 + c4] = t;
+                    acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                    acc2.x += v[j].x * gs[j]; acc2.y += v[j].y * gs[j]; acc2.z += v[j].z * gs[j]; acc2.w += v[j].w * gs[j];
+                }
+            }
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c4 < H4) {
+        float4 t = red[0][cl];
+        for (int k = 1; k < 4; ++k) { const float4 u = red[k][cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        reinterpret_cast<float4*>(partial + ((size_t)blockIdx.z * gridDim.y + ch) * H)[c4] = t;
+    }
+    if (!head) return;
+    __syncthreads();
+    red[rl][cl] = acc2;
+    __syncthreads();
+    if (rl == 0 && c4 < H4) {
+        float4 t = red[0][cl];
+        for (int k = 1; k < 4; ++k) { const float4 u = red[k][cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        reinterpret_cast<float4*>(vpartial + (size_t)ch * H)[c4] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Deferred reductions: every slab producer of a learner step (fused mixture kernel, bias-gradient partials, the
+// critic head, the state-normaliser moments) leaves its per-block partials in its own workspace, and ONE launch at
+// the end of the backward pass reduces them all in fixed order.  Each of the five ~5 us latency-bound finalize
+// launches this replaces sat on the step's critical path between two GEMMs.
+// ---------------------------------------------------------------------------------------
+struct ReduceJobTable {
+    PfpnReduceJob job[PFPN_MAX_REDUCE_JOBS];
+    int first_block[PFPN_MAX_REDUCE_JOBS + 1];
+    int n_jobs;
+};
+
+__global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t) {
+    __shared__ double dred[2][16][64];
+    float (*red)[64] = reinterpret_cast<float (*)[64]>(&dred[0][0][0]);
+    int j = 0;
+    while (j + 1 < t.n_jobs && (int)blockIdx.x >= t.first_block[j + 1]) ++j;
+    const PfpnReduceJob& q = t.job[j];
+    const int blk = blockIdx.x - t.first_block[j];
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    if (q.kind == PFPN_JOB_COLSUM) {                      // out[i] = sum_k src[k*stride + i]       (k_bias_grad_final)
+        const int i = blk * 64 + cl;
+        const float s = slab_reduce_1024<false>((const float*)q.src, q.nslab, (size_t)q.stride, i, i < q.n, red);
+        if (kl == 0 && i < q.n) q.out[i] = s;
+    } else if (q.kind == PFPN_JOB_VECSUM) {               // out[0] = sum_i src[i]                  (value-head bias)
+        float s = 0.f;
+        for (int i = threadIdx.x; i < q.n; i += blockDim.x) s += ((const float*)q.src)[i];
+        s = block_sum(s, &red[0][0]);
+        if (threadIdx.x == 0) q.out[0] = s;
+    } else if (q.kind == PFPN_JOB_PPO_LOSS) {             // two loss columns -> loss3              (k_finalize)
+        __shared__ float lsum[2];
+        const float s = slab_reduce_1024<false>((const float*)q.src, q.nslab, (size_t)q.stride, cl & 1, cl < 2, red);
+        if (kl == 0 && cl < 2) lsum[cl] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float pl = -lsum[0] * q.p0, vl = lsum[1] * q.p0 * q.p1;
+            q.out[0] = pl + vl;
+            q.out[1] = pl;
+            q.out[2] = vl;
+        }
+    } else if (q.kind == PFPN_JOB_NORM_EMA) {             // chunk moments -> EMA of mean / std      (k_norm_ema)
+        const double* partial = (const double*)q.src;
+        const int S = q.n, C = q.nslab, c = blk * 64 + cl;
+        double a1 = 0.0, a2 = 0.0;
+        if (c < S) {
+            for (int k = kl; k < C; k += 16) {
+                a1 += partial[((size_t)k * 2 + 0) * S + c];
+                a2 += partial[((size_t)k * 2 + 1) * S + c];
+            }
+        }
+        dred[0][kl][cl] = a1; dred[1][kl][cl] = a2;
+        __syncthreads();
+        if (kl != 0 || c >= S) return;
+        for (int m = 1; m < 16; ++m) { a1 += dred[0][m][cl]; a2 += dred[1][m][cl]; }
+        const double Bd = (double)q.stride;               // batch rows
+        const double mu = a1 / Bd;
+        double var = a2 / Bd - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float bmean = (float)mu, bvar = (float)var;
+        const float step = q.in0[0];
+        const float d = fminf(0.9999f, (1.f + step) / (10.f + step));
+        const float omd = 1.f - d;
+        q.out[c] = d * q.in1[c] + omd * bmean;
+        q.out2[c] = fmaxf(1e-6f, d * q.in2[c] + omd * sqrtf(bvar));
+    }
+}
+
 // Row-chunk count of the column-reduction kernels: 16-row chunks (4 rows per wave in flight),
 // at most PFPN_MAX_CHUNKS slabs in the workspace.
 #define PFPN_MAX_CHUNKS 1024
@@ -906,6 +1099,79 @@ int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group
                        relu6, partial);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bias_grad_final, dim3((H + 63) / 64, G), dim3(1024), 0, st, partial, cpg, G, H, db);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_state_moment_chunks(int B) {
+    int C = row_chunks(B);
+    return C > 256 ? 256 : C;
+}
+
+int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_rows, int relu6, int value_group,
+                        const float* value_w, const float* value_b, float* v, void* stream) {
+    PFPN_BEGIN();
+    if (!y || !bias || !value_w || !value_b || !v || rows < 1 || H < 4 || (H & 3) || ((uintptr_t)y & 15) ||
+        ((uintptr_t)bias & 15) || ((uintptr_t)value_w & 15) || group_rows < 4 || (group_rows & 3) || rows % group_rows ||
+        value_group < 0 || value_group >= rows / group_rows)
+        return PFPN_ERR_ARG;
+    const int waves = (rows + 3) / 4;
+    hipLaunchKernelGGL(k_bias_act_value, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, bias, rows, H,
+                       group_rows, relu6, value_group, value_w, value_b, v);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_rows, int relu6, int value_group,
+                         const float* value_w, const float* dvalue, float* value_partial, float* partial,
+                         size_t partial_floats, int* chunks_per_group, void* stream) {
+    PFPN_BEGIN();
+    if (!dy || !partial || !chunks_per_group || (relu6 && !y) || rows < 1 || H < 4 || (H & 3) || ((uintptr_t)dy & 15))
+        return PFPN_ERR_ARG;
+    const int G = group_rows > 0 ? rows / group_rows : 1;
+    const int grows = group_rows > 0 ? group_rows : rows;
+    if (group_rows > 0 && rows % group_rows) return PFPN_ERR_ARG;
+    int cpg = row_chunks(grows);
+    if (cpg * G > PFPN_MAX_CHUNKS) cpg = PFPN_MAX_CHUNKS / G;
+    if (cpg < 1) return PFPN_ERR_ARG;
+    if (partial_floats < (size_t)G * cpg * H) return PFPN_ERR_WORKSPACE;
+    const int len = (grows + cpg - 1) / cpg;
+    *chunks_per_group = cpg;
+    hipStream_t st = (hipStream_t)stream;
+    if (value_w) {
+        if (!dvalue || !value_partial || !relu6 || value_group < 0 || value_group >= G || ((uintptr_t)value_w & 15))
+            return PFPN_ERR_ARG;
+        hipLaunchKernelGGL(k_act_bwd_partial_value, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy, grows,
+                           H, len, partial, value_group, value_w, dvalue, value_partial);
+    } else {
+        hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy, grows, H, len,
+                           relu6, partial);
+    }
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream) {
+    PFPN_BEGIN();
+    if (!jobs || n_jobs < 1 || n_jobs > PFPN_MAX_REDUCE_JOBS) return PFPN_ERR_ARG;
+    ReduceJobTable t{};
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const PfpnReduceJob& q = jobs[j];
+        if (!q.src || !q.out || q.n < 1 || q.nslab < 1) return PFPN_ERR_ARG;
+        int nb = 1;
+        if (q.kind == PFPN_JOB_COLSUM) nb = (q.n + 63) / 64;
+        else if (q.kind == PFPN_JOB_NORM_EMA) {
+            if (!q.out2 || !q.in0 || !q.in1 || !q.in2 || q.stride < 1) return PFPN_ERR_ARG;
+            nb = (q.n + 63) / 64;
+        } else if (q.kind != PFPN_JOB_VECSUM && q.kind != PFPN_JOB_PPO_LOSS) return PFPN_ERR_ARG;
+        t.job[j] = q;
+        t.first_block[j] = blocks;
+        blocks += nb;
+    }
+    t.first_block[n_jobs] = blocks;
+    t.n_jobs = n_jobs;
+    hipLaunchKernelGGL(k_reduce_jobs, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, t);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

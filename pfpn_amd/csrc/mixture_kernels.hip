@@ -1317,6 +1317,16 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
     return PFPN_OK;
 }
 
+int pfpn_ppo_mixture_slabs(int B, int A, int N, int want_dbias, const float* logits, const float* dlogits,
+                           int* nslab, int* stride) {
+    if (!nslab || !stride || !logits || !dlogits || B < 1 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    PackPlan pl = plan_packed(B, A, N, logits, dlogits);
+    if (!(pl.ok && packed_has(N))) return PFPN_ERR_ARG;
+    *nslab = pl.grid;
+    *stride = (want_dbias ? 3 : 2) * A * N + 4;
+    return PFPN_OK;
+}
+
 int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const float* loc, const float* logstd,
                              const float* logp_old, const float* adv, const float* value,
                              const float* value_old, const float* adv_stats,

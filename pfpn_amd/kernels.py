@@ -93,9 +93,11 @@ def adv_stats(adv, normalize=True, out=None):
 
 
 def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value_old, stats,
-                        clip_eps=0.2, value_coef=0.5, out=None, dbias=None, finalize=True):
+                        clip_eps=0.2, value_coef=0.5, out=None, dbias=None, finalize=True, ws=None):
     """Fused learner kernel.  Returns dict(logp, dlogits, dloc, dlogstd, dvalue, loss3).
-    `dbias` [A*N] (optional): receives the column sums of dlogits (fc_policy bias gradient)."""
+    `dbias` [A*N] (optional): receives the column sums of dlogits (fc_policy bias gradient).
+    `finalize=False` leaves dloc / dlogstd / dbias / loss3 as per-block slabs in `ws` (a private uint8 workspace)
+    for `reduce_jobs` (geometry: `ppo_mixture_slabs`)."""
     lib = _lib.load()
     A, N = loc.shape
     B = action.shape[0]
@@ -117,14 +119,14 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
     _f32(out["dlogits"].view(B, A * N), B, A * N, name="dlogits")
     _f32(out["dloc"], A, N, name="dloc"); _f32(out["dlogstd"], A, N, name="dlogstd")
     _f32(out["logp"], B, name="logp"); _f32(out["dvalue"], B, name="dvalue"); _f32(out["loss3"], 3, name="loss3")
-    ws, wsn = _mix_ws(B, A, N, dev)
+    ws, wsn = _mix_ws(B, A, N, dev) if ws is None else (ws.data_ptr(), ws.numel())
     rc = lib.pfpn_ppo_mixture_fwd_bwd(pl, pa, ploc, pls, *ptrs, B, A, N, float(clip_eps),
                                       float(value_coef), out["logp"].data_ptr(),
                                       out["dlogits"].data_ptr(), out["dloc"].data_ptr(),
                                       out["dlogstd"].data_ptr(), out["dvalue"].data_ptr(),
                                       _f32(dbias.view(-1), A * N, name="dbias") if dbias is not None else None,
                                       out["loss3"].data_ptr() if finalize else None, ws, wsn, _stream())
-    if rc == 1 and B >= 1:
+    if rc == 1 and B >= 1 and finalize:
         # shape outside the fused kernel's coverage (N > 64, no template instance, A*N % 4 != 0): the
         # documented composition of the three HIP entry points (include/pfpn_hip.h)
         out["logp"].copy_(logprob_fwd(logits, action, loc, logstd))
@@ -359,11 +361,13 @@ def state_norm_update(s, step, mean, std, mean_out=None, std_out=None):
     return mean_out, std_out
 
 
-def state_prologue(s, mean, std, clip, out_x, want_moments=True, adv=None, normalize_adv=False, adv_stats=None):
-    """x = clip((s-mean)/std) + float64 column moments of s (for state_norm_ema) + advantage moments, one launch."""
+def state_prologue(s, mean, std, clip, out_x, want_moments=True, adv=None, normalize_adv=False, adv_stats=None,
+                   ws=None):
+    """x = clip((s-mean)/std) + float64 column moments of s (for state_norm_ema) + advantage moments, one launch.
+    `ws`: private uint8 workspace for the moments (deferred EMA: `job_norm_ema`)."""
     lib = _lib.load()
     B, S = s.shape
-    ws, wsn = _learn_ws(B, S, s.device)
+    ws, wsn = _learn_ws(B, S, s.device) if ws is None else (ws.data_ptr(), ws.numel())
     _lib.check(lib.pfpn_state_prologue(_f32(s, B, S), _f32(mean, S), _f32(std, S), B, S, float(clip or 0.0),
                                        _f32(out_x, B, S), int(want_moments),
                                        _f32(adv, B) if adv_stats is not None else None, int(normalize_adv),
@@ -396,6 +400,99 @@ def act_bwd_bias_grad(y, dy, db, relu6=True, group_rows=0):
                                           int(group_rows), int(relu6), _f32(db), ws, wsn, _stream()),
                "pfpn_act_bwd_bias_grad")
     return dy, db
+
+
+def learner_workspace(rows, H, device):
+    """a PRIVATE workspace (uint8 tensor) big enough for the chunk slabs of a [rows, H] column reduction; producers
+    whose reductions are deferred to `reduce_jobs` each need their own."""
+    lib = _lib.load()
+    return torch.empty(int(max(lib.pfpn_learner_workspace_bytes(rows, H), 4096 * 4)), dtype=torch.uint8, device=device)
+
+
+def mixture_workspace(B, A, N, device):
+    lib = _lib.load()
+    return torch.empty(int(lib.pfpn_mixture_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
+
+
+def bias_act_value(y, bias, group_rows, value_group, value_w, value_b, v, relu6=True):
+    """last trunk layer: y <- act(y + bias) and v = y[value_group] . value_w + value_b in ONE pass."""
+    lib = _lib.load()
+    rows, H = y.shape
+    _lib.check(lib.pfpn_bias_act_value(_f32(y, rows, H), _f32(bias), rows, H, int(group_rows), int(relu6),
+                                       int(value_group), _f32(value_w.view(-1), H), _f32(value_b.view(-1), 1),
+                                       _f32(v, group_rows), _stream()), "pfpn_bias_act_value")
+    return v
+
+
+def act_bwd_partial(y, dy, group_rows, ws, relu6=True, value=None):
+    """Relu6Grad in place + per-chunk bias-gradient partials left in `ws` (float view [G*cpg, H]); returns cpg.
+    value = (group, w [H], dvalue [group_rows], ws_value): fold the critic head's backward into that group."""
+    lib = _lib.load()
+    rows, H = dy.shape
+    cpg = ctypes.c_int(0)
+    vg, vw, dv, vws = (value[0], _f32(value[1].view(-1), H), _f32(value[2], group_rows or rows),
+                       value[3].data_ptr()) if value is not None else (0, None, None, None)
+    _lib.check(lib.pfpn_act_bwd_partial(_f32(y, rows, H) if y is not None else None, _f32(dy, rows, H), rows, H,
+                                        int(group_rows), int(relu6), int(vg), vw, dv, vws, ws.data_ptr(),
+                                        ws.numel() // 4, ctypes.addressof(cpg), _stream()), "pfpn_act_bwd_partial")
+    return cpg.value
+
+
+def ppo_mixture_slabs(B, A, N, want_dbias, logits, dlogits):
+    """(nslab, stride) of the slabs ppo_mixture_fwd_bwd(finalize=False) leaves in its workspace."""
+    lib = _lib.load()
+    ns, sd = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.pfpn_ppo_mixture_slabs(B, A, N, int(want_dbias), logits.data_ptr(), dlogits.data_ptr(),
+                                          ctypes.addressof(ns), ctypes.addressof(sd)), "pfpn_ppo_mixture_slabs")
+    return ns.value, sd.value
+
+
+class ReduceJob(ctypes.Structure):
+    """mirror of PfpnReduceJob (include/pfpn_hip.h)"""
+    _fields_ = [("kind", ctypes.c_int), ("nslab", ctypes.c_int), ("stride", ctypes.c_int), ("n", ctypes.c_int),
+                ("src", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out2", ctypes.c_void_p),
+                ("in0", ctypes.c_void_p), ("in1", ctypes.c_void_p), ("in2", ctypes.c_void_p),
+                ("p0", ctypes.c_float), ("p1", ctypes.c_float)]
+
+
+JOB_COLSUM, JOB_VECSUM, JOB_PPO_LOSS, JOB_NORM_EMA = 0, 1, 2, 3
+MAX_REDUCE_JOBS = 16
+
+
+def job_colsum(ws, float_offset, nslab, stride, n, out):
+    """out[i] = sum_k ws_f32[float_offset + k*stride + i], i < n"""
+    if out.numel() < n or ws.numel() < 4 * (float_offset + (nslab - 1) * stride + n):
+        raise ValueError("column-sum job outside its buffers")
+    return ReduceJob(JOB_COLSUM, nslab, stride, n, ws.data_ptr() + 4 * float_offset, _f32(out), None, None, None, None,
+                     0.0, 0.0)
+
+
+def job_vecsum(vec, out):
+    return ReduceJob(JOB_VECSUM, 1, 0, vec.numel(), _f32(vec), _f32(out), None, None, None, None, 0.0, 0.0)
+
+
+def job_ppo_loss(ws, float_offset, nslab, stride, inv_B, value_coef, loss3):
+    return ReduceJob(JOB_PPO_LOSS, nslab, stride, 2, ws.data_ptr() + 4 * float_offset, _f32(loss3, 3), None, None, None,
+                     None, float(inv_B), float(value_coef))
+
+
+def job_norm_ema(ws, B, S, step, mean, std, mean_out, std_out):
+    """EMA of the state normaliser from the float64 moments state_prologue(ws=ws) left behind."""
+    lib = _lib.load()
+    C = lib.pfpn_state_moment_chunks(B)
+    if ws.numel() < C * 2 * S * 8:
+        raise ValueError("moment workspace too small")
+    return ReduceJob(JOB_NORM_EMA, C, B, S, ws.data_ptr(), _f32(mean_out, S), _f32(std_out, S), _f32(step, 1),
+                     _f32(mean, S), _f32(std, S), 0.0, 0.0)
+
+
+def reduce_jobs(jobs):
+    """ONE launch for every deferred fixed-order reduction of the step."""
+    lib = _lib.load()
+    if not 1 <= len(jobs) <= MAX_REDUCE_JOBS:
+        raise ValueError("1..%d reduce jobs per launch" % MAX_REDUCE_JOBS)
+    arr = (ReduceJob * len(jobs))(*jobs)
+    _lib.check(lib.pfpn_reduce_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_reduce_jobs")
 
 
 def value_head_fwd(h, w, bias, out=None):

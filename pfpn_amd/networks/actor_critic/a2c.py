@@ -155,6 +155,8 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             "loss3": torch.empty(3, dtype=torch.float32, device=dev),
         }
         self.adv_stats = torch.empty(2, dtype=torch.float32, device=dev)
+        self.ws_mix = kernels.mixture_workspace(B, self.n_actions, self.particles, dev)   # private: deferred finalize
+        self._mix_slabs = {}
         if self.trunk is not None:
             self.dh = torch.empty(2, B, hc, dtype=torch.float32, device=dev)
         else:
@@ -221,11 +223,22 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         m = self.last_entropy_mask
         return float(((H * m).sum() / m.sum()).item())
 
-    def _backward_heads(self, ha, hc, dlogits, dvalue, fused_db):
-        """fc_policy and critic-head backward, then the trunks; gradients land in the flat gradient buffer."""
+    def _backward_heads(self, ha, hc, dlogits, dvalue, fused_db, deferred=None):
+        """fc_policy and critic-head backward, then the trunks; gradients land in the flat gradient buffer.
+        `deferred` (merged trunk only): the critic head's backward runs inside the trunk's last-layer pass and every
+        bias-gradient reduction becomes a job of the caller's single `kernels.reduce_jobs` launch."""
         st = self.store
         w3 = st["critic/fc3/weight"].view(-1)
         dh_a, dh_c = (self.dh[0], self.dh[1]) if self.trunk is not None else (self.dh_a[0], self.dh_c[0])
+        if deferred is not None:
+            if not fused_db:
+                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+            torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+            torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
+            self.trunk.backward(self.dh, deferred=deferred,
+                                value=(1, w3, dvalue, st.g("critic/fc3/weight"), st.g("critic/fc3/bias")))
+            self._dw_pending = False
+            return
         # critic-head backward and the fc_policy bias gradient (column sums of dlogits) are short
         # latency-bound launches (optionally beside the two fc_policy GEMMs: PFPN_OVERLAP_AUX)
         with self.aux():

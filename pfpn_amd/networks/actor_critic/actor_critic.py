@@ -219,6 +219,8 @@ class ActorCriticNetwork(object):
             dev = self.device
             self.xn = torch.empty(B, self.S, dtype=torch.float32, device=dev)
             self.value_buf = torch.empty(B, dtype=torch.float32, device=dev)
+            if self.trainable and self.normalize_state and self.state_normalizer is not None:
+                self.ws_moments = kernels.learner_workspace(B, self.S, dev)     # private: deferred normaliser EMA
             self._alloc_policy_buffers(B)
             cache[B] = {k: v for k, v in self.__dict__.items()
                         if k not in ("_B", "_buf_cache", "_buf_pinned") and (k not in before or before[k] is not v)}
@@ -242,11 +244,14 @@ class ActorCriticNetwork(object):
             return self.state_normalizer.normalize(state, self.clip_state or 0.0, out=self.xn)
         return torch.clamp(state, -self.clip_state, self.clip_state, out=self.xn)
 
-    def _trunks_forward(self, x):
-        """-> (actor hidden [B,Ha], critic hidden [B,Hc]) (views of the stacks' activation buffers)."""
+    def _trunks_forward(self, x, value_head=None):
+        """-> (actor hidden [B,Ha], critic hidden [B,Hc]) (views of the stacks' activation buffers).
+        `value_head` = (w, b, out): also evaluate the critic head inside the merged trunk's last epilogue."""
         if self.trunk is not None:
-            h = self.trunk.forward(x)
+            h = self.trunk.forward(x, value_head=(1,) + tuple(value_head) if value_head is not None else None)
             return h[0], h[1]
+        if value_head is not None:
+            raise ValueError("the folded critic head needs the merged actor+critic trunk")
         return self.actor_trunk.forward(x)[0], self.critic_trunk.forward(x)[0]
 
     def _to_dev(self, a, dtype=torch.float32):
@@ -323,7 +328,7 @@ class ActorCriticNetwork(object):
         optimizer.apply(self)
         return loss3
 
-    def prologue(self, state, advantage=None):
+    def prologue(self, state, advantage=None, deferred=None):
         """First launches of a learner step: x = normalised state, the state-normaliser EMA on this minibatch
         (UPDATE_OPS, reference sync_model.py:123-138) and -- when `advantage` is given -- its normalisation
         moments into self.adv_stats.  With the normaliser on this is two launches (fused prologue + EMA
@@ -338,9 +343,19 @@ class ActorCriticNetwork(object):
             return x
         nz, tail, S = self.state_normalizer, self.store.tail, self.S
         B = state.shape[0]
+        in_place = self.dp_world == 1 or getattr(self, "_stats_in_tail", False)
+        if deferred is not None:
+            # the moments stay in a private workspace; the EMA itself is one job of the step's single reduce launch
+            # (its result is first read by the NEXT step's prologue)
+            kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
+                                   self.normalize_advantage, self.adv_stats if advantage is not None else None,
+                                   ws=self.ws_moments)
+            mo, so = (nz.mean, nz.std) if in_place else (tail[:S], tail[S:2 * S])
+            deferred.append(kernels.job_norm_ema(self.ws_moments, B, S, self.step_dev, nz.mean, nz.std, mo, so))
+            return self.xn
         kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
                                self.normalize_advantage, self.adv_stats if advantage is not None else None)
-        if self.dp_world == 1 or getattr(self, "_stats_in_tail", False):
+        if in_place:
             # in place: visible to the NEXT step's forward (x above used the old moments); with the statistics
             # resident in the bucket tail this IS the write into the tail
             kernels.state_norm_ema(B, S, self.step_dev, nz.mean, nz.std, nz.mean, nz.std)

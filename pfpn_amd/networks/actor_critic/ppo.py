@@ -9,6 +9,8 @@ One learner step = state-norm(+EMA) -> actor & critic MLP forward (PyTorch-ROCm 
 fused HIP kernel [mixture log-prob of action_hist + PPO ratio/clip/value loss + full backward of
 the mixture] -> MLP backward -> optimizer (clip, all-reduce, TF-Adam, resample tick).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -26,6 +28,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
             self.epsilon = epsilon
             self.running_log_prob = "pi_running"
             self.running_value = "value_running"
+            self._defer_ok = {}
 
         # -- rollout ---------------------------------------------------------------------------
         def run(self, sess, state, ops=None):
@@ -47,27 +50,65 @@ def clip_ppo_network_wrapper(a2c_base_class):
             B = state.shape[0]
             st = self.store
             self._ensure_buffers(B)
-            x = self.prologue(state, advantage)         # normalised state, state-norm EMA, advantage moments
-            ha, hc = self._trunks_forward(x)
-            with self.aux():                           # critic head beside the policy-head GEMM
-                v = self._value(hc)
+            deferred = self._deferred_jobs(B)
+            x = self.prologue(state, advantage, deferred=deferred)   # normalised state, state-norm EMA, advantage moments
+            w3, b3 = st["critic/fc3/weight"], st["critic/fc3/bias"]
+            if deferred is not None:
+                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf))
+                v = self.value_buf
+            else:
+                ha, hc = self._trunks_forward(x)
+                with self.aux():                           # critic head beside the policy-head GEMM
+                    v = self._value(hc)
             policy = MixtureGaussianDistribution(self._policy_logits(ha), self.loc, self.logstd,
                                                  self.normalize_policy_output_)
             self.aux_join()
             # without an entropy term dlogits is final when the fused kernel ends: it then also emits the
             # fc_policy bias gradient (column sums of dlogits), saving a 20 MB pass
             fused_db = not self.entropy_beta
+            gbias = st.g("actor/fc_policy/bias")
             out = kernels.ppo_mixture_fwd_bwd(policy.logits, action, self.loc, self.logstd, log_prob, advantage, v,
                                               value, self.adv_stats, self.epsilon, self.value_loss_coef,
-                                              out=self.train_out,
-                                              dbias=st.g("actor/fc_policy/bias") if fused_db else None)
+                                              out=self.train_out, dbias=gbias if fused_db else None,
+                                              finalize=deferred is None, ws=self.ws_mix if deferred is not None else None)
             dlogits = out["dlogits"]
+            if deferred is not None:
+                # dloc / dlogstd / dbias / loss3 stay as per-block slabs until the step's single reduce launch
+                AN = self.n_actions * self.particles
+                nslab, stride = self._mix_slabs[fused_db]
+                deferred.append(kernels.job_colsum(self.ws_mix, 0, nslab, stride, AN, out["dloc"].view(-1)))
+                deferred.append(kernels.job_colsum(self.ws_mix, AN, nslab, stride, AN, out["dlogstd"].view(-1)))
+                if fused_db:
+                    deferred.append(kernels.job_colsum(self.ws_mix, 2 * AN, nslab, stride, AN, gbias.view(-1)))
+                deferred.append(kernels.job_ppo_loss(self.ws_mix, stride - 4, nslab, stride, 1.0 / B,
+                                                     self.value_loss_coef, out["loss3"]))
             if self.entropy_beta:
                 self._entropy_term(policy, dlogits, B)
+            self._backward_heads(ha, hc, dlogits, out["dvalue"], fused_db, deferred=deferred)
+            if deferred is not None:
+                kernels.reduce_jobs(deferred)
             if self.fixed_sigma:
                 out["dlogstd"].zero_()
-            self._backward_heads(ha, hc, dlogits, out["dvalue"], fused_db)
             return out["loss3"]
+
+        def _deferred_jobs(self, B):
+            """[] when this step can leave its small reductions to ONE launch at the end of the backward pass
+            (merged trunk, fused prologue, packed mixture kernel; PFPN_DEFER_REDUCE=0 disables), else None."""
+            ok = self._defer_ok.get(B)
+            if ok is None:
+                ok = self.trunk is not None and self.trunk.L > 1 and B % 4 == 0 and not self.overlap_ema and \
+                    not self.overlap_aux and not self.overlap_dw and self.state_normalizer is not None and \
+                    self.normalize_state and os.environ.get("PFPN_DEFER_REDUCE", "1") != "0" and \
+                    os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+                if ok:
+                    try:
+                        for want_db in (False, True):
+                            self._mix_slabs[want_db] = kernels.ppo_mixture_slabs(
+                                B, self.n_actions, self.particles, want_db, self.logits, self.train_out["dlogits"])
+                    except Exception:
+                        ok = False
+                self._defer_ok[B] = ok
+            return [] if ok else None
 
         def train_device(self, optimizer, state, action, value, log_prob, advantage):
             """One learner step on device tensors; returns loss3 (device tensor, no sync)."""

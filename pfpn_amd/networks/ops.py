@@ -171,8 +171,17 @@ class DenseStack:
         a = [alloc(i) for i in range(self.L)]
         d = [alloc(i) for i in range(self.L)]
         self._bufs[key] = {"act2d": [t[0] for t in a], "act": [t[1] for t in a],
-                           "dact2d": [t[0] for t in d], "dact": [t[1] for t in d], "x": None, "B": B}
+                           "dact2d": [t[0] for t in d], "dact": [t[1] for t in d], "x": None, "B": B, "ws": None}
         return self._bufs[key]
+
+    def _slab_workspaces(self, buf):
+        """private partial-sum workspaces (one per layer + one for a folded critic head): their reductions are
+        deferred to the step's single `kernels.reduce_jobs` launch, so no two producers may share slabs."""
+        if buf["ws"] is None:
+            B = buf["B"]
+            buf["ws"] = [kernels.learner_workspace(self.G * B, a.shape[1], self.store.device) for a in buf["act2d"]]
+            buf["ws_value"] = kernels.learner_workspace(B, self.dims[-1], self.store.device)
+        return buf["ws"], buf["ws_value"]
 
     @property
     def act(self):
@@ -182,11 +191,12 @@ class DenseStack:
         """`group_rows` of the epilogue kernels: layer 0 merged is one [B, G*H] matrix with a [G*H] bias."""
         return 0 if (i == 0 and self.merged0) else B
 
-    def forward(self, x, slot=0, params=None):
+    def forward(self, x, slot=0, params=None, value_head=None):
         """x: [B, in], shared by all groups.  Returns act[-1]  [G, B, H_last].
         `slot` selects an activation set (a stack evaluated on several inputs in one step keeps one
         set per input for the backward); `params` = another ParamStore with the same layout (SAC
-        target network)."""
+        target network).  `value_head` = (group, w [H_last], b [1], out [B]): the scalar head on that group's
+        output is evaluated inside the last layer's epilogue pass (no launch of its own)."""
         B = x.shape[0]
         st = params if params is not None else self.store
         buf = self._buffers(B, slot)
@@ -202,12 +212,24 @@ class DenseStack:
                     torch.mm(x, w[g], out=act[0][g])
             else:
                 torch.bmm(act[i - 1], w, out=act[i])
-            kernels.bias_act(act2d[i], b, relu6=True, group_rows=self._group_rows(i, B))
+            if value_head is not None and i == self.L - 1 and self._group_rows(i, B) and B % 4 == 0:
+                g, vw, vb, vout = value_head
+                kernels.bias_act_value(act2d[i], b, B, g, vw, vb, vout, relu6=True)
+                value_head = None
+            else:
+                kernels.bias_act(act2d[i], b, relu6=True, group_rows=self._group_rows(i, B))
+        if value_head is not None:
+            g, vw, vb, vout = value_head
+            kernels.value_head_fwd(act[-1][g], vw.view(-1), vb, out=vout)
         return act[-1]
 
-    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None):
+    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output (the stack's own dact[-1] buffer
         or any contiguous tensor); masked in place.
+        `deferred` (a list): the bias-gradient column sums are left as per-chunk partials and a reduce job per
+        tensor is appended instead of being launched (the caller runs `kernels.reduce_jobs(deferred)` once).
+        `value` = (group, w, dvalue [B], grad_w, grad_b) (with `deferred` only): the backward of a scalar head on that
+        group's output is folded into the last layer's pass -- dlast[group] is formed as dvalue (x) w, not read.
         Weight/bias gradients are written into the store's flat gradient buffer (need_dw).
         `dw_stream`: run the weight-gradient GEMMs (independent of the dX chain) on that stream so they
         overlap the next layer's dX GEMM; the caller joins the stream before using the gradients."""
@@ -226,10 +248,30 @@ class DenseStack:
             with torch.cuda.stream(dw_stream):
                 return fn()
 
+        if value is not None and (deferred is None or not need_dw or not self._group_rows(self.L - 1, B)):
+            raise ValueError("a folded value head needs deferred reductions on a batched last layer")
         for i in reversed(range(self.L)):
             w = self.store[self.wn[i]]
-            kernels.act_bwd_bias_grad(act2d[i], d2d, self.store.g(self.bn[i]) if need_dw else self._scratch_bias(i),
-                                      relu6=True, group_rows=self._group_rows(i, B))
+            if deferred is not None and need_dw:
+                ws, ws_value = self._slab_workspaces(buf)
+                grows, H = self._group_rows(i, B), act2d[i].shape[1]
+                fold = None
+                if value is not None and i == self.L - 1:
+                    fold = (value[0], value[1], value[2], ws_value)
+                cpg = kernels.act_bwd_partial(act2d[i], d2d, grows, ws[i], relu6=True, value=fold)
+                gb = self.store.g(self.bn[i])
+                if grows:
+                    for g in range(self.G):
+                        deferred.append(kernels.job_colsum(ws[i], g * cpg * H, cpg, H, H, gb[g]))
+                else:
+                    deferred.append(kernels.job_colsum(ws[i], 0, cpg, H, H, gb.view(-1)))
+                if fold is not None:
+                    deferred.append(kernels.job_colsum(ws_value, 0, cpg, H, H, value[3].view(-1)))
+                    deferred.append(kernels.job_vecsum(value[2], value[4].view(-1)))
+            else:
+                kernels.act_bwd_bias_grad(act2d[i], d2d,
+                                          self.store.g(self.bn[i]) if need_dw else self._scratch_bias(i),
+                                          relu6=True, group_rows=self._group_rows(i, B))
             gw = self.store.g(self.wn[i])
             if i == 0:
                 xt = x.t()

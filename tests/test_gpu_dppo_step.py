@@ -143,3 +143,32 @@ def test_train_captures_itself_and_matches_eager(dev, monkeypatch):
         assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
     assert len(nets[0]._train_graphs) == 1 and len(nets[1]._train_graphs) == 0
     assert nets[0].global_step == 9 and nets[0].train_flag == nets[1].train_flag      # resample ticks ran on both
+
+
+@pytest.mark.parametrize("B", [32, 4096])
+def test_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
+    """The step that leaves its small reductions (mixture finalize, bias gradients, critic head, normaliser EMA) to
+    ONE launch produces the same bits as the step that launches each of them where the reference's graph has them."""
+    from pfpn_amd.models import SyncReplicasApplier
+    nets, opts = [], []
+    for i in range(2):
+        monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
+        monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
+        nets.append(make_net(dev, seed=5, resample_interval=3))
+        opts.append(SyncReplicasApplier(nets[-1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1))
+    rng = np.random.default_rng(B)
+    for it in range(4):
+        b = make_batch(rng, B)
+        b["log_prob"] = np.full(B, -40.0, F)
+        out = []
+        for i, (net, opt) in enumerate(zip(nets, opts)):
+            monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
+            out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
+                                 b["advantage"]))
+        assert nets[0]._defer_ok[B] is True and nets[1]._defer_ok[B] is False
+        assert out[0] == out[1], it
+        assert torch.equal(nets[0].store.grad, nets[1].store.grad), it
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat), it
+        assert torch.equal(nets[0].value_buf, nets[1].value_buf)
+        assert torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)

@@ -248,3 +248,72 @@ def test_dp_split_step_matches_separate_kernels(dev):
                         bp2, 1.0 / W, step_counter=s2)
     assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and torch.equal(s1, s2)
     assert torch.equal(bp2[0, :2], bp1)
+
+
+@pytest.mark.parametrize("B,H", [(4096, 512), (32, 512), (8, 64), (12, 260)])
+def test_last_layer_epilogue_with_value_head_matches_separate_launches(dev, B, H):
+    """bias+ReLU6 with the critic head folded in == pfpn_bias_act followed by pfpn_value_head_fwd, bit for bit."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(B + H)
+    y0 = rng.normal(0, 3, (2 * B, H)).astype(F)
+    bias = rng.normal(0, 1, (2, H)).astype(F)
+    w = rng.normal(0, 0.1, H).astype(F)
+    b3 = np.array([0.37], F)
+    ya, yb, db, dw, dbb = to_dev(dev, y0, y0, bias, w, b3)
+    kernels.bias_act(ya, db, True, B)
+    v_ref = kernels.value_head_fwd(ya[B:], dw, dbb)
+    v = torch.empty(B, dtype=torch.float32, device=dev)
+    kernels.bias_act_value(yb, db, B, 1, dw, dbb, v, relu6=True)
+    assert torch.equal(ya, yb)
+    assert torch.equal(v, v_ref)
+    # group 0 carrying the head instead
+    yc = to_dev(dev, y0)[0]
+    kernels.bias_act_value(yc, db, B, 0, dw, dbb, v, relu6=True)
+    assert torch.equal(v, kernels.value_head_fwd(ya[:B], dw, dbb))
+
+
+@pytest.mark.parametrize("B,H", [(4096, 512), (32, 512), (7, 64), (300, 260)])
+def test_deferred_reductions_match_immediate_ones(dev, B, H):
+    """partials + ONE reduce_jobs launch == pfpn_act_bwd_bias_grad / pfpn_value_head_bwd, bit for bit, including the
+    critic head's backward folded into the last layer's pass and the state-normaliser EMA job."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(B * 3 + H)
+    y = np.clip(rng.normal(2, 3, (2 * B, H)), 0, 6).astype(F)
+    g = rng.normal(0, 1, (2 * B, H)).astype(F)
+    w = rng.normal(0, 0.1, H).astype(F)
+    dv = rng.normal(0, 1, B).astype(F)
+    dy, dg_a, dg_b, dw, ddv = to_dev(dev, y, g, g, w, dv)
+    # immediate: critic head backward writes group 1's gradient, then the layer epilogue
+    dw_ref, db3_ref = torch.empty(H, device=dev), torch.empty(1, device=dev)
+    kernels.value_head_bwd(dy[B:], dw, ddv, dg_a[B:], dw_ref, db3_ref, relu6=True)
+    db_ref = torch.empty(2, H, device=dev)
+    kernels.act_bwd_bias_grad(dy, dg_a, db_ref, relu6=True, group_rows=B)
+    # deferred
+    ws, wsv = kernels.learner_workspace(2 * B, H, dev), kernels.learner_workspace(B, H, dev)
+    cpg = kernels.act_bwd_partial(dy, dg_b, B, ws, relu6=True, value=(1, dw, ddv, wsv))
+    db, dw3, db3 = torch.zeros(2, H, device=dev), torch.zeros(H, device=dev), torch.zeros(1, device=dev)
+    S = 197
+    s = to_dev(dev, (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F))[0]
+    mean, std = to_dev(dev, rng.normal(0, 0.1, S).astype(F), (1 + rng.random(S)).astype(F))
+    step = torch.tensor([5.0], device=dev)
+    wsm = kernels.learner_workspace(B, S, dev)
+    x = torch.empty_like(s)
+    kernels.state_prologue(s, mean, std, 5.0, x, True, ws=wsm)
+    m_out, s_out = torch.empty_like(mean), torch.empty_like(std)
+    jobs = [kernels.job_colsum(ws, gi * cpg * H, cpg, H, H, db[gi]) for gi in range(2)]
+    jobs += [kernels.job_colsum(wsv, 0, cpg, H, H, dw3), kernels.job_vecsum(ddv, db3),
+             kernels.job_norm_ema(wsm, B, S, step, mean, std, m_out, s_out)]
+    kernels.reduce_jobs(jobs)
+    assert torch.equal(dg_a, dg_b)
+    assert torch.equal(db, db_ref)
+    assert torch.equal(dw3, dw_ref)
+    assert torch.equal(db3, db3_ref)
+    m_ref, s_ref = kernels.state_norm_update(s, step, mean, std)
+    assert torch.equal(m_out, m_ref) and torch.equal(s_out, s_ref)
+    # the no-head form of the partial kernel
+    dg_c = to_dev(dev, g)[0]
+    dg_c[B:].copy_(dg_a[B:])
+    cpg2 = kernels.act_bwd_partial(dy, dg_c, B, ws, relu6=True)
+    db2 = torch.zeros(2, H, device=dev)
+    kernels.reduce_jobs([kernels.job_colsum(ws, gi * cpg2 * H, cpg2, H, H, db2[gi]) for gi in range(2)])
+    assert torch.equal(db2, db_ref)

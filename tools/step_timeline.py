@@ -1,0 +1,21 @@
+"""Timeline of ONE learner step from a rocprofv3 --kernel-trace CSV: per kernel start offset, duration and the idle gap
+to the previous kernel's end.  Usage: python tools/step_timeline.py <kernel_trace.csv> [anchor-kernel-substring]
+The step is delimited by consecutive launches of the anchor kernel (default: k_state_prologue)."""
+import csv, sys
+path = sys.argv[1]
+anchor = sys.argv[2] if len(sys.argv) > 2 else "k_state_prologue"
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
+rows.sort()
+idx = [i for i, r in enumerate(rows) if anchor in r[2]]
+if len(idx) < 3:
+    sys.exit("anchor kernel not found often enough")
+a, b = idx[-3], idx[-2]                       # a full step well inside the timed region
+t0 = rows[a][0]
+prev_end = t0
+busy = 0
+print("%8s %8s %7s  %s" % ("start_us", "dur_us", "gap_us", "kernel"))
+for s, e, n in rows[a:b]:
+    print("%8.1f %8.2f %7.2f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, n[:110]))
+    busy += e - s
+    prev_end = max(prev_end, e)
+print("step %.1f us, kernels busy %.1f us, idle %.1f us, %d launches" % ((rows[b][0] - t0) / 1e3, busy / 1e3, (rows[b][0] - t0 - busy) / 1e3, b - a))
