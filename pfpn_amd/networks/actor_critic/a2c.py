@@ -83,6 +83,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             raise ValueError("Particle Filtering Policy Network only supports continuous action space.")
         self.n_actions = int(self.action_shape[0])
         self.particles = int(particles)
+        self._defer_ok = {}
         self.dis_action_shape = [self.particles] * self.n_actions
         if resample and resample > 0:
             raise NotImplementedError("resample=k (top-k source choice, a2c.py:405-408) is not built; "
@@ -257,14 +258,41 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             self.critic_trunk.backward(self.dh_c)
         self._dw_pending = dws is not None
 
+    def _deferred_jobs(self, B, fused_mixture=False):
+        """[] when this step can leave its small reductions (bias gradients, critic head, normaliser EMA and -- PPO --
+        the fused mixture kernel's slabs) to ONE launch at the end of the backward pass: merged trunk, fused prologue
+        (and the packed mixture kernel for `fused_mixture`).  PFPN_DEFER_REDUCE=0 disables.  Else None."""
+        key = (B, fused_mixture)
+        ok = self._defer_ok.get(key)
+        if ok is None:
+            ok = self.trunk is not None and self.trunk.L > 1 and B % 4 == 0 and not self.overlap_ema and \
+                not self.overlap_aux and not self.overlap_dw and self.state_normalizer is not None and \
+                self.normalize_state and os.environ.get("PFPN_DEFER_REDUCE", "1") != "0" and \
+                os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+            if ok and fused_mixture:
+                try:
+                    for want_db in (False, True):
+                        self._mix_slabs[want_db] = kernels.ppo_mixture_slabs(
+                            B, self.n_actions, self.particles, want_db, self.logits, self.train_out["dlogits"])
+                except Exception:
+                    ok = False
+            self._defer_ok[key] = ok
+        return [] if ok else None
+
     def _pg_gradients(self, state, action, targets):
         """Policy-gradient (A2C) loss: forward, `targets(logp, value) -> (value_target, advantage, mask)`,
         loss head, backward.  Returns loss4 (device): {loss, policy_loss, value_loss*coef, n_valid}."""
         B = state.shape[0]
         self._ensure_buffers(B)
-        x = self.prologue(state)
-        ha, hc = self._trunks_forward(x)
-        v = self._value(hc)
+        deferred = self._deferred_jobs(B)
+        x = self.prologue(state, deferred=deferred)
+        if deferred is not None:
+            st = self.store
+            ha, hc = self._trunks_forward(x, value_head=(st["critic/fc3/weight"], st["critic/fc3/bias"], self.value_buf))
+            v = self.value_buf
+        else:
+            ha, hc = self._trunks_forward(x)
+            v = self._value(hc)
         policy = MixtureGaussianDistribution(self._policy_logits(ha), self.loc, self.logstd,
                                              self.normalize_policy_output_)
         logp = policy.log_prob(action)
@@ -283,7 +311,9 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             self._entropy_term(policy, dlogits, B, mask, loss4[3] if mask is not None else None)
         if self.fixed_sigma:
             self.store.g("actor/samples_std").zero_()
-        self._backward_heads(ha, hc, dlogits, dvalue, fused_db=False)
+        self._backward_heads(ha, hc, dlogits, dvalue, fused_db=False, deferred=deferred)
+        if deferred is not None:
+            kernels.reduce_jobs(deferred)
         self.last_targets = (value_target, advantage, mask, logp, v)
         return loss4
 

@@ -28,7 +28,6 @@ def clip_ppo_network_wrapper(a2c_base_class):
             self.epsilon = epsilon
             self.running_log_prob = "pi_running"
             self.running_value = "value_running"
-            self._defer_ok = {}
 
         # -- rollout ---------------------------------------------------------------------------
         def run(self, sess, state, ops=None):
@@ -50,7 +49,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
             B = state.shape[0]
             st = self.store
             self._ensure_buffers(B)
-            deferred = self._deferred_jobs(B)
+            deferred = self._deferred_jobs(B, fused_mixture=True)
             x = self.prologue(state, advantage, deferred=deferred)   # normalised state, state-norm EMA, advantage moments
             w3, b3 = st["critic/fc3/weight"], st["critic/fc3/bias"]
             if deferred is not None:
@@ -90,25 +89,6 @@ def clip_ppo_network_wrapper(a2c_base_class):
             if self.fixed_sigma:
                 out["dlogstd"].zero_()
             return out["loss3"]
-
-        def _deferred_jobs(self, B):
-            """[] when this step can leave its small reductions to ONE launch at the end of the backward pass
-            (merged trunk, fused prologue, packed mixture kernel; PFPN_DEFER_REDUCE=0 disables), else None."""
-            ok = self._defer_ok.get(B)
-            if ok is None:
-                ok = self.trunk is not None and self.trunk.L > 1 and B % 4 == 0 and not self.overlap_ema and \
-                    not self.overlap_aux and not self.overlap_dw and self.state_normalizer is not None and \
-                    self.normalize_state and os.environ.get("PFPN_DEFER_REDUCE", "1") != "0" and \
-                    os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
-                if ok:
-                    try:
-                        for want_db in (False, True):
-                            self._mix_slabs[want_db] = kernels.ppo_mixture_slabs(
-                                B, self.n_actions, self.particles, want_db, self.logits, self.train_out["dlogits"])
-                    except Exception:
-                        ok = False
-                self._defer_ok[B] = ok
-            return [] if ok else None
 
         def train_device(self, optimizer, state, action, value, log_prob, advantage):
             """One learner step on device tensors; returns loss3 (device tensor, no sync)."""

@@ -165,7 +165,7 @@ def test_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
             monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
             out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
                                  b["advantage"]))
-        assert nets[0]._defer_ok[B] is True and nets[1]._defer_ok[B] is False
+        assert nets[0]._defer_ok[(B, True)] is True and nets[1]._defer_ok[(B, True)] is False
         assert out[0] == out[1], it
         assert torch.equal(nets[0].store.grad, nets[1].store.grad), it
         assert torch.equal(nets[0].store.flat, nets[1].store.flat), it
