@@ -234,11 +234,19 @@ __global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict_
             if (threadIdx.x == 0) { adv_stats[0] = 0.f; adv_stats[1] = 1.f; }
             return;
         }
+        // the first 16 values per thread (all of them up to B = 4096) are loaded at once and kept for the second pass
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int i = threadIdx.x + j * 256; a[j] = i < B ? adv[i] : 0.f; }
         float sm = 0.f;
-        for (int i = threadIdx.x; i < B; i += blockDim.x) sm += adv[i];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if ((int)threadIdx.x + j * 256 < B) sm += a[j];
+        for (int i = threadIdx.x + 4096; i < B; i += blockDim.x) sm += adv[i];
         const float mu = block_sum(sm, fred) / (float)B;
         float vv = 0.f;
-        for (int i = threadIdx.x; i < B; i += blockDim.x) { const float d = adv[i] - mu; vv = fmaf(d, d, vv); }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if ((int)threadIdx.x + j * 256 < B) { const float d = a[j] - mu; vv = fmaf(d, d, vv); }
+        for (int i = threadIdx.x + 4096; i < B; i += blockDim.x) { const float d = adv[i] - mu; vv = fmaf(d, d, vv); }
         const float var = block_sum(vv, fred) / (float)B;
         if (threadIdx.x == 0) { adv_stats[0] = mu; adv_stats[1] = 1.0f / (sqrtf(var) + 1e-8f); }
         return;
@@ -293,7 +301,18 @@ __global__ __launch_bounds__(1024) void k_norm_ema(const double* __restrict__ pa
     const int c = blockIdx.x * 64 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < S) {
-        for (int k = kl; k < C; k += 16) {
+        int k = kl;
+        for (; k + 112 < C; k += 128) {                   // 16 loads in flight; additions stay in k order
+            double u[8], w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                u[m] = partial[((size_t)(k + 16 * m) * 2 + 0) * S + c];
+                w[m] = partial[((size_t)(k + 16 * m) * 2 + 1) * S + c];
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { a1 += u[m]; a2 += w[m]; }
+        }
+        for (; k < C; k += 16) {
             a1 += partial[((size_t)k * 2 + 0) * S + c];
             a2 += partial[((size_t)k * 2 + 1) * S + c];
         }
@@ -484,15 +503,32 @@ __global__ __launch_bounds__(256) void k_value_head_bwd_partial(
 // ---------------------------------------------------------------------------------------
 // K9: global-norm clip + TF-Adam on one flat parameter buffer
 // ---------------------------------------------------------------------------------------
+// per-thread sum of squares over the grid-stride float4 stream, eight loads in flight (a load per iteration made the
+// kernel a chain of dependent HBM round trips); additions stay in stream order, so the sum is the plain loop's.
+__device__ __forceinline__ float sqsum_stream(const float* __restrict__ g, size_t n4) {
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s = 0.f;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g4[i + j * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+    }
+    for (; i < n4; i += stride) {
+        const float4 v = g4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(256) void k_sqsum_partial(const float* __restrict__ g, size_t n,
                                                        float* __restrict__ partial) {
     __shared__ float red[4];
-    float s = 0.f;
     const size_t n4 = n >> 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(g)[i];
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
+    float s = sqsum_stream(g, n4);
     if (blockIdx.x == 0)
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
     s = block_sum(s, red);
@@ -618,12 +654,8 @@ __global__ __launch_bounds__(256) void k_sqsum_partial_rot(const float* __restri
                                                            float* __restrict__ partial, float* __restrict__ beta_pow,
                                                            int n_groups, float b1, float b2) {
     __shared__ float red[4];
-    float s = 0.f;
     const size_t n4 = n >> 2;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 v = reinterpret_cast<const float4*>(g)[i];
-        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
+    float s = sqsum_stream(g, n4);
     if (blockIdx.x == 0)
         for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += g[i] * g[i];
     s = block_sum(s, red);
@@ -914,7 +946,18 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t) {
         const int S = q.n, C = q.nslab, c = blk * 64 + cl;
         double a1 = 0.0, a2 = 0.0;
         if (c < S) {
-            for (int k = kl; k < C; k += 16) {
+            int k = kl;
+            for (; k + 112 < C; k += 128) {               // 16 loads in flight (the chain of dependent round trips
+                double u[8], w[8];                        // was this job's -- and k_norm_ema's -- whole duration)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    u[m] = partial[((size_t)(k + 16 * m) * 2 + 0) * S + c];
+                    w[m] = partial[((size_t)(k + 16 * m) * 2 + 1) * S + c];
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { a1 += u[m]; a2 += w[m]; }
+            }
+            for (; k < C; k += 16) {
                 a1 += partial[((size_t)k * 2 + 0) * S + c];
                 a2 += partial[((size_t)k * 2 + 1) * S + c];
             }

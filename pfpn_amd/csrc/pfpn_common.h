@@ -157,6 +157,14 @@ __device__ __forceinline__ float slab_reduce_1024(const float* __restrict__ slab
     float acc = IS_MAX ? -INFINITY : 0.f;
     if (col_ok) {
         int k = kl;
+        // 16 loads in flight per thread (K = 256 slabs: one round trip instead of four); additions stay in k order
+        for (; k + 240 < K; k += 256) {
+            float a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = slab[(size_t)(k + 16 * j) * stride + col];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = IS_MAX ? fmaxf(acc, a[j]) : acc + a[j];
+        }
         for (; k + 48 < K; k += 64) {
             const float a0 = slab[(size_t)k * stride + col];
             const float a1 = slab[(size_t)(k + 16) * stride + col];
