@@ -124,15 +124,18 @@ int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd,
                      void* stream);
 
 /* ---- resample (K5) ------------------------------------------------------------------------ */
-/* ParticleFilteringA2CNetwork.build_resample_ops, resample == -1 -- a2c.py:385-474.  In place on
+/* ParticleFilteringA2CNetwork.build_resample_ops -- a2c.py:385-474.  topk = 0: the `resample == -1` branch
+ * (source = categorical draw over log avg activation, :400-404); topk = k > 0: the `resample == k` branch (source =
+ * candidate number min(k-1, floor(u_resample*k)) among the k most active particles, ties to the lower index, :405-408;
+ * k is clamped to N).  In place on
  * loc/logstd [A,N], bias [A*N], weight [H, A*N] (fc_policy, a particle is a column).
- * u_resample [A,N] float64 in [0,1): uniforms of tf.random.categorical(log avg, N);
+ * u_resample [A,N] float64 in [0,1): uniforms of tf.random.categorical(log avg, N) / of the uniform candidate choice;
  * u_noise [A,N] in [-1,1): tf.random.uniform for dead slot (a,j).  threshold <= 0 -> 0.05/N.
  * dead_out / src_out [A,N] int32: dead mask and drawn source index per slot.  The caller zeroes
  * max_active/sum_active/train_flag afterwards (a2c.py:373-378). */
 int pfpn_resample(float* loc, float* logstd, float* bias, float* weight, int H,
                   const float* max_active, const float* sum_active, const double* u_resample,
-                  const float* u_noise, int A, int N, float threshold, int tanh_mode,
+                  const float* u_noise, int A, int N, float threshold, int tanh_mode, int topk,
                   int32_t* dead_out, int32_t* src_out, void* stream);
 
 /* ---- host utility ------------------------------------------------------------------------- */

@@ -269,9 +269,12 @@ def _seq_sum_rows(x):
 
 
 def resample_particles(loc, logstd, bias, weight, max_active, sum_active,
-                       u_resample, u_noise, threshold=None, tanh_mode=False):
-    """ParticleFilteringA2CNetwork.build_resample_ops, `resample == -1` branch
-    (a2c.py:385-474; the only branch the shipped settings use, deepmimic_dppo_pfpn.py:5).
+                       u_resample, u_noise, threshold=None, tanh_mode=False, topk=0):
+    """ParticleFilteringA2CNetwork.build_resample_ops (a2c.py:385-474).  topk = 0: the `resample == -1` branch
+    (:400-404, the one the shipped settings use, deepmimic_dppo_pfpn.py:5); topk = k > 0: the `resample == k` branch
+    (:405-408): source = candidate number min(k-1, floor(u_resample*k)) among the k most active particles of the
+    action dimension (tf.math.top_k; ties to the lower index; the reference's sorted=False order is unspecified and the
+    choice is uniform, so the distribution does not depend on it).
 
     loc, logstd, max_active, sum_active [A,N]; bias [A*N]; weight [H, A*N] (a particle is a
     column).  u_resample [A,N] in [0,1): uniforms for `tf.random.categorical(log avg, N)`;
@@ -287,9 +290,15 @@ def resample_particles(loc, logstd, bias, weight, max_active, sum_active,
         avg = (sum_active.astype(F) / s[:, None]).astype(F)      # a2c.py:394
         log_avg = np.log(avg.astype(np.float64)).astype(F)       # a2c.py:402 (tf.math.log)
     dead = max_active.astype(F) < thr                            # a2c.py:395
-    cand = multinomial_index(log_avg, np.asarray(u_resample, np.float64))   # [A,N] draws
-    # choice = invalid[:,1] (a2c.py:403): dead particle (a,j) takes draw number j
-    src = cand                                                    # src[a,j] = cand[a, j]
+    if topk and topk > 0:
+        k = min(N, int(topk))                                     # a2c.py:405
+        order = np.argsort(-avg, axis=1, kind="stable")[:, :k]    # a2c.py:407 (ties: lower index first)
+        choice = np.clip((np.asarray(u_resample, np.float64) * k).astype(np.int64), 0, k - 1)   # a2c.py:408
+        src = np.take_along_axis(order, choice, axis=1)           # src[a,j] = cand[a, choice(a,j)]
+    else:
+        cand = multinomial_index(log_avg, np.asarray(u_resample, np.float64))   # [A,N] draws
+        # choice = invalid[:,1] (a2c.py:403): dead particle (a,j) takes draw number j
+        src = cand                                                # src[a,j] = cand[a, j]
     loc = loc.astype(F).copy(); logstd = logstd.astype(F).copy()
     bias = bias.astype(F).copy(); weight = weight.astype(F).copy()
     old_loc, old_logstd, old_bias, old_weight = loc.copy(), logstd.copy(), bias.copy(), weight.copy()

@@ -1,12 +1,17 @@
 // K5: dead-particle resampling for gfx950.
 //
-// Replaces ParticleFilteringA2CNetwork.build_resample_ops, `resample == -1` branch (reference
-// networks/actor_critic/a2c.py:385-474; ~370 TF graph nodes: Where, Multinomial, GatherNd,
+// Replaces ParticleFilteringA2CNetwork.build_resample_ops (reference networks/actor_critic/a2c.py:385-474), both
+// source-choice branches: `resample == -1` (categorical draw over the average activation, :400-404; what every
+// shipped setting uses) and `resample == k > 0` (uniform choice among the k most active particles, :405-408);
+// ~370 TF graph nodes: Where, Multinomial / TopKV2, GatherNd,
 // UniqueWithCounts + map_fn, ScatterNdUpdate/ScatterUpdate).  Runs once every
 // `resample_interval` learner steps: latency-only, but all index arithmetic is bit-exact:
 //   * avg = sum_active / rowsum (fp32, left-to-right sum), log_avg = fl32(log_f64(avg));
 //   * categorical draw = TF-1.14 CPU Multinomial rule on log_avg with float64 running sums
 //     (sequential in one lane, identical rounding order to the oracle);
+//   * top-k branch: the k largest averages, ties to the lower index (TF TopKV2's rule; the reference asks for
+//     sorted=False, whose order is unspecified -- the draw over the set is uniform, so any order is the same
+//     distribution), candidate number min(k-1, floor(u*k));
 //   * counts/deltas in integers; the two bias scatters in the reference's order.
 // One block per action dimension updates loc/logstd/bias and records (dead, src); a second
 // kernel copies weight columns row by row through LDS (gather-before-scatter semantics:
@@ -21,7 +26,7 @@ __global__ __launch_bounds__(256) void k_resample_dims(
     float* __restrict__ loc, float* __restrict__ logstd, float* __restrict__ bias,
     const float* __restrict__ max_active, const float* __restrict__ sum_active,
     const double* __restrict__ u_resample, const float* __restrict__ u_noise,
-    int A, int N, float threshold, int tanh_mode,
+    int A, int N, float threshold, int tanh_mode, int topk,
     int* __restrict__ dead_out, int* __restrict__ src_out)
 {
     __shared__ double cdf[RS_MAXN];
@@ -39,6 +44,35 @@ __global__ __launch_bounds__(256) void k_resample_dims(
         dead[n] = max_active[a * N + n] < threshold ? 1 : 0;            // a2c.py:395
     }
     __syncthreads();
+    if (topk > 0) {
+        // a2c.py:405-408: cand = top_k(avg, k) per action dim, choice ~ U{0..k-1} per dead particle
+        __shared__ float avg_s[RS_MAXN];
+        __shared__ int cand[RS_MAXN];
+        __shared__ float rowsum;
+        if (t == 0) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += sa[n];                     // a2c.py:394 (row sum)
+            rowsum = s;
+        }
+        __syncthreads();
+        for (int n = t; n < N; n += blockDim.x) avg_s[n] = sa[n] / rowsum;
+        __syncthreads();
+        for (int n = t; n < N; n += blockDim.x) {
+            const float v = avg_s[n];
+            int rank = 0;
+            for (int i = 0; i < N; ++i) rank += (avg_s[i] > v || (avg_s[i] == v && i < n)) ? 1 : 0;
+            if (rank < topk) cand[rank] = n;
+        }
+        __syncthreads();
+        for (int j = t; j < N; j += blockDim.x) {
+            int c = (int)(u_resample[a * N + j] * (double)topk);
+            c = min(max(c, 0), topk - 1);
+            const int k = cand[c];
+            if (dead[j]) atomicAdd(&cnt[k], 1);
+            src[j] = k;
+        }
+        __syncthreads();
+    } else {
     if (t == 0) {
         float s = 0.f;
         for (int n = 0; n < N; ++n) s += sa[n];                         // a2c.py:394 (row sum)
@@ -72,6 +106,7 @@ __global__ __launch_bounds__(256) void k_resample_dims(
         src[j] = k;
     }
     __syncthreads();
+    }
     // bias of a source u: old - log(count + 1 - delta), delta = 1 when u is itself dead (a2c.py:453-458)
     for (int n = t; n < N; n += blockDim.x)
         nb[n] = cnt[n] > 0 ? o_bias[n] - logf((float)cnt[n] + 1.f - (float)dead[n]) : o_bias[n];
@@ -117,18 +152,19 @@ using namespace pfpn;
 
 extern "C" int pfpn_resample(float* loc, float* logstd, float* bias, float* weight, int H,
                              const float* max_active, const float* sum_active, const double* u_resample,
-                             const float* u_noise, int A, int N, float threshold, int tanh_mode,
+                             const float* u_noise, int A, int N, float threshold, int tanh_mode, int topk,
                              int32_t* dead_out, int32_t* src_out, void* stream) {
     PFPN_BEGIN();
     if (!loc || !logstd || !bias || !weight || !max_active || !sum_active || !u_resample || !u_noise ||
-        !dead_out || !src_out || A < 1 || N < 1 || N > RS_MAXN || H < 1)
+        !dead_out || !src_out || A < 1 || N < 1 || N > RS_MAXN || H < 1 || topk < 0)
         return PFPN_ERR_ARG;
+    if (topk > N) topk = N;                                               // a2c.py:405  k = min(n, resample)
     const size_t lds = (size_t)A * N * sizeof(float);
     if (lds > 64 * 1024) return PFPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (threshold <= 0.f) threshold = (float)(0.05 / (double)N);         // a2c.py:391 (.05/n in float64, then fp32)
     hipLaunchKernelGGL(k_resample_dims, dim3(A), dim3(256), 0, st, loc, logstd, bias, max_active, sum_active,
-                       u_resample, u_noise, A, N, threshold, tanh_mode, (int*)dead_out, (int*)src_out);
+                       u_resample, u_noise, A, N, threshold, tanh_mode, topk, (int*)dead_out, (int*)src_out);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_resample_weight, dim3(H), dim3(256), lds, st, weight, H, A * N, N, (const int*)dead_out,
                        (const int*)src_out);

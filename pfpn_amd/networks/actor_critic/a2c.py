@@ -85,9 +85,10 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         self.particles = int(particles)
         self._defer_ok = {}
         self.dis_action_shape = [self.particles] * self.n_actions
-        if resample and resample > 0:
-            raise NotImplementedError("resample=k (top-k source choice, a2c.py:405-408) is not built; "
-                                      "every shipped PFPN setting uses resample=-1")
+        if resample and resample < 0 and resample != -1:
+            raise ValueError("resample is -1 (categorical source draw) or k > 0 (top-k), a2c.py:399-408")
+        if resample and resample > self.particles:
+            raise ValueError("resample=k needs k <= particles (a2c.py:390)")
         self.resample = resample
         self.resample_interval = resample_interval
         self.resample_threshold = resample_threshold
@@ -433,5 +434,6 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         thr = float(self.resample_threshold) if self.resample_threshold else 0.0
         self.last_resample = kernels.resample(self.loc, self.logstd, self.policy_bias, self.policy_weight,
                                               self.max_active, self.sum_active, u_resample, u_noise, thr,
-                                              self.normalize_policy_output_)
+                                              self.normalize_policy_output_,
+                                              topk=self.resample if self.resample and self.resample > 0 else 0)
         return self.last_resample

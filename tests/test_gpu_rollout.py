@@ -201,3 +201,46 @@ def test_resample_noop_when_all_alive(oracle, dev):
     assert dead.sum().item() == 0
     for got, ref in zip(d[:4], case[:4]):
         assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("A,N,H,k,tanh_mode", [(36, 35, 128, 3, False), (36, 35, 128, 35, False), (6, 50, 64, 1, True),
+                                               (3, 200, 32, 17, False)])
+def test_resample_topk_branch(oracle, dev, A, N, H, k, tanh_mode):
+    """`resample = k > 0` (a2c.py:405-408): source drawn uniformly among the k most active particles; indices
+    bit-exact against the oracle, ties (equal averages) to the lower index."""
+    from pfpn_amd import kernels
+    case = list(_resample_case(oracle, A, N, H, 31 + A + N + k, tanh_mode))
+    case[5][0, 3] = case[5][0, 4] = case[5][0].max() * 2            # a tie at the top of dim 0
+    loc, logstd, bias, weight, mx, sm, ur, un = case
+    r_loc, r_ls, r_bias, r_w, info = oracle.resample_particles(loc, logstd, bias, weight, mx, sm, ur, un,
+                                                               tanh_mode=tanh_mode, topk=k)
+    d = to_dev(dev, *case)
+    dead, src = kernels.resample(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], 0.0, tanh_mode, topk=k)
+    dead = dead.cpu().numpy().astype(bool); src = src.cpu().numpy()
+    assert np.array_equal(dead, info["dead"]) and dead.sum() > 0
+    assert np.array_equal(src, info["src"]), "top-k source indices must be bit-exact"
+    # every source is one of the k most active particles of its action dimension
+    avg = sm / sm.sum(1, keepdims=True)
+    for a in range(A):
+        kth = np.sort(avg[a])[::-1][min(k, N) - 1]
+        assert np.all(avg[a, src[a]] >= kth)
+    if k == 1:
+        assert np.all(src == src[:, :1])
+    np.testing.assert_allclose(d[0].cpu().numpy(), r_loc, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(d[1].cpu().numpy(), r_ls, rtol=0, atol=0)
+    np.testing.assert_allclose(d[2].cpu().numpy(), r_bias, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(d[3].cpu().numpy(), r_w)
+
+
+def test_network_resample_topk_option(dev):
+    """the reference default `resample=3` (a2c.py:311) builds and ticks."""
+    from test_gpu_dppo_step import make_net
+    net = make_net(dev, resample=3, resample_interval=1)
+    net.max_active.fill_(1.0); net.sum_active.copy_(torch.rand_like(net.sum_active) + 0.1)
+    net.max_active[:, :5] = 0.0
+    before = net.loc.clone()
+    dead, src = net.resample_now()
+    assert dead[:, :5].all() and dead.sum().item() == 5 * net.n_actions
+    top3 = torch.topk(net.sum_active, 3, dim=1).indices
+    assert all(int(src[a, j]) in top3[a].tolist() for a in range(net.n_actions) for j in range(5))
+    assert not torch.equal(before[:, :5], net.loc[:, :5]) and torch.equal(before[:, 5:], net.loc[:, 5:])

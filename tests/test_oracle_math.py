@@ -264,3 +264,32 @@ def test_sac_grads_match_autograd(oracle):
         ref = g.numpy()
         got = np.asarray(G[k]).reshape(ref.shape)
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * (np.abs(ref).max() + 1e-12), err_msg=k)
+
+
+def test_resample_topk_sources_and_mass_split():
+    """oracle `resample = k` branch (a2c.py:405-408): sources lie in the top-k set, ties go to the lower index, and the
+    bias split keeps the softmax mass of {source + clones} equal to the source's old mass."""
+    import oracle.pfpn_oracle as o
+    rng = np.random.default_rng(3)
+    A, N, H, k = 4, 12, 8, 3
+    loc, logstd = o.init_particles(A, N, False)
+    bias = rng.normal(0, 0.5, A * N).astype(np.float32)
+    weight = rng.normal(0, 0.1, (H, A * N)).astype(np.float32)
+    sum_active = (rng.random((A, N)) * 10 + 1).astype(np.float32)
+    sum_active[0, 2] = sum_active[0, 7] = 100.0                      # tie at the top of dim 0
+    max_active = np.ones((A, N), np.float32)
+    max_active[:, 9:] = 0.0                                          # three dead particles per dim
+    sum_active[:, 9:] = 0.01
+    u = rng.random((A, N)); un = rng.uniform(-1, 1, (A, N)).astype(np.float32)
+    u[0, 9], u[0, 10] = 0.0, 0.34                                    # candidate 0 and candidate 1 of dim 0
+    nl, nls, nb, nw, info = o.resample_particles(loc, logstd, bias, weight, max_active, sum_active, u, un, topk=k)
+    src, dead = info["src"], info["dead"]
+    assert src[0, 9] == 2 and src[0, 10] == 7                        # tie broken towards the lower index
+    for a in range(A):
+        top = set(np.argsort(-sum_active[a], kind="stable")[:k].tolist())
+        assert set(src[a, 9:].tolist()) <= top
+        for s in set(src[a, 9:].tolist()):
+            grp = [s] + [j for j in range(9, N) if src[a, j] == s]
+            new_mass = np.exp(nb[a * N:(a + 1) * N][grp].astype(np.float64)).sum()
+            np.testing.assert_allclose(new_mass, np.exp(np.float64(bias[a * N + s])), rtol=1e-5)
+    assert np.array_equal(nw[:, 9], weight[:, src[0, 9]])
