@@ -112,6 +112,10 @@ int pfpn_entropy_fwd(const float* logits, int B, int A, int N, float* H, void* s
 int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, int accumulate,
                      float* dlogits, void* stream);
 
+/* Gumbel noise from uniforms in [0,1), in place: g = -log(-log(max(u, FLT_MIN))) -- the sampler of TFP 0.7's
+ * RelaxedOneHotCategorical behind utils.py:96, :156-160 (the uniforms themselves come from the caller's generator). */
+int pfpn_gumbel_from_uniform(float* u, size_t n, void* stream);
+
 /* SAC reparameterised sample (K4) -- utils.py:156-186.  gumbel [B,A*N] = -log(-log u), eps [B,A*N]:
  * k = argmax(logits+gumbel), s_out = p_k = loc+exp(logstd)*eps, a_out = tanh(p_k).
  * bwd: custom gradients `mask`/`mask2` (utils.py:165-183) with upstream da, ds [B,A]. */
@@ -193,13 +197,16 @@ int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, 
 int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group_rows, int relu6, float* db,
                            void* workspace, size_t workspace_bytes, void* stream);
 /* Last trunk layer's epilogue with the critic head folded in (ops.py:105-117 + actor_critic.py:206-210):
- * y <- act(y + bias) on all rows, and v[b] = y[value_group rows][b,:] . value_w + value_b[0].  group_rows % 4 == 0. */
+ * y <- act(y + bias) on all rows, and v[b] = y[value_group rows][b,:] . value_w + value_b[0].  group_rows % 4 == 0.
+ * value_group < 0: EVERY group g has its own head (twin Q networks, sac.py:123-139): value_w [G,H],
+ * group g's bias at value_b[g*value_b_stride], v [G*B]. */
 int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_rows, int relu6, int value_group,
-                        const float* value_w, const float* value_b, float* v, void* stream);
+                        const float* value_w, const float* value_b, int value_b_stride, float* v, void* stream);
 /* Relu6Grad + per-chunk BiasAddGrad partials only: like pfpn_act_bwd_bias_grad but the column sums stay as
  * partial[G][chunks_per_group][H] (chunks_per_group is returned) for pfpn_reduce_jobs.  With value_w != NULL the critic
  * head's backward is folded in: on group value_group, dy is FORMED as dvalue[b]*value_w[c] (not read), masked and
- * written, and value_partial[chunks_per_group][H] receives the partials of dW_fc3 = sum_b y[b,:]*dvalue[b]. */
+ * written, and value_partial[chunks_per_group][H] receives the partials of dW_fc3 = sum_b y[b,:]*dvalue[b].
+ * value_group < 0: every group has a head -- value_w [G,H], dvalue [G*group_rows], value_partial [G][chunks][H]. */
 int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_rows, int relu6, int value_group,
                          const float* value_w, const float* dvalue, float* value_partial, float* partial,
                          size_t partial_floats, int* chunks_per_group, void* stream);

@@ -778,22 +778,24 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
 
 
 // Last trunk layer: y <- act(y + bias) AND the scalar critic head v[b] = y[b,:] . w + vb on the rows of group
-// `vgroup` (critic fc3, actor_critic.py:206-210) in the same pass -- the head's own launch re-read 8 MB to do
+// `vgroup` (critic fc3, actor_critic.py:206-210; vgroup < 0: every group has its own head, vw [G,H], vb [G], v [G*B] --
+// the twin Q networks of SAC, sac.py:123-139) in the same pass -- the head's own launch re-read 8 MB to do
 // 2 flops per element.  One wave per row, four rows in flight; the dot product is accumulated exactly like
 // k_value_head_fwd (lane partial over i = lane, lane+64, ..; wave_sum), so both paths agree bit for bit.
 __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, const float* __restrict__ bias, int rows,
                                                         int H, int group_rows, int relu6, int vgroup,
                                                         const float* __restrict__ vw, const float* __restrict__ vb,
-                                                        float* __restrict__ v) {
+                                                        int vb_stride, float* __restrict__ v) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int r0 = wave * 4;
     if (r0 >= rows) return;
     const int H4 = H >> 2;
     const int g = group_rows > 0 ? r0 / group_rows : 0;          // group_rows % 4 == 0: the four rows share a group
-    const bool head = g == vgroup;
+    const bool all = vgroup < 0;                                  // every group carries its own head (twin Q networks)
+    const bool head = all || g == vgroup;
     const float4* b4 = reinterpret_cast<const float4*>(bias + (size_t)g * H);
-    const float4* w4 = reinterpret_cast<const float4*>(vw);
+    const float4* w4 = reinterpret_cast<const float4*>(vw + (all ? (size_t)g * H : 0));
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = lane; i < H4; i += 64) {
         float4 t[4];
@@ -818,12 +820,12 @@ __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, c
         }
     }
     if (!head) return;
-    const float b0 = vb[0];
+    const float b0 = vb[all ? g * vb_stride : 0];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float sacc = wave_sum(acc[j]);
         const int r = r0 + j;
-        if (lane == 0 && r < rows) v[r - vgroup * group_rows] = sacc + b0;
+        if (lane == 0 && r < rows) v[all ? r : r - vgroup * group_rows] = sacc + b0;
     }
 }
 
@@ -841,7 +843,9 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial_value(const float* __re
     const int c4 = blockIdx.x * 64 + cl;
     const int H4 = H >> 2;
     const int ch = blockIdx.y;
-    const bool head = (int)blockIdx.z == vgroup;
+    const bool all = vgroup < 0;                                  // every group has a head: vw [G,H], dv [G*grows],
+    const bool head = all || (int)blockIdx.z == vgroup;           // vpartial [G][chunks][H]
+    if (all) { vw += (size_t)blockIdx.z * H; dv += (size_t)blockIdx.z * grows; vpartial += (size_t)blockIdx.z * gridDim.y * H; }
     const size_t goff = (size_t)blockIdx.z * grows * H4;
     const int b0 = ch * chunk_len, b1 = min(grows, b0 + chunk_len);
     const float4* y4 = reinterpret_cast<const float4*>(y) + goff;
@@ -1152,15 +1156,15 @@ int pfpn_state_moment_chunks(int B) {
 }
 
 int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_rows, int relu6, int value_group,
-                        const float* value_w, const float* value_b, float* v, void* stream) {
+                        const float* value_w, const float* value_b, int value_b_stride, float* v, void* stream) {
     PFPN_BEGIN();
     if (!y || !bias || !value_w || !value_b || !v || rows < 1 || H < 4 || (H & 3) || ((uintptr_t)y & 15) ||
         ((uintptr_t)bias & 15) || ((uintptr_t)value_w & 15) || group_rows < 4 || (group_rows & 3) || rows % group_rows ||
-        value_group < 0 || value_group >= rows / group_rows)
+        value_group >= rows / group_rows || value_b_stride < 1)
         return PFPN_ERR_ARG;
     const int waves = (rows + 3) / 4;
     hipLaunchKernelGGL(k_bias_act_value, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, bias, rows, H,
-                       group_rows, relu6, value_group, value_w, value_b, v);
+                       group_rows, relu6, value_group, value_w, value_b, value_b_stride, v);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
@@ -1182,7 +1186,7 @@ int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_r
     *chunks_per_group = cpg;
     hipStream_t st = (hipStream_t)stream;
     if (value_w) {
-        if (!dvalue || !value_partial || !relu6 || value_group < 0 || value_group >= G || ((uintptr_t)value_w & 15))
+        if (!dvalue || !value_partial || !relu6 || value_group >= G || ((uintptr_t)value_w & 15))
             return PFPN_ERR_ARG;
         hipLaunchKernelGGL(k_act_bwd_partial_value, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy, grows,
                            H, len, partial, value_group, value_w, dvalue, value_partial);

@@ -432,6 +432,17 @@ static inline int stats_chunks(int B) {
     return C;
 }
 
+// Gumbel noise of the relaxed one-hot draw from uniforms, in place: g = -log(-log(max(u, tiny)))
+// (TFP 0.7 ExpRelaxedOneHotCategorical's sampler behind utils.py:96, :156-160).  One launch instead of the five
+// elementwise passes (clamp, log, neg, log, neg) the same transform takes as tensor ops.
+__global__ __launch_bounds__(256) void k_gumbel_inplace(float* __restrict__ u, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float v = fmaxf(u[i], 1.17549435e-38f);
+        u[i] = -logf(-logf(v));
+    }
+}
+
 }  // namespace pfpn
 
 using namespace pfpn;
@@ -529,6 +540,17 @@ int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, 
     const int S = B * A;
     hipLaunchKernelGGL(k_entropy_bwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, dH, S, N,
                        accumulate, dlogits);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_gumbel_from_uniform(float* u, size_t n, void* stream) {
+    PFPN_BEGIN();
+    if (!u) return PFPN_ERR_ARG;
+    if (n == 0) return PFPN_OK;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_gumbel_inplace, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, u, n);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -8,6 +8,8 @@ the graph: the resample kernels run eagerly between replays.
 """
 import torch
 
+from . import kernels
+
 
 def refill_noise(noise, generator):
     """fresh draws into static noise buffers, same distributions as MixtureGaussianDistribution.make_noise /
@@ -16,8 +18,7 @@ def refill_noise(noise, generator):
         if k == "u_cat":
             t.uniform_(generator=generator)
         elif k.startswith("gumbel"):
-            t.uniform_(generator=generator).clamp_(min=float(torch.finfo(torch.float32).tiny))
-            torch.log(t, out=t); t.neg_(); torch.log(t, out=t); t.neg_()
+            kernels.gumbel_from_uniform_(t.uniform_(generator=generator))
         else:
             t.normal_(generator=generator)
 

@@ -301,6 +301,13 @@ def rsample_bwd(logits, loc, logstd, gumbel, eps, da, ds, dlogits=None, dloc=Non
     return dlogits, dloc, dlogstd
 
 
+def gumbel_from_uniform_(u):
+    """in place: u in [0,1) -> Gumbel(0,1) noise -log(-log(max(u, tiny))), one launch."""
+    lib = _lib.load()
+    _lib.check(lib.pfpn_gumbel_from_uniform(_f32(u), u.numel(), _stream()), "pfpn_gumbel_from_uniform")
+    return u
+
+
 def resample(loc, logstd, bias, weight, max_active, sum_active, u_resample, u_noise, threshold=0.0,
              tanh_mode=False, topk=0):
     """In place on loc/logstd/bias/weight.  Returns (dead [A,N] int32, src [A,N] int32).
@@ -416,12 +423,17 @@ def mixture_workspace(B, A, N, device):
 
 
 def bias_act_value(y, bias, group_rows, value_group, value_w, value_b, v, relu6=True):
-    """last trunk layer: y <- act(y + bias) and v = y[value_group] . value_w + value_b in ONE pass."""
+    """last trunk layer: y <- act(y + bias) and v = y[value_group] . value_w + value_b in ONE pass.
+    value_group = -1: every group has its own head -- value_w [G,H], value_b [G], v [G, group_rows]."""
     lib = _lib.load()
     rows, H = y.shape
+    nh = rows // group_rows if value_group < 0 else 1
+    bstride = value_b.stride(0) if (value_group < 0 and value_b.dim() == 2) else 1      # [G, pad]: bias at [g, 0]
+    if value_b.numel() < (nh - 1) * bstride + 1:
+        raise ValueError("value_b too short")
     _lib.check(lib.pfpn_bias_act_value(_f32(y, rows, H), _f32(bias), rows, H, int(group_rows), int(relu6),
-                                       int(value_group), _f32(value_w.view(-1), H), _f32(value_b.view(-1), 1),
-                                       _f32(v, group_rows), _stream()), "pfpn_bias_act_value")
+                                       int(value_group), _f32(value_w.view(-1), nh * H), _f32(value_b), int(bstride),
+                                       _f32(v.view(-1), nh * group_rows), _stream()), "pfpn_bias_act_value")
     return v
 
 
@@ -431,8 +443,13 @@ def act_bwd_partial(y, dy, group_rows, ws, relu6=True, value=None):
     lib = _lib.load()
     rows, H = dy.shape
     cpg = ctypes.c_int(0)
-    vg, vw, dv, vws = (value[0], _f32(value[1].view(-1), H), _f32(value[2], group_rows or rows),
-                       value[3].data_ptr()) if value is not None else (0, None, None, None)
+    vg, vw, dv, vws = 0, None, None, None
+    if value is not None:
+        nh = rows // group_rows if value[0] < 0 else 1
+        if value[3].numel() < 4 * nh * 1024 * H:
+            raise ValueError("value-head partial workspace too small")
+        vg, vw, dv, vws = (value[0], _f32(value[1].view(-1), nh * H), _f32(value[2].view(-1), nh * (group_rows or rows)),
+                           value[3].data_ptr())
     _lib.check(lib.pfpn_act_bwd_partial(_f32(y, rows, H) if y is not None else None, _f32(dy, rows, H), rows, H,
                                         int(group_rows), int(relu6), int(vg), vw, dv, vws, ws.data_ptr(),
                                         ws.numel() // 4, ctypes.addressof(cpg), _stream()), "pfpn_act_bwd_partial")

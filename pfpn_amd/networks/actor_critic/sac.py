@@ -8,6 +8,8 @@ Q loss (:160-164), policy loss with target_entropy = -|A| (:166-173), soft targe
 hard sync at init (:75-86), `run` -> [action] (:91-95), `train` feed (:97-105).
 The policy sample is the Gumbel-softmax rsample branch of MixtureGaussianDistribution (utils.py:156-186).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -144,12 +146,12 @@ def sac_network_wrapper(base_class):
             self.sac_out = {"dq_pi": f(2, B), "dq_run": f(2, B), "dlogp": f(B), "dlog_alpha": self.store.g("alpha/log_alpha"),
                             "loss3": f(3)}
             self.scratch_w3, self.scratch_b3 = f(hc), f(1)
+            self.ws_pbias = kernels.learner_workspace(B, AN, dev)      # private: deferred fc_policy bias gradient
 
         # -- rollout ----------------------------------------------------------------------------------
         def _actor_logits(self, x, slot, out):
             ha = self.actor_trunk.forward(x, slot=slot)[0]
-            torch.mm(ha, self.policy_weight, out=out)
-            kernels.bias_act(out, self.policy_bias, relu6=False)
+            torch.addmm(self.policy_bias, ha, self.policy_weight, out=out)     # bias in the GEMM epilogue
             return ha
 
         def run_batch(self, states, noise=None, running_update=True):
@@ -179,22 +181,33 @@ def sac_network_wrapper(base_class):
             raise NotImplementedError("SAC has no state-value head; the SAC worker never calls evaluate()")
 
         # -- learner step -----------------------------------------------------------------------------
-        def _q_forward(self, xin, slot, out, target=False):
+        def _q_forward(self, xin, slot, out, target=False, fold=False):
             params = self.target_store if target else None
-            h = self.q_stack.forward(xin, slot=slot, params=params)
             w3 = (self.target_store if target else self.store)["critic/q1+critic/q2|fc3/weight"]
             b3 = (self.target_store if target else self.store)["critic/q1+critic/q2|fc3/bias"]
+            if fold:       # both Q heads inside the last trunk layer's epilogue pass
+                return self.q_stack.forward(xin, slot=slot, params=params, value_head=(-1, w3, b3, out))
+            h = self.q_stack.forward(xin, slot=slot, params=params)
             for g in range(2):
                 kernels.value_head_fwd(h[g], w3[g], b3[g], out=out[g])
             return h
 
+        def _deferred_jobs(self, B, fused_mixture=False):
+            """[] when the step's small reductions (bias gradients, both Q heads, the normaliser EMA) can wait for ONE
+            launch at the end of the backward pass (PFPN_DEFER_REDUCE=0 disables), else None."""
+            ok = self._defer_ok.get(B)
+            if ok is None:
+                ok = B % 4 == 0 and not self.overlap_ema and not self.overlap_aux and not self.overlap_dw and \
+                    self.state_normalizer is not None and self.normalize_state and self.q_stack.L > 1 and \
+                    os.environ.get("PFPN_DEFER_REDUCE", "1") != "0" and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+                self._defer_ok[B] = ok
+            return [] if ok else None
+
         def make_train_noise(self, B):
             AN = self.n_actions * self.particles
-            tiny = float(np.finfo(np.float32).tiny)
             out = {}
             for k in ("gumbel", "gumbel_"):
-                u = torch.rand(B, AN, device=self.device, generator=self.rng).clamp_(min=tiny)
-                out[k] = -torch.log(-torch.log(u))
+                out[k] = kernels.gumbel_from_uniform_(torch.rand(B, AN, device=self.device, generator=self.rng))
             for k in ("eps", "eps_"):
                 out[k] = torch.randn(B, AN, device=self.device, generator=self.rng)
             return out
@@ -206,9 +219,15 @@ def sac_network_wrapper(base_class):
             if not self._target_initialised:
                 self.sync_target_net_hard()
             noise = noise or self.make_train_noise(B)
-            x = self._normalize(state)
-            x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
-            self.update_state_normalizer(state)        # side stream, joined in the optimiser
+            deferred = self._deferred_jobs(B)
+            if deferred is not None:
+                x = self.prologue(state, deferred=deferred)      # normalise + moments in one launch, EMA as a job
+                x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
+            else:
+                x = self._normalize(state)
+                x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
+                self.update_state_normalizer(state)        # side stream, joined in the optimiser
+            fold = deferred is not None
             # eval actor on s, shared actor on s' (sac.py:141-153)
             ha = self._actor_logits(x, 0, self.logits)
             self._actor_logits(x2, 1, self.logits2)
@@ -220,25 +239,31 @@ def sac_network_wrapper(base_class):
             self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
             # Q inputs
             for buf, xs, act in ((self.xa, x, a), (self.xh, x, action), (self.xa2, x2, a2)):
-                buf[:, :S].copy_(xs)
-                buf[:, S:].copy_(act)
-            hq_pi = self._q_forward(self.xa, 0, self.q_pi)
-            hq_run = self._q_forward(self.xh, 1, self.q_run)
-            self._q_forward(self.xa2, 2, self.q_tgt, target=True)
+                torch.cat((xs, act), dim=1, out=buf)
+            hq_pi = self._q_forward(self.xa, 0, self.q_pi, fold=fold)
+            hq_run = self._q_forward(self.xh, 1, self.q_run, fold=fold)
+            self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
             out = kernels.sac_loss(self.q_pi, self.q_run, self.q_tgt, logp, logp2, reward, not_terminal,
                                    self.log_alpha, self.gamma, self.value_loss_coef, -float(A), self.sac_out)
             # critic gradients (value loss through Q(s, action_hist))
             gw3, gb3 = st.g("critic/q1+critic/q2|fc3/weight"), st.g("critic/q1+critic/q2|fc3/bias")
             gb3.zero_()
-            for g in range(2):
-                kernels.value_head_bwd(hq_run[g], self.q_w3[g], out["dq_run"][g], self.dh_run[g], gw3[g],
-                                       gb3[g, :1], relu6=True)
-            self.q_stack.backward(self.dh_run, slot=1, need_dw=True)
-            # actor gradients: through Q(s, a_pi) to the action only (Q parameters are skipped, sac.py:167)
-            for g in range(2):
-                kernels.value_head_bwd(hq_pi[g], self.q_w3[g], out["dq_pi"][g], self.dh_pi[g], self.scratch_w3,
-                                       self.scratch_b3, relu6=True)
-            dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True)
+            if fold:
+                # both heads' backward inside the trunks' last-layer passes; bias-gradient sums become jobs
+                self.q_stack.backward(self.dh_run, slot=1, need_dw=True, deferred=deferred,
+                                      value=(-1, self.q_w3, out["dq_run"], gw3, gb3))
+                dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True, deferred=deferred,
+                                            value=(-1, self.q_w3, out["dq_pi"], None, None))
+            else:
+                for g in range(2):
+                    kernels.value_head_bwd(hq_run[g], self.q_w3[g], out["dq_run"][g], self.dh_run[g], gw3[g],
+                                           gb3[g, :1], relu6=True)
+                self.q_stack.backward(self.dh_run, slot=1, need_dw=True)
+                # actor gradients: through Q(s, a_pi) to the action only (Q parameters are skipped, sac.py:167)
+                for g in range(2):
+                    kernels.value_head_bwd(hq_pi[g], self.q_w3[g], out["dq_pi"][g], self.dh_pi[g], self.scratch_w3,
+                                           self.scratch_b3, relu6=True)
+                dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True)
             da = dxa[:, S:].contiguous()
             dlogits, dloc, dlogstd, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True)
             dlogits = dlogits.view(B, -1)
@@ -247,9 +272,16 @@ def sac_network_wrapper(base_class):
             st.g("actor/samples").copy_(dloc)
             st.g("actor/samples_std").copy_(dlogstd)
             torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
-            kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+            gpb = st.g("actor/fc_policy/bias")
+            if fold:
+                cpg = kernels.act_bwd_partial(None, dlogits, 0, self.ws_pbias, relu6=False)
+                deferred.append(kernels.job_colsum(self.ws_pbias, 0, cpg, dlogits.shape[1], dlogits.shape[1], gpb))
+            else:
+                kernels.act_bwd_bias_grad(None, dlogits, gpb, relu6=False)
             torch.mm(dlogits, self.policy_weight.t(), out=self.dha[0])
-            self.actor_trunk.backward(self.dha, slot=0)
+            self.actor_trunk.backward(self.dha, slot=0, deferred=deferred)
+            if fold:
+                kernels.reduce_jobs(deferred)
             return out["loss3"]
 
         def train_device(self, optimizer, state, action, reward, not_terminal, state_, noise=None):

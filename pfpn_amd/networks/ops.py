@@ -180,7 +180,7 @@ class DenseStack:
         if buf["ws"] is None:
             B = buf["B"]
             buf["ws"] = [kernels.learner_workspace(self.G * B, a.shape[1], self.store.device) for a in buf["act2d"]]
-            buf["ws_value"] = kernels.learner_workspace(B, self.dims[-1], self.store.device)
+            buf["ws_value"] = kernels.learner_workspace(self.G * B, self.G * self.dims[-1], self.store.device)
         return buf["ws"], buf["ws_value"]
 
     @property
@@ -220,7 +220,11 @@ class DenseStack:
                 kernels.bias_act(act2d[i], b, relu6=True, group_rows=self._group_rows(i, B))
         if value_head is not None:
             g, vw, vb, vout = value_head
-            kernels.value_head_fwd(act[-1][g], vw.view(-1), vb, out=vout)
+            if g < 0:
+                for gi in range(self.G):
+                    kernels.value_head_fwd(act[-1][gi], vw[gi].view(-1), vb[gi].view(-1), out=vout[gi])
+            else:
+                kernels.value_head_fwd(act[-1][g], vw.view(-1), vb, out=vout)
         return act[-1]
 
     def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None):
@@ -230,6 +234,8 @@ class DenseStack:
         tensor is appended instead of being launched (the caller runs `kernels.reduce_jobs(deferred)` once).
         `value` = (group, w, dvalue [B], grad_w, grad_b) (with `deferred` only): the backward of a scalar head on that
         group's output is folded into the last layer's pass -- dlast[group] is formed as dvalue (x) w, not read.
+        group = -1: a head on EVERY group (w [G,H], dvalue [G,B], grad_w [G,H], grad_b [G,1]; twin Q networks).
+        With need_dw=False the partial sums are left unreduced (no jobs; grad_w / grad_b may be None).
         Weight/bias gradients are written into the store's flat gradient buffer (need_dw).
         `dw_stream`: run the weight-gradient GEMMs (independent of the dX chain) on that stream so they
         overlap the next layer's dX GEMM; the caller joins the stream before using the gradients."""
@@ -248,11 +254,12 @@ class DenseStack:
             with torch.cuda.stream(dw_stream):
                 return fn()
 
-        if value is not None and (deferred is None or not need_dw or not self._group_rows(self.L - 1, B)):
+        if value is not None and (deferred is None or not self._group_rows(self.L - 1, B)):
             raise ValueError("a folded value head needs deferred reductions on a batched last layer")
         for i in reversed(range(self.L)):
             w = self.store[self.wn[i]]
-            if deferred is not None and need_dw:
+            if deferred is not None:
+                # need_dw=False (gradient w.r.t. the input only): the partials are simply never reduced
                 ws, ws_value = self._slab_workspaces(buf)
                 grows, H = self._group_rows(i, B), act2d[i].shape[1]
                 fold = None
@@ -260,14 +267,19 @@ class DenseStack:
                     fold = (value[0], value[1], value[2], ws_value)
                 cpg = kernels.act_bwd_partial(act2d[i], d2d, grows, ws[i], relu6=True, value=fold)
                 gb = self.store.g(self.bn[i])
-                if grows:
+                if need_dw and grows:
                     for g in range(self.G):
                         deferred.append(kernels.job_colsum(ws[i], g * cpg * H, cpg, H, H, gb[g]))
-                else:
+                elif need_dw:
                     deferred.append(kernels.job_colsum(ws[i], 0, cpg, H, H, gb.view(-1)))
-                if fold is not None:
-                    deferred.append(kernels.job_colsum(ws_value, 0, cpg, H, H, value[3].view(-1)))
-                    deferred.append(kernels.job_vecsum(value[2], value[4].view(-1)))
+                if fold is not None and need_dw:
+                    if value[0] < 0:        # a head per group: grad_w [G,H], grad_b [G,>=1], dvalue [G,B]
+                        for g in range(self.G):
+                            deferred.append(kernels.job_colsum(ws_value, g * cpg * H, cpg, H, H, value[3][g].view(-1)))
+                            deferred.append(kernels.job_vecsum(value[2][g], value[4][g].view(-1)[:1]))
+                    else:
+                        deferred.append(kernels.job_colsum(ws_value, 0, cpg, H, H, value[3].view(-1)))
+                        deferred.append(kernels.job_vecsum(value[2], value[4].view(-1)))
             else:
                 kernels.act_bwd_bias_grad(act2d[i], d2d,
                                           self.store.g(self.bn[i]) if need_dw else self._scratch_bias(i),

@@ -69,8 +69,7 @@ class MixtureGaussianDistribution(object):
         B, dev = self.batch, self.logits.device
         if self.normalize_output:
             # TFP 0.7 ExpRelaxedOneHotCategorical: u ~ U(tiny, 1), g = -log(-log u)
-            u = torch.rand(B, self.A * self.N, device=dev, generator=generator).clamp_(min=float(np.finfo(np.float32).tiny))
-            gumbel = -torch.log(-torch.log(u))
+            gumbel = kernels.gumbel_from_uniform_(torch.rand(B, self.A * self.N, device=dev, generator=generator))
             eps = torch.randn(B, self.A * self.N, device=dev, generator=generator)
             return {"gumbel": gumbel, "eps": eps}
         u = torch.rand(B, self.A, device=dev, dtype=torch.float64, generator=generator)

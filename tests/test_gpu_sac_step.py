@@ -126,3 +126,48 @@ def test_sac_step_as_graph_matches_eager(dev):
         assert torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
         assert torch.equal(nets[0].target_store.flat, nets[1].target_store.flat)
         assert nets[0].global_step == nets[1].global_step == it + 1
+
+
+@pytest.mark.parametrize("B", [64, 1024])
+def test_sac_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
+    """SAC step with both Q heads folded into the trunk epilogues and ONE deferred reduction launch == the step that
+    launches every head / bias-gradient reduction / EMA on its own (same draws): same bits."""
+    from pfpn_amd.models import SyncReplicasApplier
+    rng = np.random.default_rng(B)
+    nets, opts = [], []
+    for _ in range(2):
+        net = make_net(dev)
+        nets.append(net)
+        opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                              {"names": net.actor_param_names(), "lr": 1e-4}],
+                                        norm_clip=1.0, world_size=1))
+    for it in range(3):
+        batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                       rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                       rng.normal(0.5, 0.3, B).astype(F),
+                                                       (rng.uniform(size=B) > 0.05).astype(F),
+                                                       (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
+        noise = nets[0].make_train_noise(B)
+        losses = []
+        for i, (net, opt) in enumerate(zip(nets, opts)):
+            monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
+            losses.append(net.compute_gradients(*batch, {k: t.clone() for k, t in noise.items()}).clone())
+            assert net._defer_ok[B] is (i == 0)
+            g = net.store.grad.clone()
+            opt.apply(net)
+            losses.append(g)
+        assert torch.equal(losses[0], losses[2]), it
+        assert torch.equal(losses[1], losses[3]), it
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat)
+        assert torch.equal(nets[0].q_pi, nets[1].q_pi) and torch.equal(nets[0].q_tgt, nets[1].q_tgt)
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+
+
+def test_gumbel_transform_matches_tensor_ops(dev):
+    from pfpn_amd import kernels
+    u = torch.rand(1000, 1260, device=dev)
+    u[0, 0] = 0.0                                      # clamped to FLT_MIN like TFP's minval=tiny
+    ref = -torch.log(-torch.log(u.clamp(min=float(np.finfo(np.float32).tiny))))
+    g = kernels.gumbel_from_uniform_(u.clone())
+    assert torch.isfinite(g).all()
+    torch.testing.assert_close(g, ref, rtol=2e-6, atol=2e-6)

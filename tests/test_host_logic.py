@@ -160,8 +160,10 @@ def test_out_of_scope_options_raise():
                 action_upper_bound=[1, 1], common_net_shape=[], critic_net_shape=[8], actor_net_shape=[8])
     with pytest.raises(NotImplementedError):
         ParticleFilteringClipPPONetwork(normalize_value=True, **base)
+    with pytest.raises(ValueError):                                 # a2c.py:390 asserts n >= resample
+        ParticleFilteringClipPPONetwork(resample=51, **base)
     with pytest.raises(NotImplementedError):
-        ParticleFilteringClipPPONetwork(resample=3, **base)
+        ParticleFilteringClipPPONetwork(resample=3, fixed_sigma=0.1, **base)
     with pytest.raises(NotImplementedError):
         ParticleFilteringClipPPONetwork(**dict(base, common_net_shape=[16]))
 
