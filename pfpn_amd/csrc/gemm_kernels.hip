@@ -9,27 +9,32 @@
 // so the separate bias/activation/mask/bias-grad passes over the activations (~95 us of a 600 us learner step)
 // disappear into the GEMMs.
 //
-// STATUS (round 1): parity-green (tests/test_gpu_gemm.py) but NOT the default dense path yet: measured 87-90 TFLOP/s
-// on the 2 x [4096x1024x512] layer against 118-128 for hipBLASLt's MT128x128x64 kernel with the same
-// v_mfma_f32_16x16x4_f32 count (a bare MFMA loop of this shape tops out at ~109 TFLOP/s here, the clock drops under
-// load), so the fused epilogues (~94 us/step) only break even.  The learner uses PyTorch-ROCm GEMMs + the
-// streaming epilogue kernels of learner_kernels.hip; these kernels stay as the base for the next round.
+// STATUS (round 1): parity-green (tests/test_gpu_gemm.py) but NOT the default dense path: 88-90 TFLOP/s on the
+// 2 x [4096x1024x512] layer against 125-142 for the hipBLASLt kernels TunableOp picks (MT128x64x32, two workgroups
+// per CU).  What the measurements say (tools/gemm_probe3.py): the MFMA shape does not matter (16x16x4 and 32x32x2
+// give the same rate), neither does the XCD-aware tile order (the operands of this layer fit the L2s either way);
+// with the global loads and LDS stores removed the loop runs at 108 TFLOP/s and with the fragment reads removed too
+// at 115 -- with 256 tiles this kernel has ONE workgroup per CU (one wave per SIMD), so every wave's staging phase
+// and barrier idles its MFMA pipe.  A 128x64 tile (two resident workgroups, as hipBLASLt does) is the next step;
+// until it beats hipBLASLt + the streaming epilogue passes (~44 us of a 475 us step) the learner uses PyTorch-ROCm
+// GEMMs + learner_kernels.hip.
 //
-// Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 4x4 MFMA 16x16x4 tiles (64 accumulator
-// VGPRs, 16 independent chains: the 40-cycle dependent latency never stalls the 32-cycle issue).
+// Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 2x2 MFMA 32x32x2 tiles (64 accumulator
+// VGPRs, 4 independent chains: a chain is revisited every 4 x 64 cycles, far beyond the dependent latency).
 // LDS staging keeps EVERY store a direct float4 (no transposes, no swizzle arithmetic) and every fragment address
-// a per-thread base + compile-time immediate:
-//   * K-contiguous operand (rows of memory = rows of the tile): LDS [128][40]; an MFMA k-quad q takes, on lane
-//     row f = lane>>4, k = 4f + q (q < 4) or 16 + 4f + (q-4): each lane's 8 k-values are two float4s, so a
-//     whole k-step needs 2 ds_read_b128 per 16-row block (conflict-free at leading dim 40).
-//   * tile-contiguous operand (k indexes memory rows): LDS [32][132]; same k mapping, one ds_read_b32 per quad
-//     (132 = 4 mod 8 puts rows k and k+4 sixteen banks apart: conflict-free).
+// a per-thread base + compile-time immediate.  A k-tile of 32 is four chunks of 8; MFMA step q of a chunk multiplies
+// k = 8c + 4h + q on lane half h = lane >> 5:
+//   * K-contiguous operand (rows of memory = rows of the tile): LDS [128][36]; a lane's four k-values of a chunk are
+//     ONE ds_read_b128 per 32-row block (36 = 4 mod 32 floats: the 16 rows of a b128 lane group land on 16 disjoint
+//     16-B slots -- conflict-free);
+//   * tile-contiguous operand (k indexes memory rows): LDS [32][136]; one ds_read_b32 per step (rows k and k+4 are
+//     32 banks apart, so the two lane halves never share a bank).
 // Both operands of a product use the same k mapping, so the sum over k is unchanged (any bijection works).
-// LDS is double buffered (one barrier per k-step); the next k-tile is prefetched from HBM/L2 into registers and the
-// fragments of the next half k-step are read while the 64 MFMAs of the current half issue.
+// LDS is double buffered (one barrier per k-tile); the next k-tile is prefetched from HBM/L2 into registers and the
+// fragments of chunk c+1 are read while the 16 MFMAs of chunk c issue.  Workgroups are re-dealt so that each XCD works
+// a contiguous range of tiles (the column tiles of a row panel share its A operand in one L2).
 #include <cstdlib>
 #include "pfpn_common.h"
-#include <stdlib.h>
 
 namespace pfpn {
 
@@ -199,10 +204,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += GBK) {
         const float* Ac = buf ? As1 : As0;
         const float* Bc = buf ? Bs1 : Bs0;
-#ifndef GEMM_EXP
-#define GEMM_EXP 0
-#endif
-        if (!(GEMM_EXP & 1) && k0 + GBK < kend) {           // tile k+1 (in registers) -> the other buffer
+        if (k0 + GBK < kend) {                              // tile k+1 (in registers) -> the other buffer
             if (buf) GEMM_STORE(As0, Bs0); else GEMM_STORE(As1, Bs1);
             GEMM_FETCH(k0 + 2 * GBK);                       // tile k+2 in flight during the MFMAs (past the end: zeros)
         }
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
         opB.frags(fb[0], Bc, 0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (c < 3 && !(GEMM_EXP & 4)) {
+            if (c < 3) {
                 opA.frags(fa[(c + 1) & 1], Ac, c + 1);
                 opB.frags(fb[(c + 1) & 1], Bc, c + 1);
             }
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][i][q], fb[c & 1][j][q], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!(GEMM_EXP & 2)) __syncthreads();               // tile k consumed by everyone, tile k+1 fully stored
+        __syncthreads();                                    // tile k consumed by everyone, tile k+1 fully stored
         buf ^= 1;
     }
 #undef GEMM_FETCH
@@ -295,9 +297,7 @@ static void launch_gemm(const GemmArgs& g_in, int batch, hipStream_t st) {
     static const int remap = getenv("PFPN_GEMM_XCD_REMAP") ? atoi(getenv("PFPN_GEMM_XCD_REMAP")) : 1;
     g.xcd_remap = remap;
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch * (SPLITK ? g.ksplit : 1));
-    constexpr size_t lds_need = (size_t)2 * ((AKC ? KC_FLOATS : TC_FLOATS) + (BKC ? KC_FLOATS : TC_FLOATS)) * sizeof(float);
-    static const size_t lds_pad = getenv("PFPN_GEMM_LDS_PAD") ? (size_t)atoi(getenv("PFPN_GEMM_LDS_PAD")) : 0;
-    const size_t lds = lds_need + lds_pad;
+    constexpr size_t lds = (size_t)2 * ((AKC ? KC_FLOATS : TC_FLOATS) + (BKC ? KC_FLOATS : TC_FLOATS)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, EPI, SPLITK>),
