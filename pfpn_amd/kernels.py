@@ -14,7 +14,12 @@ _ws = {}
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of torch's current HIP stream (the private accessor is ~10x cheaper than building a Stream object,
+    and this runs once per kernel launch)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream().cuda_stream
 
 
 def _f32(t, *shape, name="tensor"):
@@ -29,8 +34,7 @@ def workspace(nbytes, device):
     """Grow-only per-device scratch buffer (never reallocated inside a captured region if it was
     sized by a warm-up call first)."""
     # one buffer per (device, stream): kernels on a side stream must not share slabs with the main stream
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
