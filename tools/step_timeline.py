@@ -1,11 +1,15 @@
 """Timeline of ONE learner step from a rocprofv3 --kernel-trace CSV: per kernel start offset, duration and the idle gap
-to the previous kernel's end.  Usage: python tools/step_timeline.py <kernel_trace.csv> [anchor-kernel-substring]
+to the previous kernel's end.  Usage: python tools/step_timeline.py <kernel_trace.csv | results.db> [anchor-kernel-substring]
 The step is delimited by consecutive launches of the anchor kernel (default: k_state_prologue)."""
 import csv, sys
 path = sys.argv[1]
 anchor = sys.argv[2] if len(sys.argv) > 2 else "k_state_prologue"
-rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
-rows.sort()
+if path.endswith(".db"):                      # rocprofv3's default rocpd database
+    import sqlite3
+    rows = list(sqlite3.connect(path).execute("select start, end, name from kernels order by start"))
+else:                                          # --output-format csv
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
+    rows.sort()
 idx = [i for i, r in enumerate(rows) if anchor in r[2]]
 if len(idx) < 3:
     sys.exit("anchor kernel not found often enough")
