@@ -101,15 +101,11 @@ def main():
     from pfpn_amd.networks import ParticleFilteringClipPPONetwork
     from pfpn_amd import kernels, graphs
 
+    tuned = None
     if not args.no_tune:
-        # let PyTorch pick the fastest rocBLAS/hipBLASLt solution per GEMM shape during the (untimed) warm-up
-        try:
-            torch.cuda.tunable.enable(True)
-            torch.cuda.tunable.set_max_tuning_duration(30)
-            torch.cuda.tunable.set_max_tuning_iterations(20)
-            torch.cuda.tunable.write_file_on_exit(False)
-        except Exception:
-            pass
+        # the GEMM selection found offline on an MI355X (tools/tune_gemms.py); shapes it lacks are tuned in the warm-up
+        from pfpn_amd.tuning import enable_tuned_gemms
+        tuned = enable_tuned_gemms(tune_missing=True)
     if args.one_device:
         os.environ["LOCAL_RANK"] = "0"
     rank, world, local_rank = init_process_group(args.backend if args.gpus > 1 else None)
@@ -173,6 +169,8 @@ def main():
                                    "(S=197, A=36, N=35, MLP 1024/512), random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B,
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "gemm_selection": ("shipped TunableOp file" if tuned else "TunableOp in warm-up") if not args.no_tune
+                       else "library default",
                        "step": "state-norm, MLP fwd (+critic head), fused mixture logp+PPO+bwd, MLP bwd, one deferred "
                                "reduction launch (bias grads, particle grads, loss, state-norm EMA), clip, "
                                + ("RCCL all-reduce, " if world > 1 else "") + "TF-Adam, resample tick"},

@@ -46,8 +46,12 @@ def parse(argv=None):
 
 
 def build(settings):
+    import os
     from . import models, networks
     from .envs import make_env
+    if os.environ.get("PFPN_TUNED_GEMMS", "1") != "0":       # shipped hipBLASLt / rocBLAS selection for the MLP GEMMs
+        from .tuning import enable_tuned_gemms
+        enable_tuned_gemms(tune_missing=True)
     worker = getattr(models, settings.worker)                # resolved by string name (main.py:56-58)
     network = getattr(networks, settings.network)
     model = getattr(models, settings.model)

@@ -1,0 +1,48 @@
+"""Offline GEMM selection for the learner step: run the step under PyTorch TunableOp with a generous budget, write the
+chosen hipBLASLt / rocBLAS solutions to a CSV, then time the step with exactly that file loaded and tuning OFF.
+Usage (GPU box): python tools/tune_gemms.py <out.csv> [iterations] ; the result is committed as
+pfpn_amd/tuned/tunableop_gfx950.csv and loaded by bench.py (pfpn_amd/tuning.py)."""
+import os, sys, time
+import numpy as np, torch
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+out = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+torch.cuda.tunable.enable(True)
+torch.cuda.tunable.tuning_enable(True)
+torch.cuda.tunable.set_max_tuning_duration(200)
+torch.cuda.tunable.set_max_tuning_iterations(iters)
+torch.cuda.tunable.set_filename(out)
+from test_gpu_dppo_step import make_net, make_batch
+from test_gpu_sac_step import make_net as make_sac
+from pfpn_amd.models import SyncReplicasApplier
+from pfpn_amd import graphs
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(0)
+
+
+def dppo(B):
+    net = make_net(dev)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    b = make_batch(rng, B); b["log_prob"] = np.full(B, -40.0, np.float32)
+    args = [torch.from_numpy(b[k]).to(dev) for k in ("state", "action", "value", "log_prob", "advantage")]
+    return net, opt, args
+
+
+net, opt, args = dppo(4096)
+for _ in range(3):
+    net.train_device(opt, *args)
+for B in (32, 64, 256, 1024):                      # minibatch sizes of the shipped settings / SAC replay batches
+    n2, o2, a2 = dppo(B)
+    for _ in range(2):
+        n2.train_device(o2, *a2)
+torch.cuda.synchronize()
+torch.cuda.tunable.tuning_enable(False)
+step = graphs.GraphedLearnerStep(net, opt, *args)
+for _ in range(20):
+    step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(300):
+    step()
+torch.cuda.synchronize()
+print("tuned file %s: %d entries; learner step %.1f us" % (out, len(torch.cuda.tunable.get_results()), (time.perf_counter() - t0) / 300 * 1e6))
