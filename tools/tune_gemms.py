@@ -36,6 +36,24 @@ for B in (32, 64, 256, 1024):                      # minibatch sizes of the ship
     n2, o2, a2 = dppo(B)
     for _ in range(2):
         n2.train_device(o2, *a2)
+# rollout inference (one state per call, and a pool of environments per call)
+for E in (1, 8, 64):
+    st = torch.randn(E, 197, device=dev)
+    for _ in range(2):
+        net.run_batch(st)
+# SAC-PFPN learner step at the reference's replay batch (256) and BASELINE.json config 3 (1024)
+for B in (256, 1024):
+    sac = make_sac(dev)
+    so = SyncReplicasApplier(sac, [{"names": sac.critic_param_names(), "lr": 1e-4}, {"names": sac.actor_param_names(), "lr": 1e-4}],
+                             norm_clip=1.0, world_size=1)
+    sb = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(np.float32),
+                                                rng.uniform(-0.9, 0.9, (B, 36)).astype(np.float32),
+                                                rng.normal(0.5, 0.3, B).astype(np.float32),
+                                                (rng.uniform(size=B) > 0.02).astype(np.float32),
+                                                (rng.normal(0, 1, (B, 197)) * 2).astype(np.float32))]
+    for _ in range(2):
+        sac.train_device(so, *sb)
+    sac.run_batch(torch.randn(1, 197, device=dev))
 torch.cuda.synchronize()
 torch.cuda.tunable.tuning_enable(False)
 step = graphs.GraphedLearnerStep(net, opt, *args)
