@@ -10,14 +10,19 @@
 // disappear into the GEMMs.
 //
 // STATUS (round 1): parity-green (tests/test_gpu_gemm.py) but NOT the default dense path: 88-90 TFLOP/s on the
-// 2 x [4096x1024x512] layer against 125-142 for the hipBLASLt kernels TunableOp picks (MT128x64x32, two workgroups
-// per CU).  What the measurements say (tools/gemm_probe3.py): the MFMA shape does not matter (16x16x4 and 32x32x2
-// give the same rate), neither does the XCD-aware tile order (the operands of this layer fit the L2s either way);
-// with the global loads and LDS stores removed the loop runs at 108 TFLOP/s and with the fragment reads removed too
-// at 115 -- with 256 tiles this kernel has ONE workgroup per CU (one wave per SIMD), so every wave's staging phase
-// and barrier idles its MFMA pipe.  A 128x64 tile (two resident workgroups, as hipBLASLt does) is the next step;
-// until it beats hipBLASLt + the streaming epilogue passes (~44 us of a 475 us step) the learner uses PyTorch-ROCm
-// GEMMs + learner_kernels.hip.
+// 2 x [4096x1024x512] layer against 125-143 for the hipBLASLt kernels TunableOp picks (MT128x64x32 MI16x16x4).
+// What the measurements say (tools/gemm_probe3.py, tools/mfma_probe.hip, in-kernel s_memtime stamps):
+//   * one wave per SIMD issuing nothing but MFMAs reaches 156 TFLOP/s (99 % of peak) with either fp32 MFMA shape, even
+//     on a single dependent accumulator chain: occupancy and the MFMA shape are not the limit, and indeed 16x16x4 and
+//     32x32x2 give this kernel the same rate, as does the XCD-aware tile order (the operands fit the L2s either way);
+//   * inside this kernel the core clock sits at ~2.0 GHz (2.24-2.38 GHz in the pure MFMA loop), a k-tile of 64 MFMAs
+//     (4096 cycles) takes ~5500 cycles -- the chunk that carries the 8 LDS stores +730, the chunk with the 8 global
+//     loads +300, pure fragment+MFMA chunks +110 each, barrier +125 -- and the epilogue 9 us (128-B row segments);
+//   * a fully hand-interleaved variant of the loop (branch-free clamped loads whose k-tail mask is applied at LDS-store
+//     time, every LDS store / global load / fragment read placed in an MFMA shadow, barrier before the last chunk) was
+//     built and is bit-exact, but no faster (90-98 us): at 2.0 GHz even a stall-free loop needs ~70 us here, which only
+//     ties hipBLASLt (60-64 us) + the streaming epilogue pass (7.5 us) it would replace.
+// So the learner keeps PyTorch-ROCm GEMMs + learner_kernels.hip; these kernels stay as the fused-epilogue base.
 //
 // Tiling: 128x128x32 block tile, 256 threads = 2x2 waves, each wave 64x64 = 2x2 MFMA 32x32x2 tiles (64 accumulator
 // VGPRs, 4 independent chains: a chain is revisited every 4 x 64 cycles, far beyond the dependent latency).
