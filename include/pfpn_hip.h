@@ -287,12 +287,14 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
  * the mean of the clipped gradients is applied): pfpn_clip_scale_inplace scales grads by the clip factor (2 launches;
  * with beta_pow it also rotates the Adam powers exactly as pfpn_clip_adam's first launch does), then -- after the
  * caller's all-reduce (sum) -- pfpn_adam_groups applies TF-Adam with grad_mul = 1/W, using the "used" pair of
- * beta_pow, and bumps step_counter (1 launch). */
+ * beta_pow, and bumps step_counter (1 launch); scale_buf[0..scale_n) *= scale_mul in the same launch (the replicated
+ * statistics in the bucket tail: sums -> replica means, sync_model.py:37-46; scale_n = 0: none). */
 int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm_scale, float* beta_pow, int n_groups,
                             float beta1, float beta2, void* workspace, size_t workspace_bytes, void* stream);
 int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                      const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
-                     float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter, void* stream);
+                     float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter,
+                     float* scale_buf, size_t scale_n, float scale_mul, void* stream);
 /* SAC loss head -- sac.py:123-139 (vf_target, q_target) and :160-173 (Q and policy losses).
  * q_pi, q_run, q_tgt are [2,B] (Q1 row then Q2 row): Q(s, a_pi), Q(s, action_hist), Q'(s', a').
  * Outputs dq_pi [2,B] (d policy_loss/dQ through tf.minimum), dq_run [2,B] (d value_loss/dQ),

@@ -675,8 +675,13 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
                                                    float b1, float b2, float eps, const float* __restrict__ beta_pow,
                                                    const float* __restrict__ partial, int nblk, float clip_norm,
                                                    float grad_mul, float* __restrict__ norm_scale,
-                                                   float* __restrict__ step) {
+                                                   float* __restrict__ step, float* __restrict__ scale_buf = nullptr,
+                                                   size_t scale_n = 0, float scale_mul = 1.f) {
     __shared__ float red[4];
+    // data parallel: the replicated statistics behind the gradients in the all-reduce bucket turn from sums into
+    // replica means here (sync_model.py:37-46 push_weights) instead of in a launch of their own
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < scale_n; i += (size_t)gridDim.x * blockDim.x)
+        scale_buf[i] *= scale_mul;
     float gs = 1.0f;
     if (nblk > 0) {
         // every block forms the same scale from the same partial sums, in k_clip_scale's order
@@ -1347,10 +1352,11 @@ int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm
 
 int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                      const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
-                     float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter, void* stream) {
+                     float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter,
+                     float* scale_buf, size_t scale_n, float scale_mul, void* stream) {
     PFPN_BEGIN();
     if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || n < 1 || n_groups < 1 ||
-        n_groups > 4)
+        n_groups > 4 || (scale_n > 0 && !scale_buf))
         return PFPN_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
     AdamGroups gr{};
@@ -1365,7 +1371,7 @@ int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size
     }
     hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
                        v, gr, beta1, beta2, eps, beta_pow, (const float*)nullptr, 0, 0.f, grad_mul, (float*)nullptr,
-                       step_counter);
+                       step_counter, scale_buf, scale_n, scale_mul);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -582,14 +582,17 @@ def clip_scale_inplace(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0
 
 
 def adam_groups(params, grads, m, v, group_off, group_len, group_lr, beta_pow, grad_mul=1.0, beta1=0.9, beta2=0.999,
-                eps=1e-8, step_counter=None):
-    """TF-Adam of every parameter group in one launch, on the powers pfpn_clip_scale_inplace / pfpn_clip_adam rotated."""
+                eps=1e-8, step_counter=None, scale=None, scale_mul=1.0):
+    """TF-Adam of every parameter group in one launch, on the powers pfpn_clip_scale_inplace / pfpn_clip_adam rotated.
+    `scale` (a float tensor): multiplied by `scale_mul` in the same launch (bucket-tail statistics -> replica means)."""
     lib = _lib.load()
     G = len(group_lr)
     _lib.check(lib.pfpn_adam_groups(_f32(params), _f32(grads), _f32(m), _f32(v), params.numel(), G,
                                     ctypes.addressof(group_off), ctypes.addressof(group_len), ctypes.addressof(group_lr),
                                     float(beta1), float(beta2), float(eps), _f32(beta_pow, G, 4), float(grad_mul),
-                                    _f32(step_counter, 1) if step_counter is not None else None, _stream()),
+                                    _f32(step_counter, 1) if step_counter is not None else None,
+                                    _f32(scale) if scale is not None else None,
+                                    scale.numel() if scale is not None else 0, float(scale_mul), _stream()),
                "pfpn_adam_groups")
 
 

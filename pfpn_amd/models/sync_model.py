@@ -80,9 +80,12 @@ class SyncReplicasApplier(object):
             # sum with 1/W folded in (1 launch), statistics <- mean (1 launch)
             kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2)
             self.reduce(net)
+            in_tail = getattr(net, "_stats_in_tail", False) and st.tail.numel() > 0
             kernels.adam_groups(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
-                                1.0 / W, self.beta1, self.beta2, self.epsilon, step_counter=net.step_dev)
-            net.unpack_synced_stats(st.tail, 1.0 / W)
+                                1.0 / W, self.beta1, self.beta2, self.epsilon, step_counter=net.step_dev,
+                                scale=st.tail if in_tail else None, scale_mul=1.0 / W)
+            if not in_tail:
+                net.unpack_synced_stats(st.tail, 1.0 / W)
             return
         if self.norm_clip:
             # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica
