@@ -30,7 +30,8 @@ class GraphedLearnerStep(object):
     replay -- random draws stay outside the graph."""
 
     def __init__(self, net, optimizer, *inputs, warmup=3, noise=None):
-        assert optimizer.world == 1, "graph capture covers the single-GPU step (RCCL runs eagerly)"
+        assert not getattr(optimizer, "exchange", optimizer.world > 1), \
+            "graph capture covers the single-GPU step (RCCL runs eagerly)"
         self.net, self.opt = net, optimizer
         self.inputs = tuple(inputs)
         self.noise = noise

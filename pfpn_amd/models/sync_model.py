@@ -31,7 +31,7 @@ class SyncReplicasApplier(object):
     reference base_worker.py:33-45)."""
 
     def __init__(self, net, groups, norm_clip=None, beta1=0.9, beta2=0.999, epsilon=1e-8,
-                 process_group=None, world_size=None):
+                 process_group=None, world_size=None, force_exchange=False):
         self.net = net
         st = net.store
         self.norm_clip = norm_clip
@@ -40,6 +40,10 @@ class SyncReplicasApplier(object):
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.world = int(world_size)
+        # the exchange path (clip in place, bucket all-reduce, Adam with 1/W, statistics in the bucket tail) is taken
+        # for W > 1; `force_exchange` takes it with ONE replica too (a world-size-1 group: the RCCL call, its stream
+        # ordering against the kernels and the tail-resident statistics can then be checked on a single GPU)
+        self.exchange = self.world > 1 or bool(force_exchange)
         net.dp_world = self.world
         self.norm_scale = torch.zeros(2, dtype=torch.float32, device=st.device)
         # beta powers of all groups in one [G,4] tensor: {b1^t, b2^t as TF's beta*_power hold them | the pair the
@@ -59,7 +63,7 @@ class SyncReplicasApplier(object):
         self._g_len = (ctypes.c_longlong * G)(*[g["len"] for g in self.groups])
         self._g_lr = (ctypes.c_float * G)(*[g["lr"] for g in self.groups])
         self.fused = os.environ.get("PFPN_FUSED_OPT", "1") != "0"
-        if self.world > 1 and hasattr(net, "adopt_tail_statistics"):
+        if self.exchange and hasattr(net, "adopt_tail_statistics"):
             net.adopt_tail_statistics()        # replicated statistics live in the all-reduce bucket from now on
 
     # -- device part (no host sync; capturable when world == 1) -------------------------------------
@@ -68,14 +72,14 @@ class SyncReplicasApplier(object):
         W = self.world
         fused_scale = None
         net.join_side_stream()
-        if W == 1 and self.norm_clip and self.fused and len(self.groups) <= 4:
+        if not self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:
             # one replica: clip + every group's Adam + power / step-counter advance in two launches
             kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
                               step_counter=net.step_dev)
             net.unpack_synced_stats(st.tail, 1.0)
             return
-        if W > 1 and self.norm_clip and self.fused and len(self.groups) <= 4:
+        if self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:
             # data parallel: clip in place (2 launches), ONE all-reduce of [clipped grads | statistics], Adam on the
             # sum with 1/W folded in (1 launch), statistics <- mean (1 launch)
             kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2)
@@ -89,10 +93,10 @@ class SyncReplicasApplier(object):
             return
         if self.norm_clip:
             # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica
-            kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=(W > 1))
-            if W == 1:
+            kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=self.exchange)
+            if not self.exchange:
                 fused_scale = self.norm_scale          # folded into the Adam kernel
-        if W > 1:
+        if self.exchange:
             self.reduce(net)
         for gi, g in enumerate(self.groups):
             sl = slice(g["off"], g["off"] + g["len"])

@@ -317,7 +317,7 @@ class ActorCriticNetwork(object):
         g = self._train_graphs.get(key)
         if g is None:
             n = self._train_calls[key] = self._train_calls.get(key, 0) + 1
-            if n > 4 and optimizer.world == 1 and self.device.type == "cuda" and len(self._train_graphs) < 4 and \
+            if n > 4 and not getattr(optimizer, "exchange", optimizer.world > 1) and self.device.type == "cuda" and len(self._train_graphs) < 4 and \
                     os.environ.get("PFPN_GRAPH_TRAIN", "1") != "0":
                 from ...graphs import GraphedLearnerStep
                 g = self._train_graphs[key] = GraphedLearnerStep(

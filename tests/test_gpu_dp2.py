@@ -104,3 +104,60 @@ def test_two_rank_learner_step_matches_oracle(dev):
         p.join(60)
     assert all(r[1] for r in res), res
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3], "replicas diverged"
+
+
+def _rccl_rank(port, q):
+    """world-size-1 RCCL group: the exchange path of the step (clip in place, bucket all-reduce through RCCL, Adam with
+    1/W and the statistics tail in one launch) must give the bits of the single-replica fused path."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        from pfpn_amd.models import SyncReplicasApplier
+        from test_gpu_dppo_step import make_batch, make_net
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        nets = [make_net(dev, seed=9, resample_interval=3) for _ in range(2)]
+        opts = [SyncReplicasApplier(nets[0], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True),
+                SyncReplicasApplier(nets[1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)]
+        assert opts[0].exchange and not opts[1].exchange and nets[0]._stats_in_tail
+        rng = np.random.default_rng(4)
+        ok = True
+        for it in range(4):
+            b = make_batch(rng, 256)
+            b["log_prob"] = np.full(256, -40.0, F)
+            mx = torch.rand(36, 35, device=dev); sm = torch.rand(36, 35, device=dev) * 5
+            out = []
+            for net, opt in zip(nets, opts):
+                net.max_active.copy_(mx); net.sum_active.copy_(sm)
+                out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
+                                     b["advantage"]))
+            ok &= out[0] == out[1]
+            ok &= torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
+            ok &= torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
+            ok &= torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+            ok &= torch.equal(nets[0].max_active, nets[1].max_active) and torch.equal(nets[0].sum_active, nets[1].sum_active)
+        ok &= nets[0].global_step == 4 and len(nets[0]._train_graphs) == 0      # the exchange path never self-captures
+        q.put((0, bool(ok), "", ""))
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        q.put((0, False, repr(e), ""))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_exchange_path_over_rccl_single_rank_matches_fused_path(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_rank, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert res[1], res
