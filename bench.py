@@ -81,6 +81,15 @@ def cpu_baseline(budget_s=20.0):
                       "default); not TF1" % n}
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +101,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); "
                                                       "`gloo` + --one-device smoke-tests the multi-rank path on one GPU")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (control-flow smoke test only)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N=1 only: run the data-parallel step (clip in place, RCCL all-reduce in a world-size-1 group, "
+                         "Adam with 1/W) instead of the fused single-replica step -- its cost without the links")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +120,8 @@ def main():
         tuned = enable_tuned_gemms(tune_missing=True)
     if args.one_device:
         os.environ["LOCAL_RANK"] = "0"
-    rank, world, local_rank = init_process_group(args.backend if args.gpus > 1 else None)
+    rank, world, local_rank = init_process_group(args.backend if (args.gpus > 1 or args.force_exchange) else None,
+                                                 single_rank_group=args.force_exchange)
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -117,7 +130,8 @@ def main():
                                           action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
                                           device=dev, seed=SEED, **NET_OPTS)
     net.init()
-    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world,
+                              force_exchange=args.force_exchange)
 
     rng = np.random.default_rng(SEED + rank)      # every rank owns a different 4096-transition shard
     hb = synth_batch(rng, B)
@@ -129,7 +143,7 @@ def main():
         logp_old = policy.log_prob(action).clone()
         value_old = net._value(hc).clone()
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and not args.no_graph and not args.force_exchange
     if use_graph:
         step = graphs.GraphedLearnerStep(net, opt, state, action, value_old, logp_old, adv)
     else:
@@ -169,11 +183,12 @@ def main():
                                    "(S=197, A=36, N=35, MLP 1024/512), random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B,
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       **({"exchange": "forced on one replica (RCCL world size 1)"} if args.force_exchange else {}),
                        "gemm_selection": ("shipped TunableOp file" if tuned else "TunableOp in warm-up") if not args.no_tune
                        else "library default",
                        "step": "state-norm, MLP fwd (+critic head), fused mixture logp+PPO+bwd, MLP bwd, one deferred "
                                "reduction launch (bias grads, particle grads, loss, state-norm EMA), clip, "
-                               + ("RCCL all-reduce, " if world > 1 else "") + "TF-Adam, resample tick"},
+                               + ("RCCL all-reduce, " if (world > 1 or args.force_exchange) else "") + "TF-Adam, resample tick"},
         }
 
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
@@ -299,11 +314,18 @@ def main():
                                 "frac": tf / MFMA_F32_PEAK_TF, "us_per_step": gus, "flops": gemm_flops(B)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    # The JSON line must be the LAST thing on stdout.  RCCL leaves a version banner in the C stdio buffer of every rank,
+    # which would otherwise reach the pipe at process exit -- after a line printed from Python.  So every rank flushes
+    # its C streams, the ranks meet at a barrier, the group is torn down, and only then rank 0 prints.
+    if dist.is_initialized():
         dist.barrier()
+        _flush_c_stdio()
+        dist.barrier()                      # every rank has flushed its banner
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -275,15 +275,15 @@ class AbstractDistributedWorker(object):
         return [self.exp["state"], self.exp["action"], self.exp["reward"]]
 
 
-def init_process_group(backend=None):
+def init_process_group(backend=None, single_rank_group=False):
     """One process per GPU: RANK/WORLD_SIZE/LOCAL_RANK/MASTER_ADDR/MASTER_PORT from torchrun.
-    Returns (rank, world_size, local_rank)."""
+    Returns (rank, world_size, local_rank).  `single_rank_group`: create the group even for one rank."""
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
