@@ -115,6 +115,9 @@ int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, 
 /* Gumbel noise from uniforms in [0,1), in place: g = -log(-log(max(u, FLT_MIN))) -- the sampler of TFP 0.7's
  * RelaxedOneHotCategorical behind utils.py:96, :156-160 (the uniforms themselves come from the caller's generator). */
 int pfpn_gumbel_from_uniform(float* u, size_t n, void* stream);
+/* The four noise tensors of one SAC learner step (utils.py:156-161 for s and s') from uniforms u [4][n] in [0,1), in place:
+ * rows 0, 1 -> Gumbel noise as above; rows 2, 3 -> a Box-Muller pair of independent N(0,1) draws. */
+int pfpn_sac_noise_from_uniform(float* u, size_t n, void* stream);
 
 /* SAC reparameterised sample (K4) -- utils.py:156-186.  gumbel [B,A*N] = -log(-log u), eps [B,A*N]:
  * k = argmax(logits+gumbel), s_out = p_k = loc+exp(logstd)*eps, a_out = tanh(p_k).

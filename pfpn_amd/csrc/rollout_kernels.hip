@@ -435,6 +435,22 @@ static inline int stats_chunks(int B) {
 // Gumbel noise of the relaxed one-hot draw from uniforms, in place: g = -log(-log(max(u, tiny)))
 // (TFP 0.7 ExpRelaxedOneHotCategorical's sampler behind utils.py:96, :156-160).  One launch instead of the five
 // elementwise passes (clamp, log, neg, log, neg) the same transform takes as tensor ops.
+// All four noise tensors of a SAC learner step from ONE buffer of uniforms [4][n], in place: rows 0 and 1 become
+// Gumbel noise (as k_gumbel_inplace), rows 2 and 3 a pair of independent standard normals by Box-Muller
+// (z0 = r cos t, z1 = r sin t, r = sqrt(-2 ln max(u2, tiny)), t = 2 pi u3) -- tf.random.normal's role in utils.py:161.
+__global__ __launch_bounds__(256) void k_sac_noise_inplace(float* __restrict__ u, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        u[i] = -logf(-logf(fmaxf(u[i], 1.17549435e-38f)));
+        u[n + i] = -logf(-logf(fmaxf(u[n + i], 1.17549435e-38f)));
+        const float r = sqrtf(-2.f * logf(fmaxf(u[2 * n + i], 1.17549435e-38f)));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u[3 * n + i], &sn, &cs);
+        u[2 * n + i] = r * cs;
+        u[3 * n + i] = r * sn;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gumbel_inplace(float* __restrict__ u, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -540,6 +556,17 @@ int pfpn_entropy_bwd(const float* logits, const float* dH, int B, int A, int N, 
     const int S = B * A;
     hipLaunchKernelGGL(k_entropy_bwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, dH, S, N,
                        accumulate, dlogits);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_sac_noise_from_uniform(float* u, size_t n, void* stream) {
+    PFPN_BEGIN();
+    if (!u) return PFPN_ERR_ARG;
+    if (n == 0) return PFPN_OK;
+    size_t g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_sac_noise_inplace, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, u, n);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

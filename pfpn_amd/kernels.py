@@ -312,6 +312,15 @@ def gumbel_from_uniform_(u):
     return u
 
 
+def sac_noise_from_uniform_(buf):
+    """buf [4, ...] uniforms in [0,1) -> rows 0,1 Gumbel(0,1), rows 2,3 N(0,1) (Box-Muller pair), in place, one launch."""
+    lib = _lib.load()
+    if buf.shape[0] != 4:
+        raise ValueError("expected a [4, ...] buffer")
+    _lib.check(lib.pfpn_sac_noise_from_uniform(_f32(buf), buf[0].numel(), _stream()), "pfpn_sac_noise_from_uniform")
+    return buf
+
+
 def resample(loc, logstd, bias, weight, max_active, sum_active, u_resample, u_noise, threshold=0.0,
              tanh_mode=False, topk=0):
     """In place on loc/logstd/bias/weight.  Returns (dead [A,N] int32, src [A,N] int32).

@@ -204,13 +204,11 @@ def sac_network_wrapper(base_class):
             return [] if ok else None
 
         def make_train_noise(self, B):
+            """the step's four draws (Gumbel + normal for s and for s') from ONE uniform fill and ONE transform launch;
+            `_buf` is the backing buffer (graphs.refill_noise redraws through it)."""
             AN = self.n_actions * self.particles
-            out = {}
-            for k in ("gumbel", "gumbel_"):
-                out[k] = kernels.gumbel_from_uniform_(torch.rand(B, AN, device=self.device, generator=self.rng))
-            for k in ("eps", "eps_"):
-                out[k] = torch.randn(B, AN, device=self.device, generator=self.rng)
-            return out
+            buf = kernels.sac_noise_from_uniform_(torch.rand(4, B, AN, device=self.device, generator=self.rng))
+            return {"gumbel": buf[0], "gumbel_": buf[1], "eps": buf[2], "eps_": buf[3], "_buf": buf}
 
         def compute_gradients(self, state, action, reward, not_terminal, state_, noise=None):
             B, S, A = state.shape[0], self.S, self.n_actions

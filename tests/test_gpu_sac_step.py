@@ -171,3 +171,21 @@ def test_gumbel_transform_matches_tensor_ops(dev):
     g = kernels.gumbel_from_uniform_(u.clone())
     assert torch.isfinite(g).all()
     torch.testing.assert_close(g, ref, rtol=2e-6, atol=2e-6)
+
+
+def test_sac_noise_transform_distributions(dev):
+    """rows 0,1 Gumbel(0,1) (mean = Euler's constant, var = pi^2/6); rows 2,3 independent N(0,1) (Box-Muller pair)."""
+    from pfpn_amd import kernels
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    u = torch.rand(4, 2048, 1260, device=dev, generator=g)
+    u[0, 0, 0] = 0.0; u[2, 0, 0] = 0.0
+    ref_g = -torch.log(-torch.log(u[1].clamp(min=float(np.finfo(np.float32).tiny))))
+    z = kernels.sac_noise_from_uniform_(u)
+    assert torch.isfinite(z).all()
+    torch.testing.assert_close(z[1], ref_g, rtol=2e-6, atol=2e-6)
+    for r in (0, 1):
+        assert abs(z[r].mean().item() - 0.5772157) < 5e-3 and abs(z[r].var().item() - np.pi ** 2 / 6) < 2e-2
+    for r in (2, 3):
+        assert abs(z[r].mean().item()) < 3e-3 and abs(z[r].var().item() - 1.0) < 5e-3
+        assert abs((z[r] ** 4).mean().item() - 3.0) < 5e-2                      # kurtosis of a normal
+    assert abs((z[2] * z[3]).mean().item()) < 3e-3                                # the pair is uncorrelated
