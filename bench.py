@@ -59,8 +59,15 @@ def gemm_flops(rows):
 
 
 def cpu_baseline(budget_s=20.0):
-    """NumPy oracle learner step on a 4096-row batch, host cores (threads = BLAS default)."""
+    """NumPy oracle learner step on a 4096-row batch on the host cores: all BLAS threads (the headline `value`, `cores` =
+    the BLAS pool size actually used) and, for SURVEY 8d's like-for-like ratio, one thread."""
     from oracle import pfpn_oracle as orc
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        pools = [p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"]
+        blas_threads = max(pools) if pools else 1
+    except Exception:
+        threadpool_limits, blas_threads = None, os.cpu_count()
     rng = np.random.default_rng(SEED)
     st = orc.DPPOState(rng, S, A, NP)
     b = synth_batch(rng, B)
@@ -69,16 +76,28 @@ def cpu_baseline(budget_s=20.0):
     b["log_prob"], _ = orc.mixture_log_prob(logits, b["action"], st.P["actor/samples"], st.P["actor/samples_std"])
     b["value"], _ = orc.critic_forward(st.P, x)
     orc.dppo_learner_step(st, [b])          # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        orc.dppo_learner_step(st, [b])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 20:
-            break
-    return {"value": n / el, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d oracle learner steps on one 4096-transition batch (NumPy restatement, BLAS threads "
-                      "default); not TF1" % n}
+
+    def timed(max_steps, budget):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.dppo_learner_step(st, [b])
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= max_steps:
+                return n, el
+
+    n, el = timed(20, budget_s * 0.6)
+    runs = [{"value": n / el, "cores": blas_threads, "sample": "%d steps, %d BLAS threads" % (n, blas_threads)}]
+    if threadpool_limits is not None and blas_threads > 1:
+        with threadpool_limits(limits=1):
+            n1, el1 = timed(20, budget_s * 0.4)
+        runs.append({"value": n1 / el1, "cores": 1, "sample": "%d steps, 1 BLAS thread" % n1})
+    best = max(runs, key=lambda r: r["value"])          # the baseline is the FASTER arrangement on this host
+    out = {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "host_cpus": os.cpu_count(), "kind": "port",
+           "sample": "oracle learner steps on one 4096-transition batch (NumPy restatement; NumPy's elementwise part is "
+                     "single-threaded, the GEMMs use the BLAS pool): " + best["sample"] + "; not TF1",
+           "runs": runs}
+    return out
 
 
 def _flush_c_stdio():
@@ -312,6 +331,30 @@ def main():
         out["roofline_gemm"] = {"kernel": "11 fp32 GEMMs via PyTorch-ROCm (+bias/ReLU6 epilogue kernels)",
                                 "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": tf / MFMA_F32_PEAK_TF, "us_per_step": gus, "flops": gemm_flops(B)}
+        # the reference's own schedule is 16 optimiser steps of global batch 256 (8 workers x 32 rows) per 4096
+        # transitions (deepmimic_dppo_base.py) -- one 256-row step on this GPU, captured like the headline step
+        try:
+            rb = synth_batch(np.random.default_rng(SEED + 1), 256)
+            rt = [torch.from_numpy(rb[k]).to(dev) for k in ("state", "action", "advantage")]
+            with torch.no_grad():
+                rp, _, rhc = net._forward(rt[0])
+                r_lp = rp.log_prob(rt[1]).clone()
+                r_v = net._value(rhc).clone()
+            rstep = graphs.GraphedLearnerStep(net, opt, rt[0], rt[1], r_v, r_lp, rt[2])
+            for _ in range(10):
+                rstep()
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            for _ in range(200):
+                rstep()
+            torch.cuda.synchronize()
+            rus = (time.perf_counter() - tr) / 200 * 1e6
+            out["reference_schedule"] = {"global_batch": 256, "steps_per_4096_transitions": 16, "us_per_step": rus,
+                                         "transitions_per_s": 256 / (rus * 1e-6),
+                                         "note": "the headline step consumes 4096 transitions per step: %.0f transitions/s"
+                                                 % (B * out["value"])}
+        except Exception as e:          # informational only
+            out["reference_schedule"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
     # The JSON line must be the LAST thing on stdout.  RCCL leaves a version banner in the C stdio buffer of every rank,
