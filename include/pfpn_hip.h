@@ -134,7 +134,8 @@ int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd,
 /* ParticleFilteringA2CNetwork.build_resample_ops -- a2c.py:385-474.  topk = 0: the `resample == -1` branch
  * (source = categorical draw over log avg activation, :400-404); topk = k > 0: the `resample == k` branch (source =
  * candidate number min(k-1, floor(u_resample*k)) among the k most active particles, ties to the lower index, :405-408;
- * k is clamped to N).  In place on
+ * k is clamped to N).  fixed_sigma > 0: the `fixed_sigma` setting (:430-440, :463-465): the jitter uses that std, in tanh
+ * mode around tanh(source loc), and logstd is left alone.  In place on
  * loc/logstd [A,N], bias [A*N], weight [H, A*N] (fc_policy, a particle is a column).
  * u_resample [A,N] float64 in [0,1): uniforms of tf.random.categorical(log avg, N) / of the uniform candidate choice;
  * u_noise [A,N] in [-1,1): tf.random.uniform for dead slot (a,j).  threshold <= 0 -> 0.05/N.
@@ -142,7 +143,7 @@ int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd,
  * max_active/sum_active/train_flag afterwards (a2c.py:373-378). */
 int pfpn_resample(float* loc, float* logstd, float* bias, float* weight, int H,
                   const float* max_active, const float* sum_active, const double* u_resample,
-                  const float* u_noise, int A, int N, float threshold, int tanh_mode, int topk,
+                  const float* u_noise, int A, int N, float threshold, int tanh_mode, int topk, float fixed_sigma,
                   int32_t* dead_out, int32_t* src_out, void* stream);
 
 /* ---- host utility ------------------------------------------------------------------------- */

@@ -269,7 +269,7 @@ def _seq_sum_rows(x):
 
 
 def resample_particles(loc, logstd, bias, weight, max_active, sum_active,
-                       u_resample, u_noise, threshold=None, tanh_mode=False, topk=0):
+                       u_resample, u_noise, threshold=None, tanh_mode=False, topk=0, fixed_sigma=None):
     """ParticleFilteringA2CNetwork.build_resample_ops (a2c.py:385-474).  topk = 0: the `resample == -1` branch
     (:400-404, the one the shipped settings use, deepmimic_dppo_pfpn.py:5); topk = k > 0: the `resample == k` branch
     (:405-408): source = candidate number min(k-1, floor(u_resample*k)) among the k most active particles of the
@@ -319,13 +319,18 @@ def resample_particles(loc, logstd, bias, weight, max_active, sum_active,
             bias[a * N + sidx] = new_bias_src[sidx]
         for j, sidx in zip(js, srcs):
             bias[a * N + j] = new_bias_src[sidx]
-            noise = (scale[a, sidx] * F(u_noise[a, j])).astype(F)                     # a2c.py:441
+            sc = F(fixed_sigma) if fixed_sigma else scale[a, sidx]                    # a2c.py:438-439
+            base = old_loc[a, sidx]
+            if fixed_sigma and tanh_mode:
+                base = np.tanh(base, dtype=F)                                         # a2c.py:430-432
+            noise = (sc * F(u_noise[a, j])).astype(F)                                 # a2c.py:441
             noise = (noise + (F(-1e-4) if noise < 0 else F(1e-4))).astype(F)          # a2c.py:442-444
-            nl = (old_loc[a, sidx] + noise).astype(F)                                 # a2c.py:445
+            nl = (base + noise).astype(F)                                             # a2c.py:445
             if tanh_mode:   # a2c.py:448-450 (quirk: atanh of a pre-tanh value, and/or precedence)
                 nl = np.arctanh(np.clip(nl, F(1e-6 - 1), F(1 - 1e-6)), dtype=F)
             loc[a, j] = nl
-            logstd[a, j] = np.clip(old_logstd[a, sidx], F(-20), F(2))                 # a2c.py:451
+            if not fixed_sigma:                                                       # a2c.py:463-465
+                logstd[a, j] = np.clip(old_logstd[a, sidx], F(-20), F(2))             # a2c.py:451
             weight[:, a * N + j] = old_weight[:, a * N + sidx]                        # a2c.py:467-469
     return loc, logstd, bias, weight, {"dead": dead, "src": src.astype(np.int32)}
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_resample_dims(
     float* __restrict__ loc, float* __restrict__ logstd, float* __restrict__ bias,
     const float* __restrict__ max_active, const float* __restrict__ sum_active,
     const double* __restrict__ u_resample, const float* __restrict__ u_noise,
-    int A, int N, float threshold, int tanh_mode, int topk,
+    int A, int N, float threshold, int tanh_mode, int topk, float fixed_sigma,
     int* __restrict__ dead_out, int* __restrict__ src_out)
 {
     __shared__ double cdf[RS_MAXN];
@@ -117,16 +117,19 @@ __global__ __launch_bounds__(256) void k_resample_dims(
         src_out[col] = src[j];
         if (dead[j]) {
             const int k = src[j];
-            const float sc = expf(o_ls[k]);
+            const bool fixed = fixed_sigma > 0.f;                       // fixed_sigma: jitter with init_sigma, a2c.py:438-439
+            const float sc = fixed ? fixed_sigma : expf(o_ls[k]);
+            float base = o_loc[k];
+            if (fixed && tanh_mode) base = tanhf(base);                 // a2c.py:430-432
             float noise = sc * u_noise[col];                            // a2c.py:441
             noise = noise + (noise < 0.f ? -1e-4f : 1e-4f);             // a2c.py:442-444
-            float nl = o_loc[k] + noise;                                // a2c.py:445
+            float nl = base + noise;                                    // a2c.py:445
             if (tanh_mode) {                                            // a2c.py:448-450 (reference quirk)
                 nl = fmaxf(fminf(nl, 0.999999f), -0.999999f);
                 nl = atanhf(nl);
             }
             loc[col] = nl;
-            logstd[col] = fmaxf(fminf(o_ls[k], 2.f), -20.f);            // a2c.py:451
+            if (!fixed) logstd[col] = fmaxf(fminf(o_ls[k], 2.f), -20.f);   // a2c.py:451, :463-465 (not with fixed_sigma)
             bias[col] = nb[k];                                          // second scatter wins (a2c.py:466)
         } else {
             bias[col] = nb[j];                                          // first scatter (a2c.py:465)
@@ -153,7 +156,7 @@ using namespace pfpn;
 extern "C" int pfpn_resample(float* loc, float* logstd, float* bias, float* weight, int H,
                              const float* max_active, const float* sum_active, const double* u_resample,
                              const float* u_noise, int A, int N, float threshold, int tanh_mode, int topk,
-                             int32_t* dead_out, int32_t* src_out, void* stream) {
+                             float fixed_sigma, int32_t* dead_out, int32_t* src_out, void* stream) {
     PFPN_BEGIN();
     if (!loc || !logstd || !bias || !weight || !max_active || !sum_active || !u_resample || !u_noise ||
         !dead_out || !src_out || A < 1 || N < 1 || N > RS_MAXN || H < 1 || topk < 0)
@@ -164,7 +167,7 @@ extern "C" int pfpn_resample(float* loc, float* logstd, float* bias, float* weig
     hipStream_t st = (hipStream_t)stream;
     if (threshold <= 0.f) threshold = (float)(0.05 / (double)N);         // a2c.py:391 (.05/n in float64, then fp32)
     hipLaunchKernelGGL(k_resample_dims, dim3(A), dim3(256), 0, st, loc, logstd, bias, max_active, sum_active,
-                       u_resample, u_noise, A, N, threshold, tanh_mode, topk, (int*)dead_out, (int*)src_out);
+                       u_resample, u_noise, A, N, threshold, tanh_mode, topk, fixed_sigma, (int*)dead_out, (int*)src_out);
     PFPN_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_resample_weight, dim3(H), dim3(256), lds, st, weight, H, A * N, N, (const int*)dead_out,
                        (const int*)src_out);

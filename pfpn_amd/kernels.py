@@ -322,7 +322,7 @@ def sac_noise_from_uniform_(buf):
 
 
 def resample(loc, logstd, bias, weight, max_active, sum_active, u_resample, u_noise, threshold=0.0,
-             tanh_mode=False, topk=0):
+             tanh_mode=False, topk=0, fixed_sigma=0.0):
     """In place on loc/logstd/bias/weight.  Returns (dead [A,N] int32, src [A,N] int32).
     topk = 0: categorical source draw (`resample=-1`); topk = k: uniform choice among the k most active (`resample=k`)."""
     lib = _lib.load()
@@ -334,7 +334,7 @@ def resample(loc, logstd, bias, weight, max_active, sum_active, u_resample, u_no
     _lib.check(lib.pfpn_resample(_f32(loc, A, N), _f32(logstd, A, N), _f32(bias, A * N), _f32(weight, H, A * N), H,
                                  _f32(max_active, A, N), _f32(sum_active, A, N),
                                  _typed(u_resample, torch.float64, A, N, name="u_resample"), _f32(u_noise, A, N),
-                                 A, N, float(threshold), int(tanh_mode), int(topk), dead.data_ptr(), src.data_ptr(),
+                                 A, N, float(threshold), int(tanh_mode), int(topk), float(fixed_sigma or 0.0), dead.data_ptr(), src.data_ptr(),
                                  _stream()), "pfpn_resample")
     return dead, src
 

@@ -94,9 +94,8 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         self.resample_threshold = resample_threshold
         self.init_sigma = fixed_sigma if fixed_sigma and fixed_sigma is not True else init_sigma
         self.fixed_sigma = True if fixed_sigma else False
-        if self.fixed_sigma and resample:
-            raise NotImplementedError("fixed_sigma resampling (a2c.py:430-440) is not built; unset in every "
-                                      "shipped PFPN setting")
+        if self.fixed_sigma and resample and not self.init_sigma:
+            raise ValueError("fixed_sigma=True with resampling needs init_sigma (a2c.py:438-439 jitters with it)")
         self.normalize_policy_output = False                      # tanh squash after the mixture (unused)
         self.normalize_policy_output_ = bool(normalize_policy_output)   # tanh squash before the mixture
         self.train_flag = 0
@@ -435,5 +434,6 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         self.last_resample = kernels.resample(self.loc, self.logstd, self.policy_bias, self.policy_weight,
                                               self.max_active, self.sum_active, u_resample, u_noise, thr,
                                               self.normalize_policy_output_,
-                                              topk=self.resample if self.resample and self.resample > 0 else 0)
+                                              topk=self.resample if self.resample and self.resample > 0 else 0,
+                                              fixed_sigma=float(self.init_sigma) if self.fixed_sigma else 0.0)
         return self.last_resample

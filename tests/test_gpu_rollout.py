@@ -244,3 +244,25 @@ def test_network_resample_topk_option(dev):
     top3 = torch.topk(net.sum_active, 3, dim=1).indices
     assert all(int(src[a, j]) in top3[a].tolist() for a in range(net.n_actions) for j in range(5))
     assert not torch.equal(before[:, :5], net.loc[:, :5]) and torch.equal(before[:, 5:], net.loc[:, 5:])
+
+
+@pytest.mark.parametrize("tanh_mode", [False, True])
+def test_resample_fixed_sigma(oracle, dev, tanh_mode):
+    """`fixed_sigma` resampling (a2c.py:430-440, :463-465): jitter with the fixed std (around tanh(loc) in tanh mode), the
+    log-std variable is not touched."""
+    from pfpn_amd import kernels
+    A, N, H = 36, 35, 64
+    case = _resample_case(oracle, A, N, H, 17, tanh_mode)
+    loc, logstd, bias, weight, mx, sm, ur, un = case
+    r_loc, r_ls, r_bias, r_w, info = oracle.resample_particles(loc, logstd, bias, weight, mx, sm, ur, un,
+                                                               tanh_mode=tanh_mode, fixed_sigma=0.07)
+    d = to_dev(dev, *case)
+    dead, src = kernels.resample(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], 0.0, tanh_mode, fixed_sigma=0.07)
+    assert np.array_equal(src.cpu().numpy(), info["src"]) and np.array_equal(dead.cpu().numpy().astype(bool), info["dead"])
+    assert np.array_equal(d[1].cpu().numpy(), logstd) and np.array_equal(r_ls, logstd)
+    np.testing.assert_allclose(d[0].cpu().numpy(), r_loc, rtol=3e-6, atol=2e-7)
+    np.testing.assert_allclose(d[2].cpu().numpy(), r_bias, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(d[3].cpu().numpy(), r_w)
+    dd = info["dead"]
+    if not tanh_mode:      # the jitter is bounded by the fixed std (+1e-4)
+        assert np.all(np.abs(d[0].cpu().numpy()[dd] - loc[np.nonzero(dd)[0], info["src"][dd]]) <= 0.07 + 1.1e-4)

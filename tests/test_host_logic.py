@@ -162,8 +162,8 @@ def test_out_of_scope_options_raise():
         ParticleFilteringClipPPONetwork(normalize_value=True, **base)
     with pytest.raises(ValueError):                                 # a2c.py:390 asserts n >= resample
         ParticleFilteringClipPPONetwork(resample=51, **base)
-    with pytest.raises(NotImplementedError):
-        ParticleFilteringClipPPONetwork(resample=3, fixed_sigma=0.1, **base)
+    with pytest.raises(ValueError):                                 # fixed_sigma=True jitters with init_sigma (a2c.py:438-439)
+        ParticleFilteringClipPPONetwork(resample=3, fixed_sigma=True, **base)
     with pytest.raises(NotImplementedError):
         ParticleFilteringClipPPONetwork(**dict(base, common_net_shape=[16]))
 
