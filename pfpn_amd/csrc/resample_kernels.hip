@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void k_resample_dims(
             rowsum = s;
         }
         __syncthreads();
-        for (int n = t; n < N; n += blockDim.x) avg_s[n] = sa[n] / rowsum;
+        for (int n = t; n < N; n += blockDim.x) {
+            avg_s[n] = sa[n] / rowsum;
+            cand[n] = n;                      // NaN averages (an all-zero row) rank nothing: every slot stays a valid index
+        }
         __syncthreads();
         for (int n = t; n < N; n += blockDim.x) {
             const float v = avg_s[n];
