@@ -61,7 +61,10 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Advantage moments for normalize_advantage -- reference actor_critic.py:151-156:
- * stats = {mean, 1/(sqrt(population var)+1e-8)}; normalize=0 writes {0,1}. */
+ * stats = {mean, 1/(sqrt(population var)+1e-8)}; normalize=0 writes {0,1}.
+ * Everywhere below, `adv_stats` / `stats` is a device array of FOUR floats {mean, rstd, clip_lo, clip_hi}: the loss heads
+ * use clip((adv - mean) * rstd, clip_lo, clip_hi) (clip_advantage, actor_critic.py:158-170); this entry point and
+ * pfpn_state_prologue write only the first two, the caller keeps the bounds (-inf, +inf: no clipping). */
 int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* stream);
 
 /* Fused learner kernel: log_prob(action_hist) + clipped-PPO loss head + full backward in one pass

@@ -446,7 +446,17 @@ def _fc_bwd(x_in, w, y_out, dy, act):
 # --------------------------------------------------------------------------- #
 # PPO loss (ppo.py:14-74, actor_critic.py:132-184)                            #
 # --------------------------------------------------------------------------- #
-def ppo_loss(logp, logp_old, adv, v, v_old, eps_clip=0.2, value_loss_coef=0.5, normalize_adv=True):
+def clip_advantage_bounds(clip_advantage):
+    """actor_critic.py:160-168: a scalar c means [-c, c], a pair its sorted ends; None / False: no clipping."""
+    if not clip_advantage:
+        return None
+    if hasattr(clip_advantage, "__len__"):
+        return F(min(clip_advantage)), F(max(clip_advantage))
+    return F(-clip_advantage), F(clip_advantage)
+
+
+def ppo_loss(logp, logp_old, adv, v, v_old, eps_clip=0.2, value_loss_coef=0.5, normalize_adv=True,
+             clip_advantage=None):
     """Returns (loss, policy_loss, value_loss*coef, dlogp[B], dv[B])."""
     logp = np.asarray(logp, F); adv = np.asarray(adv, F); v = np.asarray(v, F)
     B = F(len(adv))
@@ -456,6 +466,9 @@ def ppo_loss(logp, logp_old, adv, v, v_old, eps_clip=0.2, value_loss_coef=0.5, n
         nadv = ((adv - m) / (np.sqrt(var, dtype=F) + F(1e-8))).astype(F)
     else:
         nadv = adv
+    bounds = clip_advantage_bounds(clip_advantage)               # actor_critic.py:158-170 (value target is NOT clipped)
+    if bounds is not None:
+        nadv = np.maximum(np.minimum(nadv, bounds[1]), bounds[0])
     with np.errstate(over="ignore", invalid="ignore"):
         ratio = np.exp(logp - np.asarray(logp_old, F), dtype=F)   # ppo.py:47-48
         sur = (ratio * nadv).astype(F)
@@ -773,7 +786,7 @@ def vtrace(logp_target, logp_behavior, value, reward, not_terminal, E, gamma, rh
     return flat(vs), flat(pg), flat(mask)
 
 
-def a2c_loss(logp, adv, v, v_target, value_loss_coef=0.5, mask=None, normalize_adv=False):
+def a2c_loss(logp, adv, v, v_target, value_loss_coef=0.5, mask=None, normalize_adv=False, clip_advantage=None):
     """reference a2c.py:53-65 + actor_critic.py:132-184: policy_loss = -mean(valid(logp*adv_n)),
     value_loss = coef*mean(valid((v - vt)^2)).  Returns (loss, policy_loss, value_loss*coef, dlogp, dv)."""
     m = np.ones_like(logp, F) if mask is None else np.asarray(mask, F)
@@ -782,6 +795,9 @@ def a2c_loss(logp, adv, v, v_target, value_loss_coef=0.5, mask=None, normalize_a
     if normalize_adv:
         va = adv[m > 0]
         adv = ((adv - va.mean(dtype=F)) / (np.sqrt(va.var(dtype=F)) + F(1e-8))).astype(F)
+    bounds = clip_advantage_bounds(clip_advantage)
+    if bounds is not None:
+        adv = np.maximum(np.minimum(adv, bounds[1]), bounds[0])
     pl = -F((m * (logp * adv)).sum(dtype=F) / n)
     d = (v - v_target).astype(F)
     vl = F((m * d * d).sum(dtype=F) / n) * F(value_loss_coef)

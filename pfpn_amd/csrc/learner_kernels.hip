@@ -61,12 +61,12 @@ __global__ __launch_bounds__(1024) void k_ppo_loss(
     float* __restrict__ dlogp, float* __restrict__ dvalue, float* __restrict__ loss3)
 {
     __shared__ float red[16];
-    const float mean = stats[0], rstd = stats[1];
+    const float mean = stats[0], rstd = stats[1], alo = stats[2], ahi = stats[3];
     const float inv_B = 1.0f / (float)B;
     float ps = 0.f, vs = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float a = adv[b];
-        const float nadv = (a - mean) * rstd;
+        const float nadv = clip_adv((a - mean) * rstd, alo, ahi);
         const float ratio = expf(logp[b] - logp_old[b]);
         const float sur = ratio * nadv;
         const float cr = fmaxf(fminf(ratio, clip_hi), clip_lo);
@@ -149,11 +149,11 @@ __global__ __launch_bounds__(1024) void k_a2c_loss(const float* __restrict__ log
     for (int b = threadIdx.x; b < B; b += blockDim.x) nv += mask ? mask[b] : 1.f;
     nv = block_sum(nv, red);
     const float inv_n = 1.0f / nv;
-    const float mean = stats[0], rstd = stats[1];
+    const float mean = stats[0], rstd = stats[1], alo = stats[2], ahi = stats[3];
     float ps = 0.f, vs = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float m = mask ? mask[b] : 1.f;
-        const float nadv = (adv[b] - mean) * rstd;
+        const float nadv = clip_adv((adv[b] - mean) * rstd, alo, ahi);
         ps += m * (logp[b] * nadv);
         const float d = value[b] - value_target[b];
         vs += m * (d * d);

@@ -33,7 +33,7 @@ struct PpoArgs {
     const float* adv;        // [B]
     const float* value;      // [B]
     const float* value_old;  // [B]
-    const float* adv_stats;  // [2] mean, 1/(std+1e-8)   (device)
+    const float* adv_stats;  // [4] mean, 1/(std+1e-8), clip lo, clip hi   (device)
     float inv_B;             // 1/B (rank-local batch, reference per-worker minibatch mean)
     float clip_lo, clip_hi;  // 1-eps, 1+eps
     float value_coef;        // 0.5
@@ -385,8 +385,11 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             b_isc[i] = bank[AN + a * N + n];
             b_ct[i] = bank[2 * AN + a * N + n];
         }
-        float adv_mean = 0.f, adv_rstd = 1.f;
-        if (MODE == MODE_PPO) { adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1]; }
+        float adv_mean = 0.f, adv_rstd = 1.f, adv_lo = -INFINITY, adv_hi = INFINITY;
+        if (MODE == MODE_PPO) {
+            adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1];
+            adv_lo = ppo.adv_stats[2]; adv_hi = ppo.adv_stats[3];
+        }
         PFPN_STAMP(1);
 
         // tile k of this block lives in plane k % P; wait until both loaders have landed their part
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                     const int rkc = min(rk, R - 1);
                     const float* rs = rpl + slot * 64;
                     const float adv = rs[rkc], lpo = rs[16 + rkc], val_b = rs[32 + rkc], vold_b = rs[48 + rkc];
-                    const float nadv = (adv - adv_mean) * adv_rstd;
+                    const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
                     const float ratio = expf(s - lpo);
                     const float sur = ratio * nadv;
                     const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);

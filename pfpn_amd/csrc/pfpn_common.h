@@ -188,4 +188,11 @@ __device__ __forceinline__ float slab_reduce_1024(const float* __restrict__ slab
     return s;          // valid on k-lane 0
 }
 
+// tf.clip_by_value of the normalised advantage (actor_critic.py:158-170); bounds -inf / +inf = no clipping.  Written
+// with comparisons so a NaN advantage stays NaN, as Minimum/Maximum leave it in TensorFlow.
+__device__ __forceinline__ float clip_adv(float a, float lo, float hi) {
+    a = a < lo ? lo : a;
+    return a > hi ? hi : a;
+}
+
 }  // namespace pfpn

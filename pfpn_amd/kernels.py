@@ -86,12 +86,22 @@ def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False):
     return (dlogits, dloc, dlogstd, dx) if want_dx else (dlogits, dloc, dlogstd)
 
 
+def new_adv_stats(device, clip=None):
+    """the 4-float {mean, rstd, clip_lo, clip_hi} array of the loss heads; `clip`: None | c (-> +-c) | (lo, hi)."""
+    lo, hi = -float("inf"), float("inf")
+    if clip:
+        lo, hi = (min(clip), max(clip)) if hasattr(clip, "__len__") else (-float(clip), float(clip))
+    return torch.tensor([0.0, 1.0, lo, hi], dtype=torch.float32, device=device)
+
+
 def adv_stats(adv, normalize=True, out=None):
+    """moments of the advantages into out[0:2] (out[2:4] = the clip bounds are the caller's; a fresh `out` has none)."""
     lib = _lib.load()
     B = adv.shape[0]
     pa = _f32(adv, B, name="advantage")
     if out is None:
-        out = torch.empty(2, dtype=torch.float32, device=adv.device)
+        out = new_adv_stats(adv.device)
+    _f32(out, 4, name="adv_stats")
     _lib.check(lib.pfpn_adv_stats(pa, B, int(normalize), out.data_ptr(), _stream()), "pfpn_adv_stats")
     return out
 
@@ -110,7 +120,7 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
     pa = _f32(action, B, A, name="action")
     ploc, pls = _f32(loc, A, N, name="loc"), _f32(logstd, A, N, name="logstd")
     ptrs = [_f32(logp_old, B, name="log_prob"), _f32(adv, B, name="advantage"), _f32(value, B, name="value"),
-            _f32(value_old, B, name="value_old"), _f32(stats, 2, name="adv_stats")]
+            _f32(value_old, B, name="value_old"), _f32(stats, 4, name="adv_stats")]
     if out is None:
         out = {
             "logp": torch.empty(B, dtype=torch.float32, device=dev),
@@ -170,7 +180,7 @@ def ppo_loss(logp, logp_old, adv, value, value_old, stats, clip_eps=0.2, value_c
     dvalue = torch.empty(B, dtype=torch.float32, device=dev)
     loss3 = torch.empty(3, dtype=torch.float32, device=dev)
     _lib.check(lib.pfpn_ppo_loss(_f32(logp, B), _f32(logp_old, B), _f32(adv, B), _f32(value, B), _f32(value_old, B),
-                                 _f32(stats, 2), B, float(clip_eps), float(value_coef), dlogp.data_ptr(),
+                                 _f32(stats, 4), B, float(clip_eps), float(value_coef), dlogp.data_ptr(),
                                  dvalue.data_ptr(), loss3.data_ptr(), _stream()), "pfpn_ppo_loss")
     return dlogp, dvalue, loss3
 
@@ -205,7 +215,7 @@ def a2c_loss(logp, adv, value, value_target, stats, value_coef=0.5, mask=None):
     dlogp = torch.empty(B, dtype=torch.float32, device=dev)
     dvalue = torch.empty(B, dtype=torch.float32, device=dev)
     loss4 = torch.empty(4, dtype=torch.float32, device=dev)
-    _lib.check(lib.pfpn_a2c_loss(_f32(logp, B), _f32(adv, B), _f32(value, B), _f32(value_target, B), _f32(stats, 2),
+    _lib.check(lib.pfpn_a2c_loss(_f32(logp, B), _f32(adv, B), _f32(value, B), _f32(value_target, B), _f32(stats, 4),
                                  _f32(mask, B) if mask is not None else None, B, float(value_coef),
                                  dlogp.data_ptr(), dvalue.data_ptr(), loss4.data_ptr(), _stream()), "pfpn_a2c_loss")
     return dlogp, dvalue, loss4
@@ -392,7 +402,7 @@ def state_prologue(s, mean, std, clip, out_x, want_moments=True, adv=None, norma
     _lib.check(lib.pfpn_state_prologue(_f32(s, B, S), _f32(mean, S), _f32(std, S), B, S, float(clip or 0.0),
                                        _f32(out_x, B, S), int(want_moments),
                                        _f32(adv, B) if adv_stats is not None else None, int(normalize_adv),
-                                       _f32(adv_stats, 2) if adv_stats is not None else None, ws, wsn, _stream()),
+                                       _f32(adv_stats, 4) if adv_stats is not None else None, ws, wsn, _stream()),
                "pfpn_state_prologue")
     return out_x
 

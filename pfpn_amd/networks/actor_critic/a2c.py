@@ -155,7 +155,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             "dvalue": torch.empty(B, dtype=torch.float32, device=dev),
             "loss3": torch.empty(3, dtype=torch.float32, device=dev),
         }
-        self.adv_stats = torch.empty(2, dtype=torch.float32, device=dev)
+        self.adv_stats = kernels.new_adv_stats(dev, self.clip_advantage)     # {mean, rstd | clip bounds}
         self.ws_mix = kernels.mixture_workspace(B, self.n_actions, self.particles, dev)   # private: deferred finalize
         self._mix_slabs = {}
         if self.trunk is not None:

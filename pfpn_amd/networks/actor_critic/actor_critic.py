@@ -56,8 +56,8 @@ class ActorCriticNetwork(object):
             raise NotImplementedError("common_net_shape: no shipped PFPN setting uses a shared trunk")
         if normalize_value or clip_value:
             raise NotImplementedError("value normaliser: normalize_value=False in every DeepMimic setting")
-        if clip_advantage:
-            raise NotImplementedError("clip_advantage is unset in every DeepMimic setting")
+        if clip_advantage and hasattr(clip_advantage, "__len__") and len(clip_advantage) != 2:
+            raise ValueError("clip_advantage is a bound c (-> [-c, c]) or a pair (actor_critic.py:160-168)")
         if critic_regularizer or actor_regularizer:
             raise NotImplementedError("L2 regularisers are unset in every DeepMimic setting")
         act_name = getattr(activator, "__name__", activator)
@@ -74,6 +74,7 @@ class ActorCriticNetwork(object):
         self.normalize_state = normalize_state
         self.clip_state = clip_state
         self.normalize_advantage = normalize_advantage
+        self.clip_advantage = clip_advantage or None
         self.entropy_beta = entropy_beta
         self.value_loss_coef = value_loss_coef
         self.init_ops, self.train_ops, self.running_update_ops = [], [], []

@@ -176,7 +176,7 @@ def test_fused_prologue_matches_separate_launches(dev):
         m_ref, sd_ref = kernels.state_norm_update(s, step, mean, std)
         st_ref = kernels.adv_stats(adv, normalize=B > 1)
         x = torch.empty_like(s)
-        st = torch.empty(2, device=dev)
+        st = kernels.new_adv_stats(dev)
         kernels.state_prologue(s, mean, std, 5.0, x, True, adv, B > 1, st)
         m, sd = torch.empty_like(mean), torch.empty_like(std)
         kernels.state_norm_ema(B, S, step, mean, std, m, sd)

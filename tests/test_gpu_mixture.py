@@ -139,3 +139,41 @@ def test_bitwise_reproducible(oracle, dev):
     b = kernels.logprob_bwd(*d)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("clip", [0.8, (-0.3, 1.5)])
+def test_clip_advantage_in_every_loss_head(oracle, dev, clip):
+    """clip_advantage (actor_critic.py:158-170): the normalised advantage is clipped inside the fused PPO kernel, the
+    unfused PPO head and the A2C head alike (bounds ride in adv_stats[2:4]); value targets are not clipped."""
+    from pfpn_amd import kernels
+    B, A, N = 512, 36, 35
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 41, spread=1.05)
+    rng = np.random.default_rng(41)
+    ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+    lp_old = (ref_lp + rng.normal(0, 0.15, B)).astype(np.float32)
+    adv = rng.normal(0, 1.5, B).astype(np.float32)
+    v = rng.normal(0, 1, B).astype(np.float32)
+    v_old = rng.normal(0, 1, B).astype(np.float32)
+    loss, pl, vl, dlogp, dv = oracle.ppo_loss(ref_lp, lp_old, adv, v, v_old, 0.2, 0.5, clip_advantage=clip)
+    loss_nc = oracle.ppo_loss(ref_lp, lp_old, adv, v, v_old, 0.2, 0.5)[0]
+    assert abs(loss - loss_nc) > 1e-3                      # the bounds bite on this batch
+    r_dl, _, _, _ = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, dlogp)
+    d = to_dev(dev, logits, x, loc, logstd, lp_old, adv, v, v_old)
+    stats = kernels.new_adv_stats(dev, clip)
+    kernels.adv_stats(d[5], True, out=stats)
+    lo, hi = (min(clip), max(clip)) if hasattr(clip, "__len__") else (-clip, clip)
+    assert stats[2].item() == np.float32(lo) and stats[3].item() == np.float32(hi)      # moments leave the bounds alone
+    out = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    np.testing.assert_allclose(out["loss3"].cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(out["dvalue"].cpu().numpy(), dv, rtol=1e-5, atol=1e-9)
+    sc = np.abs(r_dl).max() + 1e-30
+    np.testing.assert_allclose(out["dlogits"].cpu().numpy().reshape(B, A, N), r_dl, rtol=2e-4, atol=2e-6 * sc)
+    g_lp, g_v, l3 = kernels.ppo_loss(to_dev(dev, ref_lp)[0], d[4], d[5], d[6], d[7], stats)
+    np.testing.assert_allclose(l3.cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(g_lp.cpu().numpy(), dlogp, rtol=2e-5, atol=1e-9)
+    # A2C head on host-computed targets
+    vt = rng.normal(0, 1, B).astype(np.float32)
+    a_ref = oracle.a2c_loss(ref_lp, adv, v, vt, 0.5, normalize_adv=True, clip_advantage=clip)
+    dlp, dvv, l4 = kernels.a2c_loss(to_dev(dev, ref_lp)[0], d[5], d[6], to_dev(dev, vt)[0], stats, 0.5)
+    np.testing.assert_allclose(l4.cpu().numpy()[:3], a_ref[:3], rtol=3e-5, atol=5e-6)
+    np.testing.assert_allclose(dlp.cpu().numpy(), a_ref[3], rtol=2e-5, atol=1e-9)
