@@ -13,7 +13,11 @@ else:                                          # --output-format csv
 idx = [i for i, r in enumerate(rows) if anchor in r[2]]
 if len(idx) < 3:
     sys.exit("anchor kernel not found often enough")
-a, b = idx[-3], idx[-2]                       # a full step well inside the timed region
+# steps = spans between consecutive anchors; a run mixes shapes (warm-up, other batch sizes): show a step at the 80th
+# percentile of duration, i.e. a typical step of the longest-running (headline) shape
+spans = sorted(range(len(idx) - 1), key=lambda i: rows[idx[i + 1]][0] - rows[idx[i]][0])
+pick = spans[int(0.8 * (len(spans) - 1))]
+a, b = idx[pick], idx[pick + 1]
 t0 = rows[a][0]
 prev_end = t0
 busy = 0
