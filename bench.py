@@ -114,7 +114,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replays")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="learner steps captured per hipGraph replay (1: one replay per step).  Replays of a one-step "
+                         "graph idle the GPU ~10 us between them; the remainder of --steps and anything across a "
+                         "resample tick runs on a one-step graph")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the informational extras (CPU baseline, 256-row reference-schedule step)")
     ap.add_argument("--no-tune", action="store_true", help="skip PyTorch TunableOp GEMM selection")
@@ -164,21 +168,34 @@ def main():
         value_old = net._value(hc).clone()
 
     use_graph = (world == 1) and not args.no_graph and not args.force_exchange
+    spg = max(1, args.steps_per_graph) if use_graph else 1
     if use_graph:
         step = graphs.GraphedLearnerStep(net, opt, state, action, value_old, logp_old, adv)
+        step_k = graphs.GraphedLearnerStep(net, opt, state, action, value_old, logp_old, adv,
+                                           steps_per_replay=spg) if spg > 1 else None
     else:
+        step_k = None
+
         def step():
             return net.train_device(opt, state, action, value_old, logp_old, adv)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n):
+        """exactly n learner steps: K-step replays while they fit (and no resample tick falls inside), else single steps"""
+        while n > 0:
+            if step_k is not None and n >= spg and step_k.can_replay():
+                step_k()
+                n -= spg
+            else:
+                step()
+                n -= 1
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -202,7 +219,7 @@ def main():
             "config": {"workload": "DeepMimicWalk-v0 DPPO-PFPN 35 particles, 4096-transition batch per GPU "
                                    "(S=197, A=36, N=35, MLP 1024/512), random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B,
-                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "parallelism": "dp%d" % world, "launch": ("hipGraph, %d learner steps per replay" % spg if spg > 1 else "hipGraph") if use_graph else "eager",
                        **({"exchange": "forced on one replica (RCCL world size 1)"} if args.force_exchange else {}),
                        "gemm_selection": ("shipped TunableOp file" if tuned else "TunableOp in warm-up") if not args.no_tune
                        else "library default",

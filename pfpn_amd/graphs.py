@@ -30,17 +30,24 @@ class GraphedLearnerStep(object):
     """`net.compute_gradients(*inputs[, noise])` + the optimiser's device part as one hipGraph.
     `inputs` are static device tensors (a call with `batch` copies into them); `noise` (SAC: the
     reparameterisation draws) is a dict of static tensors refilled from the network's generator before every
-    replay -- random draws stay outside the graph."""
+    replay -- random draws stay outside the graph.
 
-    def __init__(self, net, optimizer, *inputs, warmup=3, noise=None):
+    `steps_per_replay = K > 1` captures K consecutive learner steps (each on its own static input set, `input_sets`;
+    default: the same `inputs` K times) in ONE graph: consecutive replays of a one-step graph leave the GPU idle for
+    ~10 us between them, K steps per replay pay that once.  The host part of every step (step counter, resample tick)
+    runs after the replay, so a K-step replay is only legal while no resample falls inside it: `can_replay()`."""
+
+    def __init__(self, net, optimizer, *inputs, warmup=3, noise=None, steps_per_replay=1, input_sets=None):
         assert not getattr(optimizer, "exchange", optimizer.world > 1), \
             "graph capture covers the single-GPU step (RCCL runs eagerly)"
         self.net, self.opt = net, optimizer
-        self.inputs = tuple(inputs)
+        self.K = int(steps_per_replay)
+        assert self.K >= 1 and (self.K == 1 or noise is None), "one noise set per captured step is not built"
+        self.input_sets = [tuple(inputs)] * self.K if input_sets is None else [tuple(t) for t in input_sets]
+        assert len(self.input_sets) == self.K
+        self.inputs = self.input_sets[0]
         self.noise = noise
-        args = self.inputs if noise is None else self.inputs + (noise,)
-        net._ensure_buffers(inputs[0].shape[0], pin=True)    # the graph keeps pointing at this size's buffers
-        st = net.store
+        net._ensure_buffers(self.inputs[0].shape[0], pin=True)    # the graph keeps pointing at this size's buffers
         if hasattr(net, "sync_target_net_hard"):
             net.sync_target_net_hard()                       # SAC: the init op must not happen inside the warm-up
         # warm up on a side stream (lazy hipBLASLt/workspace init), then restore every piece of state
@@ -49,7 +56,7 @@ class GraphedLearnerStep(object):
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                net.compute_gradients(*args)
+                net.compute_gradients(*self._args(0))
                 optimizer.apply_device(net)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -58,9 +65,18 @@ class GraphedLearnerStep(object):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s):      # same stream as the warm-up: per-stream workspaces exist
-            self.loss3 = net.compute_gradients(*args)
-            optimizer.apply_device(net)
+            for k in range(self.K):
+                self.loss3 = net.compute_gradients(*self._args(k))
+                optimizer.apply_device(net)
         # capture does not execute; state is untouched
+
+    def _args(self, k):
+        return self.input_sets[k] if self.noise is None else self.input_sets[k] + (self.noise,)
+
+    def can_replay(self):
+        """True while the next K steps contain no resample tick before their last one."""
+        f = getattr(self.net, "steps_until_tick", None)
+        return self.K == 1 or f is None or f() >= self.K
 
     def _state_tensors(self):
         net, opt, st = self.net, self.opt, self.net.store
@@ -74,13 +90,20 @@ class GraphedLearnerStep(object):
         return ts
 
     def __call__(self, batch=None):
+        """one replay = K learner steps.  `batch`: K = 1: the step's tensors; K > 1: a list of K such tuples."""
         if batch is not None:
-            for dst, src in zip(self.inputs, batch):
-                dst.copy_(src, non_blocking=True)
+            sets = [batch] if self.K == 1 else batch
+            assert len(sets) == self.K
+            for dsts, srcs in zip(self.input_sets, sets):
+                for dst, src in zip(dsts, srcs):
+                    dst.copy_(src, non_blocking=True)
+        if not self.can_replay():
+            raise ValueError("a resample tick falls inside this %d-step replay: run one-step replays up to it" % self.K)
         if self.noise is not None:
             refill_noise(self.noise, self.net.rng)
         self.graph.replay()
-        self.opt.apply_host(self.net)
+        for _ in range(self.K):
+            self.opt.apply_host(self.net)
         return self.loss3
 
 

@@ -413,6 +413,12 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         return self._value(hc).clone()
 
     # -- resample ----------------------------------------------------------------------------------
+    def steps_until_tick(self):
+        """optimiser applies left until (and including) the one whose train op resamples (a2c.py:367-383)."""
+        if not (self.trainable and self.resample):
+            return 1 << 30
+        return max(1, self.resample_interval - self.train_flag)
+
     def resample_tick(self):
         """train op run after every optimiser apply (a2c.py:367-383)."""
         self.train_flag += 1

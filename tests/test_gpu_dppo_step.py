@@ -172,3 +172,36 @@ def test_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
         assert torch.equal(nets[0].value_buf, nets[1].value_buf)
         assert torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
         assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+
+
+def test_multi_step_graph_replay_matches_single_steps(dev):
+    """K learner steps captured in one hipGraph == K one-step replays, bit for bit; a replay is refused when a resample
+    tick would fall inside it, and the tick still fires on the right step."""
+    from pfpn_amd.graphs import GraphedLearnerStep
+    from pfpn_amd.models import SyncReplicasApplier
+    B, K = 64, 3
+    nets = [make_net(dev, seed=13, resample_interval=7) for _ in range(2)]
+    opts = [SyncReplicasApplier(n, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1) for n in nets]
+    rng = np.random.default_rng(8)
+    sets = []
+    for _ in range(K):
+        b = make_batch(rng, B); b["log_prob"] = np.full(B, -40.0, F)
+        sets.append(tuple(torch.from_numpy(b[k]).to(dev) for k in ("state", "action", "value", "log_prob", "advantage")))
+    gk = GraphedLearnerStep(nets[0], opts[0], steps_per_replay=K, input_sets=[tuple(t.clone() for t in s) for s in sets])
+    g1 = GraphedLearnerStep(nets[1], opts[1], *[t.clone() for t in sets[0]])
+    for rep in range(2):                                   # steps 1-3 and 4-6: no tick inside (interval 7)
+        assert gk.can_replay()
+        gk()
+        for s in sets:
+            g1(s)
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat), rep
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+        assert nets[0].global_step == nets[1].global_step == 3 * (rep + 1) and nets[0].train_flag == nets[1].train_flag
+    assert nets[0].steps_until_tick() == 1 and not gk.can_replay()          # step 7 resamples: not inside a 3-step replay
+    with pytest.raises(ValueError):
+        gk()
+    nets[0].max_active.fill_(1.0); nets[1].max_active.fill_(1.0)
+    g1k = GraphedLearnerStep(nets[0], opts[0], *[t.clone() for t in sets[0]])
+    g1k(sets[0]); g1(sets[0])
+    assert nets[0].train_flag == nets[1].train_flag == 0 and torch.equal(nets[0].store.flat, nets[1].store.flat)
+    assert gk.can_replay()
