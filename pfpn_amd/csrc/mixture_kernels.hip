@@ -897,6 +897,28 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             sum[u] = s2.x + s2.y;
             num[u] = n2.x + n2.y;
         }
+        if (MODE == MODE_FWD) {
+            // forward: nothing after the reductions needs a row's totals in every lane, so they stay distributed (lane l
+            // holds row ur = wave_reduce4_row(l)) and the per-row tail -- v_rcp, v_log (quarter rate), the denormal
+            // guard, the store -- runs ONCE across the four rows instead of four times on wave-uniform values
+            const float ks = wave_reduce4_dist<false>(sum[0], sum[1], sum[2], sum[3], lane);
+            const float kn = wave_reduce4_dist<false>(num[0], num[1], num[2], num[3], lane);
+            const int ur = wave_reduce4_row(lane);
+            const int b = b0 + ur * C;
+            float p = (kn * two_m64) * __builtin_amdgcn_rcpf(ks);
+            if (p < 1.401298464324817e-45f) p = 0.f;         // below the smallest fp32 denormal: the reference's p is 0
+            float lpr = __builtin_amdgcn_logf(p) * 0.6931471805599453f;     // v_log_f32 is log2
+            if (TANH) {
+                const float xr = ur == 0 ? xv[0] : ur == 1 ? xv[1] : ur == 2 ? xv[2] : xv[3];
+                lpr -= tanh_log_det(xr);
+            }
+            // 16 lanes per row store the same value to the same address: one instruction, four transactions, no branch
+            if (FULL || b < B) {
+                lpseg_out[(size_t)b * A + a] = lpr;
+                if (pmix_out) pmix_out[(size_t)b * A + a] = p;
+            }
+            return;
+        }
         wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
         wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
         float dxa[U];

@@ -119,6 +119,28 @@ __device__ __forceinline__ void wave_reduce4(float& r0, float& r1, float& r2, fl
     r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 3));
 }
 
+// The same butterfly, results left DISTRIBUTED: every lane returns the total of row wave_reduce4_row(lane) -- for
+// per-row follow-up math that can then run once across the four rows instead of four times on wave-uniform values.
+__device__ __forceinline__ int wave_reduce4_row(int lane) { return ((lane & 1) << 1) | ((lane >> 1) & 1); }   // 0,2,1,3
+
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce4_dist(float r0, float r1, float r2, float r3, int lane) {
+    const float id = IS_MAX ? -INFINITY : 0.f;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float k0 = b0 ? r2 : r0, k1 = b0 ? r3 : r1;
+    const float s0 = b0 ? r0 : r2, s1 = b0 ? r1 : r3;
+    k0 = red_comb<IS_MAX>(k0, dpp_shift<0xB1, 0xf>(s0, id));
+    k1 = red_comb<IS_MAX>(k1, dpp_shift<0xB1, 0xf>(s1, id));
+    float k = b1 ? k1 : k0;
+    const float sn = b1 ? k0 : k1;
+    k = red_comb<IS_MAX>(k, dpp_shift<0x4E, 0xf>(sn, id));
+    k = red_comb<IS_MAX>(k, dpp_shift<0x124, 0xf>(k, id));
+    k = red_comb<IS_MAX>(k, dpp_shift<0x128, 0xf>(k, id));
+    k = red_comb<IS_MAX>(k, __shfl_xor(k, 16, 64));
+    k = red_comb<IS_MAX>(k, __shfl_xor(k, 32, 64));
+    return k;
+}
+
 // Block-wide sum in a fixed order (deterministic): wave shuffle, then wave 0 adds the
 // per-wave partials left to right.  `red` needs >= blockDim.x/64 floats of LDS.
 __device__ __forceinline__ float block_sum(float v, float* red) {
