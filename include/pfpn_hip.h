@@ -203,6 +203,15 @@ int pfpn_bias_act(float* y, const float* bias, int rows, int H, int group_rows, 
 /* Relu6Grad + BiasAddGrad: dy <- dy*[0<y<6] in place (relu6), db [G,H] = column sums of dy per group. */
 int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group_rows, int relu6, float* db,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* BiasAdd + Relu6 (ops.py:105-117) that also leaves the Relu6Grad mask as bits -- bit (i & 63) of the 64-bit word
+ * mask[(i >> 6) * 4 + k] = (0 < y + bias < 6) for float4 index i (row-major over [rows, H/4]) and component k -- and the
+ * Relu6Grad + per-chunk BiasAddGrad partials of pfpn_act_bwd_partial reading those bits instead of the activations (1 bit
+ * instead of 4 bytes per element).  pfpn_act_bwd_partial_mask needs H % 256 == 0. */
+size_t pfpn_relu6_mask_bytes(int rows, int H);
+int pfpn_bias_act_mask(float* y, const float* bias, int rows, int H, int group_rows, void* mask, size_t mask_bytes,
+                       void* stream);
+int pfpn_act_bwd_partial_mask(float* dy, const void* mask, int rows, int H, int group_rows, float* partial,
+                              size_t partial_floats, int* chunks_per_group, void* stream);
 /* Last trunk layer's epilogue with the critic head folded in (ops.py:105-117 + actor_critic.py:206-210):
  * y <- act(y + bias) on all rows, and v[b] = y[value_group rows][b,:] . value_w + value_b[0].  group_rows % 4 == 0.
  * value_group < 0: EVERY group g has its own head (twin Q networks, sac.py:123-139): value_w [G,H],

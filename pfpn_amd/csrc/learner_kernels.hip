@@ -782,6 +782,101 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
 }
 
 
+// BiasAdd + Relu6 that also leaves the Relu6Grad mask as BITS: for float4 index i (row-major over [rows, H/4]) and
+// component k, bit (i & 63) of mask[(i >> 6) * 4 + k] = (0 < y + bias < 6).  The backward pass then reads 1 bit per
+// element instead of re-reading the activations (33.5 MB -> 1 MB for the merged first layer).  A wave's 64 lanes own 64
+// consecutive float4s, so the four words of a chunk are four wave ballots, stored by every lane to the same address
+// (one transaction, no branch).
+__global__ __launch_bounds__(256) void k_bias_act_mask(float* __restrict__ y, const float* __restrict__ bias, int rows,
+                                                       int H, int group_rows, unsigned long long* __restrict__ mask) {
+    const int H4 = H >> 2;
+    const size_t n4 = (size_t)rows * H4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nround = (n4 + 63) & ~(size_t)63;             // whole waves: every lane of a live chunk takes part
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nround; i0 += 4 * stride) {
+        float4 v[4], bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = i0 + j * stride;
+            const size_t ic = i < n4 ? i : 0;
+            const int row = (int)(ic / H4);
+            const int c4 = (int)(ic - (size_t)row * H4);
+            const int g = group_rows > 0 ? row / group_rows : 0;
+            v[j] = reinterpret_cast<float4*>(y)[ic];
+            bb[j] = reinterpret_cast<const float4*>(bias + (size_t)g * H)[c4];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t i = i0 + j * stride;
+            const bool live = i < n4;
+            float4 t = v[j];
+            t.x += bb[j].x; t.y += bb[j].y; t.z += bb[j].z; t.w += bb[j].w;
+            const unsigned long long m0 = __ballot(live && t.x > 0.f && t.x < 6.f);
+            const unsigned long long m1 = __ballot(live && t.y > 0.f && t.y < 6.f);
+            const unsigned long long m2 = __ballot(live && t.z > 0.f && t.z < 6.f);
+            const unsigned long long m3 = __ballot(live && t.w > 0.f && t.w < 6.f);
+            t.x = fminf(fmaxf(t.x, 0.f), 6.f); t.y = fminf(fmaxf(t.y, 0.f), 6.f);
+            t.z = fminf(fmaxf(t.z, 0.f), 6.f); t.w = fminf(fmaxf(t.w, 0.f), 6.f);
+            if (live) reinterpret_cast<float4*>(y)[i] = t;
+            if (i < nround) {                                   // wave-uniform: the whole chunk or nothing
+                unsigned long long* mw = mask + (i >> 6) * 4;
+                mw[0] = m0; mw[1] = m1; mw[2] = m2; mw[3] = m3;
+            }
+        }
+    }
+}
+
+// k_act_bwd_partial reading the mask bits of k_bias_act_mask instead of the activations (H/4 a multiple of 64, so a
+// wave's 64 float4s are one mask chunk: its four words arrive as one wave-uniform 32-byte load).
+__global__ __launch_bounds__(256) void k_act_bwd_partial_mask(float* __restrict__ dy,
+                                                              const unsigned long long* __restrict__ mask, int grows,
+                                                              int H, int chunk_len, float* __restrict__ partial) {
+    __shared__ float4 red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + cl;
+    const int H4 = H >> 2;
+    const int ch = blockIdx.y;
+    const size_t goff = (size_t)blockIdx.z * grows * H4;
+    const int b0 = ch * chunk_len, b1 = min(grows, b0 + chunk_len);
+    float4* d4 = reinterpret_cast<float4*>(dy) + goff;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned long long bit = 1ull << cl;
+    for (int b = b0 + rl; b < b1; b += 16) {
+        float4 g[4];
+        unsigned long long m[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = b + 4 * j;
+            const int rc = r < b1 ? r : b;
+            g[j] = d4[(size_t)rc * H4 + c4];
+            // chunk index of this wave's 64 float4s: wave-uniform
+            const size_t chunk = (goff + (size_t)rc * H4 + (size_t)blockIdx.x * 64) >> 6;
+            const unsigned long long* mw = mask + chunk * 4;
+            m[j][0] = mw[0]; m[j][1] = mw[1]; m[j][2] = mw[2]; m[j][3] = mw[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = b + 4 * j;
+            if (r < b1) {
+                float4 t = g[j];
+                t.x = (m[j][0] & bit) ? t.x : 0.f;
+                t.y = (m[j][1] & bit) ? t.y : 0.f;
+                t.z = (m[j][2] & bit) ? t.z : 0.f;
+                t.w = (m[j][3] & bit) ? t.w : 0.f;
+                d4[(size_t)r * H4 + c4] = t;
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+        }
+    }
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        float4 s = red[0][cl];
+        for (int k = 1; k < 4; ++k) { const float4 t = red[k][cl]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+        reinterpret_cast<float4*>(partial + ((size_t)blockIdx.z * gridDim.y + ch) * H)[c4] = s;
+    }
+}
+
 // Last trunk layer: y <- act(y + bias) AND the scalar critic head v[b] = y[b,:] . w + vb on the rows of group
 // `vgroup` (critic fc3, actor_critic.py:206-210; vgroup < 0: every group has its own head, vw [G,H], vb [G], v [G*B] --
 // the twin Q networks of SAC, sac.py:123-139) in the same pass -- the head's own launch re-read 8 MB to do
@@ -1158,6 +1253,45 @@ int pfpn_act_bwd_bias_grad(const float* y, float* dy, int rows, int H, int group
 int pfpn_state_moment_chunks(int B) {
     int C = row_chunks(B);
     return C > 256 ? 256 : C;
+}
+
+size_t pfpn_relu6_mask_bytes(int rows, int H) {
+    const size_t n4 = (size_t)rows * (size_t)(H >> 2);
+    return ((n4 + 63) >> 6) * 4 * sizeof(unsigned long long);
+}
+
+int pfpn_bias_act_mask(float* y, const float* bias, int rows, int H, int group_rows, void* mask, size_t mask_bytes,
+                       void* stream) {
+    PFPN_BEGIN();
+    if (!y || !bias || !mask || rows < 1 || H < 4 || (H & 3) || ((uintptr_t)y & 15) || ((uintptr_t)bias & 15) ||
+        ((uintptr_t)mask & 7) || (group_rows > 0 && rows % group_rows))
+        return PFPN_ERR_ARG;
+    if (mask_bytes < pfpn_relu6_mask_bytes(rows, H)) return PFPN_ERR_WORKSPACE;
+    hipLaunchKernelGGL(k_bias_act_mask, dim3(stream_grid((size_t)rows * (H >> 2))), dim3(256), 0, (hipStream_t)stream, y,
+                       bias, rows, H, group_rows, (unsigned long long*)mask);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_act_bwd_partial_mask(float* dy, const void* mask, int rows, int H, int group_rows, float* partial,
+                              size_t partial_floats, int* chunks_per_group, void* stream) {
+    PFPN_BEGIN();
+    if (!dy || !mask || !partial || !chunks_per_group || rows < 1 || H < 256 || (H & 255) || ((uintptr_t)dy & 15) ||
+        ((uintptr_t)mask & 7))
+        return PFPN_ERR_ARG;                         // H/4 must be a multiple of 64: a wave's float4s are one mask chunk
+    const int G = group_rows > 0 ? rows / group_rows : 1;
+    const int grows = group_rows > 0 ? group_rows : rows;
+    if (group_rows > 0 && rows % group_rows) return PFPN_ERR_ARG;
+    int cpg = row_chunks(grows);
+    if (cpg * G > PFPN_MAX_CHUNKS) cpg = PFPN_MAX_CHUNKS / G;
+    if (cpg < 1) return PFPN_ERR_ARG;
+    if (partial_floats < (size_t)G * cpg * H) return PFPN_ERR_WORKSPACE;
+    const int len = (grows + cpg - 1) / cpg;
+    *chunks_per_group = cpg;
+    hipLaunchKernelGGL(k_act_bwd_partial_mask, dim3((H >> 2) / 64, cpg, G), dim3(256), 0, (hipStream_t)stream, dy,
+                       (const unsigned long long*)mask, grows, H, len, partial);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
 }
 
 int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_rows, int relu6, int value_group,

@@ -445,6 +445,21 @@ def mixture_workspace(B, A, N, device):
     return torch.empty(int(lib.pfpn_mixture_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
 
 
+def relu6_mask(rows, H, device):
+    """bit-mask buffer of a [rows, H] ReLU6 layer (bias_act_mask writes it, act_bwd_partial(mask=...) reads it)"""
+    lib = _lib.load()
+    return torch.empty(int(lib.pfpn_relu6_mask_bytes(rows, H)), dtype=torch.uint8, device=device)
+
+
+def bias_act_mask(y, bias, mask, group_rows=0):
+    """y <- relu6(y + bias) and the Relu6Grad mask as bits (1 bit per element) into `mask`."""
+    lib = _lib.load()
+    rows, H = y.shape
+    _lib.check(lib.pfpn_bias_act_mask(_f32(y, rows, H), _f32(bias), rows, H, int(group_rows), mask.data_ptr(),
+                                      mask.numel(), _stream()), "pfpn_bias_act_mask")
+    return y
+
+
 def bias_act_value(y, bias, group_rows, value_group, value_w, value_b, v, relu6=True):
     """last trunk layer: y <- act(y + bias) and v = y[value_group] . value_w + value_b in ONE pass.
     value_group = -1: every group has its own head -- value_w [G,H], value_b [G], v [G, group_rows]."""
@@ -460,12 +475,22 @@ def bias_act_value(y, bias, group_rows, value_group, value_w, value_b, v, relu6=
     return v
 
 
-def act_bwd_partial(y, dy, group_rows, ws, relu6=True, value=None):
+def act_bwd_partial(y, dy, group_rows, ws, relu6=True, value=None, mask=None):
     """Relu6Grad in place + per-chunk bias-gradient partials left in `ws` (float view [G*cpg, H]); returns cpg.
-    value = (group, w [H], dvalue [group_rows], ws_value): fold the critic head's backward into that group."""
+    value = (group, w [H], dvalue [group_rows], ws_value): fold the critic head's backward into that group.
+    mask (from bias_act_mask, H % 256 == 0): read the mask bits instead of the activations `y`."""
     lib = _lib.load()
     rows, H = dy.shape
     cpg = ctypes.c_int(0)
+    if mask is not None:
+        if value is not None or not relu6:
+            raise ValueError("the mask-bit form has no folded head and is ReLU6 only")
+        if mask.numel() < lib.pfpn_relu6_mask_bytes(rows, H):
+            raise ValueError("mask buffer too small")
+        _lib.check(lib.pfpn_act_bwd_partial_mask(_f32(dy, rows, H), mask.data_ptr(), rows, H, int(group_rows),
+                                                 ws.data_ptr(), ws.numel() // 4, ctypes.addressof(cpg), _stream()),
+                   "pfpn_act_bwd_partial_mask")
+        return cpg.value
     vg, vw, dv, vws = 0, None, None, None
     if value is not None:
         nh = rows // group_rows if value[0] < 0 else 1

@@ -288,7 +288,8 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         x = self.prologue(state, deferred=deferred)
         if deferred is not None:
             st = self.store
-            ha, hc = self._trunks_forward(x, value_head=(st["critic/fc3/weight"], st["critic/fc3/bias"], self.value_buf))
+            ha, hc = self._trunks_forward(x, value_head=(st["critic/fc3/weight"], st["critic/fc3/bias"], self.value_buf),
+                                          masks=True)
             v = self.value_buf
         else:
             ha, hc = self._trunks_forward(x)

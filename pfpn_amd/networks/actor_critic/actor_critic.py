@@ -245,11 +245,13 @@ class ActorCriticNetwork(object):
             return self.state_normalizer.normalize(state, self.clip_state or 0.0, out=self.xn)
         return torch.clamp(state, -self.clip_state, self.clip_state, out=self.xn)
 
-    def _trunks_forward(self, x, value_head=None):
+    def _trunks_forward(self, x, value_head=None, masks=False):
         """-> (actor hidden [B,Ha], critic hidden [B,Hc]) (views of the stacks' activation buffers).
-        `value_head` = (w, b, out): also evaluate the critic head inside the merged trunk's last epilogue."""
+        `value_head` = (w, b, out): also evaluate the critic head inside the merged trunk's last epilogue;
+        `masks`: hidden layers leave their ReLU6 masks as bits for the deferred backward."""
         if self.trunk is not None:
-            h = self.trunk.forward(x, value_head=(1,) + tuple(value_head) if value_head is not None else None)
+            h = self.trunk.forward(x, value_head=(1,) + tuple(value_head) if value_head is not None else None,
+                                   masks=masks)
             return h[0], h[1]
         if value_head is not None:
             raise ValueError("the folded critic head needs the merged actor+critic trunk")

@@ -53,7 +53,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
             x = self.prologue(state, advantage, deferred=deferred)   # normalised state, state-norm EMA, advantage moments
             w3, b3 = st["critic/fc3/weight"], st["critic/fc3/bias"]
             if deferred is not None:
-                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf))
+                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf), masks=True)
                 v = self.value_buf
             else:
                 ha, hc = self._trunks_forward(x)

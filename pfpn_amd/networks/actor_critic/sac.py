@@ -149,8 +149,8 @@ def sac_network_wrapper(base_class):
             self.ws_pbias = kernels.learner_workspace(B, AN, dev)      # private: deferred fc_policy bias gradient
 
         # -- rollout ----------------------------------------------------------------------------------
-        def _actor_logits(self, x, slot, out):
-            ha = self.actor_trunk.forward(x, slot=slot)[0]
+        def _actor_logits(self, x, slot, out, masks=False):
+            ha = self.actor_trunk.forward(x, slot=slot, masks=masks)[0]
             torch.addmm(self.policy_bias, ha, self.policy_weight, out=out)     # bias in the GEMM epilogue
             return ha
 
@@ -185,8 +185,9 @@ def sac_network_wrapper(base_class):
             params = self.target_store if target else None
             w3 = (self.target_store if target else self.store)["critic/q1+critic/q2|fc3/weight"]
             b3 = (self.target_store if target else self.store)["critic/q1+critic/q2|fc3/bias"]
-            if fold:       # both Q heads inside the last trunk layer's epilogue pass
-                return self.q_stack.forward(xin, slot=slot, params=params, value_head=(-1, w3, b3, out))
+            if fold:       # both Q heads inside the last trunk layer's epilogue pass; mask bits where a backward follows
+                return self.q_stack.forward(xin, slot=slot, params=params, value_head=(-1, w3, b3, out),
+                                            masks=not target)
             h = self.q_stack.forward(xin, slot=slot, params=params)
             for g in range(2):
                 kernels.value_head_fwd(h[g], w3[g], b3[g], out=out[g])
@@ -227,7 +228,7 @@ def sac_network_wrapper(base_class):
                 self.update_state_normalizer(state)        # side stream, joined in the optimiser
             fold = deferred is not None
             # eval actor on s, shared actor on s' (sac.py:141-153)
-            ha = self._actor_logits(x, 0, self.logits)
+            ha = self._actor_logits(x, 0, self.logits, masks=fold)
             self._actor_logits(x2, 1, self.logits2)
             loc, logstd = self.loc, self.logstd
             a, s_, k = kernels.rsample_fwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"])

@@ -171,7 +171,8 @@ class DenseStack:
         a = [alloc(i) for i in range(self.L)]
         d = [alloc(i) for i in range(self.L)]
         self._bufs[key] = {"act2d": [t[0] for t in a], "act": [t[1] for t in a],
-                           "dact2d": [t[0] for t in d], "dact": [t[1] for t in d], "x": None, "B": B, "ws": None}
+                           "dact2d": [t[0] for t in d], "dact": [t[1] for t in d], "x": None, "B": B, "ws": None,
+                           "mask": [None] * self.L, "mask_ok": [False] * self.L}
         return self._bufs[key]
 
     def _slab_workspaces(self, buf):
@@ -191,12 +192,14 @@ class DenseStack:
         """`group_rows` of the epilogue kernels: layer 0 merged is one [B, G*H] matrix with a [G*H] bias."""
         return 0 if (i == 0 and self.merged0) else B
 
-    def forward(self, x, slot=0, params=None, value_head=None):
+    def forward(self, x, slot=0, params=None, value_head=None, masks=False):
         """x: [B, in], shared by all groups.  Returns act[-1]  [G, B, H_last].
         `slot` selects an activation set (a stack evaluated on several inputs in one step keeps one
         set per input for the backward); `params` = another ParamStore with the same layout (SAC
         target network).  `value_head` = (group, w [H_last], b [1], out [B]): the scalar head on that group's
-        output is evaluated inside the last layer's epilogue pass (no launch of its own)."""
+        output is evaluated inside the last layer's epilogue pass (no launch of its own).
+        `masks`: the hidden layers below the last also leave their Relu6Grad masks as bits (1 bit per element), which the
+        deferred backward then reads instead of the activations."""
         B = x.shape[0]
         st = params if params is not None else self.store
         buf = self._buffers(B, slot)
@@ -216,8 +219,15 @@ class DenseStack:
                 g, vw, vb, vout = value_head
                 kernels.bias_act_value(act2d[i], b, B, g, vw, vb, vout, relu6=True)
                 value_head = None
+            elif masks and i < self.L - 1 and act2d[i].shape[1] % 256 == 0:
+                if buf["mask"][i] is None:
+                    buf["mask"][i] = kernels.relu6_mask(act2d[i].shape[0], act2d[i].shape[1], self.store.device)
+                kernels.bias_act_mask(act2d[i], b, buf["mask"][i], group_rows=self._group_rows(i, B))
+                buf["mask_ok"][i] = True
+                continue
             else:
                 kernels.bias_act(act2d[i], b, relu6=True, group_rows=self._group_rows(i, B))
+            buf["mask_ok"][i] = False
         if value_head is not None:
             g, vw, vb, vout = value_head
             if g < 0:
@@ -265,7 +275,10 @@ class DenseStack:
                 fold = None
                 if value is not None and i == self.L - 1:
                     fold = (value[0], value[1], value[2], ws_value)
-                cpg = kernels.act_bwd_partial(act2d[i], d2d, grows, ws[i], relu6=True, value=fold)
+                if fold is None and buf["mask_ok"][i]:
+                    cpg = kernels.act_bwd_partial(None, d2d, grows, ws[i], mask=buf["mask"][i])
+                else:
+                    cpg = kernels.act_bwd_partial(act2d[i], d2d, grows, ws[i], relu6=True, value=fold)
                 gb = self.store.g(self.bn[i])
                 if need_dw and grows:
                     for g in range(self.G):

@@ -317,3 +317,34 @@ def test_deferred_reductions_match_immediate_ones(dev, B, H):
     db2 = torch.zeros(2, H, device=dev)
     kernels.reduce_jobs([kernels.job_colsum(ws, gi * cpg2 * H, cpg2, H, H, db2[gi]) for gi in range(2)])
     assert torch.equal(db2, db_ref)
+
+
+@pytest.mark.parametrize("rows,H,G", [(4096, 2048, 1), (33, 512, 1), (2 * 40, 1024, 2), (7, 256, 1)])
+def test_relu6_mask_bits_match_activation_reads(dev, rows, H, G):
+    """bias+ReLU6 that leaves the Relu6Grad mask as bits, and the backward reading the bits: the same bits as the pair
+    that re-reads the activations (outputs, masked gradient, bias-gradient sums)."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(rows + H)
+    y0 = rng.normal(1.5, 3, (rows, H)).astype(F)
+    y0[0, :4] = [0.0, 6.0, -0.0, 5.9999995]                      # the edges of the open interval (0, 6)
+    bias = rng.normal(0, 1, (G, H)).astype(F)
+    bias[0, :4] = 0.0
+    g = rng.normal(0, 1, (rows, H)).astype(F)
+    gr = rows // G if G > 1 else 0
+    ya, yb, db, ga, gb = to_dev(dev, y0, y0, bias, g, g)
+    kernels.bias_act(ya, db, True, gr)
+    mask = kernels.relu6_mask(rows, H, dev)
+    kernels.bias_act_mask(yb, db, mask, gr)
+    assert torch.equal(ya, yb)
+    # decode the bits on the host and compare with the activations' open-interval test
+    m64 = mask.cpu().numpy().view(np.uint64)[: ((rows * H // 4 + 63) // 64) * 4].reshape(-1, 4)
+    i = np.arange(rows * H // 4)
+    bits = np.stack([(m64[i >> 6, k] >> (i & 63).astype(np.uint64)) & np.uint64(1) for k in range(4)], 1).reshape(rows, H)
+    ref = ya.cpu().numpy()
+    assert np.array_equal(bits.astype(bool), (ref > 0) & (ref < 6))
+    ws1, ws2 = kernels.learner_workspace(rows, H, dev), kernels.learner_workspace(rows, H, dev)
+    c1 = kernels.act_bwd_partial(ya, ga, gr, ws1, relu6=True)
+    c2 = kernels.act_bwd_partial(None, gb, gr, ws2, mask=mask)
+    assert c1 == c2 and torch.equal(ga, gb)
+    n = G * c1 * H
+    assert torch.equal(ws1.view(torch.float32)[:n], ws2.view(torch.float32)[:n])
