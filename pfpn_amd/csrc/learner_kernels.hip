@@ -1046,13 +1046,20 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t) {
             q.out[2] = vl;
         }
     } else if (q.kind == PFPN_JOB_NORM_EMA) {             // chunk moments -> EMA of mean / std      (k_norm_ema)
+        // 16 columns per block (first 256 threads = 16 columns x 16 chunk lanes; the rest only keep the barriers): with
+        // 64 columns per block the whole 800 KB of moments went through FOUR CUs' load paths (~3 us); 13 blocks spread
+        // it.  The arithmetic order per column (chunk lane kl sums k = kl, kl+16, ..; then lanes 0..15 in order) is
+        // k_norm_ema's, so both give the same bits.
         const double* partial = (const double*)q.src;
-        const int S = q.n, C = q.nslab, c = blk * 64 + cl;
+        const int S = q.n, C = q.nslab;
+        const int ecl = threadIdx.x & 15, ekl = (threadIdx.x >> 4) & 15;
+        const int c = blk * 16 + ecl;
+        const bool active = threadIdx.x < 256 && c < S;
         double a1 = 0.0, a2 = 0.0;
-        if (c < S) {
-            int k = kl;
-            for (; k + 112 < C; k += 128) {               // 16 loads in flight (the chain of dependent round trips
-                double u[8], w[8];                        // was this job's -- and k_norm_ema's -- whole duration)
+        if (active) {
+            int k = ekl;
+            for (; k + 112 < C; k += 128) {               // 16 loads in flight per thread
+                double u[8], w[8];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     u[m] = partial[((size_t)(k + 16 * m) * 2 + 0) * S + c];
@@ -1066,10 +1073,10 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t) {
                 a2 += partial[((size_t)k * 2 + 1) * S + c];
             }
         }
-        dred[0][kl][cl] = a1; dred[1][kl][cl] = a2;
+        if (threadIdx.x < 256) { dred[0][ekl][ecl] = a1; dred[1][ekl][ecl] = a2; }
         __syncthreads();
-        if (kl != 0 || c >= S) return;
-        for (int m = 1; m < 16; ++m) { a1 += dred[0][m][cl]; a2 += dred[1][m][cl]; }
+        if (!active || ekl != 0) return;
+        for (int m = 1; m < 16; ++m) { a1 += dred[0][m][ecl]; a2 += dred[1][m][ecl]; }
         const double Bd = (double)q.stride;               // batch rows
         const double mu = a1 / Bd;
         double var = a2 / Bd - mu * mu;
@@ -1349,7 +1356,7 @@ int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream) {
         if (q.kind == PFPN_JOB_COLSUM) nb = (q.n + 63) / 64;
         else if (q.kind == PFPN_JOB_NORM_EMA) {
             if (!q.out2 || !q.in0 || !q.in1 || !q.in2 || q.stride < 1) return PFPN_ERR_ARG;
-            nb = (q.n + 63) / 64;
+            nb = (q.n + 15) / 16;
         } else if (q.kind != PFPN_JOB_VECSUM && q.kind != PFPN_JOB_PPO_LOSS) return PFPN_ERR_ARG;
         t.job[j] = q;
         t.first_block[j] = blocks;
