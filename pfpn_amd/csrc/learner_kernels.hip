@@ -882,13 +882,17 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial_mask(float* __restrict_
 // the twin Q networks of SAC, sac.py:123-139) in the same pass -- the head's own launch re-read 8 MB to do
 // 2 flops per element.  One wave per row, four rows in flight; the dot product is accumulated exactly like
 // k_value_head_fwd (lane partial over i = lane, lane+64, ..; wave_sum), so both paths agree bit for bit.
+#ifndef PFPN_BAV_ROWS
+#define PFPN_BAV_ROWS 2
+#endif
 __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, const float* __restrict__ bias, int rows,
                                                         int H, int group_rows, int relu6, int vgroup,
                                                         const float* __restrict__ vw, const float* __restrict__ vb,
                                                         int vb_stride, float* __restrict__ v) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int r0 = wave * 4;
+    constexpr int RW = PFPN_BAV_ROWS;                             // rows per wave (group_rows % 4 == 0 covers 2 and 4)
+    const int r0 = wave * RW;
     if (r0 >= rows) return;
     const int H4 = H >> 2;
     const int g = group_rows > 0 ? r0 / group_rows : 0;          // group_rows % 4 == 0: the four rows share a group
@@ -896,11 +900,13 @@ __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, c
     const bool head = all || g == vgroup;
     const float4* b4 = reinterpret_cast<const float4*>(bias + (size_t)g * H);
     const float4* w4 = reinterpret_cast<const float4*>(vw + (all ? (size_t)g * H : 0));
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = lane; i < H4; i += 64) {
-        float4 t[4];
+    float acc[RW];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RW; ++j) acc[j] = 0.f;
+    for (int i = lane; i < H4; i += 64) {
+        float4 t[RW];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
             const int r = r0 + j < rows ? r0 + j : r0;
             t[j] = reinterpret_cast<const float4*>(y)[(size_t)r * H4 + i];
         }
@@ -908,7 +914,7 @@ __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, c
         float4 ww = make_float4(0.f, 0.f, 0.f, 0.f);
         if (head) ww = w4[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < RW; ++j) {
             float4 u = t[j];
             u.x += bb.x; u.y += bb.y; u.z += bb.z; u.w += bb.w;
             if (relu6) {
@@ -922,7 +928,7 @@ __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, c
     if (!head) return;
     const float b0 = vb[all ? g * vb_stride : 0];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < RW; ++j) {
         const float sacc = wave_sum(acc[j]);
         const int r = r0 + j;
         if (lane == 0 && r < rows) v[all ? r : r - vgroup * group_rows] = sacc + b0;
@@ -1308,7 +1314,7 @@ int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_
         ((uintptr_t)bias & 15) || ((uintptr_t)value_w & 15) || group_rows < 4 || (group_rows & 3) || rows % group_rows ||
         value_group >= rows / group_rows || value_b_stride < 1)
         return PFPN_ERR_ARG;
-    const int waves = (rows + 3) / 4;
+    const int waves = (rows + PFPN_BAV_ROWS - 1) / PFPN_BAV_ROWS;
     hipLaunchKernelGGL(k_bias_act_value, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, bias, rows, H,
                        group_rows, relu6, value_group, value_w, value_b, value_b_stride, v);
     PFPN_CHECK_LAUNCH();
