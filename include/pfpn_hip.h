@@ -235,11 +235,12 @@ int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_r
  *                     p1 = value_coef; n = 2
  *   PFPN_JOB_NORM_EMA src = float64 moments of pfpn_state_prologue (nslab = pfpn_state_moment_chunks(B) chunks),
  *                     n = S, stride = B; in0 = step, in1 = mean_in, in2 = std_in; out = mean_out, out2 = std_out */
-#define PFPN_MAX_REDUCE_JOBS 16
+#define PFPN_MAX_REDUCE_JOBS 32
 #define PFPN_JOB_COLSUM 0
 #define PFPN_JOB_VECSUM 1
 #define PFPN_JOB_PPO_LOSS 2
 #define PFPN_JOB_NORM_EMA 3
+#define PFPN_JOB_SQSUM 4
 typedef struct PfpnReduceJob {
     int kind, nslab, stride, n;
     const void* src;
@@ -249,8 +250,20 @@ typedef struct PfpnReduceJob {
     const float* in1;
     const float* in2;
     float p0, p1;
+    int norm;               /* COLSUM / VECSUM: the output is a gradient, count its squares (pfpn_reduce_jobs_norm) */
 } PfpnReduceJob;
 int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream);
+/* The same launch also yielding the partial sums of the global gradient norm (tf.clip_by_global_norm, base_worker.py:97-102):
+ * outputs of jobs with norm = 1 are squared where they are produced; PFPN_JOB_SQSUM jobs (src = a finished gradient
+ * segment, n floats, 16-byte aligned, n % 4 == 0, nslab = blocks to spread it over) cover every other gradient.  Block b
+ * writes sq_partial[b]; *n_partials = number of blocks.  beta_pow != NULL: block 0 rotates the Adam powers as
+ * pfpn_clip_adam's first launch does.  pfpn_clip_adam_prenorm is pfpn_clip_adam's second launch on those partials. */
+int pfpn_reduce_jobs_norm(const PfpnReduceJob* jobs, int n_jobs, float* sq_partial, size_t sq_capacity, int* n_partials,
+                          float* beta_pow, int n_groups, float beta1, float beta2, void* stream);
+int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                           const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                           float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,
+                           float* step_counter, const float* sq_partial, int n_partials, void* stream);
 int pfpn_state_moment_chunks(int B);
 /* Slab geometry of pfpn_ppo_mixture_fwd_bwd called with loss3 = NULL (same arguments): nslab slabs of `stride`
  * floats laid out [dloc A*N | dlogstd A*N | (dbias A*N) | policy-loss, value-loss, pad, pad].  PFPN_ERR_ARG when the

@@ -1023,7 +1023,19 @@ struct ReduceJobTable {
     int n_jobs;
 };
 
-__global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t) {
+// With `na.sq_partial` the launch also yields the global gradient norm's partial sums (tf.clip_by_global_norm,
+// base_worker.py:97-102): every gradient that a job of this launch produces is squared where it is produced, every other
+// gradient is final before the launch (the last GEMM precedes it) and is covered by PFPN_JOB_SQSUM jobs; block b
+// writes sq_partial[b] (0 for jobs that produce no gradient).  Block 0 then also rotates the Adam powers, i.e. the
+// launch replaces k_sqsum_partial_rot.
+struct NormArgs {
+    float* sq_partial;
+    float* beta_pow;
+    int n_groups;
+    float b1, b2;
+};
+
+__global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t, NormArgs na) {
     __shared__ double dred[2][16][64];
     float (*red)[64] = reinterpret_cast<float (*)[64]>(&dred[0][0][0]);
     int j = 0;
@@ -1031,15 +1043,48 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t) {
     const PfpnReduceJob& q = t.job[j];
     const int blk = blockIdx.x - t.first_block[j];
     const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    if (na.sq_partial && threadIdx.x == 0) {
+        if (q.kind == PFPN_JOB_PPO_LOSS || q.kind == PFPN_JOB_NORM_EMA) na.sq_partial[blockIdx.x] = 0.f;
+        if (blockIdx.x == 0 && na.beta_pow)
+            for (int k = 0; k < na.n_groups; ++k) {
+                float* bp = na.beta_pow + 4 * k;
+                bp[2] = bp[0]; bp[3] = bp[1];
+                bp[0] *= na.b1; bp[1] *= na.b2;
+            }
+    }
     if (q.kind == PFPN_JOB_COLSUM) {                      // out[i] = sum_k src[k*stride + i]       (k_bias_grad_final)
         const int i = blk * 64 + cl;
         const float s = slab_reduce_1024<false>((const float*)q.src, q.nslab, (size_t)q.stride, i, i < q.n, red);
         if (kl == 0 && i < q.n) q.out[i] = s;
+        if (na.sq_partial && kl == 0) {                    // wave 0 holds the block's 64 outputs
+            const float sq = wave_sum((q.norm && i < q.n) ? s * s : 0.f);
+            if (cl == 0) na.sq_partial[blockIdx.x] = sq;
+        }
     } else if (q.kind == PFPN_JOB_VECSUM) {               // out[0] = sum_i src[i]                  (value-head bias)
         float s = 0.f;
         for (int i = threadIdx.x; i < q.n; i += blockDim.x) s += ((const float*)q.src)[i];
         s = block_sum(s, &red[0][0]);
-        if (threadIdx.x == 0) q.out[0] = s;
+        if (threadIdx.x == 0) {
+            q.out[0] = s;
+            if (na.sq_partial) na.sq_partial[blockIdx.x] = q.norm ? s * s : 0.f;
+        }
+    } else if (q.kind == PFPN_JOB_SQSUM) {                // sum of squares of a finished gradient segment, block `blk`'s share
+        const float4* g4 = reinterpret_cast<const float4*>(q.src);
+        const size_t n4 = (size_t)q.n >> 2;
+        const size_t share = (n4 + q.nslab - 1) / q.nslab;
+        const size_t lo = (size_t)blk * share, hi = lo + share < n4 ? lo + share : n4;
+        float s = 0.f;
+        size_t i = lo + threadIdx.x;
+        for (; i + 3 * 1024 < hi; i += 4 * 1024) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = g4[i + u * 1024];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+        }
+        for (; i < hi; i += 1024) { const float4 v = g4[i]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+        s = block_sum(s, &red[0][0]);
+        if (threadIdx.x == 0 && na.sq_partial) na.sq_partial[blockIdx.x] = s;
     } else if (q.kind == PFPN_JOB_PPO_LOSS) {             // two loss columns -> loss3              (k_finalize)
         __shared__ float lsum[2];
         const float s = slab_reduce_1024<false>((const float*)q.src, q.nslab, (size_t)q.stride, cl & 1, cl < 2, red);
@@ -1350,19 +1395,22 @@ int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_r
     return PFPN_OK;
 }
 
-int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream) {
-    PFPN_BEGIN();
+static int reduce_jobs_launch(const PfpnReduceJob* jobs, int n_jobs, NormArgs na, size_t sq_capacity, int* n_blocks,
+                              void* stream) {
     if (!jobs || n_jobs < 1 || n_jobs > PFPN_MAX_REDUCE_JOBS) return PFPN_ERR_ARG;
     ReduceJobTable t{};
     int blocks = 0;
     for (int j = 0; j < n_jobs; ++j) {
         const PfpnReduceJob& q = jobs[j];
-        if (!q.src || !q.out || q.n < 1 || q.nslab < 1) return PFPN_ERR_ARG;
+        if (!q.src || (!q.out && q.kind != PFPN_JOB_SQSUM) || q.n < 1 || q.nslab < 1) return PFPN_ERR_ARG;
         int nb = 1;
         if (q.kind == PFPN_JOB_COLSUM) nb = (q.n + 63) / 64;
         else if (q.kind == PFPN_JOB_NORM_EMA) {
             if (!q.out2 || !q.in0 || !q.in1 || !q.in2 || q.stride < 1) return PFPN_ERR_ARG;
             nb = (q.n + 15) / 16;
+        } else if (q.kind == PFPN_JOB_SQSUM) {
+            if (!na.sq_partial || (q.n & 3) || ((uintptr_t)q.src & 15)) return PFPN_ERR_ARG;
+            nb = q.nslab;
         } else if (q.kind != PFPN_JOB_VECSUM && q.kind != PFPN_JOB_PPO_LOSS) return PFPN_ERR_ARG;
         t.job[j] = q;
         t.first_block[j] = blocks;
@@ -1370,9 +1418,24 @@ int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream) {
     }
     t.first_block[n_jobs] = blocks;
     t.n_jobs = n_jobs;
-    hipLaunchKernelGGL(k_reduce_jobs, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, t);
+    if (na.sq_partial && (size_t)blocks > sq_capacity) return PFPN_ERR_WORKSPACE;
+    if (n_blocks) *n_blocks = blocks;
+    hipLaunchKernelGGL(k_reduce_jobs, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, t, na);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
+}
+
+int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream) {
+    PFPN_BEGIN();
+    return reduce_jobs_launch(jobs, n_jobs, NormArgs{nullptr, nullptr, 0, 0.f, 0.f}, 0, nullptr, stream);
+}
+
+int pfpn_reduce_jobs_norm(const PfpnReduceJob* jobs, int n_jobs, float* sq_partial, size_t sq_capacity, int* n_partials,
+                          float* beta_pow, int n_groups, float beta1, float beta2, void* stream) {
+    PFPN_BEGIN();
+    if (!sq_partial || !n_partials || (beta_pow && n_groups < 1)) return PFPN_ERR_ARG;
+    return reduce_jobs_launch(jobs, n_jobs, NormArgs{sq_partial, beta_pow, n_groups, beta1, beta2}, sq_capacity, n_partials,
+                              stream);
 }
 
 int pfpn_value_head_fwd(const float* h, const float* w, const float* bias, int B, int H, float* v, void* stream) {
@@ -1475,6 +1538,32 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
 }
 
 // ---- data-parallel optimiser step around the all-reduce: clip per replica (2 launches), Adam on the sum (1) ----
+int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                           const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                           float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,
+                           float* step_counter, const float* sq_partial, int n_partials, void* stream) {
+    PFPN_BEGIN();
+    if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || !sq_partial || n < 1 ||
+        n_groups < 1 || n_groups > 4 || n_partials < 1)
+        return PFPN_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
+    AdamGroups gr{};
+    gr.n = n_groups;
+    size_t longest = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (group_off[k] < 0 || group_len[k] < 0 || (group_off[k] & 3) || (group_len[k] & 3) ||
+            (size_t)(group_off[k] + group_len[k]) > n)
+            return PFPN_ERR_ARG;
+        gr.off[k] = group_off[k]; gr.len[k] = group_len[k]; gr.lr[k] = group_lr[k];
+        if ((size_t)group_len[k] > longest) longest = (size_t)group_len[k];
+    }
+    hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
+                       v, gr, beta1, beta2, eps, beta_pow, sq_partial, n_partials, clip_norm, 1.0f, norm_scale,
+                       step_counter);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
 int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm_scale, float* beta_pow, int n_groups,
                             float beta1, float beta2, void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();

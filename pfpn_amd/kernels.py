@@ -518,11 +518,11 @@ class ReduceJob(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("nslab", ctypes.c_int), ("stride", ctypes.c_int), ("n", ctypes.c_int),
                 ("src", ctypes.c_void_p), ("out", ctypes.c_void_p), ("out2", ctypes.c_void_p),
                 ("in0", ctypes.c_void_p), ("in1", ctypes.c_void_p), ("in2", ctypes.c_void_p),
-                ("p0", ctypes.c_float), ("p1", ctypes.c_float)]
+                ("p0", ctypes.c_float), ("p1", ctypes.c_float), ("norm", ctypes.c_int)]
 
 
-JOB_COLSUM, JOB_VECSUM, JOB_PPO_LOSS, JOB_NORM_EMA = 0, 1, 2, 3
-MAX_REDUCE_JOBS = 16
+JOB_COLSUM, JOB_VECSUM, JOB_PPO_LOSS, JOB_NORM_EMA, JOB_SQSUM = 0, 1, 2, 3, 4
+MAX_REDUCE_JOBS = 32
 
 
 def job_colsum(ws, float_offset, nslab, stride, n, out):
@@ -530,16 +530,16 @@ def job_colsum(ws, float_offset, nslab, stride, n, out):
     if out.numel() < n or ws.numel() < 4 * (float_offset + (nslab - 1) * stride + n):
         raise ValueError("column-sum job outside its buffers")
     return ReduceJob(JOB_COLSUM, nslab, stride, n, ws.data_ptr() + 4 * float_offset, _f32(out), None, None, None, None,
-                     0.0, 0.0)
+                     0.0, 0.0, 0)
 
 
 def job_vecsum(vec, out):
-    return ReduceJob(JOB_VECSUM, 1, 0, vec.numel(), _f32(vec), _f32(out), None, None, None, None, 0.0, 0.0)
+    return ReduceJob(JOB_VECSUM, 1, 0, vec.numel(), _f32(vec), _f32(out), None, None, None, None, 0.0, 0.0, 0)
 
 
 def job_ppo_loss(ws, float_offset, nslab, stride, inv_B, value_coef, loss3):
     return ReduceJob(JOB_PPO_LOSS, nslab, stride, 2, ws.data_ptr() + 4 * float_offset, _f32(loss3, 3), None, None, None,
-                     None, float(inv_B), float(value_coef))
+                     None, float(inv_B), float(value_coef), 0)
 
 
 def job_norm_ema(ws, B, S, step, mean, std, mean_out, std_out):
@@ -549,16 +549,37 @@ def job_norm_ema(ws, B, S, step, mean, std, mean_out, std_out):
     if ws.numel() < C * 2 * S * 8:
         raise ValueError("moment workspace too small")
     return ReduceJob(JOB_NORM_EMA, C, B, S, ws.data_ptr(), _f32(mean_out, S), _f32(std_out, S), _f32(step, 1),
-                     _f32(mean, S), _f32(std, S), 0.0, 0.0)
+                     _f32(mean, S), _f32(std, S), 0.0, 0.0, 0)
 
 
-def reduce_jobs(jobs):
-    """ONE launch for every deferred fixed-order reduction of the step."""
+def job_sqsum(ptr, n_floats, blocks):
+    """sum of squares of a FINISHED gradient segment (address `ptr`, 16-byte aligned, n_floats % 4 == 0), over `blocks`
+    blocks; only inside reduce_jobs(..., norm=...)."""
+    if ptr % 16 or n_floats % 4 or n_floats < 4 or blocks < 1:
+        raise ValueError("sqsum segment must be 16-byte aligned with a multiple of 4 floats")
+    return ReduceJob(JOB_SQSUM, int(blocks), 0, int(n_floats), ptr, None, None, None, None, None, 0.0, 0.0, 0)
+
+
+def reduce_jobs(jobs, norm=None):
+    """ONE launch for every deferred fixed-order reduction of the step.
+    norm = dict(partial [>= #blocks] f32, beta_pow [G,4] or None, beta1, beta2): the launch also leaves the global-norm
+    partial sums (outputs of jobs with .norm = 1 + the JOB_SQSUM segments) and rotates the Adam powers; returns the
+    number of partials (for clip_adam(prenorm=...))."""
     lib = _lib.load()
     if not 1 <= len(jobs) <= MAX_REDUCE_JOBS:
         raise ValueError("1..%d reduce jobs per launch" % MAX_REDUCE_JOBS)
     arr = (ReduceJob * len(jobs))(*jobs)
-    _lib.check(lib.pfpn_reduce_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_reduce_jobs")
+    if norm is None:
+        _lib.check(lib.pfpn_reduce_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_reduce_jobs")
+        return 0
+    nb = ctypes.c_int(0)
+    bp = norm.get("beta_pow")
+    G = bp.shape[0] if bp is not None else 0
+    _lib.check(lib.pfpn_reduce_jobs_norm(ctypes.addressof(arr), len(jobs), _f32(norm["partial"]), norm["partial"].numel(),
+                                         ctypes.addressof(nb), _f32(bp, G, 4) if bp is not None else None, G,
+                                         float(norm.get("beta1", 0.9)), float(norm.get("beta2", 0.999)), _stream()),
+               "pfpn_reduce_jobs_norm")
+    return nb.value
 
 
 def value_head_fwd(h, w, bias, out=None):
@@ -601,12 +622,22 @@ def tf_adam(params, grads, m, v, beta_pow, lr, beta1=0.9, beta2=0.999, eps=1e-8,
 
 
 def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, clip_norm, norm_scale, beta1=0.9,
-              beta2=0.999, eps=1e-8, step_counter=None):
+              beta2=0.999, eps=1e-8, step_counter=None, prenorm=None):
     """One-replica optimiser step in two launches (global-norm clip folded into TF-Adam).  group_* are ctypes
-    arrays (host); beta_pow is [G,4] (see include/pfpn_hip.h)."""
+    arrays (host); beta_pow is [G,4] (see include/pfpn_hip.h).
+    prenorm = (partial, count) from reduce_jobs(norm=...): the norm's partial sums exist and the powers are rotated
+    already -- ONE launch."""
     lib = _lib.load()
     n = params.numel()
     G = len(group_lr)
+    if prenorm is not None:
+        _lib.check(lib.pfpn_clip_adam_prenorm(_f32(params), _f32(grads), _f32(m), _f32(v), n, G,
+                                              ctypes.addressof(group_off), ctypes.addressof(group_len),
+                                              ctypes.addressof(group_lr), float(beta1), float(beta2), float(eps),
+                                              _f32(beta_pow, G, 4), float(clip_norm), _f32(norm_scale, 2),
+                                              _f32(step_counter, 1) if step_counter is not None else None,
+                                              _f32(prenorm[0]), int(prenorm[1]), _stream()), "pfpn_clip_adam_prenorm")
+        return
     ws, wsn = _learn_ws(1, 1, params.device)
     _lib.check(lib.pfpn_clip_adam(_f32(params), _f32(grads), _f32(m), _f32(v), n, G, ctypes.addressof(group_off),
                                   ctypes.addressof(group_len), ctypes.addressof(group_lr), float(beta1), float(beta2),

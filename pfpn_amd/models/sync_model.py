@@ -63,6 +63,13 @@ class SyncReplicasApplier(object):
         self._g_len = (ctypes.c_longlong * G)(*[g["len"] for g in self.groups])
         self._g_lr = (ctypes.c_float * G)(*[g["lr"] for g in self.groups])
         self.fused = os.environ.get("PFPN_FUSED_OPT", "1") != "0"
+        # one replica with a global-norm clip: the step's reduction launch can also produce the norm's partial sums and
+        # rotate the powers (ActorCriticNetwork._finish_deferred), leaving ONE optimiser launch.  PFPN_FUSED_NORM=0: off.
+        net._norm_hook = None
+        if not self.exchange and self.fused and self.norm_clip and len(self.groups) <= 4 and st.device.type == "cuda" \
+                and os.environ.get("PFPN_FUSED_NORM", "1") != "0":
+            net._norm_hook = {"partial": torch.zeros(4096, dtype=torch.float32, device=st.device),
+                              "beta_pow": self.beta_pow, "beta1": beta1, "beta2": beta2}
         if self.exchange and hasattr(net, "adopt_tail_statistics"):
             net.adopt_tail_statistics()        # replicated statistics live in the all-reduce bucket from now on
 
@@ -74,9 +81,12 @@ class SyncReplicasApplier(object):
         net.join_side_stream()
         if not self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:
             # one replica: clip + every group's Adam + power / step-counter advance in two launches
+            ready = getattr(net, "_norm_ready", 0)
+            net._norm_ready = 0
             kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
-                              step_counter=net.step_dev)
+                              step_counter=net.step_dev,
+                              prenorm=(net._norm_hook["partial"], ready) if ready and net._norm_hook else None)
             net.unpack_synced_stats(st.tail, 1.0)
             return
         if self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:

@@ -314,7 +314,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             self.store.g("actor/samples_std").zero_()
         self._backward_heads(ha, hc, dlogits, dvalue, fused_db=False, deferred=deferred)
         if deferred is not None:
-            kernels.reduce_jobs(deferred)
+            self._finish_deferred(deferred, allow_norm=not self.fixed_sigma)
         self.last_targets = (value_target, advantage, mask, logp, v)
         return loss4
 

@@ -257,6 +257,43 @@ class ActorCriticNetwork(object):
             raise ValueError("the folded critic head needs the merged actor+critic trunk")
         return self.actor_trunk.forward(x)[0], self.critic_trunk.forward(x)[0]
 
+    def _finish_deferred(self, deferred, allow_norm=True):
+        """The step's single reduction launch.  When the optimiser left a norm hook (one replica, global-norm clip:
+        SyncReplicasApplier), the same launch also produces the partial sums of the global gradient norm -- job outputs
+        that are gradients are squared where they are produced, every other part of the flat gradient buffer is final by
+        now (the last GEMM precedes this launch) and is covered by square-sum jobs -- and rotates the Adam powers, so the
+        optimiser needs ONE launch (pfpn_clip_adam_prenorm) instead of two.  A step that takes this path MUST be followed
+        by the optimiser's apply (the powers have moved)."""
+        hook = getattr(self, "_norm_hook", None)
+        self._norm_ready = 0
+        if hook is None or not allow_norm:
+            kernels.reduce_jobs(deferred)
+            return
+        st = self.store
+        base, end = st.grad.data_ptr(), st.grad.data_ptr() + 4 * st.size
+        cover = []
+        for j in deferred:
+            if j.kind in (kernels.JOB_COLSUM, kernels.JOB_VECSUM) and j.out is not None and base <= j.out < end:
+                n = j.n if j.kind == kernels.JOB_COLSUM else 1
+                if j.out % 16:                       # cannot express the complement in float4s: plain launch
+                    kernels.reduce_jobs(deferred)
+                    return
+                j.norm = 1
+                cover.append((j.out, min(end, (j.out + 4 * n + 15) // 16 * 16)))     # the padding behind a tensor is zero
+        cover.sort()
+        jobs, pos = list(deferred), base
+        for lo, hi in cover + [(end, end)]:
+            if lo > pos:
+                nfl = (lo - pos) // 4
+                jobs.append(kernels.job_sqsum(pos, nfl, max(1, min(64, nfl // 16384))))
+            pos = max(pos, hi)
+        if len(jobs) > kernels.MAX_REDUCE_JOBS:
+            for j in deferred:
+                j.norm = 0
+            kernels.reduce_jobs(deferred)
+            return
+        self._norm_ready = kernels.reduce_jobs(jobs, norm=hook)
+
     def _to_dev(self, a, dtype=torch.float32):
         if isinstance(a, torch.Tensor):
             return a.to(self.device, dtype).contiguous()

@@ -85,7 +85,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
                 self._entropy_term(policy, dlogits, B)
             self._backward_heads(ha, hc, dlogits, out["dvalue"], fused_db, deferred=deferred)
             if deferred is not None:
-                kernels.reduce_jobs(deferred)
+                self._finish_deferred(deferred, allow_norm=not self.fixed_sigma)
             if self.fixed_sigma:
                 out["dlogstd"].zero_()
             return out["loss3"]

@@ -280,7 +280,7 @@ def sac_network_wrapper(base_class):
             torch.mm(dlogits, self.policy_weight.t(), out=self.dha[0])
             self.actor_trunk.backward(self.dha, slot=0, deferred=deferred)
             if fold:
-                kernels.reduce_jobs(deferred)
+                self._finish_deferred(deferred, allow_norm=not self.fixed_sigma)
             return out["loss3"]
 
         def train_device(self, optimizer, state, action, reward, not_terminal, state_, noise=None):

@@ -112,6 +112,7 @@ def _rccl_rank(port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["PFPN_FUSED_NORM"] = "0"             # bitwise comparison: same grouping of the norm's partial sums
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -151,6 +151,7 @@ def test_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
     ONE launch produces the same bits as the step that launches each of them where the reference's graph has them."""
     from pfpn_amd.models import SyncReplicasApplier
     nets, opts = [], []
+    monkeypatch.setenv("PFPN_FUSED_NORM", "0")      # the norm's partial sums group differently when fused: own test below
     for i in range(2):
         monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
         monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
@@ -205,3 +206,35 @@ def test_multi_step_graph_replay_matches_single_steps(dev):
     g1k(sets[0]); g1(sets[0])
     assert nets[0].train_flag == nets[1].train_flag == 0 and torch.equal(nets[0].store.flat, nets[1].store.flat)
     assert gk.can_replay()
+
+
+@pytest.mark.parametrize("B", [64, 4096])
+def test_global_norm_from_the_reduction_launch(dev, monkeypatch, B):
+    """The reduction launch that also yields the global-norm partial sums (+ the one-launch optimiser) against the separate
+    square-sum launch: identical gradients, the same norm to fp32 summation order, the same parameters to that precision,
+    identical Adam powers."""
+    from pfpn_amd.models import SyncReplicasApplier
+    nets, opts = [], []
+    monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
+    for i in range(2):
+        monkeypatch.setenv("PFPN_FUSED_NORM", "1" if i == 0 else "0")
+        nets.append(make_net(dev, seed=17, resample_interval=3))
+        opts.append(SyncReplicasApplier(nets[-1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1))
+    assert nets[0]._norm_hook is not None and nets[1]._norm_hook is None
+    rng = np.random.default_rng(B + 1)
+    for it in range(4):
+        b = make_batch(rng, B)
+        b["log_prob"] = np.full(B, -40.0, F)
+        out = [net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+               for net, opt in zip(nets, opts)]
+        assert out[0] == out[1], it
+        if it == 0:
+            assert torch.equal(nets[0].store.grad, nets[1].store.grad)
+        n0, n1 = opts[0].norm_scale.cpu().numpy(), opts[1].norm_scale.cpu().numpy()
+        np.testing.assert_allclose(n0, n1, rtol=2e-6)
+        ref = nets[0].store.grad.double().pow(2).sum().sqrt().item() if it == 0 else None
+        if ref is not None:
+            np.testing.assert_allclose(n0[0], ref, rtol=2e-6)
+        assert torch.equal(opts[0].beta_pow, opts[1].beta_pow)
+        torch.testing.assert_close(nets[0].store.flat, nets[1].store.flat, rtol=1e-5, atol=2e-8)   # Adam amplifies the 1e-7 relative norm difference on near-zero parameters
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
