@@ -260,6 +260,9 @@ int pfpn_reduce_jobs(const PfpnReduceJob* jobs, int n_jobs, void* stream);
  * pfpn_clip_adam's first launch does.  pfpn_clip_adam_prenorm is pfpn_clip_adam's second launch on those partials. */
 int pfpn_reduce_jobs_norm(const PfpnReduceJob* jobs, int n_jobs, float* sq_partial, size_t sq_capacity, int* n_partials,
                           float* beta_pow, int n_groups, float beta1, float beta2, void* stream);
+/* pfpn_clip_scale_inplace's second launch on the partial sums of pfpn_reduce_jobs_norm (powers rotated there). */
+int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, float* norm_scale, const float* sq_partial,
+                                    int n_partials, void* stream);
 int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                            const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                            float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,

@@ -1586,6 +1586,16 @@ int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm
     return PFPN_OK;
 }
 
+int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, float* norm_scale, const float* sq_partial,
+                                    int n_partials, void* stream) {
+    PFPN_BEGIN();
+    if (!grads || !norm_scale || !sq_partial || n < 1 || n_partials < 1 || ((uintptr_t)grads & 15)) return PFPN_ERR_ARG;
+    hipLaunchKernelGGL(k_clip_scale_inplace, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, grads, n,
+                       sq_partial, n_partials, clip_norm, norm_scale);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
 int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                      const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                      float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter,

@@ -646,9 +646,15 @@ def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, cli
                "pfpn_clip_adam")
 
 
-def clip_scale_inplace(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0.9, beta2=0.999):
-    """per-replica global-norm clip applied in place (2 launches); rotates the [G,4] Adam powers when given."""
+def clip_scale_inplace(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0.9, beta2=0.999, prenorm=None):
+    """per-replica global-norm clip applied in place (2 launches); rotates the [G,4] Adam powers when given.
+    prenorm = (partial, count) from reduce_jobs(norm=...): ONE launch (the powers were rotated there)."""
     lib = _lib.load()
+    if prenorm is not None:
+        _lib.check(lib.pfpn_clip_scale_inplace_prenorm(_f32(grads_flat), grads_flat.numel(), float(clip_norm),
+                                                       _f32(norm_scale, 2), _f32(prenorm[0]), int(prenorm[1]), _stream()),
+                   "pfpn_clip_scale_inplace_prenorm")
+        return
     ws, wsn = _learn_ws(1, 1, grads_flat.device)
     G = beta_pow.shape[0] if beta_pow is not None else 0
     _lib.check(lib.pfpn_clip_scale_inplace(_f32(grads_flat), grads_flat.numel(), float(clip_norm), _f32(norm_scale, 2),

@@ -63,10 +63,11 @@ class SyncReplicasApplier(object):
         self._g_len = (ctypes.c_longlong * G)(*[g["len"] for g in self.groups])
         self._g_lr = (ctypes.c_float * G)(*[g["lr"] for g in self.groups])
         self.fused = os.environ.get("PFPN_FUSED_OPT", "1") != "0"
-        # one replica with a global-norm clip: the step's reduction launch can also produce the norm's partial sums and
-        # rotate the powers (ActorCriticNetwork._finish_deferred), leaving ONE optimiser launch.  PFPN_FUSED_NORM=0: off.
+        # global-norm clip: the step's reduction launch can also produce the norm's partial sums and rotate the powers
+        # (ActorCriticNetwork._finish_deferred), leaving ONE launch for clip + Adam (one replica) or for the in-place clip
+        # (exchange path).  PFPN_FUSED_NORM=0: off.
         net._norm_hook = None
-        if not self.exchange and self.fused and self.norm_clip and len(self.groups) <= 4 and st.device.type == "cuda" \
+        if self.fused and self.norm_clip and len(self.groups) <= 4 and st.device.type == "cuda" \
                 and os.environ.get("PFPN_FUSED_NORM", "1") != "0":
             net._norm_hook = {"partial": torch.zeros(4096, dtype=torch.float32, device=st.device),
                               "beta_pow": self.beta_pow, "beta1": beta1, "beta2": beta2}
@@ -92,7 +93,10 @@ class SyncReplicasApplier(object):
         if self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:
             # data parallel: clip in place (2 launches), ONE all-reduce of [clipped grads | statistics], Adam on the
             # sum with 1/W folded in (1 launch), statistics <- mean (1 launch)
-            kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2)
+            ready = getattr(net, "_norm_ready", 0)
+            net._norm_ready = 0
+            kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2,
+                                       prenorm=(net._norm_hook["partial"], ready) if ready and net._norm_hook else None)
             self.reduce(net)
             in_tail = getattr(net, "_stats_in_tail", False) and st.tail.numel() > 0
             kernels.adam_groups(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,

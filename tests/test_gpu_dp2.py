@@ -143,6 +143,20 @@ def _rccl_rank(port, q):
             ok &= torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
             ok &= torch.equal(nets[0].max_active, nets[1].max_active) and torch.equal(nets[0].sum_active, nets[1].sum_active)
         ok &= nets[0].global_step == 4 and len(nets[0]._train_graphs) == 0      # the exchange path never self-captures
+        # with the global norm produced by the reduction launch on both paths: equal to summation-order precision
+        os.environ["PFPN_FUSED_NORM"] = "1"
+        nets = [make_net(dev, seed=10, resample_interval=50) for _ in range(2)]
+        opts = [SyncReplicasApplier(nets[0], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True),
+                SyncReplicasApplier(nets[1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)]
+        ok &= nets[0]._norm_hook is not None and nets[1]._norm_hook is not None
+        for it in range(3):
+            b = make_batch(rng, 256)
+            b["log_prob"] = np.full(256, -40.0, F)
+            for net, opt in zip(nets, opts):
+                net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+            ok &= bool(torch.allclose(opts[0].norm_scale, opts[1].norm_scale, rtol=2e-6))
+            ok &= bool(torch.allclose(nets[0].store.flat, nets[1].store.flat, rtol=1e-5, atol=2e-8))
+            ok &= torch.equal(opts[0].beta_pow, opts[1].beta_pow)
         q.put((0, bool(ok), "", ""))
     except Exception as e:
         import traceback
