@@ -89,7 +89,7 @@ def parse_tensor(buf):
                 fvals.extend(struct.unpack("<%df" % (len(v) // 4), v))
             else:
                 fvals.append(struct.unpack("<f", v)[0])
-        elif fn == 7:
+        elif fn in (7, 10, 11):      # int_val / int64_val / bool_val
             if wt == 2:
                 j = 0
                 while j < len(v):
@@ -97,7 +97,12 @@ def parse_tensor(buf):
                     ivals.append(x if x < (1 << 63) else x - (1 << 64))
             else:
                 ivals.append(v if v < (1 << 63) else v - (1 << 64))
-    np_dt = {1: np.float32, 3: np.int32, 9: np.int64, 2: np.float64}.get(dtype)
+        elif fn == 6:                # double_val
+            if wt == 2:
+                fvals.extend(struct.unpack("<%dd" % (len(v) // 8), v))
+            else:
+                fvals.append(struct.unpack("<d", v)[0])
+    np_dt = {1: np.float32, 3: np.int32, 9: np.int64, 2: np.float64, 10: np.bool_}.get(dtype)
     if np_dt is None:
         return None
     n = int(np.prod(shape)) if shape else 1

@@ -1,0 +1,143 @@
+"""GPU: the HIP learner step / rollout against golden OUTPUT vectors evaluated from the reference's own saved graph
+(tests/golden/graph_*.npz; provenance and node names in tests/test_oracle_graph_golden.py).  No oracle in the loop:
+the product is compared with the reference's dataflow directly.
+
+Tolerances (fp32 everywhere, scale-relative: |got - ref| <= tol * max|ref| of the tensor):
+* log-prob, mixture probability, value, normaliser statistics: 1e-5 -- north_star's bar; these hang off K <= 1024 fp32
+  GEMMs whose MFMA accumulation order differs from the evaluator's BLAS.
+* losses: 1e-5 of max(|loss|, 1) -- the policy loss is a cancelling mean of O(1) surrogates.
+* gradients, Adam moments: 5e-5, and up to MASK_FLIPS entries beyond that -- a pre-activation that lands within an ulp
+  of a ReLU6 kink takes the other branch on the GPU (one unit of one row: one column of one dW moves by ~1/B of its size).
+* parameters after Adam: 1e-6 of max|ref| (the update is lr = 1e-4 times a bounded ratio).
+* sampled particles, dead set, resample sources: bit-exact.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import fixture_inputs as fi   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+MASK_FLIPS = 8
+
+
+def load(tag):
+    return np.load(os.path.join(HERE, "golden", "graph_%s.npz" % tag))
+
+
+def close(got, ref, name, tol, floor=0.0, flips=0):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    got, ref = np.asarray(got, np.float64).reshape(np.shape(ref)), np.asarray(ref, np.float64)
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(got)), name
+    assert np.array_equal(got[~fin], ref[~fin]), name
+    scale = max(np.abs(ref[fin]).max(), floor)
+    bad = np.abs(got[fin] - ref[fin]) > tol * scale
+    assert bad.sum() <= flips, "%s: %d entries beyond %.1e x %.3g (max abs err %.3g)" % (
+        name, bad.sum(), tol, scale, np.abs(got[fin] - ref[fin]).max())
+
+
+def close_big(got, fx, key, name, tol, flips=0):
+    kind, var = key.rsplit(":", 1)
+    got = got.detach().cpu().numpy().reshape(fi.SHAPES[var])
+    close(fi.subsample(var, got), fx[key], name, tol, flips=flips)
+    sums, mine = fx[kind + "_sum:" + var], fi.summarize(got)
+    assert abs(mine[1] - sums[1]) <= 1e-3 * sums[1] + 1e-30, name + " (sum of squares)"
+    assert abs(mine[2] - sums[2]) <= 1e-3 * sums[2] + 1e-30, name + " (sum of |x|)"
+
+
+def build(dev, fx, world=1):
+    from pfpn_amd.models import SyncReplicasApplier
+    from test_gpu_dppo_step import make_net
+    B, W, step, train_flag, seed = [int(v) for v in fx["meta"]]
+    init = fi.initial_state(seed, step)
+    net = make_net(dev, seed=1)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world)
+    net.load_variables(init["P"])
+    net.load_variables(init["M"], net.store.views_of(net.store.m))
+    net.load_variables(init["V"], net.store.views_of(net.store.v))
+    opt.groups[0]["beta_pow"].copy_(torch.tensor([float(init["b1p"]), float(init["b2p"])]))
+    net.state_normalizer.mean.copy_(torch.from_numpy(init["mean"]))
+    net.state_normalizer.std.copy_(torch.from_numpy(init["std"]))
+    net.global_step = step
+    net.step_dev.fill_(float(step))
+    net.train_flag = train_flag
+    net.max_active.copy_(torch.from_numpy(fx["in0:max_active"]))
+    net.sum_active.copy_(torch.from_numpy(fx["in0:sum_active"]))
+    return net, opt
+
+
+@pytest.mark.parametrize("tag", ["step_b32", "step_b256", "guard_b32", "resample_b32"])
+def test_learner_step_matches_reference_graph(dev, tag):
+    fx = load(tag)
+    net, opt = build(dev, fx)
+    if bool(fx["fired"]):       # the tick's uniforms are inputs (TF's Philox streams are not reproducible)
+        u_res = torch.from_numpy(fx["resample:u_resample"]).to(dev)
+        u_noise = torch.from_numpy(fx["resample:u_noise_slot"]).to(dev)
+        orig = net.resample_now
+        net.resample_now = lambda: orig(u_res, u_noise)
+    b = {k: fx["in0:" + k] for k in ("state", "action", "value", "log_prob", "advantage")}
+    loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+    close(net.train_out["logp"], fx["out0:logp"], "global_net/policy_loss/pi_target/Sum_1", 1e-5)
+    close(net.value_buf, fx["out0:value"], "global_net/critic/Squeeze", 1e-5)
+    close(loss[0], fx["out0:loss"], "global_net/loss/add", 1e-5, floor=1.0)
+    close(loss[2], fx["out0:policy_loss"], "global_net/policy_loss/Neg", 1e-5, floor=1.0)
+    close(loss[3], fx["out0:value_loss"], "global_net/value_loss/mul", 1e-5)
+    G = net.gradients()
+    for k in fi.TRAINABLES:
+        close_big(G[k], fx, "out0:grad:" + k, "gradients -> " + k, 5e-5, flips=MASK_FLIPS)
+    Pn, Mn, Vn = net.variables(), net.variables(net.store.views_of(net.store.m)), \
+        net.variables(net.store.views_of(net.store.v))
+    for k in fi.TRAINABLES:
+        close_big(Pn[k], fx, "P:" + k, "ApplyAdam var " + k, 1e-6, flips=MASK_FLIPS)
+        close_big(Mn[k], fx, "M:" + k, "ApplyAdam m " + k, 5e-5, flips=MASK_FLIPS)
+        close_big(Vn[k], fx, "V:" + k, "ApplyAdam v " + k, 5e-5, flips=MASK_FLIPS)
+    close(net.state_normalizer.mean, fx["post:state_normalizer/mean"], "state_normalizer/update/add_2 -> Assign", 1e-5)
+    close(net.state_normalizer.std, fx["post:state_normalizer/std"], "state_normalizer/update/Maximum -> Assign_1", 1e-5)
+    bp = opt.groups[0]["beta_pow"].cpu().numpy()
+    assert bp[0] == fx["post:beta1_power"] and bp[1] == fx["post:beta2_power"]
+    assert net.global_step == int(fx["post:global_step"]) and net.train_flag == int(fx["post:resample/train_flag"])
+    close(net.max_active, fx["post:max_active_degree"], "Assign_2 / cond/Assign", 0.0)
+    close(net.sum_active, fx["post:sum_active_degree"], "Assign_3 / cond/Assign_1", 0.0)
+    if bool(fx["fired"]):
+        dead, src = net.last_resample
+        inv = fx["resample:invalid"]
+        assert np.array_equal(np.argwhere(dead.cpu().numpy() != 0), inv)                      # cond/Where
+        a, j = inv[:, 0], inv[:, 1]
+        assert np.array_equal(src.cpu().numpy()[a, j], fx["resample:cand"][a, j])             # cond/GatherNd
+        close(net.loc.cpu().numpy()[a, j], fx["resample:loc_new"], "cond/add_4", 1e-6)
+        close(net.logstd.cpu().numpy()[a, j], fx["resample:logstd_new"], "cond/clip_by_value", 1e-6)
+        close(net.policy_bias.cpu().numpy()[fi.N * a + j], fx["resample:bias_new"], "cond/sub_1", 1e-5)
+        # a clone's weight column is a bit copy of its source column (cond/ScatterNdUpdate_2)
+        w = net.policy_weight.cpu().numpy()
+        assert np.array_equal(w[:, fx["resample:c"]], w[:, fx["resample:tc"]])
+
+
+def test_rollout_matches_reference_graph(dev):
+    """worker_0/action/*, action_logp, critic and resample/{Maximum,add} of the saved graph."""
+    from test_gpu_dppo_step import make_net
+    fx = load("rollout_e32")
+    E, seed = [int(v) for v in fx["meta"]]
+    init = fi.initial_state(seed, 100)
+    net = make_net(dev, seed=1)
+    net.load_variables(init["P"])
+    net.state_normalizer.mean.copy_(torch.from_numpy(init["mean"]))
+    net.state_normalizer.std.copy_(torch.from_numpy(init["std"]))
+    net.max_active.copy_(torch.from_numpy(fx["max_active_in"]))
+    net.sum_active.copy_(torch.from_numpy(fx["sum_active_in"]))
+    eps_sel = np.take_along_axis(fx["eps"], fx["k"][..., None].astype(np.int64), axis=-1)[..., 0]
+    noise = {"u_cat": torch.from_numpy(fx["u_cat"]).to(dev), "eps_sel": torch.from_numpy(eps_sel).to(dev)}
+    action, logp, value = net.run_batch(fx["state"], noise=noise)
+    close(net.logits, fx["logits"].reshape(E, -1), "worker_0/actor/Reshape", 1e-5)
+    assert np.array_equal(net.policy.dis_action.cpu().numpy().reshape(E, fi.A), fx["k"])     # Multinomial rule
+    close(action, fx["action"], "worker_0/action/Squeeze", 1e-6)
+    close(logp, fx["logp"], "worker_0/action/action_logp/Sum_1", 1e-5)
+    close(value, fx["value"], "worker_0/critic/Squeeze", 1e-5)
+    close(net.max_active, fx["max_active_out"], "worker_0/resample/Maximum", 1e-5)
+    close(net.sum_active, fx["sum_active_out"], "worker_0/resample/add", 1e-5)
