@@ -106,6 +106,78 @@ def test_two_rank_learner_step_matches_oracle(dev):
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3], "replicas diverged"
 
 
+def _golden_rank(rank, world, port, q, tag):
+    """Two replicas against the reference graph's own two-worker step (tests/golden/graph_*_w2.npz: per-worker clipped
+    gradients and statistics through the accumulator means, Assign..Assign_3, 14 x ApplyAdam, resample cond)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import test_gpu_graph_golden as gg
+        fi = gg.fi
+        dev = torch.device("cuda:0")
+        fx = gg.load(tag)
+        net, opt = gg.build(dev, fx, world=world)
+        net.max_active.copy_(torch.from_numpy(fx["in%d:max_active" % rank]))
+        net.sum_active.copy_(torch.from_numpy(fx["in%d:sum_active" % rank]))
+        if bool(fx["fired"]):
+            u_res = torch.from_numpy(fx["resample:u_resample"]).to(dev)
+            u_noise = torch.from_numpy(fx["resample:u_noise_slot"]).to(dev)
+            orig = net.resample_now
+            net.resample_now = lambda: orig(u_res, u_noise)
+        b = {k: fx["in%d:%s" % (rank, k)] for k in ("state", "action", "value", "log_prob", "advantage")}
+        loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+        pre = "out%d:" % rank
+        gg.close(net.train_out["logp"], fx[pre + "logp"], "logp", 1e-5)
+        gg.close(loss[0], fx[pre + "loss"], "loss", 1e-5, floor=1.0)
+        Pn, Mn, Vn = net.variables(), net.variables(net.store.views_of(net.store.m)), \
+            net.variables(net.store.views_of(net.store.v))
+        for k in fi.TRAINABLES:
+            gg.close_big(Pn[k], fx, "P:" + k, "ApplyAdam var " + k, 1e-6, flips=gg.MASK_FLIPS)
+            gg.close_big(Mn[k], fx, "M:" + k, "ApplyAdam m " + k, 5e-5, flips=gg.MASK_FLIPS)
+            gg.close_big(Vn[k], fx, "V:" + k, "ApplyAdam v " + k, 5e-5, flips=gg.MASK_FLIPS)
+        gg.close(net.state_normalizer.mean, fx["post:state_normalizer/mean"], "Assign", 1e-5)
+        gg.close(net.state_normalizer.std, fx["post:state_normalizer/std"], "Assign_1", 1e-5)
+        gg.close(net.max_active, fx["post:max_active_degree"], "Assign_2", 1e-6)
+        gg.close(net.sum_active, fx["post:sum_active_degree"], "Assign_3", 1e-6)
+        assert net.global_step == int(fx["post:global_step"]) and net.train_flag == int(fx["post:resample/train_flag"])
+        if bool(fx["fired"]):
+            dead, src = net.last_resample
+            inv = fx["resample:invalid"]
+            assert np.array_equal(np.argwhere(dead.cpu().numpy() != 0), inv)
+            a, j = inv[:, 0], inv[:, 1]
+            assert np.array_equal(src.cpu().numpy()[a, j], fx["resample:cand"][a, j])
+            gg.close(net.loc.cpu().numpy()[a, j], fx["resample:loc_new"], "cond/add_4", 1e-6)
+            gg.close(net.policy_bias.cpu().numpy()[fi.N * a + j], fx["resample:bias_new"], "cond/sub_1", 1e-5)
+        q.put((rank, True, float(net.store.flat.double().sum()), float(net.loc.double().sum())))
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        q.put((rank, False, repr(e), ""))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("tag", ["step_b64_w2", "resample_b32_w2"])
+def test_two_rank_step_matches_reference_graph(dev, tag):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_golden_rank, args=(r, 2, port, q, tag)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3], "replicas diverged"
+
+
 def _rccl_rank(port, q):
     """world-size-1 RCCL group: the exchange path of the step (clip in place, bucket all-reduce through RCCL, Adam with
     1/W and the statistics tail in one launch) must give the bits of the single-replica fused path."""
