@@ -37,7 +37,7 @@ def sync_oracle_state(oracle, net, st):
         st.P[k] = v.detach().cpu().numpy().reshape(st.P[k].shape).copy()
 
 
-@pytest.mark.parametrize("B", [32, 256])
+@pytest.mark.parametrize("B", [32, 256, 4096])          # 4096 = BASELINE.json config 2, the bench's batch
 def test_dppo_step_matches_oracle(oracle, dev, B):
     from pfpn_amd.models import SyncReplicasApplier
     net = make_net(dev)
@@ -45,7 +45,8 @@ def test_dppo_step_matches_oracle(oracle, dev, B):
     st = oracle.DPPOState(np.random.default_rng(0))
     sync_oracle_state(oracle, net, st)
     rng = np.random.default_rng(B)
-    for it in range(3):
+    n_it = 3 if B < 4096 else 2
+    for it in range(n_it):
         batch = make_batch(rng, B)
         # old log-prob: the current policy's log-prob of the action, perturbed (ratios around 1)
         x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
@@ -74,7 +75,7 @@ def test_dppo_step_matches_oracle(oracle, dev, B):
             assert_close_mostly(v.cpu().numpy().reshape(ref.shape), ref, rtol=1e-4, atol=2e-6, err_msg=name)
         np.testing.assert_allclose(net.state_normalizer.mean.cpu().numpy(), st.norm_mean, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(net.state_normalizer.std.cpu().numpy(), st.norm_std, rtol=1e-5, atol=1e-6)
-    assert net.global_step == 3 and net.train_flag == 3
+    assert net.global_step == n_it and net.train_flag == n_it
 
 
 def test_resample_tick_and_policy_api(oracle, dev):
@@ -98,15 +99,15 @@ def test_resample_tick_and_policy_api(oracle, dev):
     # drive a few particles dead, then 4 train steps trigger the resample and zero the statistics
     for _ in range(40):
         net.run(None, rng.normal(0, 1, 197).astype(F))
-    before = net.loc.clone()
     for it in range(4):
         b = make_batch(rng, 32)
         b["log_prob"] = np.full(32, -40.0, F)
         net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
     assert net.train_flag == 0 and net.sum_active.abs().sum().item() == 0 and net.max_active.abs().sum().item() == 0
     dead, src = net.last_resample
-    # with near-uniform weights (1/35 >> 0.05/35) nothing is dead: resample must have been a no-op
-    assert dead.sum().item() == 0 and torch.equal(before, before)
+    # with near-uniform weights (1/35 >> 0.05/35) nothing is dead: the tick resampled no particle (that an all-alive
+    # tick leaves every tensor untouched is tests/test_gpu_learner_utils.py::test_resample_noop_when_all_alive)
+    assert dead.sum().item() == 0
 
 
 def test_deterministic_evaluator(dev):

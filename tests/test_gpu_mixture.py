@@ -66,6 +66,75 @@ def test_logprob_bwd(oracle, dev, B, A, N, tanh_mode):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * (np.abs(ref).max() + 1e-30))
 
 
+def _config5_inputs(dev, B, A=128, N=256, seed=5):
+    """BASELINE.json config 5 inputs generated on the device (the full tensor is 1 GiB)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    logits = torch.randn(B, A * N, device=dev, generator=g)
+    x = torch.rand(B, A, device=dev, generator=g) * 2.0 - 1.0      # inside the grid: sigma = 2/255, p underflows outside
+    grid = torch.linspace(-1, 1, N, device=dev)[None, :].expand(A, N)
+    loc = (grid + 0.003 * torch.randn(A, N, device=dev, generator=g)).contiguous()
+    logstd = (float(np.log(2.0 / (N - 1))) + 0.1 * torch.randn(A, N, device=dev, generator=g)).contiguous()
+    dlogp = torch.randn(B, device=dev, generator=g)
+    return logits.view(B, A, N), x, loc, logstd, dlogp
+
+
+def test_wide_kernel_config5_slice_vs_oracle(oracle, dev):
+    """config 5 (128 action dims x 256 particles): the wide kernels against the oracle on a 1024-row shard -- every
+    wave walks several 4-row groups, all 128 dims, the multi-chunk row split."""
+    from pfpn_amd import kernels
+    B, A, N = 1024, 128, 256
+    logits, x, loc, logstd, g = _config5_inputs(dev, B)
+    h = [t.cpu().numpy() for t in (logits, x, loc, logstd, g)]
+    ref_lp, ref_p = oracle.mixture_log_prob(*h[:4])
+    lp, p = kernels.logprob_fwd(logits, x, loc, logstd, False, want_pmix=True)
+    np.testing.assert_allclose(p.cpu().numpy(), ref_p, rtol=2e-5, atol=0)
+    np.testing.assert_allclose(lp.cpu().numpy(), ref_lp, rtol=RTOL, atol=0)      # |logp| ~ 1e2: pure rtol
+    r_dl, r_dloc, r_dls, r_dx = oracle.mixture_log_prob_bwd(*h)
+    o_dl, o_dloc, o_dls, o_dx = kernels.logprob_bwd(logits, x, loc, logstd, g, False, want_dx=True)
+    sc = np.abs(r_dl).max()
+    np.testing.assert_allclose(o_dl.cpu().numpy().reshape(B, A, N), r_dl, rtol=1e-4, atol=3e-6 * sc)
+    np.testing.assert_allclose(o_dx.cpu().numpy(), r_dx, rtol=1e-4, atol=1e-5 * np.abs(r_dx).max())
+    for got, ref in ((o_dloc, r_dloc), (o_dls, r_dls)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * np.abs(ref).max())
+
+
+def test_wide_kernel_config5_full_size_properties(oracle, dev):
+    """The full 8192 x 128 x 256 shape (1 GiB of logits, BASELINE.json config 5) through size-independent properties:
+    rows are independent (full launch == two half launches, bit for bit, for the per-row outputs), a segment's logit
+    gradients sum to zero (softmax Jacobian), the particle gradients of the halves add up to the full ones, and a
+    strided sample of rows matches the oracle."""
+    from pfpn_amd import kernels
+    B, A, N = 8192, 128, 256
+    logits, x, loc, logstd, g = _config5_inputs(dev, B, seed=6)
+    lp, p = kernels.logprob_fwd(logits, x, loc, logstd, False, want_pmix=True)
+    assert bool(torch.isfinite(lp).all()) and bool((p > 0).all())
+    dl, dloc, dls = kernels.logprob_bwd(logits, x, loc, logstd, g)
+    dl = dl.view(B, A, N)
+    seg = dl.sum(-1).abs().max().item()
+    mag = dl.abs().sum(-1).max().item()
+    assert seg <= 5e-6 * mag, (seg, mag)
+    H = B // 2
+    halves = []
+    for sl in (slice(0, H), slice(H, B)):
+        lp_h = kernels.logprob_fwd(logits[sl].contiguous(), x[sl].contiguous(), loc, logstd)
+        assert torch.equal(lp_h, lp[sl])
+        dl_h, dloc_h, dls_h = kernels.logprob_bwd(logits[sl].contiguous(), x[sl].contiguous(), loc, logstd,
+                                                  g[sl].contiguous())
+        assert torch.equal(dl_h.view(H, A, N), dl[sl])
+        halves.append((dloc_h.double(), dls_h.double()))
+    for full, parts in ((dloc, 0), (dls, 1)):
+        tot = halves[0][parts] + halves[1][parts]
+        err = (full.double() - tot).abs().max().item()
+        assert err <= 2e-5 * tot.abs().max().item(), err
+    rows = torch.arange(0, B, 64, device=dev)                      # 128 rows spread over the whole batch
+    h = [t.cpu().numpy() for t in (logits[rows], x[rows], loc, logstd, g[rows])]
+    ref_lp, _ = oracle.mixture_log_prob(*h[:4])
+    np.testing.assert_allclose(lp[rows].cpu().numpy(), ref_lp, rtol=RTOL, atol=0)
+    r_dl = oracle.mixture_log_prob_bwd(*h)[0]
+    np.testing.assert_allclose(dl[rows].cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * np.abs(r_dl).max())
+
+
 def test_logprob_underflow_guard(oracle, dev):
     """x far from every particle: p underflows to 0, logp = -inf in the forward (reference computes in
     probability space), and the backward guard zeroes the gradients (utils.py:109-117)."""

@@ -23,7 +23,7 @@ def make_net(dev, trainable=True, S=197, A=36, seed=7):
     return net
 
 
-@pytest.mark.parametrize("B", [16, 256])
+@pytest.mark.parametrize("B", [16, 256, 1024])          # 1024 = BASELINE.json config 3 (replay batch)
 def test_sac_step_matches_oracle(oracle, dev, B):
     from pfpn_amd.models import SyncReplicasApplier
     S, A, N = 197, 36, 35
