@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from _parity import assert_close_mostly
+from _parity import assert_close_mostly, away_from_clip, close_scaled
 
 pytestmark = pytest.mark.gpu
 F = np.float32
@@ -52,29 +52,34 @@ def test_dppo_step_matches_oracle(oracle, dev, B):
         x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
         logits, _ = oracle.actor_forward(st.P, x, 36, 35)
         lp, _ = oracle.mixture_log_prob(logits, batch["action"], st.P["actor/samples"], st.P["actor/samples_std"])
-        batch["log_prob"] = (lp + rng.normal(0, 0.1, B)).astype(F)
+        batch["log_prob"] = away_from_clip(lp, (lp + rng.normal(0, 0.1, B)).astype(F))
         # oracle gradients of this step (before its update) for a direct gradient check
         (l_ref, pl_ref, vl_ref), G_ref, aux = oracle.dppo_grads(st.P, st.norm_mean, st.norm_std, batch, 36, 35)
         losses = oracle.dppo_learner_step(st, [batch])
         loss, extra = net.train(None, opt, ["global_step"], batch["state"], batch["action"], batch["value"],
                                 batch["log_prob"], batch["advantage"])
         assert extra == [it + 1]
-        np.testing.assert_allclose([loss[0], loss[2], loss[3]], [l_ref, pl_ref, vl_ref], rtol=1e-4, atol=2e-5)
+        # north_star: fp32 log-prob / value within 1e-5.  log-prob: per element (|logp| ~ 40); value: of the batch's
+        # value scale (a critic output can be arbitrarily close to 0); losses: of max(|loss|, 1), the size of the
+        # surrogate terms whose signed mean the policy loss is
+        np.testing.assert_allclose(net.train_out["logp"].cpu().numpy(), aux["logp"], rtol=1e-5, atol=0)
+        close_scaled(net.value_buf.cpu().numpy(), aux["value"], 1e-5, "value")
+        close_scaled([loss[0], loss[2]], [l_ref, pl_ref], 1e-5, "loss", floor=1.0)
+        close_scaled(loss[3], vl_ref, 1e-5, "value loss")
         assert loss[1] is None
-        np.testing.assert_allclose(net.train_out["logp"].cpu().numpy(), aux["logp"], rtol=1e-5, atol=2e-4)
-        np.testing.assert_allclose(net.value_buf.cpu().numpy(), aux["value"], rtol=1e-4, atol=1e-6)
-        # gradients (before clipping) -- GEMM accumulation order differs from BLAS: rtol on the tensor scale
+        # gradients (before clipping): 5e-5 of the tensor's scale -- measured 2-4e-5 on the actor side against the
+        # reference graph's own gradients (tools/parity_report.py: exp() of arguments of size ~50 carries ~50 ulp),
+        # 1e-6 on the critic side; a ReLU6 mask bit that rounds the other way moves a handful of entries
         G = net.gradients()
         for name, g_ref in G_ref.items():
-            got = G[name].cpu().numpy().reshape(g_ref.shape)
-            sc = np.abs(g_ref).max() + 1e-30
-            assert_close_mostly(got, g_ref, rtol=2e-3, atol=1e-3 * sc, err_msg=name)   # a ReLU6 mask flip upstream shifts a whole dW by ~5e-4 of its scale
-        # parameters and Adam state after the update
+            close_scaled(G[name].cpu().numpy(), g_ref, 5e-5, "grad " + name, flips=max(8, g_ref.size // 2000))
+        # parameters after the update: within 2 % of one step (lr = 1e-4).  From zero moments the first Adam steps are
+        # ~lr * sign(g): entries with |g| <~ 1e-7 (eps / sqrt(1 - beta2)) turn their gradient's relative error into
+        # the step, everything else moves by exactly +-lr
         for name, v in net.variables().items():
-            ref = st.P[name]
-            assert_close_mostly(v.cpu().numpy().reshape(ref.shape), ref, rtol=1e-4, atol=2e-6, err_msg=name)
-        np.testing.assert_allclose(net.state_normalizer.mean.cpu().numpy(), st.norm_mean, rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(net.state_normalizer.std.cpu().numpy(), st.norm_std, rtol=1e-5, atol=1e-6)
+            close_scaled(v.cpu().numpy(), st.P[name], 2e-6, name, floor=1.0, flips=max(8, st.P[name].size // 2000))
+        close_scaled(net.state_normalizer.mean.cpu().numpy(), st.norm_mean, 1e-5, "norm mean", floor=1.0)
+        close_scaled(net.state_normalizer.std.cpu().numpy(), st.norm_std, 1e-5, "norm std")
     assert net.global_step == n_it and net.train_flag == n_it
 
 

@@ -85,6 +85,9 @@ def test_learner_step_matches_reference_graph(dev, tag):
     b = {k: fx["in0:" + k] for k in ("state", "action", "value", "log_prob", "advantage")}
     loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
     close(net.train_out["logp"], fx["out0:logp"], "global_net/policy_loss/pi_target/Sum_1", 1e-5)
+    lp_ref = fx["out0:logp"]
+    ok = np.isfinite(lp_ref)                    # per element too (|logp| ~ 1e2; measured 6e-7, tools/parity_report.py)
+    np.testing.assert_allclose(net.train_out["logp"].cpu().numpy()[ok], lp_ref[ok], rtol=1e-5, atol=0)
     close(net.value_buf, fx["out0:value"], "global_net/critic/Squeeze", 1e-5)
     close(loss[0], fx["out0:loss"], "global_net/loss/add", 1e-5, floor=1.0)
     close(loss[2], fx["out0:policy_loss"], "global_net/policy_loss/Neg", 1e-5, floor=1.0)
