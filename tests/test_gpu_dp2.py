@@ -138,8 +138,8 @@ def _golden_rank(rank, world, port, q, tag):
             net.variables(net.store.views_of(net.store.v))
         for k in fi.TRAINABLES:
             gg.close_big(Pn[k], fx, "P:" + k, "ApplyAdam var " + k, 1e-6, flips=gg.MASK_FLIPS)
-            gg.close_big(Mn[k], fx, "M:" + k, "ApplyAdam m " + k, 5e-5, flips=gg.MASK_FLIPS)
-            gg.close_big(Vn[k], fx, "V:" + k, "ApplyAdam v " + k, 5e-5, flips=gg.MASK_FLIPS)
+            gg.close_big(Mn[k], fx, "M:" + k, "ApplyAdam m " + k, 1e-4, flips=gg.MASK_FLIPS)
+            gg.close_big(Vn[k], fx, "V:" + k, "ApplyAdam v " + k, 1e-4, flips=gg.MASK_FLIPS)
         gg.close(net.state_normalizer.mean, fx["post:state_normalizer/mean"], "Assign", 1e-5)
         gg.close(net.state_normalizer.std, fx["post:state_normalizer/std"], "Assign_1", 1e-5)
         gg.close(net.max_active, fx["post:max_active_degree"], "Assign_2", 1e-6)

@@ -67,12 +67,15 @@ def test_dppo_step_matches_oracle(oracle, dev, B):
         close_scaled([loss[0], loss[2]], [l_ref, pl_ref], 1e-5, "loss", floor=1.0)
         close_scaled(loss[3], vl_ref, 1e-5, "value loss")
         assert loss[1] is None
-        # gradients (before clipping): 5e-5 of the tensor's scale -- measured 2-4e-5 on the actor side against the
-        # reference graph's own gradients (tools/parity_report.py: exp() of arguments of size ~50 carries ~50 ulp),
-        # 1e-6 on the critic side; a ReLU6 mask bit that rounds the other way moves a handful of entries
+        # gradients (before clipping): 2e-4 of the tensor's scale.  Every actor gradient is proportional to the ratio
+        # exp(logp - logp_old), and a fp32 log-prob of size ~40 (36 summed terms) is only good to ~1e-4 ABSOLUTE
+        # (that is the 2.7e-6 relative measured here, inside north_star's 1e-5): the ratio, hence a whole row of
+        # dlogits, carries that 1e-4 relatively.  Measured: 9e-5 here, 2-4e-5 against the reference graph's own
+        # gradients (tools/parity_report.py); 1e-6 on the critic side.  A ReLU6 mask bit that rounds the other way
+        # moves a handful of entries
         G = net.gradients()
         for name, g_ref in G_ref.items():
-            close_scaled(G[name].cpu().numpy(), g_ref, 5e-5, "grad " + name, flips=max(8, g_ref.size // 2000))
+            close_scaled(G[name].cpu().numpy(), g_ref, 2e-4, "grad " + name, flips=max(8, g_ref.size // 2000))
         # parameters after the update: within 2 % of one step (lr = 1e-4).  From zero moments the first Adam steps are
         # ~lr * sign(g): entries with |g| <~ 1e-7 (eps / sqrt(1 - beta2)) turn their gradient's relative error into
         # the step, everything else moves by exactly +-lr

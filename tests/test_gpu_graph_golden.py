@@ -6,8 +6,10 @@ Tolerances (fp32 everywhere, scale-relative: |got - ref| <= tol * max|ref| of th
 * log-prob, mixture probability, value, normaliser statistics: 1e-5 -- north_star's bar; these hang off K <= 1024 fp32
   GEMMs whose MFMA accumulation order differs from the evaluator's BLAS.
 * losses: 1e-5 of max(|loss|, 1) -- the policy loss is a cancelling mean of O(1) surrogates.
-* gradients, Adam moments: 5e-5, and up to MASK_FLIPS entries beyond that -- a pre-activation that lands within an ulp
-  of a ReLU6 kink takes the other branch on the GPU (one unit of one row: one column of one dW moves by ~1/B of its size).
+* gradients, Adam moments: 1e-4 (measured 2-4e-5 on the actor side, 1e-6 on the critic side, tools/parity_report.py:
+  every actor gradient is proportional to exp(logp - logp_old) and a fp32 log-prob of size ~1e2 is good to ~1e-5..1e-4
+  absolute), and up to MASK_FLIPS entries beyond that -- a pre-activation that lands within an ulp of a ReLU6 kink takes
+  the other branch on the GPU (one unit of one row: one column of one dW moves by ~1/B of its size).
 * parameters after Adam: 1e-6 of max|ref| (the update is lr = 1e-4 times a bounded ratio).
 * sampled particles, dead set, resample sources: bit-exact.
 """
@@ -94,13 +96,13 @@ def test_learner_step_matches_reference_graph(dev, tag):
     close(loss[3], fx["out0:value_loss"], "global_net/value_loss/mul", 1e-5)
     G = net.gradients()
     for k in fi.TRAINABLES:
-        close_big(G[k], fx, "out0:grad:" + k, "gradients -> " + k, 5e-5, flips=MASK_FLIPS)
+        close_big(G[k], fx, "out0:grad:" + k, "gradients -> " + k, 1e-4, flips=MASK_FLIPS)
     Pn, Mn, Vn = net.variables(), net.variables(net.store.views_of(net.store.m)), \
         net.variables(net.store.views_of(net.store.v))
     for k in fi.TRAINABLES:
         close_big(Pn[k], fx, "P:" + k, "ApplyAdam var " + k, 1e-6, flips=MASK_FLIPS)
-        close_big(Mn[k], fx, "M:" + k, "ApplyAdam m " + k, 5e-5, flips=MASK_FLIPS)
-        close_big(Vn[k], fx, "V:" + k, "ApplyAdam v " + k, 5e-5, flips=MASK_FLIPS)
+        close_big(Mn[k], fx, "M:" + k, "ApplyAdam m " + k, 1e-4, flips=MASK_FLIPS)
+        close_big(Vn[k], fx, "V:" + k, "ApplyAdam v " + k, 1e-4, flips=MASK_FLIPS)
     close(net.state_normalizer.mean, fx["post:state_normalizer/mean"], "state_normalizer/update/add_2 -> Assign", 1e-5)
     close(net.state_normalizer.std, fx["post:state_normalizer/std"], "state_normalizer/update/Maximum -> Assign_1", 1e-5)
     bp = opt.groups[0]["beta_pow"].cpu().numpy()
