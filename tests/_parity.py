@@ -36,3 +36,18 @@ def away_from_clip(logp, logp_old, eps=0.2, margin=5e-4):
     out = np.array(logp_old, copy=True)
     out[near] = np.asarray(logp)[near]
     return out
+
+
+def near_kink_rows(P, x, margin=2e-6):
+    """Rows of the normalised batch x for which some hidden unit's pre-activation lies within `margin` of a ReLU6 kink
+    (0 or 6) in either trunk.  Relu6Grad is a step function: on such a row the GPU's GEMM (other summation order,
+    pre-activations differ by ~1e-7) may take the other branch, which moves a whole dW column by one row's
+    contribution.  The step tests re-draw those rows so that gradients can be compared without a flip allowance."""
+    bad = np.zeros(len(x), bool)
+    for net in ("actor", "critic"):
+        h = x
+        for layer in ("fc1", "fc2"):
+            pre = h @ P["%s/%s/weight" % (net, layer)] + P["%s/%s/bias" % (net, layer)]
+            bad |= (np.minimum(np.abs(pre), np.abs(pre - 6.0)) < margin).any(axis=1)
+            h = np.minimum(np.maximum(pre, 0), 6).astype(np.float32)
+    return bad

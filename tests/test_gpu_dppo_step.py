@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from _parity import assert_close_mostly, away_from_clip, close_scaled
+from _parity import assert_close_mostly, away_from_clip, close_scaled, near_kink_rows
 
 pytestmark = pytest.mark.gpu
 F = np.float32
@@ -48,8 +48,14 @@ def test_dppo_step_matches_oracle(oracle, dev, B):
     n_it = 3 if B < 4096 else 2
     for it in range(n_it):
         batch = make_batch(rng, B)
+        for _ in range(50):     # keep every pre-activation off the ReLU6 kinks (see near_kink_rows)
+            x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
+            bad = near_kink_rows(st.P, x)
+            if not bad.any():
+                break
+            batch["state"][bad] = make_batch(rng, int(bad.sum()))["state"]
+        assert not bad.any()
         # old log-prob: the current policy's log-prob of the action, perturbed (ratios around 1)
-        x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
         logits, _ = oracle.actor_forward(st.P, x, 36, 35)
         lp, _ = oracle.mixture_log_prob(logits, batch["action"], st.P["actor/samples"], st.P["actor/samples_std"])
         batch["log_prob"] = away_from_clip(lp, (lp + rng.normal(0, 0.1, B)).astype(F))
@@ -71,16 +77,16 @@ def test_dppo_step_matches_oracle(oracle, dev, B):
         # exp(logp - logp_old), and a fp32 log-prob of size ~40 (36 summed terms) is only good to ~1e-4 ABSOLUTE
         # (that is the 2.7e-6 relative measured here, inside north_star's 1e-5): the ratio, hence a whole row of
         # dlogits, carries that 1e-4 relatively.  Measured: 9e-5 here, 2-4e-5 against the reference graph's own
-        # gradients (tools/parity_report.py); 1e-6 on the critic side.  A ReLU6 mask bit that rounds the other way
-        # moves a handful of entries
+        # gradients (tools/parity_report.py); 1e-6 on the critic side.  No allowance for flipped ReLU6 masks: the
+        # batch was drawn off the kinks
         G = net.gradients()
         for name, g_ref in G_ref.items():
-            close_scaled(G[name].cpu().numpy(), g_ref, 2e-4, "grad " + name, flips=max(8, g_ref.size // 2000))
+            close_scaled(G[name].cpu().numpy(), g_ref, 2e-4, "grad " + name)
         # parameters after the update: within 2 % of one step (lr = 1e-4).  From zero moments the first Adam steps are
         # ~lr * sign(g): entries with |g| <~ 1e-7 (eps / sqrt(1 - beta2)) turn their gradient's relative error into
         # the step, everything else moves by exactly +-lr
         for name, v in net.variables().items():
-            close_scaled(v.cpu().numpy(), st.P[name], 2e-6, name, floor=1.0, flips=max(8, st.P[name].size // 2000))
+            close_scaled(v.cpu().numpy(), st.P[name], 2e-6, name, floor=1.0)
         close_scaled(net.state_normalizer.mean.cpu().numpy(), st.norm_mean, 1e-5, "norm mean", floor=1.0)
         close_scaled(net.state_normalizer.std.cpu().numpy(), st.norm_std, 1e-5, "norm std")
     assert net.global_step == n_it and net.train_flag == n_it
