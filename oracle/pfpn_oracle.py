@@ -5,14 +5,26 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module; the shipped path (pfpn_amd/) never does and fails loudly when the
 HIP library is missing.
 
-PARITY UNPINNED: the reference (xupei0610/PFPN) ships no tests, no golden
-input/output vectors, and its arithmetic lives in un-vendored third-party
-packages (tensorflow-gpu==1.14, tensorflow_probability==0.7, requirements.txt:1-2)
-that cannot be installed here.  What IS pinned (tests/test_oracle_golden.py):
-the particle-grid initialisers and every scalar constant decoded from the shipped
-MetaGraphDef files (tests/golden/meta_constants.json, meta_samples*_init.npy).
-Everything else follows the reference Python source plus the op order decoded from
-the saved graphs; each function cites the lines it restates.
+PARITY PINNING.  The reference (xupei0610/PFPN) ships no tests and no golden input/output
+vectors, and its arithmetic lives in un-vendored third-party packages (tensorflow-gpu==1.14,
+tensorflow_probability==0.7, requirements.txt:1-2) that cannot be installed here.  It does ship its
+own TRAINING GRAPH (ckpt_DeepMimicWalk-v0/.../model.ckpt-78000.meta, 6,052 nodes).  The oracle is
+pinned to that graph:
+  * tests/golden/graph_*.npz hold outputs obtained by interpreting the GraphDef node by node
+    (tests/golden/graphdef_eval.py + make_graph_golden.py, build container only): log-prob, mixture
+    probability, value, the three losses, all 14 gradients of the `tf.gradients` sub-graph, the
+    global norm and clipped gradients, 14 x ApplyAdam (var, m, v, beta powers), the state-normaliser
+    update, the activation statistics, the whole `cond/...` resample sub-graph, the rollout sampler,
+    for one and two workers, including rows that hit the NaN/Inf guard.
+    tests/test_oracle_graph_golden.py: this module reproduces every one of them (<= 7.6e-6 of the
+    tensor scale, tests/golden/graph_golden_report.txt; integer outputs bit-exact).
+  * the particle-grid initialisers and every scalar constant decoded from the shipped MetaGraphDef
+    files (tests/golden/meta_constants.json, meta_samples*_init.npy; tests/test_oracle_golden.py).
+What the graph cannot pin, because it is not in it: the three random ops' streams (fed as explicit
+inputs; the categorical draw rule is this module's stated definition, `multinomial_index`), the
+per-op arithmetic of TF's kernels below fp32 summation-order level, and the SAC / V-trace variants
+(no SAC or IMPALA graph ships: those functions follow the Python source and are checked against
+independent float64 autograd, tests/test_oracle_math.py).  Each function cites the lines it restates.
 
 RNG: TF's Philox streams cannot be reproduced without TF, so every random draw is
 an explicit input (u_cat, eps, gumbel, u_resample, u_noise).  Index-critical
