@@ -338,6 +338,14 @@ int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, con
 /* SAC soft target update -- sac.py:67-73. */
 int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream);
 
+/* Minibatch slicing of a training round -- reference models/distributed_model.py:320-352 (`buf[cand]` for every experience
+ * buffer, on the host).  Here the rollout is staged on the device once and every learner step gathers its rows in ONE
+ * launch: dst_k[b, :] = src_k[rows[b], :] for k < ncol <= 8 columns of widths[k] floats.
+ * srcs / dsts / widths are HOST arrays (of device pointers / ints) -- the only host pointers of this ABI; rows [B] is
+ * device int64, clamped to [0, n_src). */
+int pfpn_gather_columns(const void* const* srcs, void* const* dsts, const int* widths, int ncol, const int64_t* rows,
+                        long long n_src, int B, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -611,6 +611,32 @@ def dppo_learner_step(st, shards, lr=1e-4, clip_norm=1.0, u_resample=None, u_noi
 
 
 # --------------------------------------------------------------------------- #
+# minibatch schedule of a training round (models/distributed_model.py:320-352) #
+# --------------------------------------------------------------------------- #
+def flat_train_schedule(n, batch_size, opt_epochs, rng, on_policy=True, sample_counter=0):
+    """Row ids of every learner step of one `flat_train` round, in order.  On-policy (:323-344): ONE id array,
+    shuffled in place once per epoch (an epoch permutes the previous epoch's order), cut into consecutive slices of
+    `batch_size` (last one ragged; no batch size -> one step on all rows).  Off-policy (:345-351): per step
+    `choice(n, batch_size)` (with replacement), `opt_epochs` steps or -- when that is None/0 -- `sample_counter`."""
+    out = []
+    if on_policy:
+        ids = np.arange(n)
+        epoch = 0
+        while epoch < opt_epochs:
+            rng.shuffle(ids)
+            if batch_size:
+                for s in range(0, n, batch_size):
+                    out.append(ids[s:s + batch_size].copy())
+            else:
+                out.append(ids.copy())
+            epoch += 1
+    elif n >= batch_size:
+        for _ in range(opt_epochs if opt_epochs else sample_counter):
+            out.append(rng.choice(n, batch_size))
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # SAC-PFPN (networks/actor_critic/sac.py:12-175, SURVEY 3.4)                  #
 # --------------------------------------------------------------------------- #
 SAC_ACTOR = ["actor/fc1/weight", "actor/fc1/bias", "actor/fc2/weight", "actor/fc2/bias",

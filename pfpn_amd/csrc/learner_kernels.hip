@@ -728,6 +728,31 @@ __global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2
     }
 }
 
+// Minibatch slicing of a training round (models/distributed_model.py flat_train :320-352): dst_c[b, :] = src_c[rows[b], :]
+// for up to 8 experience columns in ONE launch (state, action, value, log-prob, advantage of a DPPO minibatch).
+struct GatherCols {
+    const float* src[8];
+    float* dst[8];
+    int width[8];
+    int start[9];      // prefix sum of the widths: floats of one row over all columns
+    int ncol;
+};
+
+__global__ void k_gather_columns(GatherCols c, const int64_t* __restrict__ rows, long n_src, int B) {
+    const int per_row = c.start[c.ncol];
+    const long total = (long)B * per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_row), j = (int)(i - (long)b * per_row);
+        int col = 0;
+        while (j >= c.start[col + 1]) ++col;
+        const int k = j - c.start[col];
+        long r = rows[b];
+        r = r < 0 ? 0 : (r >= n_src ? n_src - 1 : r);          // never read outside the staged rollout
+        c.dst[col][(long)b * c.width[col] + k] = c.src[col][r * c.width[col] + k];
+    }
+}
+
+
 // SAC soft target update (sac.py:67-73): t <- (1-tau)*t + tau*s
 __global__ __launch_bounds__(256) void k_soft_update(float* __restrict__ t, const float* __restrict__ s, size_t n,
                                                      float tau) {
@@ -1633,6 +1658,27 @@ int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, con
     hipLaunchKernelGGL(k_sac_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, q_pi, q_run, q_tgt, logp, logp_t,
                        reward, not_terminal, log_alpha, B, gamma, value_coef, target_entropy, dq_pi, dq_run, dlogp,
                        dlog_alpha, loss3);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_gather_columns(const void* const* srcs, void* const* dsts, const int* widths, int ncol, const int64_t* rows,
+                        long long n_src, int B, void* stream) {
+    PFPN_BEGIN();
+    if (!srcs || !dsts || !widths || !rows || ncol < 1 || ncol > 8 || B < 1 || n_src < 1) return PFPN_ERR_ARG;
+    GatherCols c;
+    c.ncol = ncol;
+    c.start[0] = 0;
+    for (int k = 0; k < ncol; ++k) {
+        if (!srcs[k] || !dsts[k] || widths[k] < 1) return PFPN_ERR_ARG;
+        c.src[k] = (const float*)srcs[k];
+        c.dst[k] = (float*)dsts[k];
+        c.width[k] = widths[k];
+        c.start[k + 1] = c.start[k] + widths[k];
+    }
+    const size_t total = (size_t)B * (size_t)c.start[ncol];
+    hipLaunchKernelGGL(k_gather_columns, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, c, rows,
+                       (long)n_src, B);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

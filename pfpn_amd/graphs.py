@@ -89,6 +89,11 @@ class GraphedLearnerStep(object):
             ts += [net.max_active, net.sum_active]
         return ts
 
+    def load_rows(self, columns, rows):
+        """K = 1: gather `rows` of the staged rollout `columns` (device tensors, one per input) straight into the
+        step's static inputs -- the device side of a training round's minibatch slicing."""
+        kernels.gather_columns(list(columns), list(self.inputs), rows)
+
     def __call__(self, batch=None):
         """one replay = K learner steps.  `batch`: K = 1: the step's tensors; K > 1: a list of K such tuples."""
         if batch is not None:

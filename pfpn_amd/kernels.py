@@ -677,6 +677,31 @@ def adam_groups(params, grads, m, v, group_off, group_len, group_lr, beta_pow, g
                "pfpn_adam_groups")
 
 
+def gather_columns(srcs, dsts, rows):
+    """dsts[k][b] = srcs[k][rows[b]] for up to 8 float32 columns in one launch (a training round's minibatch slicing
+    on the device); srcs[k] [n, ...], dsts[k] [B, ...] with equal trailing shapes, rows [B] int64."""
+    lib = _lib.load()
+    K, B, n = len(srcs), rows.shape[0], srcs[0].shape[0]
+    if not (1 <= K <= 8 and len(dsts) == K):
+        raise ValueError("1..8 columns")
+    if not (rows.is_cuda and rows.dtype == torch.int64 and rows.is_contiguous() and rows.dim() == 1):
+        raise ValueError("rows must be a contiguous int64 CUDA vector")
+    widths = []
+    for s, d in zip(srcs, dsts):
+        w = s[0].numel() if s.dim() > 1 else 1
+        _f32(s, name="source column")
+        _f32(d, name="destination column")
+        if s.shape[0] != n or d.shape[0] != B or d.numel() != B * w:
+            raise ValueError("column shapes do not match: %s -> %s" % (tuple(s.shape), tuple(d.shape)))
+        widths.append(w)
+    ps = (ctypes.c_void_p * K)(*[s.data_ptr() for s in srcs])
+    pd = (ctypes.c_void_p * K)(*[d.data_ptr() for d in dsts])
+    pw = (ctypes.c_int * K)(*widths)
+    _lib.check(lib.pfpn_gather_columns(ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(pd, ctypes.c_void_p),
+                                       ctypes.cast(pw, ctypes.c_void_p), K, rows.data_ptr(), n, B, _stream()),
+               "pfpn_gather_columns")
+
+
 def soft_update(target, source, tau):
     lib = _lib.load()
     _lib.check(lib.pfpn_soft_update(_f32(target), _f32(source), target.numel(), float(tau), _stream()),

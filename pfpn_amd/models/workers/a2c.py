@@ -18,14 +18,8 @@ class SyncA2CWorker(SyncActorCriticWorker):
         kwargs["_on_policy"] = True
         super().__init__(**kwargs)
 
-    @property
-    def exp_buffers(self):
-        return ["state", "action", "reward", "value", "value_target", "advantage"]
-
-    @property
-    def train_args(self):
-        e = self.exp
-        return [e["state"], e["action"], e["value_target"], e["advantage"]]
+    BUFFERS = ("state", "action", "reward", "value", "value_target", "advantage")
+    LEARNER_INPUT = ("state", "action", "value_target", "advantage")
 
     def sample_action(self, sess, state):
         out = super().sample_action(sess, state)
@@ -38,7 +32,7 @@ class SyncA2CWorker(SyncActorCriticWorker):
         if terminal or go or self.episodic_terminal:
             lo = self.buffer_stamp
             boot = 0.0 if (terminal and not self.overtime(info)) else self.local_net.evaluate(sess, last_state)
-            values = self.exp["value"][lo:] + [boot]
+            values = np.append(self.exp["value"][lo:], np.float32(boot))
             adv = self.local_net.generalized_advantage_estimate(self.exp["reward"][lo:], values)
             self.exp["advantage"].extend(adv)
             self.exp["value_target"].extend(np.add(self.exp["value"][lo:], adv))     # a2c.py:42-49

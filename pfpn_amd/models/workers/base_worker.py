@@ -39,16 +39,25 @@ def actor_critic_worker_wrapper(base_distributed_worker_class):
 
         def train(self, *args, **kwargs):
             loss, result = super().train(*args, **kwargs)
-            if self.is_chief and loss is not None:
-                _, policy_entropy, policy_loss, value_loss = loss
-                now = time.perf_counter()
-                if np.isnan(policy_loss) or np.isnan(value_loss) or now > self.log_interval_time + self.last_notify_time:
-                    print("[TRAIN] Step: {}; Value Loss: {:.4f}; Policy Loss: {:.4f}; Policy Entropy: {:.4f}; "
-                          "Worker: {}; {}".format(self.global_step, value_loss, policy_loss,
-                                                  0.0 if policy_entropy is None else policy_entropy, self.name,
-                                                  time.strftime("%m-%d %H:%M:%S", time.localtime())))
-                    self.last_notify_time = now
+            if loss is not None:
+                self.report([(loss, result)])
             return loss, result
+
+        def report(self, losses):
+            """[TRAIN] line of the chief: at most one per `log_interval_time`, always when a loss went NaN
+            (reference base_worker.py:136-150); `losses` = the (loss tuple, fetches) pairs of the steps just taken."""
+            if not (self.is_chief and losses):
+                return
+            now = time.perf_counter()
+            nan = next((l for l, _ in losses if np.isnan(l[2]) or np.isnan(l[3])), None)
+            if nan is None and now <= self.log_interval_time + self.last_notify_time:
+                return
+            _, policy_entropy, policy_loss, value_loss = nan if nan is not None else losses[-1][0]
+            print("[TRAIN] Step: {}; Value Loss: {:.4f}; Policy Loss: {:.4f}; Policy Entropy: {:.4f}; "
+                  "Worker: {}; {}".format(self.global_step, value_loss, policy_loss,
+                                          0.0 if policy_entropy is None else policy_entropy, self.name,
+                                          time.strftime("%m-%d %H:%M:%S", time.localtime())))
+            self.last_notify_time = now
 
         @staticmethod
         def overtime(info):

@@ -1,29 +1,41 @@
-"""Off-policy worker (DDPG / SAC): replay ring, random warm-up, one learner step per environment step.
+"""Off-policy worker (DDPG / TD3 / SAC): replay ring, random warm-up, one learner step per environment step.
 
 Behaviour of reference models/workers/ddpg.py: `Buffer` (:11-27) is a fixed-capacity ring per experience key;
 `DDPGWorker` (:29-94) stores (state, action, reward, not_terminal, next state), treats a time-limit ending as not
 terminal, draws uniform-random actions until `observations` transitions are in, forces separate actor / critic
-optimisers, and trains from minibatches sampled WITH replacement (AbstractDistributedWorker.flat_train).
+optimisers, and trains from minibatches sampled WITH replacement (`replay_plan` in models/distributed_model.py).
+Here a ring is one preallocated float32 array per key, so a minibatch is a single fancy-index gather instead of a
+Python loop over a million-slot list.
 """
+import numpy as np
+
 from .base_worker import SyncActorCriticWorker
 
 __all__ = ["SyncDDPGWorker", "Buffer"]
 
 
-class Buffer(list):
-    """fixed-capacity ring: `data` holds the slots, `pointer` the next slot to overwrite, len() the fill."""
+class Buffer(object):
+    """fixed-capacity ring: `data` holds the slots (allocated at the first append, when the row shape is known),
+    `pointer` is the next slot to overwrite, len() the fill."""
 
     def __init__(self, capacity):
-        super().__init__()
         self.capacity = int(capacity)
-        self.data = [None] * self.capacity
+        self.data = None
         self.pointer = self.size = 0
 
     def append(self, item):
+        if self.data is None:
+            self.data = np.zeros((self.capacity,) + np.shape(item), np.float32)
         self.data[self.pointer] = item
         self.pointer = (self.pointer + 1) % self.capacity
-        if self.size < self.capacity:
-            self.size += 1
+        self.size = min(self.size + 1, self.capacity)
+
+    def filled(self):
+        """the valid slots as an array view (slot order, not age order: sampling is uniform over them)."""
+        return self.data[:self.size] if self.data is not None else np.zeros((0,), np.float32)
+
+    def __getitem__(self, i):
+        return self.filled()[i]
 
     def clear(self):
         self.pointer = self.size = 0
@@ -33,7 +45,7 @@ class Buffer(list):
 
 
 class SyncDDPGWorker(SyncActorCriticWorker):
-    KEYS = ("state", "action", "reward", "not_terminal", "state_")
+    BUFFERS = LEARNER_INPUT = ("state", "action", "reward", "not_terminal", "state_")
 
     def __init__(self, buffer_capacity=int(1e6), observations=0, **kwargs):
         kwargs["_on_policy"] = False
@@ -45,11 +57,8 @@ class SyncDDPGWorker(SyncActorCriticWorker):
         self.separate_optimizer = True                 # critic and actor always get their own Adam (ddpg.py:41)
         super().init()
 
-    exp_buffers = property(lambda self: list(self.KEYS))
-    train_args = property(lambda self: [self.exp[k] for k in self.KEYS])
-
     def setup_buffers(self):
-        self.exp = {k: Buffer(self.buffer_capacity) for k in self.KEYS}
+        self.exp = {k: Buffer(self.buffer_capacity) for k in self.BUFFERS}
 
     def _warming_up(self):
         return not self.is_evaluator and len(self.exp["state"]) < self.observations

@@ -6,6 +6,8 @@ are buffered with the step (:43-48); when an episode ends, the unroll is full or
 segment [buffer_stamp:] gets its GAE advantages, bootstrapped with 0 after a true terminal and with V(last state)
 after a time limit or an unroll boundary (:50-73).
 """
+import numpy as np
+
 from .base_worker import SyncActorCriticWorker
 
 __all__ = ["SyncPPOWorker", "DPPOWorker"]
@@ -19,9 +21,6 @@ class SyncPPOWorker(SyncActorCriticWorker):
         super().__init__(**dict(kwargs, _on_policy=True))
         self.buffer_stamp = 0                       # first row of the segment whose advantages are still open
 
-    exp_buffers = property(lambda self: list(self.BUFFERS))
-    train_args = property(lambda self: [self.exp[k] for k in self.LEARNER_INPUT])
-
     def sample_action(self, sess, state):
         fetched = super().sample_action(sess, state)
         if self.target_net.trainable:
@@ -34,8 +33,8 @@ class SyncPPOWorker(SyncActorCriticWorker):
         true_end = terminal and not self.overtime(info)
         bootstrap = 0.0 if true_end else self.local_net.evaluate(sess, last_state)
         lo = self.buffer_stamp
-        values = self.exp["value"][lo:] + [bootstrap]
-        self.exp["advantage"] += list(self.local_net.generalized_advantage_estimate(self.exp["reward"][lo:], values))
+        values = np.append(self.exp["value"][lo:], np.float32(bootstrap))
+        self.exp["advantage"].extend(self.local_net.generalized_advantage_estimate(self.exp["reward"][lo:], values))
         self.buffer_stamp = len(self.exp["value"])
 
     def need_train(self, sess, terminal, last_state, info):

@@ -16,14 +16,9 @@ class SyncVTraceWorker(SyncActorCriticWorker):
         kwargs["episodic_training"] = True
         super().__init__(**kwargs)
 
-    @property
-    def exp_buffers(self):
-        return ["state", "action", "reward", "log_prob", "not_terminal"]
-
-    @property
-    def train_args(self):
-        e = self.exp
-        return [e["state"], e["action"], e["reward"], e["log_prob"], e["not_terminal"], self.sequence_length]
+    BUFFERS = LEARNER_INPUT = ("state", "action", "reward", "log_prob", "not_terminal")
+    # the learner also gets the segment lengths
+    train_args = property(lambda self: [self.exp[k] for k in self.LEARNER_INPUT] + [self.sequence_length])
 
     def sample_action(self, sess, state):
         out = super().sample_action(sess, state)

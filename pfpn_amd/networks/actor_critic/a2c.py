@@ -163,7 +163,9 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         else:
             self.dh_a = torch.empty(1, B, self.actor_net_shape[-1], dtype=torch.float32, device=dev)
             self.dh_c = torch.empty(1, B, hc, dtype=torch.float32, device=dev)
-        self.entropy_buf = None
+        # per-size buffer like the rest (a captured learner step keeps pointing at it)
+        self.entropy_buf = torch.full((B, self.n_actions), -float(self.entropy_beta) / B, dtype=torch.float32,
+                                      device=dev) if self.entropy_beta else None
 
     def stat_slots(self):
         slots = super().stat_slots()
@@ -207,9 +209,6 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         """policy_loss -= beta * mean_valid(sum_a H)  (actor_critic.py:172-176, a2c.py:62-65): adds the
         entropy gradient into dlogits; keeps the per-row entropies for the loss report."""
         if mask is None:
-            if self.entropy_buf is None or self.entropy_buf.shape[0] != B:
-                self.entropy_buf = torch.full((B, self.n_actions), -float(self.entropy_beta) / B,
-                                              dtype=torch.float32, device=self.device)
             dH = self.entropy_buf
         else:
             dH = ((-float(self.entropy_beta)) * mask / n_valid).view(B, 1).expand(B, self.n_actions).contiguous()

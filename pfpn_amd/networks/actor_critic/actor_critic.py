@@ -346,15 +346,21 @@ class ActorCriticNetwork(object):
         for t, off, n, in_tail in self.stat_slots():
             torch.mul(tail[off:off + n], inv_world, out=t.view(-1))
 
-    def graphed_train(self, optimizer, args, make_noise=None):
-        """One learner step on the device tensors `args` (-> loss3, device).  A worker trains on a fixed minibatch
+    def graphed_train(self, optimizer, args, make_noise=None, rows=None):
+        """One learner step on the device tensors `args` (-> loss3, device); with `rows` (int64 device tensor) on
+        those rows of `args` (the staged rollout of a training round: the gather lands in the graph's static inputs).  A worker trains on a fixed minibatch
         size (32 rows in the DPPO setting: ~40 launches of almost no work each), so after a few eager steps at
         one size the step is captured into a hipGraph (pfpn_amd/graphs.py) and replayed: identical results,
         a third of the time.  Data-parallel runs (the RCCL all-reduce stays eager) and PFPN_GRAPH_TRAIN=0 keep the
         eager path."""
-        B = args[0].shape[0]
+        B = args[0].shape[0] if rows is None else rows.shape[0]
         key = (B, id(optimizer))
         g = self._train_graphs.get(key)
+        if rows is not None:
+            if g is not None and make_noise is None:
+                g.load_rows(args, rows)
+                return g()
+            args = [a.index_select(0, rows) for a in args]
         if g is None:
             n = self._train_calls[key] = self._train_calls.get(key, 0) + 1
             if n > 4 and not getattr(optimizer, "exchange", optimizer.world > 1) and self.device.type == "cuda" and len(self._train_graphs) < 4 and \

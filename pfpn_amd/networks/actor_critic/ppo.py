@@ -105,6 +105,31 @@ def clip_ppo_network_wrapper(a2c_base_class):
             loss3 = self.graphed_train(optimizer, args)
             return self._report(loss3, ops)
 
+        def train_round(self, sess_or_optimizer, ops, names, columns, plan):
+            """A whole training round in one call (pfpn_amd/models/distributed_model.py: flat_train): `columns` are the
+            rollout's host arrays by name (`names` = the learner's argument order), `plan` the row ids of every learner
+            step.  ONE host-to-device copy per column, device-side gathers into the captured step's inputs, ONE read
+            of all losses at the end.  Returns [((loss, entropy, policy_loss, value_loss), extra_fetches)] per step."""
+            optimizer = sess_or_optimizer
+            if self.entropy_beta or not plan:           # the entropy report reads the device every step anyway
+                return [self.train(None, optimizer, ops, *[np.asarray(columns[k])[rows] for k in names])
+                        for rows in plan]
+            cols = [self._to_dev(columns[k]) for k in names]
+            cols[0], cols[1] = cols[0].view(-1, self.S), cols[1].view(-1, self.n_actions)
+            cols[2:] = [c.view(-1) for c in cols[2:]]
+            rows = torch.from_numpy(np.concatenate(plan).astype(np.int64)).to(self.device)
+            losses = torch.empty(len(plan), 3, dtype=torch.float32, device=self.device)
+            steps, pos = [], 0
+            for i, ids in enumerate(plan):
+                losses[i].copy_(self.graphed_train(optimizer, cols, rows=rows[pos:pos + len(ids)]))
+                pos += len(ids)
+                steps.append(self.global_step)
+            host = losses.cpu().numpy()
+            wanted = list(ops) if hasattr(ops, "__len__") else ([ops] if ops else [])
+            return [((float(l[0]), None, float(l[1]), float(l[2])),
+                     [st if o in ("global_step", "step") else (o() if callable(o) else None) for o in wanted])
+                    for l, st in zip(host, steps)]
+
     return ClipPPONetwork
 
 

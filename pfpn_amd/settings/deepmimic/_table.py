@@ -7,6 +7,7 @@ the same names are three-line stubs that ask `publish()` to fill their namespace
 settings.deepmimic.deepmimic_dppo_pfpn` keeps working.  Command-line overrides (`--particles`, `--max_samples`,
 `--soft`) are read from sys.argv exactly where the reference reads them.
 """
+import os
 import sys
 
 
@@ -84,6 +85,12 @@ def publish(namespace, family=None, pfpn=False):
     out = {"network_opts": net, "worker_opts": w}
     if family is not None:
         net_over, workers, w_over, model, worker = FAMILIES[family]
+        # the replica count that the schedules below assume is the one torchrun actually started
+        world = int(os.environ.get("WORLD_SIZE", "0"))
+        if world and world != workers:
+            sys.stderr.write("[settings] %s: %d replicas running (setting's default %d): max_iterations / "
+                             "resample_interval follow the running count\n" % (family, world, workers))
+            workers = world
         net.update(net_over)
         w.update(w_over)
         out.update(workers=workers, model=model, worker=worker, max_iterations=_max_iterations(family, workers, w))

@@ -101,3 +101,48 @@ def test_graphed_rollout_matches_eager(dev):
         b["log_prob"] = np.full(64, -40.0, np.float32)
         net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
         net.run(None, st[0])
+
+
+def test_staged_training_round_matches_stepwise_training(dev):
+    """`train_round` (rollout staged once, device-side minibatch gathers into the captured step, one loss read) gives
+    the bits of per-minibatch `train()` calls on the same plan, across the switch from eager steps to hipGraph replays,
+    a ragged last minibatch and a resample tick."""
+    import numpy as np
+    import torch
+    from pfpn_amd.models import SyncReplicasApplier
+    from pfpn_amd.models.distributed_model import minibatch_plan
+    from test_gpu_dppo_step import make_net, make_batch
+    names = ["state", "action", "value", "log_prob", "advantage"]
+    rng = np.random.default_rng(5)
+    nets = [make_net(dev, seed=11, resample_interval=13) for _ in range(2)]
+    opts = [SyncReplicasApplier(n, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1) for n in nets]
+    for rnd in range(2):
+        n = 200                                             # 6 minibatches of 32 + one of 8, two epochs
+        b = make_batch(rng, n)
+        b["log_prob"] = rng.normal(-38, 0.3, n).astype(np.float32)
+        plan = minibatch_plan(n, 32, 2, np.random.RandomState(rnd))
+        cols = {k: b[k] for k in names}
+        out_round = nets[0].train_round(opts[0], ["global_step"], names, cols, plan)
+        out_steps = [nets[1].train(None, opts[1], ["global_step"], *[cols[k][rows] for k in names]) for rows in plan]
+        assert len(out_round) == len(plan) == 14
+        for (l0, e0), (l1, e1) in zip(out_round, out_steps):
+            assert l0 == l1 and e0 == e1
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
+        assert torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
+    assert nets[0].global_step == 28 and nets[0].train_flag == nets[1].train_flag == 2      # ticks at 13 and 26
+    assert len(nets[0]._train_graphs) >= 1                  # the round really ran on captured steps
+
+
+def test_gather_columns_kernel(dev):
+    import torch
+    from pfpn_amd import kernels
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    n, B = 777, 100
+    srcs = [torch.randn(n, 197, device=dev, generator=g), torch.randn(n, 36, device=dev, generator=g),
+            torch.randn(n, device=dev, generator=g), torch.randn(n, device=dev, generator=g)]
+    rows = torch.randint(0, n, (B,), device=dev, generator=g)
+    dsts = [torch.empty((B,) + tuple(s.shape[1:]), device=dev) for s in srcs]
+    kernels.gather_columns(srcs, dsts, rows)
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, s[rows])

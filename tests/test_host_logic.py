@@ -235,3 +235,84 @@ def test_variable_length_packing(oracle):
     assert w.sequence_length == [3, 5]
     st = np.asarray(w.exp["state"])
     assert st.shape == (10, 2) and list(st[:, 0]) == [30, 31, 32, 0, 0, 50, 51, 52, 53, 54]
+
+
+# --- the redesigned runtime: experience columns, learner-round plans, staged rounds -------------------------------
+def test_column_and_ring_semantics():
+    from pfpn_amd.models.distributed_model import Column
+    c = Column()
+    for i in range(200):                              # grows past its first allocation
+        c.append(np.full(3, i, np.float32))
+    assert len(c) == 200 and np.asarray(c).shape == (200, 3) and c[199][0] == 199
+    c.pad(5)
+    assert len(c) == 205 and np.all(c[200:] == 0)
+    s = Column()
+    s += [1.0, 2.0, 3.0]
+    s.shift(1, 10.0)
+    assert list(s[:]) == [1.0, 12.0, 13.0]
+    s.clear()
+    assert len(s) == 0 and np.asarray(s).shape == (0,)
+    b = Buffer(4)
+    for i in range(6):
+        b.append(np.full(2, i, np.float32))
+    assert len(b) == 4 and b.pointer == 2 and sorted(b.filled()[:, 0]) == [2, 3, 4, 5]
+    assert np.array_equal(b[np.array([0, 0, 3])][:, 0], [4, 4, 3])     # one gather, with repeats
+
+
+@pytest.mark.parametrize("n,bs,ep", [(128, 32, 1), (50, 20, 3), (7, None, 2), (64, 64, 2)])
+def test_round_plan_is_the_reference_schedule(oracle, n, bs, ep):
+    """same RNG stream -> the same rows in every learner step as reference flat_train (:320-352)."""
+    from pfpn_amd.models.distributed_model import minibatch_plan, replay_plan
+    got = minibatch_plan(n, bs, ep, np.random.RandomState(11))
+    ref = oracle.flat_train_schedule(n, bs, ep, np.random.RandomState(11))
+    assert len(got) == len(ref) and all(np.array_equal(a, b) for a, b in zip(got, ref))
+    if bs:
+        got = replay_plan(n, bs, 5, np.random.RandomState(3))
+        ref = oracle.flat_train_schedule(n, bs, 5, np.random.RandomState(3), on_policy=False)
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref))
+        assert len(oracle.flat_train_schedule(bs - 1, bs, 5, np.random.RandomState(3), on_policy=False)) == 0
+
+
+class StagedStubNet(StubNet):
+    """a network that takes a whole round at once (the product's `train_round`)."""
+    def train_round(self, optimizer, ops, names, columns, plan):
+        self.rounds = getattr(self, "rounds", 0) + 1
+        out = []
+        for rows in plan:
+            self.trained.append([np.asarray(columns[k])[rows].copy() for k in names])
+            self.global_step += 1
+            out.append(((0.1, None, 0.05, 0.05), [self.global_step]))
+        return out
+
+
+def test_staged_round_sees_the_same_minibatches_as_stepwise_training(oracle):
+    """`train_round` (one call per round) and per-minibatch `train` receive identical rows in identical order."""
+    nets = [StubNet(oracle), StagedStubNet(oracle)]
+    for net in nets:
+        w = make_worker(DPPOWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=2, batch_size=20,
+                        unroll_length=50)
+        w.work(None, max_iterations=12)
+        assert w.global_step == 12
+    assert nets[1].rounds == 2 and len(nets[0].trained) == len(nets[1].trained) == 12
+    for a, b in zip(nets[0].trained, nets[1].trained):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_evaluator_plays_whole_episodes_past_max_iterations(oracle):
+    """a player restored from a finished run (global_step >= max_iterations) still plays complete episodes."""
+    net = StubNet(oracle, trainable=False)
+    net.global_step = 10 ** 6
+    w = make_worker(DPPOWorker, net, lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=1, batch_size=32,
+                    unroll_length=128, _is_evaluator=1)
+    w.global_step = 10 ** 6
+    episodes = []
+    plain = w.after_episode
+
+    def after_episode(sess, info):
+        plain(sess, info)
+        episodes.append(w.episode_step)
+        if len(episodes) == 2:
+            w.request_stop = True
+    w.after_episode = after_episode
+    w.work(None, max_iterations=100)
+    assert episodes == [50, 50]
