@@ -5,18 +5,23 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one learner update on one 4096-transition synthetic batch PER GPU (config 2 of
-BASELINE.json: DeepMimicWalk DPPO-PFPN, S=197, A=36, N=35, MLPs 197->1024->512): state-norm(+EMA) ->
-actor & critic MLP forward -> fused particle-mixture log-prob + PPO loss + backward (HIP) -> MLP
-backward -> global-norm clip -> [N>1: one RCCL all-reduce of the clipped grads + statistics] ->
-TF-Adam -> resample tick.  Inputs are resident in HBM before the timed region.  `value` counts
-4096-transition learner batches per second over ALL ranks (weak scaling: per-GPU work fixed).
+One "step" = one learner update on one 4096-transition synthetic batch (config 2 of BASELINE.json: DeepMimicWalk
+DPPO-PFPN, S=197, A=36, N=35, MLPs 197->1024->512): state-norm(+EMA) -> actor & critic MLP forward -> fused
+particle-mixture log-prob + PPO loss + backward (HIP) -> MLP backward -> global-norm clip -> [N>1: one RCCL all-reduce
+of the clipped grads + statistics] -> TF-Adam -> resample tick.  Inputs are resident in HBM before the timed region.
+The metric is quoted on a 4096-transition batch at 1/2/4/8 GPUs ("B sharded"), so with N GPUs the SAME
+global batch is split 4096/N rows per rank ("scaling": "strong") and `value` counts global learner steps per second;
+`--weak` keeps 4096 rows per rank instead (also measured as the extra key `weak_scaling` on N > 1 runs).
 
 Rank 0 prints ONE JSON line; besides the contract keys it carries
   roofline      -- the dominant hand-written kernel (fused mixture fwd+PPO+bwd) vs the HBM roof,
   roofline_gemm -- the FC GEMMs (PyTorch-ROCm) vs the fp32 MFMA roof,
-  cpu_baseline  -- the NumPy oracle (op-for-op restatement of the reference's TF1 CPU path, NOT TF1)
-                   timed on this box's host cores on a bounded sample.
+  strong_shard  -- (N = 1) the data-parallel step of ONE rank at 2048 / 1024 / 512 rows over a world-size-1 RCCL group:
+                   what a rank of a 2 / 4 / 8-GPU run spends per step before any byte crosses a link,
+  sac_step      -- (N = 1) the SAC-PFPN learner step of BASELINE.json config 3 (replay batch 1024),
+  cpu_baseline  -- restatements of the reference's TF1 CPU path (NOT TF1) timed on this box's host cores on a bounded
+                   sample, in a child process: all-core and single-thread 4096-row steps, and the reference's own
+                   8-worker x 32-row schedule (oracle/cpu_baseline.py).
 """
 import argparse
 import json
@@ -58,46 +63,19 @@ def gemm_flops(rows):
     return 2.0 * rows * (mac_fwd + mac_bwd)
 
 
-def cpu_baseline(budget_s=20.0):
-    """NumPy oracle learner step on a 4096-row batch on the host cores: all BLAS threads (the headline `value`, `cores` =
-    the BLAS pool size actually used) and, for SURVEY 8d's like-for-like ratio, one thread."""
-    from oracle import pfpn_oracle as orc
-    try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        pools = [p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"]
-        blas_threads = max(pools) if pools else 1
-    except Exception:
-        threadpool_limits, blas_threads = None, os.cpu_count()
-    rng = np.random.default_rng(SEED)
-    st = orc.DPPOState(rng, S, A, NP)
-    b = synth_batch(rng, B)
-    x = orc.state_normalize(b["state"], st.norm_mean, st.norm_std, 5.0)
-    logits, _ = orc.actor_forward(st.P, x, A, NP)
-    b["log_prob"], _ = orc.mixture_log_prob(logits, b["action"], st.P["actor/samples"], st.P["actor/samples_std"])
-    b["value"], _ = orc.critic_forward(st.P, x)
-    orc.dppo_learner_step(st, [b])          # warm-up
-
-    def timed(max_steps, budget):
-        n, t0 = 0, time.perf_counter()
-        while True:
-            orc.dppo_learner_step(st, [b])
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget or n >= max_steps:
-                return n, el
-
-    n, el = timed(20, budget_s * 0.6)
-    runs = [{"value": n / el, "cores": blas_threads, "sample": "%d steps, %d BLAS threads" % (n, blas_threads)}]
-    if threadpool_limits is not None and blas_threads > 1:
-        with threadpool_limits(limits=1):
-            n1, el1 = timed(20, budget_s * 0.4)
-        runs.append({"value": n1 / el1, "cores": 1, "sample": "%d steps, 1 BLAS thread" % n1})
-    best = max(runs, key=lambda r: r["value"])          # the baseline is the FASTER arrangement on this host
-    out = {"value": best["value"], "unit": "steps/s", "cores": best["cores"], "host_cpus": os.cpu_count(), "kind": "port",
-           "sample": "oracle learner steps on one 4096-transition batch (NumPy restatement; NumPy's elementwise part is "
-                     "single-threaded, the GEMMs use the BLAS pool): " + best["sample"] + "; not TF1",
-           "runs": runs}
-    return out
+def cpu_baseline(budget_s=24.0):
+    """oracle/cpu_baseline.py in a CHILD process (it forks worker processes and pins BLAS threads; this process holds
+    the GPU).  Returns its JSON: value = the fastest 4096-row CPU arrangement, runs = every leg."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("OPENBLAS_NUM_THREADS", None)
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""         # the child never touches the GPU
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--budget", str(budget_s)], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(180.0, 8 * budget_s))
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "cpu_baseline child failed (rc %d): %s" % (r.returncode, r.stderr.decode()[-400:])}
+    return json.loads(lines[-1])
 
 
 def _flush_c_stdio():
@@ -125,6 +103,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL); "
                                                       "`gloo` + --one-device smoke-tests the multi-rank path on one GPU")
     ap.add_argument("--one-device", action="store_true", help="every rank on cuda:0 (control-flow smoke test only)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: 4096 rows on EVERY rank (global batch 4096 x N) instead of the metric's "
+                         "4096-row global batch split over the ranks")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: run the data-parallel step (clip in place, RCCL all-reduce in a world-size-1 group, "
                          "Adam with 1/W) instead of the fused single-replica step -- its cost without the links")
@@ -150,80 +131,104 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    net = ParticleFilteringClipPPONetwork(trainable=True, state_shape=[S], action_shape=[A],
-                                          action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
-                                          device=dev, seed=SEED, **NET_OPTS)
-    net.init()
-    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world,
-                              force_exchange=args.force_exchange)
+    def make_learner(rows, seed, exchange_group=False):
+        """a network + optimiser + `rows` synthetic transitions resident in HBM + the step callable"""
+        net_ = ParticleFilteringClipPPONetwork(trainable=True, state_shape=[S], action_shape=[A],
+                                               action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
+                                               device=dev, seed=SEED, **NET_OPTS)
+        net_.init()
+        opt_ = SyncReplicasApplier(net_, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world,
+                                   force_exchange=args.force_exchange or exchange_group)
+        hb = synth_batch(np.random.default_rng(seed), rows)
+        t = {k: torch.from_numpy(hb[k]).to(dev) for k in ("state", "action", "advantage")}
+        with torch.no_grad():      # value_old / log_prob_old = outputs of the (frozen) initial net: ratio ~ 1
+            policy, ha, hc = net_._forward(t["state"])
+            t["log_prob"] = policy.log_prob(t["action"]).clone()
+            t["value"] = net_._value(hc).clone()
+        return net_, opt_, (t["state"], t["action"], t["value"], t["log_prob"], t["advantage"])
 
-    rng = np.random.default_rng(SEED + rank)      # every rank owns a different 4096-transition shard
-    hb = synth_batch(rng, B)
-    state = torch.from_numpy(hb["state"]).to(dev)
-    action = torch.from_numpy(hb["action"]).to(dev)
-    adv = torch.from_numpy(hb["advantage"]).to(dev)
-    with torch.no_grad():      # value_old / log_prob_old = outputs of the (frozen) initial net: ratio ~ 1
-        policy, ha, hc = net._forward(state)
-        logp_old = policy.log_prob(action).clone()
-        value_old = net._value(hc).clone()
+    def make_stepper(net_, opt_, inputs, allow_multi=True):
+        """-> (run_steps(n), launch description).  One replica: hipGraph replays of `--steps-per-graph` learner steps;
+        data parallel: two hipGraphs around the RCCL all-reduce per step (pfpn_amd/graphs.py); --no-graph: eager."""
+        if args.no_graph:
+            return (lambda n: [net_.train_device(opt_, *inputs) for _ in range(n)]), "eager"
+        one = graphs.GraphedLearnerStep(net_, opt_, *inputs)
+        spg_ = max(1, args.steps_per_graph) if (allow_multi and not one.split) else 1
+        many = graphs.GraphedLearnerStep(net_, opt_, *inputs, steps_per_replay=spg_) if spg_ > 1 else None
+        one()                    # the FIRST replay of a hipGraph uploads it: keep that out of every timed region
+        if many is not None and many.can_replay():
+            many()
 
-    use_graph = (world == 1) and not args.no_graph and not args.force_exchange
-    spg = max(1, args.steps_per_graph) if use_graph else 1
-    if use_graph:
-        step = graphs.GraphedLearnerStep(net, opt, state, action, value_old, logp_old, adv)
-        step_k = graphs.GraphedLearnerStep(net, opt, state, action, value_old, logp_old, adv,
-                                           steps_per_replay=spg) if spg > 1 else None
-    else:
-        step_k = None
+        def run_steps(n):
+            """exactly n learner steps: K-step replays while they fit (and no resample tick falls inside)"""
+            while n > 0:
+                if many is not None and n >= spg_ and many.can_replay():
+                    many()
+                    n -= spg_
+                else:
+                    one()
+                    n -= 1
+        what = "two hipGraphs around the RCCL all-reduce" if one.split else \
+            ("hipGraph, %d learner steps per replay" % spg_ if spg_ > 1 else "hipGraph")
+        return run_steps, what
 
-        def step():
-            return net.train_device(opt, state, action, value_old, logp_old, adv)
+    def timed_steps(run_steps, n_steps, n_warm):
+        """the contract's timed region: barrier + synchronize on both sides, MAX over ranks."""
+        run_steps(n_warm)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(n_steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el_ = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el_], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_ = float(t.item())
+        return el_
 
-    def run_steps(n):
-        """exactly n learner steps: K-step replays while they fit (and no resample tick falls inside), else single steps"""
-        while n > 0:
-            if step_k is not None and n >= spg and step_k.can_replay():
-                step_k()
-                n -= spg
-            else:
-                step()
-                n -= 1
-
-    if use_graph:            # the FIRST replay of a hipGraph uploads it: keep that out of the timed region even when
-        step()               # --warmup is smaller than one multi-step replay (these steps are extra, untimed)
-        if step_k is not None and step_k.can_replay():
-            step_k()
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    assert B % world == 0, "--gpus must divide 4096"
+    strong = not args.weak
+    rows = B // world if strong else B            # rank r owns rows [r * B/W, (r+1) * B/W) of the global batch
+    net, opt, inputs = make_learner(rows, SEED + rank)
+    state, action, value_old, logp_old, adv = inputs
+    run_steps, launch = make_stepper(net, opt, inputs)
+    el = timed_steps(run_steps, args.steps, args.warmup)
     loss3 = net.train_out["loss3"].cpu().numpy()
     assert np.all(np.isfinite(loss3)), "non-finite loss in the benchmark loop"
+    use_graph = not args.no_graph
+    weak_extra = None
+    if world > 1 and strong:         # the other scaling mode as an extra key: 4096 rows on every rank
+        try:
+            wnet, wopt, winputs = make_learner(B, SEED + rank)
+            wrun, _ = make_stepper(wnet, wopt, winputs)
+            wel = timed_steps(wrun, args.steps, args.warmup)
+            weak_extra = {"value": world * args.steps / wel, "unit": "steps/s of 4096 transitions (4096 rows per GPU)",
+                          "ms_per_step": wel / args.steps * 1e3, "global_batch": B * world}
+            del wnet, wopt, winputs, wrun
+        except Exception as e:
+            weak_extra = {"error": repr(e)}
 
     out = None
     if rank == 0:
         ms = el / args.steps * 1e3
         out = {
             "metric": "DPPO learner steps/sec (4096 trans, 36 act-dim x 35 particles)",
-            "value": world * args.steps / el, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "value": (1 if strong else world) * args.steps / el, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DeepMimicWalk-v0 DPPO-PFPN 35 particles, 4096-transition batch per GPU "
-                                   "(S=197, A=36, N=35, MLP 1024/512), random-init weights",
-                       "global_batch": B * world, "per_gpu_batch": B,
-                       "parallelism": "dp%d" % world, "launch": ("hipGraph, %d learner steps per replay" % spg if spg > 1 else "hipGraph") if use_graph else "eager",
+            "config": {"workload": "DeepMimicWalk-v0 DPPO-PFPN 35 particles, 4096-transition batch%s "
+                                   "(S=197, A=36, N=35, MLP 1024/512), random-init weights"
+                                   % (" sharded %d rows per GPU" % rows if (strong and world > 1) else
+                                      (" per GPU" if world > 1 else "")),
+                       "global_batch": rows * world, "per_gpu_batch": rows,
+                       "parallelism": "dp%d" % world, "launch": launch,
                        **({"exchange": "forced on one replica (RCCL world size 1)"} if args.force_exchange else {}),
                        "gemm_selection": ("shipped TunableOp file" if tuned else "TunableOp in warm-up") if not args.no_tune
                        else "library default",
@@ -231,6 +236,8 @@ def main():
                                "reduction launch (bias grads, particle grads, loss, state-norm EMA), clip, "
                                + ("RCCL all-reduce, " if (world > 1 or args.force_exchange) else "") + "TF-Adam, resample tick"},
         }
+        if weak_extra is not None:
+            out["weak_scaling"] = weak_extra
 
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
     if rank == 0 and world == 1:
@@ -288,15 +295,19 @@ def main():
         us = us_b2b
         ab = algorithmic_bytes_fused(B)
         ach = ab / (us * 1e-6) / 1e9
-        traffic = None
-        try:      # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"]["k_mix_packed<35,PPO>"]["traffic_bytes"]
-        except Exception:
-            pass
+        traffic, traffic_source = None, None
+        for rnd in ("r02", "r01"):     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE)
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
+                    traffic = json.load(f)["kernels"]["k_mix_packed<35,PPO>"]["traffic_bytes"]
+                traffic_source = "profiles/%s_pmc_traffic.json: separate rocprofv3 --pmc passes of round %s over this " \
+                                 "command (tools/pmc_traffic.py), NOT measured in this run" % (rnd, rnd[1:])
+                break
+            except Exception:
+                pass
         out["roofline"] = {"kernel": "k_mix_packed<35,PPO>", "bound": "hbm", "achieved": ach,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "algorithmic_bytes": ab, "us_per_launch": us, "launches_timed": reps,
+                           "traffic_source": traffic_source, "algorithmic_bytes": ab, "us_per_launch": us, "launches_timed": reps,
                            "us_in_step_event_pairs": us_in_step, "us_with_slab_finalize_launch": us_op,
                            "note": "us_per_launch: HIP events around 200 back-to-back launches of the kernel alone (in "
                                    "the step its slab sums are finished by the single deferred reduce launch); "
@@ -379,8 +390,78 @@ def main():
                                                  % (B * out["value"])}
         except Exception as e:          # informational only
             out["reference_schedule"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
+        extras = not args.no_cpu_baseline
+        # ---- strong_shard: what ONE rank of a 2 / 4 / 8-GPU run of this metric spends per step (the data-parallel step
+        # on 2048 / 1024 / 512 rows: per-replica clip, bucket all-reduce through RCCL in a world-size-1 group, Adam with
+        # 1/W, captured as two hipGraphs) -- the compute + launch side of the scaling curve, no link time in it
+        if extras and not args.force_exchange:
+            try:
+                if not dist.is_initialized():
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                    dist.init_process_group(backend=args.backend, rank=0, world_size=1)
+                shard = {}
+                for n_gpu in (1, 2, 4, 8):
+                    snet, sopt, sin = make_learner(B // n_gpu, SEED, exchange_group=True)
+                    srun, slaunch = make_stepper(snet, sopt, sin)
+                    srun(20)
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    srun(200)
+                    torch.cuda.synchronize()
+                    us_s = (time.perf_counter() - t_s) / 200 * 1e6
+                    shard[str(B // n_gpu)] = {"gpus_of_the_run_it_stands_for": n_gpu, "us_per_step": us_s,
+                                              "steps_per_s_without_links": 1e6 / us_s}
+                    del snet, sopt, sin, srun
+                bucket_mb = (net.store.bucket.numel() * 4) / 1e6
+                out["strong_shard"] = {"rows_per_gpu": shard, "launch": slaunch, "bucket_MB": bucket_mb,
+                                       "note": "one rank's step with the RCCL call in it but nothing on the links (world size "
+                                               "1); an N-GPU strong-scaling step = the N-row entry + the all-reduce of the "
+                                               "%.2f MB bucket over xGMI" % bucket_mb}
+            except Exception as e:
+                out["strong_shard"] = {"error": repr(e)}
+        # ---- sac_step: BASELINE.json config 3 (SAC-PFPN, replay batch 1024) as one hipGraph; a parity config, timed here
+        # so its rate is bench evidence and not prose
+        if extras:
+            try:
+                from pfpn_amd.networks import ParticleFilteringSACNetwork
+                sopts = dict(NET_OPTS, normalize_advantage=False, resample_interval=12000)
+                snet = ParticleFilteringSACNetwork(trainable=True, state_shape=[S], action_shape=[A],
+                                                   action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
+                                                   device=dev, seed=SEED, **sopts)
+                snet.init()
+                for op in snet.init_ops:
+                    op()
+                sopt = SyncReplicasApplier(snet, [{"names": snet.critic_param_names(), "lr": 1e-4},
+                                                  {"names": snet.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+                srng, SB = np.random.default_rng(SEED + 3), 1024
+                sb = [torch.from_numpy(a).to(dev) for a in (
+                    (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32), np.tanh(srng.normal(0, 1, (SB, A))).astype(np.float32),
+                    srng.random(SB).astype(np.float32), (srng.random(SB) < 0.98).astype(np.float32),
+                    (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32))]
+                sstep = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB))
+                for _ in range(10):
+                    sstep()
+                torch.cuda.synchronize()
+                t_s = time.perf_counter()
+                for _ in range(100):
+                    sstep()
+                torch.cuda.synchronize()
+                sms = (time.perf_counter() - t_s) / 100 * 1e3
+                sl3 = sstep.loss3.cpu().numpy()
+                out["sac_step"] = {"workload": "DeepMimicKick-v0 SAC-PFPN 35 particles, replay batch 1024 (BASELINE.json "
+                                               "config 3), synthetic replay rows", "steps_per_s": 1e3 / sms, "ms_per_step": sms,
+                                   "launch": "hipGraph, reparameterisation draws refilled outside the graph",
+                                   "finite_loss": bool(np.all(np.isfinite(sl3)))}
+                del snet, sopt, sstep
+            except Exception as e:
+                out["sac_step"] = {"error": repr(e)}
+        if extras:
             out["cpu_baseline"] = cpu_baseline()
+            rs = out["cpu_baseline"].get("runs", {}).get("reference_schedule", {})
+            if "transitions_per_s" in rs and "transitions_per_s" in out.get("reference_schedule", {}):
+                out["reference_schedule"]["cpu_transitions_per_s"] = rs["transitions_per_s"]
+                out["reference_schedule"]["cpu_cores"] = rs["cores"]
     # The JSON line must be the LAST thing on stdout.  RCCL leaves a version banner in the C stdio buffer of every rank,
     # which would otherwise reach the pipe at process exit -- after a line printed from Python.  So every rank flushes
     # its C streams, the ranks meet at a barrier, the group is torn down, and only then rank 0 prints.

@@ -1,0 +1,188 @@
+"""The CPU side of bench.py's `cpu_baseline` (run as a child process that never touches the GPU):
+
+  python -m oracle.cpu_baseline --budget 24      -> one JSON object on the last stdout line
+
+*** TEST / BENCH INFRASTRUCTURE -- NOT PRODUCT CODE. ***  TF 1.14 cannot be installed, so the "reference CPU path" is
+this repo's restatement of it (kind = "port"), timed three ways on a BOUNDED sample:
+
+* `single_4096`: the op-for-op NumPy oracle (pfpn_oracle.dppo_learner_step) on one 4096-transition batch, one thread --
+  the like-for-like arithmetic, scalar port;
+* `allcore_4096`: the same learner step on torch-CPU ops (oracle/torch_cpu_step.py, checked against the oracle in
+  tests/test_oracle_math.py) with GEMMs AND elementwise kernels on all host threads -- the fastest CPU arrangement and
+  therefore the headline `value`;
+* `reference_schedule`: what `benchmark.sh` actually runs (deepmimic_dppo_base.py:6-12, benchmark.sh:18): 8 worker
+  processes with one BLAS thread each, every global step = 8 minibatches of 32 rows, per-worker clip, gradients averaged
+  by a parameter server that applies Adam (sync_model.py:62-101) -- 16 such steps consume 4096 transitions.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+S, A, NP, B = 197, 36, 35, 4096
+SEED = 34114
+
+
+def synth_batch(rng, rows):
+    return {"state": (rng.normal(0, 1, (rows, S)) * 2 + 0.3).astype(np.float32),
+            "action": rng.uniform(-1.1, 1.1, (rows, A)).astype(np.float32),
+            "advantage": rng.normal(0, 1, rows).astype(np.float32)}
+
+
+def complete(orc, st, b):
+    x = orc.state_normalize(b["state"], st.norm_mean, st.norm_std, 5.0)
+    logits, _ = orc.actor_forward(st.P, x, A, NP)
+    b["log_prob"], _ = orc.mixture_log_prob(logits, b["action"], st.P["actor/samples"], st.P["actor/samples_std"])
+    b["value"], _ = orc.critic_forward(st.P, x)
+    return b
+
+
+def timed(fn, budget, max_steps):
+    fn()                                     # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget or n >= max_steps:
+            return n, el
+
+
+def single_4096(orc, budget):
+    from threadpoolctl import threadpool_limits
+    rng = np.random.default_rng(SEED)
+    st = orc.DPPOState(rng, S, A, NP)
+    b = complete(orc, st, synth_batch(rng, B))
+    with threadpool_limits(limits=1):
+        n, el = timed(lambda: orc.dppo_learner_step(st, [b]), budget, 30)
+    return {"value": n / el, "unit": "steps/s", "cores": 1, "sample": "%d NumPy-oracle steps of 4096 rows, 1 thread" % n}
+
+
+def allcore_4096(orc, budget):
+    import torch
+    from oracle import torch_cpu_step as tcs
+    rng = np.random.default_rng(SEED)
+    st = orc.DPPOState(rng, S, A, NP)
+    b = complete(orc, st, synth_batch(rng, B))
+    ts = tcs.TorchCPUState(st)
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    best = None
+    for threads in sorted({min(os.cpu_count(), t) for t in (8, 32, os.cpu_count())}):
+        torch.set_num_threads(threads)
+        n, el = timed(lambda: tcs.learner_step(ts, tb), budget / 3, 60)
+        run = {"value": n / el, "unit": "steps/s", "cores": threads,
+               "sample": "%d torch-CPU steps of 4096 rows, %d threads" % (n, threads)}
+        if best is None or run["value"] > best["value"]:
+            best = run
+    return best
+
+
+# ---- reference schedule: 8 worker processes + a parameter server ------------------------------------------------
+def _flat_len(orc, st):
+    return sum(st.P[k].size for k in orc.PARAM_ORDER)
+
+
+def _worker(w, n_workers, shared_p, shared_g, go, done, stop, rows):
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"          # benchmark.sh:18
+    from threadpoolctl import threadpool_limits
+    from oracle import pfpn_oracle as orc
+    rng = np.random.default_rng(SEED + 1 + w)         # seed + task_id + 1 (distributed_model.py:568)
+    st = orc.DPPOState(np.random.default_rng(SEED), S, A, NP)
+    shapes = [st.P[k].shape for k in orc.PARAM_ORDER]
+    sizes = [int(np.prod(s)) for s in shapes]
+    params = np.frombuffer(shared_p, np.float32)
+    grads = np.frombuffer(shared_g, np.float32).reshape(n_workers, -1)
+    data = complete(orc, st, synth_batch(rng, 512))   # one 512-step unroll, re-used
+    with threadpool_limits(limits=1):
+        it = 0
+        while True:
+            go.wait()
+            if stop.value:
+                return
+            off = 0
+            for k, sz, sh in zip(orc.PARAM_ORDER, sizes, shapes):      # pull_weights
+                st.P[k] = params[off:off + sz].reshape(sh)
+                off += sz
+            lo = (it * rows) % 512
+            mb = {k: v[lo:lo + rows] for k, v in data.items()}
+            _, G, _ = orc.dppo_grads(st.P, st.norm_mean, st.norm_std, mb, A, NP)
+            clipped, _ = orc.clip_by_global_norm([G[k] for k in orc.PARAM_ORDER], 1.0)
+            off = 0
+            for c, sz in zip(clipped, sizes):
+                grads[w, off:off + sz] = c.reshape(-1)
+                off += sz
+            it += 1
+            done.wait()
+
+
+def reference_schedule(orc, budget, n_workers=8, rows=32):
+    st = orc.DPPOState(np.random.default_rng(SEED), S, A, NP)
+    n = _flat_len(orc, st)
+    ctx = mp.get_context("fork")
+    shared_p, shared_g = ctx.RawArray("f", n), ctx.RawArray("f", n * n_workers)
+    params = np.frombuffer(shared_p, np.float32)
+    grads = np.frombuffer(shared_g, np.float32).reshape(n_workers, n)
+    params[:] = np.concatenate([st.P[k].reshape(-1) for k in orc.PARAM_ORDER])
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    go, done, stop = ctx.Barrier(n_workers + 1), ctx.Barrier(n_workers + 1), ctx.Value("i", 0)
+    procs = [ctx.Process(target=_worker, args=(w, n_workers, shared_p, shared_g, go, done, stop, rows), daemon=True)
+             for w in range(n_workers)]
+    for p in procs:
+        p.start()
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+
+    def global_step():
+        nonlocal b1p, b2p, m, v
+        go.wait()                 # workers: pull, forward/backward on 32 rows, clip, push
+        done.wait()
+        g = grads.sum(0) / np.float32(n_workers)                      # accumulator mean (sync_model.py:92-95)
+        p, m, v = orc.tf_adam(params.copy(), g, m, v, b1p, b2p)       # the 14 ApplyAdam of the chief
+        params[:] = p
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+
+    try:
+        steps, el = timed(global_step, budget, 400)
+    finally:
+        stop.value = 1
+        try:
+            go.wait(timeout=10)
+        except Exception:
+            pass
+        for p in procs:
+            p.join(5)
+            if p.is_alive():
+                p.terminate()
+    return {"value": steps / el, "unit": "global steps/s (8 workers x 32 rows)", "cores": n_workers,
+            "transitions_per_s": steps * n_workers * rows / el, "steps_of_4096_per_s": steps / el / 16.0,
+            "sample": "%d global steps: %d worker processes x %d-row minibatches, 1 BLAS thread each, per-worker clip, "
+                      "parameter-server mean + Adam" % (steps, n_workers, rows)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--budget", type=float, default=24.0, help="seconds of CPU work over all legs")
+    args = ap.parse_args()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pfpn_oracle as orc
+    out = {"host_cpus": os.cpu_count(), "kind": "port", "runs": {}}
+    legs = (("reference_schedule", reference_schedule, 0.35), ("single_4096", single_4096, 0.25),
+            ("allcore_4096", allcore_4096, 0.40))
+    for name, fn, share in legs:
+        try:
+            out["runs"][name] = fn(orc, args.budget * share)
+        except Exception as e:                       # a leg that cannot run on this host must not hide the others
+            out["runs"][name] = {"error": repr(e)}
+    ok = [r for k, r in out["runs"].items() if k != "reference_schedule" and "value" in r]
+    best = max(ok, key=lambda r: r["value"])
+    out.update(value=best["value"], unit="steps/s", cores=best["cores"],
+               sample="learner steps on one 4096-transition batch, fastest CPU arrangement on this host: "
+                      + best["sample"] + "; restatement of the reference's TF1 CPU path, not TF1")
+    sys.stdout.write(json.dumps(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -38,10 +38,13 @@ class GraphedLearnerStep(object):
     runs after the replay, so a K-step replay is only legal while no resample falls inside it: `can_replay()`."""
 
     def __init__(self, net, optimizer, *inputs, warmup=3, noise=None, steps_per_replay=1, input_sets=None):
-        assert not getattr(optimizer, "exchange", optimizer.world > 1), \
-            "graph capture covers the single-GPU step (RCCL runs eagerly)"
         self.net, self.opt = net, optimizer
+        # data parallel: the step is captured as TWO graphs around the bucket all-reduce (everything up to the
+        # per-replica clip | Adam + statistics); the collective itself is enqueued between the two replays, so the
+        # capture never contains an RCCL call and the host enqueues 3 things per step instead of ~25
+        self.split = bool(getattr(optimizer, "exchange", optimizer.world > 1))
         self.K = int(steps_per_replay)
+        assert not (self.split and self.K > 1), "multi-step replays cover the single-replica step"
         assert self.K >= 1 and (self.K == 1 or noise is None), "one noise set per captured step is not built"
         self.input_sets = [tuple(inputs)] * self.K if input_sets is None else [tuple(t) for t in input_sets]
         assert len(self.input_sets) == self.K
@@ -57,7 +60,11 @@ class GraphedLearnerStep(object):
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 net.compute_gradients(*self._args(0))
-                optimizer.apply_device(net)
+                if self.split:         # the warm-up must not talk to the other replicas: skip the collective
+                    optimizer.pre_reduce(net)
+                    optimizer.post_reduce(net)
+                else:
+                    optimizer.apply_device(net)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.capture_stream = s
@@ -67,7 +74,14 @@ class GraphedLearnerStep(object):
         with torch.cuda.graph(self.graph, stream=s):      # same stream as the warm-up: per-stream workspaces exist
             for k in range(self.K):
                 self.loss3 = net.compute_gradients(*self._args(k))
-                optimizer.apply_device(net)
+                if self.split:
+                    optimizer.pre_reduce(net)
+                else:
+                    optimizer.apply_device(net)
+        if self.split:
+            self.graph_post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_post, stream=s):
+                optimizer.post_reduce(net)
         # capture does not execute; state is untouched
 
     def _args(self, k):
@@ -107,6 +121,9 @@ class GraphedLearnerStep(object):
         if self.noise is not None:
             refill_noise(self.noise, self.net.rng)
         self.graph.replay()
+        if self.split:
+            self.opt.reduce(self.net)
+            self.graph_post.replay()
         for _ in range(self.K):
             self.opt.apply_host(self.net)
         return self.loss3

@@ -74,30 +74,57 @@ class SyncReplicasApplier(object):
         if self.exchange and hasattr(net, "adopt_tail_statistics"):
             net.adopt_tail_statistics()        # replicated statistics live in the all-reduce bucket from now on
 
-    # -- device part (no host sync; capturable when world == 1) -------------------------------------
+    # -- device part (no host sync) ------------------------------------------------------------------------
+    # One replica: everything is ONE capturable sequence (apply_device).  Data parallel: the step splits at the
+    # all-reduce into `pre_reduce` (per-replica clip, in place) | `reduce` (ONE RCCL all-reduce of the bucket) |
+    # `post_reduce` (Adam on the sum with 1/W folded in, statistics <- replica mean); the two halves are captured
+    # into hipGraphs of their own (pfpn_amd/graphs.py) and the collective is enqueued between their replays.
+    def _fused_ok(self):
+        return bool(self.norm_clip) and self.fused and len(self.groups) <= 4
+
+    def _prenorm(self, net):
+        ready = getattr(net, "_norm_ready", 0)
+        net._norm_ready = 0
+        return (net._norm_hook["partial"], ready) if ready and net._norm_hook else None
+
     def apply_device(self, net):
         st = net.store
-        W = self.world
-        fused_scale = None
+        if self.exchange:
+            self.pre_reduce(net)
+            self.reduce(net)
+            self.post_reduce(net)
+            return
         net.join_side_stream()
-        if not self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:
-            # one replica: clip + every group's Adam + power / step-counter advance in two launches
-            ready = getattr(net, "_norm_ready", 0)
-            net._norm_ready = 0
+        if self._fused_ok():
+            # clip + every group's Adam + power / step-counter advance in one launch (two without the norm hook)
             kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
-                              step_counter=net.step_dev,
-                              prenorm=(net._norm_hook["partial"], ready) if ready and net._norm_hook else None)
+                              step_counter=net.step_dev, prenorm=self._prenorm(net))
             net.unpack_synced_stats(st.tail, 1.0)
             return
-        if self.exchange and self.norm_clip and self.fused and len(self.groups) <= 4:
-            # data parallel: clip in place (2 launches), ONE all-reduce of [clipped grads | statistics], Adam on the
-            # sum with 1/W folded in (1 launch), statistics <- mean (1 launch)
-            ready = getattr(net, "_norm_ready", 0)
-            net._norm_ready = 0
+        fused_scale = None
+        if self.norm_clip:
+            # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102); scale folded into Adam
+            kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=False)
+            fused_scale = self.norm_scale
+        self._adam_groups_unfused(net, fused_scale, 1.0)
+        net.unpack_synced_stats(st.tail, 1.0)
+
+    def pre_reduce(self, net):
+        """per-replica global-norm clip of the local gradients, in place (the bucket then holds what
+        `AccumulatorApplyGradient_i` receives in the reference's graph)."""
+        st = net.store
+        net.join_side_stream()
+        if self._fused_ok():
             kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2,
-                                       prenorm=(net._norm_hook["partial"], ready) if ready and net._norm_hook else None)
-            self.reduce(net)
+                                       prenorm=self._prenorm(net))
+        elif self.norm_clip:
+            kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=True)
+
+    def post_reduce(self, net):
+        """Adam on the all-reduced sum with 1/W folded in; the statistics tail becomes the replica mean."""
+        st, W = net.store, self.world
+        if self._fused_ok():
             in_tail = getattr(net, "_stats_in_tail", False) and st.tail.numel() > 0
             kernels.adam_groups(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                                 1.0 / W, self.beta1, self.beta2, self.epsilon, step_counter=net.step_dev,
@@ -105,20 +132,17 @@ class SyncReplicasApplier(object):
             if not in_tail:
                 net.unpack_synced_stats(st.tail, 1.0 / W)
             return
-        if self.norm_clip:
-            # tf.clip_by_global_norm over ALL gradients jointly (base_worker.py:97-102), per replica
-            kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=self.exchange)
-            if not self.exchange:
-                fused_scale = self.norm_scale          # folded into the Adam kernel
-        if self.exchange:
-            self.reduce(net)
+        self._adam_groups_unfused(net, None, 1.0 / W)
+        net.unpack_synced_stats(st.tail, 1.0 / W)
+
+    def _adam_groups_unfused(self, net, fused_scale, grad_mul):
+        st = net.store
         for gi, g in enumerate(self.groups):
             sl = slice(g["off"], g["off"] + g["len"])
             last = gi == len(self.groups) - 1
             kernels.tf_adam(st.flat[sl], st.grad[sl], st.m[sl], st.v[sl], g["beta_pow"], g["lr"], self.beta1,
-                            self.beta2, self.epsilon, advance=True, norm_scale=fused_scale, grad_mul=1.0 / W,
+                            self.beta2, self.epsilon, advance=True, norm_scale=fused_scale, grad_mul=grad_mul,
                             step_counter=net.step_dev if last else None)
-        net.unpack_synced_stats(st.tail, 1.0 / W)
 
     def reduce(self, net):
         """The exchange step: ONE all-reduce (sum) of the flat bucket [clipped grads | local statistics]

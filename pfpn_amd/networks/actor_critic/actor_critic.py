@@ -351,8 +351,8 @@ class ActorCriticNetwork(object):
         those rows of `args` (the staged rollout of a training round: the gather lands in the graph's static inputs).  A worker trains on a fixed minibatch
         size (32 rows in the DPPO setting: ~40 launches of almost no work each), so after a few eager steps at
         one size the step is captured into a hipGraph (pfpn_amd/graphs.py) and replayed: identical results,
-        a third of the time.  Data-parallel runs (the RCCL all-reduce stays eager) and PFPN_GRAPH_TRAIN=0 keep the
-        eager path."""
+        a third of the time.  Data-parallel steps are captured as two graphs around the RCCL all-reduce, which is
+        enqueued between their replays.  PFPN_GRAPH_TRAIN=0 keeps the eager path."""
         B = args[0].shape[0] if rows is None else rows.shape[0]
         key = (B, id(optimizer))
         g = self._train_graphs.get(key)
@@ -363,7 +363,7 @@ class ActorCriticNetwork(object):
             args = [a.index_select(0, rows) for a in args]
         if g is None:
             n = self._train_calls[key] = self._train_calls.get(key, 0) + 1
-            if n > 4 and not getattr(optimizer, "exchange", optimizer.world > 1) and self.device.type == "cuda" and len(self._train_graphs) < 4 and \
+            if n > 4 and self.device.type == "cuda" and len(self._train_graphs) < 4 and \
                     os.environ.get("PFPN_GRAPH_TRAIN", "1") != "0":
                 from ...graphs import GraphedLearnerStep
                 g = self._train_graphs[key] = GraphedLearnerStep(

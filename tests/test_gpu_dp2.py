@@ -200,21 +200,32 @@ def _rccl_rank(port, q):
         assert opts[0].exchange and not opts[1].exchange and nets[0]._stats_in_tail
         rng = np.random.default_rng(4)
         ok = True
-        for it in range(4):
+        # a third replica takes the exchange path EAGERLY for all steps: nets[0] switches to its captured form (two
+        # hipGraphs around the RCCL all-reduce) after four steps and must keep producing the same bits
+        nets.append(make_net(dev, seed=9, resample_interval=3))
+        opts.append(SyncReplicasApplier(nets[2], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1,
+                                        force_exchange=True))
+        for it in range(9):
             b = make_batch(rng, 256)
             b["log_prob"] = np.full(256, -40.0, F)
             mx = torch.rand(36, 35, device=dev); sm = torch.rand(36, 35, device=dev) * 5
             out = []
-            for net, opt in zip(nets, opts):
+            for i, (net, opt) in enumerate(zip(nets, opts)):
+                os.environ["PFPN_GRAPH_TRAIN"] = "0" if i == 2 else "1"
                 net.max_active.copy_(mx); net.sum_active.copy_(sm)
                 out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
                                      b["advantage"]))
-            ok &= out[0] == out[1]
-            ok &= torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
-            ok &= torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
-            ok &= torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
-            ok &= torch.equal(nets[0].max_active, nets[1].max_active) and torch.equal(nets[0].sum_active, nets[1].sum_active)
-        ok &= nets[0].global_step == 4 and len(nets[0]._train_graphs) == 0      # the exchange path never self-captures
+            ok &= out[0] == out[1] == out[2]
+            for other in nets[1:]:
+                ok &= torch.equal(nets[0].store.flat, other.store.flat) and torch.equal(nets[0].store.v, other.store.v)
+                ok &= torch.equal(nets[0].state_normalizer.mean, other.state_normalizer.mean)
+                ok &= torch.equal(nets[0].state_normalizer.std, other.state_normalizer.std)
+                ok &= torch.equal(nets[0].max_active, other.max_active) and torch.equal(nets[0].sum_active, other.sum_active)
+        os.environ["PFPN_GRAPH_TRAIN"] = "1"
+        ok &= nets[0].global_step == 9 and nets[0].train_flag == 0
+        g = list(nets[0]._train_graphs.values())
+        ok &= len(g) == 1 and g[0].split and len(nets[2]._train_graphs) == 0      # captured as two graphs | eager
+        nets, opts = nets[:2], opts[:2]
         # with the global norm produced by the reduction launch on both paths: equal to summation-order precision
         os.environ["PFPN_FUSED_NORM"] = "1"
         nets = [make_net(dev, seed=10, resample_interval=50) for _ in range(2)]

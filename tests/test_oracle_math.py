@@ -293,3 +293,39 @@ def test_resample_topk_sources_and_mass_split():
             new_mass = np.exp(nb[a * N:(a + 1) * N][grp].astype(np.float64)).sum()
             np.testing.assert_allclose(new_mass, np.exp(np.float64(bias[a * N + s])), rtol=1e-5)
     assert np.array_equal(nw[:, 9], weight[:, src[0, 9]])
+
+
+def test_torch_cpu_step_is_the_oracle_step(oracle):
+    """bench.py's all-core CPU baseline (oracle/torch_cpu_step.py: torch-CPU ops + autograd) computes the same learner
+    step as the op-for-op NumPy oracle: losses, every gradient, parameters after two steps."""
+    import torch
+    from oracle import torch_cpu_step as tcs
+    rng = np.random.default_rng(3)
+    st = oracle.DPPOState(rng)
+    for k in ("actor/fc1/weight", "actor/fc2/weight", "actor/fc_policy/weight", "critic/fc1/weight", "critic/fc2/weight"):
+        st.P[k] = (st.P[k] * 8).astype(np.float32)          # off the near-linear regime of the 0.01-sigma init
+    B = 64
+    ts = tcs.TorchCPUState(st)
+    for it in range(2):
+        b = {"state": (rng.normal(0, 1, (B, 197)) * 2 + 0.3).astype(np.float32),
+             "action": rng.uniform(-1.1, 1.1, (B, 36)).astype(np.float32),
+             "value": rng.normal(0, 0.1, B).astype(np.float32), "advantage": rng.normal(0, 1, B).astype(np.float32)}
+        x = oracle.state_normalize(b["state"], st.norm_mean, st.norm_std, 5.0)
+        logits, _ = oracle.actor_forward(st.P, x, 36, 35)
+        lp, _ = oracle.mixture_log_prob(logits, b["action"], st.P["actor/samples"], st.P["actor/samples_std"])
+        b["log_prob"] = (lp + rng.normal(0, 0.1, B)).astype(np.float32)
+        tb = {k: torch.from_numpy(v) for k, v in b.items()}
+        (l, pl, vl), G, aux = oracle.dppo_grads(st.P, st.norm_mean, st.norm_std, b, 36, 35)
+        loss, tpl, tvl, tlogp, tval = tcs.losses(ts, tb)
+        grads = torch.autograd.grad(loss, [ts.P[k] for k in tcs.ORDER])
+        np.testing.assert_allclose([loss.item(), tpl.item(), tvl.item()], [l, pl, vl], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(tlogp.detach().numpy(), aux["logp"], rtol=1e-5)
+        for k, g in zip(tcs.ORDER, grads):
+            ref = G[k]
+            np.testing.assert_allclose(g.numpy().reshape(ref.shape), ref, rtol=0, atol=2e-4 * np.abs(ref).max())
+        oracle.dppo_learner_step(st, [b])
+        tcs.learner_step(ts, tb)
+        for k in tcs.ORDER:
+            # from zero moments Adam's first steps are ~lr * sign(g): entries with |g| ~ 1e-7 amplify rounding
+            np.testing.assert_allclose(ts.P[k].detach().numpy().reshape(st.P[k].shape), st.P[k], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(ts.mean.numpy(), st.norm_mean, rtol=1e-5, atol=1e-6)
