@@ -797,6 +797,31 @@ __global__ __launch_bounds__(256) void k_mix_wave(
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// The wide kernel's read-once logits stream (1 GiB at 8192 x 128 x 256) with the non-temporal cache policy in the
+// FORWARD kernel: measured 207 -> 195 us there (0.65 -> 0.69 of 8 TB/s, two boxes, A/B in one session).  In the backward
+// kernel, which also streams 1 GiB of stores, nt loads measured 2-4 % SLOWER and nt stores changed nothing (431-436 us
+// either way, = a device copy of the same bytes), so it keeps the default policy.  PFPN_WIDE_NT overrides for A/B runs:
+// bit 0 = nt loads in every mode, bit 1 = nt stores, bit 2 = no nt anywhere.
+#ifndef PFPN_WIDE_NT
+#define PFPN_WIDE_NT 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+    if (NT) {
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return ld4(p);
+}
+__device__ __forceinline__ void st4_stream(float* p, float a, float b, float c, float d) {
+#if PFPN_WIDE_NT & 2
+    __builtin_nontemporal_store((f4v){a, b, c, d}, reinterpret_cast<f4v*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#endif
+}
+
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 
 template <int M, int MODE, bool TANH, bool FULLN>
@@ -812,6 +837,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     float* __restrict__ partial)             // [C][2*A*N]  (BWD)
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
+    constexpr bool NT_LOADS = !(PFPN_WIDE_NT & 4) && ((PFPN_WIDE_NT & 1) || MODE == MODE_FWD);
     const int lane = threadIdx.x & 63;
     // wave-uniform indices through readfirstlane: row/segment address arithmetic goes to the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -960,8 +986,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                                 acc_ls2[j][h]);
                             if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, b_isc2[j][h] * PFPN_2LN2, dx2);
                         }
-                        if (live)
-                            *reinterpret_cast<float4*>(drow + 4 * (lane + 64 * j)) = make_float4(d[0].x, d[0].y, d[1].x, d[1].y);
+                        if (live) st4_stream(drow + 4 * (lane + 64 * j), d[0].x, d[0].y, d[1].x, d[1].y);
                     }
                 }
                 dxa[u] = dx2.x + dx2.y;
@@ -989,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
         const int b_ = min((b0_) + u * C, B - 1);            /* clamped: loads unconditional */     \
         const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;                              \
-        _Pragma("unroll") for (int j = 0; j < M; ++j) ln[u][j] = ld4(row_ + 4 * (ok[j] ? lane + 64 * j : 0)); \
+        _Pragma("unroll") for (int j = 0; j < M; ++j) ln[u][j] = ld4_stream<NT_LOADS>(row_ + 4 * (ok[j] ? lane + 64 * j : 0)); \
         xn[u] = x[(size_t)b_ * A + a];                                                             \
         gn[u] = (MODE == MODE_BWD) ? dlogp_in[b_] : 0.f;                                           \
     }
