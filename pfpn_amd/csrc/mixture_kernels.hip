@@ -188,6 +188,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ dlogp_in,      // MODE_BWD: [B]
     int B, int A, int R, int tanh_mode, int P,           // P: LDS planes in the ring
+    int tbase, int trem,                     // tiles per block = tbase (+1 for the first trem blocks): no device division
     float* __restrict__ logp_out,            // [B]   (FWD, PPO)
     float* __restrict__ pmix_out,            // [B,A] optional
     float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
@@ -220,17 +221,29 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     float* bank = lossbuf + 2 * nwaves;                   // [3][AN]: loc | isc2 | 64 - ct2   (see below)
 
     const int t = threadIdx.x;
-    // counters first, so the loaders are released before the compute waves' index arithmetic
-    for (int i = t; i < 2 * R + 2 * P + 1; i += blockDim.x) cnt[i] = 0;   // cnt, ready, freed, bank_done are contiguous
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave index as a scalar: uniform control flow
 #ifdef PFPN_ENABLE_STAMPS
     unsigned long long* stamps = g_stamps;
 #endif
     PFPN_STAMP(0);
-    const int ntiles = (B + R - 1) / R;
     const int gs = (int)gridDim.x;
-    const int T = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + gs - 1) / gs : 0;   // my tiles
+    const int T = tbase + ((int)blockIdx.x < trem ? 1 : 0);                    // my tiles: blockIdx, +gs, +2gs, ...
+
+    // Start-up order (what the in-kernel stamps showed: 9,000 of a block's 36,000 cycles went by before the first
+    // tile's forward): every wave FIRST puts its long-latency requests in flight -- the loaders the DMAs of the first
+    // tiles, the compute waves the loads of the [A,N] particle tables -- and only then the block zeroes its counters
+    // and meets at the one start-up barrier.  The barrier is the raw s_barrier behind an LDS-only wait: a
+    // __syncthreads() fence would also wait for the DMAs / loads just issued (vmcnt(0)).
+    constexpr int BKU = 4;                                                    // table elements per thread and round
+    float bank_ls[BKU], bank_lc[BKU];
+    if (wave < nwaves) {
+#pragma unroll
+        for (int u = 0; u < BKU; ++u) {
+            const int i = min(t + u * nwaves * 64, AN - 1);
+            bank_ls[u] = logstd[i];
+            bank_lc[u] = loc[i];
+        }
+    }
 
     // =========================== loader waves ================================================
     if (wave >= nwaves) {
@@ -248,68 +261,77 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         // tile of a cold start lands ~1000 + 120 ticks per KB requested per CU); vmcnt immediate <= 63 caps it too.
         int dmax = PACK_DEPTH;
         while (dmax > 1 && (dmax - 1) * Q > 63) --dmax;
+        if (dmax > P) dmax = P;
         const unsigned tile_b = (unsigned)(uintptr_t)tile, xpl_b = (unsigned)(uintptr_t)xpl,
                        rpl_b = (unsigned)(uintptr_t)rpl;
         int issued = 0, signalled = 0;
         int slot_i = 0, wrap_i = 0, slot_s = 0;            // issued % P, issued / P, signalled % P without dividing
+        // all DMAs of tile number `issued` of this block into plane `slot_i`
+        auto issue_tile = [&]() __attribute__((always_inline)) {
+            const int tid = (int)blockIdx.x + issued * gs;
+            const int row0 = tid * R, rows = min(R, B - row0);
+            const int slot = slot_i;
+            const int nv4 = rows * AN / 4;             // valid float4 of this tile
+            const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN);
+            // item i (tile chunks, then action-value chunks, then the row scalars) belongs to loader i % NL.
+            // A wave issues at most one instruction per ~4 cycles, so the full-tile path below keeps the
+            // per-DMA overhead to a pointer bump (measured: 250 -> ~50 cycles per DMA).
+            if (rows == R) {
+                const char* gp = reinterpret_cast<const char*>(g4) + (size_t)(l * 64 + lane) * 16;
+                unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + l * 1024));
+                int c = l;
+                for (; c < nct - 1; c += PACK_NL) {
+                    dma16(gp, lb);
+                    gp += PACK_NL * 1024;
+                    lb += PACK_NL * 1024;
+                }
+                if (c == nct - 1 && c * 64 + lane < nv4) dma16(gp, lb);        // last chunk: partial (never empty)
+                int cx = ((l - nct) % PACK_NL + PACK_NL) % PACK_NL;
+                for (; cx < ncx; cx += PACK_NL) {
+                    const int i = cx * 64 + lane;
+                    dma4(x + (size_t)row0 * A + min(i, nseg - 1),
+                         __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + cx * 64) * 4)));
+                }
+            } else {
+                for (int it_ = l; it_ < nct + ncx; it_ += PACK_NL) {
+                    if (it_ < nct) {
+                        const int i4 = it_ * 64 + lane;
+                        if (i4 < cap4)                 // never past the plane; short tiles re-read their last float4
+                            dma16(g4 + min(i4, nv4 - 1),
+                                  __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + it_ * 1024)));
+                    } else {
+                        const int c = it_ - nct;
+                        const int i = c * 64 + lane;
+                        dma4(x + (size_t)row0 * A + min(i, rows * A - 1),
+                             __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + c * 64) * 4)));
+                    }
+                }
+            }
+            if (nrs && (nct + ncx) % PACK_NL == l) {
+                // lane j -> array j/16, row j%16 (R <= 16)
+                const int arr = lane >> 4, rw = min(lane & 15, rows - 1);
+                const float* src;
+                if (MODE == MODE_PPO)
+                    src = (arr == 0 ? ppo.adv : arr == 1 ? ppo.logp_old : arr == 2 ? ppo.value : ppo.value_old) +
+                          row0 + rw;
+                else
+                    src = dlogp_in + row0 + rw;
+                dma4(src, __builtin_amdgcn_readfirstlane(rpl_b + (unsigned)(slot * 64 * 4)));
+            }
+            ++issued;
+            if (++slot_i == P) { slot_i = 0; ++wrap_i; }
+            if (issued <= 4) PFPN_STAMP(3 + (issued - 1) * 6);
+        };
+        // the first tiles go out before anything else happens in the block (fresh planes: no `freed` check)
+        while (issued < T && issued < dmax) issue_tile();
+        for (int i = t - nwaves * 64; i < 2 * R + 2 * P + 1; i += PACK_NL * 64) cnt[i] = 0;   // cnt, ready, freed, bank_done
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         while (signalled < T) {
             bool can = issued < T && issued - signalled < dmax;
             if (can && wrap_i > 0)                         // plane still being read by the compute waves?
                 can = lds_counter(&freed[slot_i]) >= nwaves * wrap_i;
             if (can) {
-                const int tid = (int)blockIdx.x + issued * gs;
-                const int row0 = tid * R, rows = min(R, B - row0);
-                const int slot = slot_i;
-                const int nv4 = rows * AN / 4;             // valid float4 of this tile
-                const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN);
-                // item i (tile chunks, then action-value chunks, then the row scalars) belongs to loader i % NL.
-                // A wave issues at most one instruction per ~4 cycles, so the full-tile path below keeps the
-                // per-DMA overhead to a pointer bump (measured: 250 -> ~50 cycles per DMA).
-                if (rows == R) {
-                    const char* gp = reinterpret_cast<const char*>(g4) + (size_t)(l * 64 + lane) * 16;
-                    unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + l * 1024));
-                    int c = l;
-                    for (; c < nct - 1; c += PACK_NL) {
-                        dma16(gp, lb);
-                        gp += PACK_NL * 1024;
-                        lb += PACK_NL * 1024;
-                    }
-                    if (c == nct - 1 && c * 64 + lane < nv4) dma16(gp, lb);        // last chunk: partial (never empty)
-                    int cx = ((l - nct) % PACK_NL + PACK_NL) % PACK_NL;
-                    for (; cx < ncx; cx += PACK_NL) {
-                        const int i = cx * 64 + lane;
-                        dma4(x + (size_t)row0 * A + min(i, nseg - 1),
-                             __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + cx * 64) * 4)));
-                    }
-                } else {
-                    for (int it_ = l; it_ < nct + ncx; it_ += PACK_NL) {
-                        if (it_ < nct) {
-                            const int i4 = it_ * 64 + lane;
-                            if (i4 < cap4)                 // never past the plane; short tiles re-read their last float4
-                                dma16(g4 + min(i4, nv4 - 1),
-                                      __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + it_ * 1024)));
-                        } else {
-                            const int c = it_ - nct;
-                            const int i = c * 64 + lane;
-                            dma4(x + (size_t)row0 * A + min(i, rows * A - 1),
-                                 __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + c * 64) * 4)));
-                        }
-                    }
-                }
-                if (nrs && (nct + ncx) % PACK_NL == l) {
-                    // lane j -> array j/16, row j%16 (R <= 16)
-                    const int arr = lane >> 4, rw = min(lane & 15, rows - 1);
-                    const float* src;
-                    if (MODE == MODE_PPO)
-                        src = (arr == 0 ? ppo.adv : arr == 1 ? ppo.logp_old : arr == 2 ? ppo.value : ppo.value_old) +
-                              row0 + rw;
-                    else
-                        src = dlogp_in + row0 + rw;
-                    dma4(src, __builtin_amdgcn_readfirstlane(rpl_b + (unsigned)(slot * 64 * 4)));
-                }
-                ++issued;
-                if (++slot_i == P) { slot_i = 0; ++wrap_i; }
-                if (issued <= 4) PFPN_STAMP(3 + (issued - 1) * 6);
+                issue_tile();
             } else if (issued > signalled) {
                 // oldest unsignalled tile: everything issued after it may stay in flight
                 wait_vmcnt(Q * (issued - signalled - 1));
@@ -321,6 +343,8 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 __builtin_amdgcn_s_sleep(2);               // ring full and nothing of mine in flight
             }
         }
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the loaders zeroed the counters
     }
 
     // (index arithmetic of the compute waves: after the loader branch, so the loaders do not execute it)
@@ -355,16 +379,17 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         //   to base 2:  z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale
         //   +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
         //   down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
-        for (int i0 = t; i0 < AN; i0 += 4 * nwaves * 64) {
-            float ls[4], lc[4];
+        for (int i0 = t; i0 < AN; i0 += BKU * nwaves * 64) {
+            float ls[BKU], lc[BKU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {                  // one round trip for up to four elements per thread
+            for (int u = 0; u < BKU; ++u) {                // one round trip for up to four elements per thread
+                if (i0 == t) { ls[u] = bank_ls[u]; lc[u] = bank_lc[u]; continue; }      // in flight since the kernel's first instructions
                 const int i = min(i0 + u * nwaves * 64, AN - 1);
                 ls[u] = logstd[i];
                 lc[u] = loc[i];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BKU; ++u) {
                 const int i = i0 + u * nwaves * 64;
                 if (i < AN) {
                     const float sc = expf(ls[u]);
@@ -393,20 +418,21 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         PFPN_STAMP(1);
 
         // tile k of this block lives in plane k % P; wait until both loaders have landed their part
-        auto wait_ready = [&](int k) __attribute__((always_inline)) {
-            const int target = PACK_NL * (k / P + 1);
-            while (lds_counter(&ready[k % P]) < target) __builtin_amdgcn_s_sleep(1);
+        // (slot, lap) = (k % P, k / P) are carried as counters: P is a run-time value and a scalar division costs
+        // ~100 cycles each time
+        auto wait_ready = [&](int slot, int lap) __attribute__((always_inline)) {
+            const int target = PACK_NL * (lap + 1);
+            while (lds_counter(&ready[slot]) < target) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
         };
         // forward of tile k: softmax numerators stay in the plane, per-segment log p is published to
         // segbuf[k mod 4] and the row arrival counters of that parity are bumped.
-        auto forward = [&](int k, float& p_o, float& inv_o) __attribute__((always_inline)) {
+        auto forward = [&](int k, int slot, float& p_o, float& inv_o) __attribute__((always_inline)) {
             const int tid = (int)blockIdx.x + k * gs;
             const int row0 = tid * R;
             const int rows = min(R, B - row0);
             const int nact = rows * A;                     // active segments in this tile
             const bool active = seg_lane && sidx < nact;
-            const int slot = k % P;
             float* seg = seg0 + slot * TS;
             // four log-p buffers: a wave that has run ahead writes tile k+2's (and, one iteration later, k+3's)
             // values while a neighbour may still be summing tile k's; it cannot reach k+4 before that neighbour
@@ -491,16 +517,16 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         };
 
         float p = 0.f, inv_sum = 0.f, p1 = 0.f, inv1 = 0.f;
-        if (T > 0) { wait_ready(0); forward(0, p, inv_sum); }
+        if (T > 0) { wait_ready(0, 0); forward(0, 0, p, inv_sum); }
         PFPN_STAMP(2);
 
+        int slot = 0, slot_n = (P > 1) ? 1 : 0, lap_n = (P > 1) ? 0 : 1;       // plane of tile k | plane and lap of tile k+1
         for (int k = 0; k < T; ++k) {
             const int tileid = (int)blockIdx.x + k * gs;
             const int row0 = tileid * R;
             const int rows = min(R, B - row0);
             const int nact = rows * A;                     // active segments in this tile
             const int nfl = max(0, min(nact * N - s_lo * N, SLICE));   // valid floats in my slice
-            const int slot = k % P;
             float* sb = segbuf + (k & 3) * nseg;
             float* slice = slice0 + slot * TS;
             float* seg = seg0 + slot * TS;
@@ -508,7 +534,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             if (k < 4) PFPN_STAMP(3 + k * 6);
 
             // ---- forward of the next tile --------------------------------------------------------
-            if (k + 1 < T) { wait_ready(k + 1); forward(k + 1, p1, inv1); }
+            if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1); }
             if (k < 4) PFPN_STAMP(4 + k * 6);
 
             // ---- row stage of this tile ----------------------------------------------------------
@@ -644,6 +670,8 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 if (k < 4) PFPN_STAMP(8 + k * 6);
             }
             p = p1; inv_sum = inv1;
+            slot = slot_n;
+            if (++slot_n == P) { slot_n = 0; ++lap_n; }
         }
     }
 
@@ -1114,9 +1142,23 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // ---------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------
-struct PackPlan { int R; int grid; int threads; size_t lds; int P; bool ok; };
+struct PackPlan { int R; int grid; int threads; size_t lds; int P; bool ok; int ntiles; };
 
 static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// compute units of the current device (MI355X: 256); asked once
+static int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
 
 static PackPlan plan_packed(int B, int A, int N, const void* logits, const void* dlogits) {
     PackPlan pl{};
@@ -1156,10 +1198,11 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     pl.P = P;
     pl.lds = P * plane + small;
     const int ntiles = (B + R - 1) / R;
+    pl.ntiles = ntiles;
     int per_cu = 1;                                     // one block (compute + loader waves) per CU
     static const int env_pcu = getenv("PFPN_MIX_PER_CU") ? atoi(getenv("PFPN_MIX_PER_CU")) : 0;   // tuning knob
     if (env_pcu > 0) per_cu = env_pcu;
-    const int cap = 256 * per_cu;
+    const int cap = cu_count() * per_cu;
     pl.grid = ntiles < cap ? ntiles : cap;
     pl.ok = pl.lds <= PACK_MAX_LDS && waves <= 14 && R <= 16;
     return pl;
@@ -1178,8 +1221,8 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
             big_lds_ok = true;                                                                              \
         }                                                                                                   \
         hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
-                           loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.P, logp, pmix, dlogits, dx,        \
-                           partial, ppo);                                                                   \
+                           loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.P, pl.ntiles / pl.grid,            \
+                           pl.ntiles % pl.grid, logp, pmix, dlogits, dx, partial, ppo);                     \
     } while (0)
 #define PFPN_LAUNCH_PACKED(NN)                                                  \
     do {                                                                        \
@@ -1212,7 +1255,7 @@ static int wide_chunks(int B, int A, bool bwd = false) {
     // forward (C = 38..48: 199-207 us; 32: 209-213; 24: 245; 64: 232) and ~12 waves/CU backward, which also
     // streams 1 KiB stores per segment (C = 22..24: 419-433 us; 32: 484; 48: 467).  More in flight only lengthens
     // the HBM queues (tools/bw_probe.hip), and power-of-two row strides between a wave's rows alias HBM channels.
-    int C = ((bwd ? 256 * 12 : 256 * 20) + A - 1) / A;
+    int C = ((bwd ? cu_count() * 12 : cu_count() * 20) + A - 1) / A;
     if (C > 64) C = 64;
     if (wide_c_env() > 0) C = wide_c_env();
     if (C > (B + 3) / 4) C = (B + 3) / 4;      // at least U = 4 rows per wave
