@@ -227,7 +227,14 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
 #endif
     PFPN_STAMP(0);
     const int gs = (int)gridDim.x;
-    const int T = tbase + ((int)blockIdx.x < trem ? 1 : 0);                    // my tiles: blockIdx, +gs, +2gs, ...
+    const int T = tbase + ((int)blockIdx.x < trem ? 1 : 0);                    // my tiles
+    // which ones: a CONTIGUOUS run (tile0, +1, ...): a block then touches one or two pages of each tensor instead of T
+    // pages ~B/T rows apart.  PFPN_MIX_INTERLEAVE builds the older blockIdx, +grid, +2 grid, ... order for A/B runs.
+#ifdef PFPN_MIX_INTERLEAVE
+    const int tile0 = (int)blockIdx.x, tstep = gs;
+#else
+    const int tile0 = (int)blockIdx.x * tbase + min((int)blockIdx.x, trem), tstep = 1;
+#endif
 
     // Start-up order (what the in-kernel stamps showed: 9,000 of a block's 36,000 cycles went by before the first
     // tile's forward): every wave FIRST puts its long-latency requests in flight -- the loaders the DMAs of the first
@@ -245,6 +252,8 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         }
     }
 
+    int q = 0, g = 0, sidx = 0, r = 0, a = 0, s_lo = 0, s_hi = -1, r_lo = 0, r_hi = -1;
+    bool seg_lane = false;
     // =========================== loader waves ================================================
     if (wave >= nwaves) {
         const int l = wave - nwaves;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         int slot_i = 0, wrap_i = 0, slot_s = 0;            // issued % P, issued / P, signalled % P without dividing
         // all DMAs of tile number `issued` of this block into plane `slot_i`
         auto issue_tile = [&]() __attribute__((always_inline)) {
-            const int tid = (int)blockIdx.x + issued * gs;
+            const int tid = tile0 + issued * tstep;
             const int row0 = tid * R, rows = min(R, B - row0);
             const int slot = slot_i;
             const int nv4 = rows * AN / 4;             // valid float4 of this tile
@@ -322,8 +331,10 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             if (++slot_i == P) { slot_i = 0; ++wrap_i; }
             if (issued <= 4) PFPN_STAMP(3 + (issued - 1) * 6);
         };
-        // the first tiles go out before anything else happens in the block (fresh planes: no `freed` check)
-        while (issued < T && issued < dmax) issue_tile();
+        // the first tile goes out before anything else happens in the block (fresh plane: no `freed` check), at raised
+        // priority: the loaders share SIMDs 1 and 2 with compute waves that are busy with the table transform
+        __builtin_amdgcn_s_setprio(3);
+        if (T > 0) issue_tile();
         for (int i = t - nwaves * 64; i < 2 * R + 2 * P + 1; i += PACK_NL * 64) cnt[i] = 0;   // cnt, ready, freed, bank_done
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         while (signalled < T) {
@@ -344,33 +355,14 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             }
         }
     } else {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the loaders zeroed the counters
-    }
-
-    // (index arithmetic of the compute waves: after the loader branch, so the loaders do not execute it)
-    const int q = lane >> 2, g = lane & 3;
-    const int sidx = wave * PACK_WSEG + q;                // segment slot in the tile (compute waves)
-    const bool seg_lane = wave < nwaves && sidx < nseg;
-    const int r = seg_lane ? sidx / A : 0;
-    const int a = seg_lane ? sidx - r * A : 0;
-    float* slice0 = tile + wave * SLICE;
-    float* seg0 = slice0 + q * N + g;                     // == tile + sidx*N + g
-    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
-    // rows this wave touches
-    const int s_lo = wave * PACK_WSEG, s_hi = min(nseg, s_lo + PACK_WSEG) - 1;     // inclusive
-    const int r_lo = s_lo / A, r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;
-
-    // =========================== compute waves ===============================================
-    // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
-    // as the reference graph computes them, pre-scaled to base 2:
-    //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale, ct2 = cterm*log2 e
-    float b_loc[NP], b_isc[NP], b_ct[NP];
-    float acc_loc[NP], acc_ls[NP], acc_db[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) { b_loc[i] = 0.f; b_isc[i] = 0.f; b_ct[i] = 0.f; acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
-    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
-    float pol_sum = 0.f, val_sum = 0.f;
-    if (wave < nwaves) {
+        // index arithmetic of the compute waves (divisions by the run-time A), also ahead of the barrier
+        q = lane >> 2; g = lane & 3;
+        sidx = wave * PACK_WSEG + q;                      // segment slot in the tile
+        seg_lane = sidx < nseg;
+        r = seg_lane ? sidx / A : 0;
+        a = seg_lane ? sidx - r * A : 0;
+        s_lo = wave * PACK_WSEG; s_hi = min(nseg, s_lo + PACK_WSEG) - 1;           // inclusive
+        r_lo = s_lo / A; r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;              // rows this wave touches
         // The [A,N] tables are tiny, but read per lane they are ~20 scattered lines per wave-instruction x 18
         // instructions x every wave of every CU, all on the same few L2 lines: measured ~3 us of queueing in
         // front of the first tile's loads.  So: each element is transformed ONCE per block (coalesced loads,
@@ -379,6 +371,8 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         //   to base 2:  z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale
         //   +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
         //   down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
+        // All of it happens BEFORE the start-up barrier -- the ~2,500 cycles of expf / logf run while the first
+        // tile's DMAs are in flight, and the barrier itself publishes the bank (no separate counter to spin on).
         for (int i0 = t; i0 < AN; i0 += BKU * nwaves * 64) {
             float ls[BKU], lc[BKU];
 #pragma unroll
@@ -399,10 +393,27 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) atomicAdd(bank_done, 1);
-        while (lds_counter(bank_done) < nwaves) __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
+        PFPN_STAMP(43);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // counters zeroed (loaders), bank complete
+        PFPN_STAMP(42);
+    }
+
+    float* slice0 = tile + wave * SLICE;
+    float* seg0 = slice0 + q * N + g;                     // == tile + sidx*N + g
+    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
+
+    // =========================== compute waves ===============================================
+    // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
+    // as the reference graph computes them, pre-scaled to base 2:
+    //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale, ct2 = cterm*log2 e
+    float b_loc[NP], b_isc[NP], b_ct[NP];
+    float acc_loc[NP], acc_ls[NP], acc_db[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { b_loc[i] = 0.f; b_isc[i] = 0.f; b_ct[i] = 0.f; acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
+    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
+    float pol_sum = 0.f, val_sum = 0.f;
+    if (wave < nwaves) {
+        PFPN_STAMP(44);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int n = min(g + PACK_G * i, N - 1);
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         // forward of tile k: softmax numerators stay in the plane, per-segment log p is published to
         // segbuf[k mod 4] and the row arrival counters of that parity are bumped.
         auto forward = [&](int k, int slot, float& p_o, float& inv_o) __attribute__((always_inline)) {
-            const int tid = (int)blockIdx.x + k * gs;
+            const int tid = tile0 + k * tstep;
             const int row0 = tid * R;
             const int rows = min(R, B - row0);
             const int nact = rows * A;                     // active segments in this tile
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
 
         int slot = 0, slot_n = (P > 1) ? 1 : 0, lap_n = (P > 1) ? 0 : 1;       // plane of tile k | plane and lap of tile k+1
         for (int k = 0; k < T; ++k) {
-            const int tileid = (int)blockIdx.x + k * gs;
+            const int tileid = tile0 + k * tstep;
             const int row0 = tileid * R;
             const int rows = min(R, B - row0);
             const int nact = rows * A;                     // active segments in this tile
@@ -680,11 +691,15 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     // ---- block partials: dloc / dlogstd (/ dlogits column sums) summed over the R segments that share an
     //      action dim, in row order; loss sums in wave order.  Slab layout [nq*AN + 4] per block.
     //      The ring's first three planes are free now: all sums are staged in one pass.
+    // raw barriers behind an LDS-only wait: __syncthreads()'s fence would first drain the last tile's dlogits stores
+    // (vmcnt(0): ~2,000-3,000 cycles), which nothing below depends on
+    auto tail_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
     float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
     {
         float* lsb = tile + TS;
-        __syncthreads();
+        tail_barrier();
+        PFPN_STAMP(45);
         if (seg_lane) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
@@ -694,37 +709,56 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                     if (nq == 3) lsb[TS + sidx * N + g + PACK_G * i] = acc_db[i];
                 }
         }
-        __syncthreads();
-        for (int idx = t; idx < nq * AN; idx += blockDim.x) {
-            const int which = idx >= 2 * AN ? 2 : idx >= AN ? 1 : 0;
-            const int i = idx - which * AN;
-            const float* src = which == 0 ? tile : lsb + (which - 1) * TS;
-            float s = 0.f;
-            int rr = 0;
-            for (; rr + 4 <= R; rr += 4) {                  // four loads in flight, summed in row order
-                const float v0 = src[rr * AN + i], v1 = src[(rr + 1) * AN + i];
-                const float v2 = src[(rr + 2) * AN + i], v3 = src[(rr + 3) * AN + i];
-                s = (((s + v0) + v1) + v2) + v3;
-            }
-            for (; rr < R; ++rr) s += src[rr * AN + i];
-            slab[idx] = s;
+        // the waves' loss sums ride behind the same barrier (no third one): summed in wave order by one lane of the
+        // last wave, which has nothing else to do
+        if (MODE == MODE_PPO) {
+            pol_sum = wave_sum_dpp(pol_sum);              // held by the 4 group-leading lanes
+            val_sum = wave_sum_dpp(val_sum);
+            if (lane == 0 && wave < nwaves) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
         }
-    }
-    if (MODE == MODE_PPO) {
-        pol_sum = wave_sum_dpp(pol_sum);                  // held by the 4 group-leading lanes
-        val_sum = wave_sum_dpp(val_sum);
-        if (lane == 0 && wave < nwaves) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
-        __syncthreads();
-        if (t == 0) {
+        tail_barrier();
+        PFPN_STAMP(46);
+        if (t == (int)blockDim.x - 64) {
             float ps = 0.f, vs = 0.f;
-            for (int i = 0; i < nwaves; ++i) { ps += lossbuf[i]; vs += lossbuf[nwaves + i]; }
+            if (MODE == MODE_PPO)
+                for (int i = 0; i < nwaves; ++i) { ps += lossbuf[i]; vs += lossbuf[nwaves + i]; }
             slab[nq * AN + 0] = ps;
             slab[nq * AN + 1] = vs;
         }
-    } else if (t == 0) {
-        slab[nq * AN + 0] = 0.f;
-        slab[nq * AN + 1] = 0.f;
+        // column sums over the R rows of the tile, in row order.  Up to TQ outputs per thread per round with all of
+        // their LDS reads issued before the first add (one LDS round trip per round instead of one per output).
+        constexpr int TQ = 6;
+        const int total = nq * AN, bd = (int)blockDim.x;
+        for (int base = t; base < total; base += TQ * bd) {
+            float v[TQ][4];
+            if (R == 4) {
+#pragma unroll
+                for (int k = 0; k < TQ; ++k) {
+                    const int idx = min(base + k * bd, total - 1);
+                    const int which = idx >= 2 * AN ? 2 : idx >= AN ? 1 : 0;
+                    const float* src = (which == 0 ? tile : lsb + (which - 1) * TS) + (idx - which * AN);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) v[k][rr] = src[rr * AN];
+                }
+#pragma unroll
+                for (int k = 0; k < TQ; ++k) {
+                    const int idx = base + k * bd;
+                    if (idx < total) slab[idx] = (((0.f + v[k][0]) + v[k][1]) + v[k][2]) + v[k][3];
+                }
+            } else {
+                for (int k = 0; k < TQ; ++k) {
+                    const int idx = base + k * bd;
+                    if (idx >= total) break;
+                    const int which = idx >= 2 * AN ? 2 : idx >= AN ? 1 : 0;
+                    const float* src = (which == 0 ? tile : lsb + (which - 1) * TS) + (idx - which * AN);
+                    float s_ = 0.f;
+                    for (int rr = 0; rr < R; ++rr) s_ += src[rr * AN];
+                    slab[idx] = s_;
+                }
+            }
+        }
     }
+    PFPN_STAMP(47);
     PFPN_STAMP(41);
 }
 

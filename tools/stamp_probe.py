@@ -25,7 +25,7 @@ names = {0:"start",1:"bank done",2:"barrier0"}
 for it in range(4):
     for k,nm in enumerate(["top","fwd done","wait done","row done","bwd done","staged next"]):
         names[3+it*6+k] = "t%d %s" % (it, nm)
-names[40]="loop end"; names[41]="slab done"
+names[40]="loop end"; names[41]="slab done"; names[42]="past barrier"; names[43]="bank written"; names[44]="bank complete"
 t0 = s[:9,0].min()
 for w in (0, 4, 8):
     print("wave", w)
@@ -49,4 +49,6 @@ print("loader waves: tile k issued / landed (ticks)")
 for w in (9, 10):
     print("   w%d " % w + "  ".join("t%d issued %6d landed %6d" % (k, s[w, 3 + k * 6] - t0, s[w, 4 + k * 6] - t0) for k in range(4)))
 
+print("tail: " + "  ".join("w%d loop end %d all arrived %d staged %d slabs out %d done %d" % (w, s[w,40]-t0, s[w,45]-t0, s[w,46]-t0, s[w,47]-t0, s[w,41]-t0) for w in (0,8,9)))
+print("start-up: " + "  ".join("w%d barrier %d written %d complete %d regs %d" % (w, s[w,42]-t0, s[w,43]-t0, s[w,44]-t0, s[w,1]-t0) for w in (0,4,8)))
 print("starts: " + "  ".join("w%d s0 %d s1 %d s2 %d" % (w, s[w,0]-t0, s[w,1]-t0, (s[w,2]-t0) if s[w,2] else -1) for w in (0,4,8,9,10)))
