@@ -586,7 +586,9 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                     const float* rs = rpl + slot * 64;
                     const float adv = rs[rkc], lpo = rs[16 + rkc], val_b = rs[32 + rkc], vold_b = rs[48 + rkc];
                     const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
-                    const float ratio = expf(s - lpo);
+                    // v_exp_f32 on (s - lpo) * log2 e: |s - lpo| is O(0.1-1), so the product's rounding is far below the
+                    // instruction's own 1 ulp; libm's expf costs ~25 VALU slots in a stage every wave runs for every tile
+                    const float ratio = __builtin_amdgcn_exp2f((s - lpo) * PFPN_LOG2E);
                     const float sur = ratio * nadv;
                     const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
                     const float csur = cr * nadv;
