@@ -784,6 +784,137 @@ def sac_learner_step(st, batch, noise, lr_c=1e-4, lr_a=1e-4, clip_norm=1.0, tau=
 # --------------------------------------------------------------------------------------- #
 # V-trace / A2C (A3C, IMPALA) learner -- SURVEY 8(f)-2                                    #
 # --------------------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------- #
+# TD3 / DDPG-PFPN (networks/actor_critic/ddpg.py:11-243)                      #
+# --------------------------------------------------------------------------- #
+TD3_ACTOR = ["actor/fc1/weight", "actor/fc1/bias", "actor/fc2/weight", "actor/fc2/bias",
+             "actor/samples", "actor/samples_std", "actor/fc_policy/weight", "actor/fc_policy/bias"]
+TD3_CRITIC = ["critic/%s/fc%d/%s" % (q, i, k) for q in ("q", "twin_q") for i in (1, 2, 3) for k in ("weight", "bias")]
+
+
+def init_td3_params(rng, S, A, N, hidden=(1024, 512), sigma=0.01, act_noise=0.1):
+    """eval net of ParticleFilteringDDPGNetwork: the PFPN actor on the tanh grid with a FIXED particle width
+    (`act_noise` becomes `init_sigma` with `fixed_sigma=True`, ddpg.py:48-50) + the critics `q` and `twin_q` on
+    concat(normalised state, action) (ddpg.py:174-197)."""
+    P = init_params(rng, S, A, N, hidden, tanh_mode=True, sigma=sigma)
+    P = {k: v for k, v in P.items() if k.startswith("actor")}
+    P["actor/samples"], P["actor/samples_std"] = init_particles(A, N, tanh_mode=True, init_sigma=act_noise)
+    sacP = init_sac_params(rng, S, A, N, hidden, sigma)
+    for k, v in sacP.items():
+        if k.startswith("critic/q1"):
+            P[k.replace("critic/q1", "critic/q")] = v
+        elif k.startswith("critic/q2"):
+            P[k.replace("critic/q2", "critic/twin_q")] = v
+    return P
+
+
+def deterministic_action_bwd(logits, loc, da):
+    """Custom gradient `mask` of MixtureGaussianDistribution.mean(), tanh mode (utils.py:205-221):
+    a = tanh(loc)[argmax softmax(logits)];  d a / d w_n = tanh(loc_n) - tanh(loc_k);  d a / d tanh(loc) = onehot(k),
+    summed over the batch; then the softmax Jacobian and tanh'.  -> dlogits [B,A,N], dloc [A,N]."""
+    logits = np.asarray(logits, F)
+    w = softmax(logits)
+    k = logits.argmax(axis=-1)
+    t = np.tanh(loc, dtype=F)[None]                                             # [1,A,N]
+    tk = np.take_along_axis(np.broadcast_to(t, logits.shape), k[..., None], axis=-1)
+    gw = ((t - tk) * np.asarray(da, F)[..., None]).astype(F)
+    dlogits = (w * (gw - (gw * w).sum(axis=-1, keepdims=True, dtype=F))).astype(F)
+    m = np.zeros_like(logits)
+    np.put_along_axis(m, k[..., None], F(1), axis=-1)
+    dt = (m * np.asarray(da, F)[..., None]).sum(axis=0, dtype=F)                # [A,N]
+    dloc = (dt * (F(1) - t[0] * t[0])).astype(F)
+    return dlogits, dloc
+
+
+def td3_grads(P, PT, norm, norm_t, batch, noise_t, A, N, sync, gamma=0.95, value_loss_coef=0.5,
+              target_noise=0.2, lb=-1.0, ub=1.0):
+    """One TD3-PFPN forward/backward (twin_q=True).  P: eval params, PT: the target net's own copy of EVERY variable
+    (actor, critics; its state-normaliser statistics are `norm_t`), ddpg.py:31-36, :201-219.
+    target action = clip(mean_target(s') + target_noise * noise_t, lb, ub) (ddpg.py:136-158 with act_noise=target_noise);
+    q_target = r + gamma * not_terminal * min(Q', twin_Q')(s', a') (:190-197, :216-219);
+    value loss = mean_b((Q - y)^2 + (twin_Q - y)^2) * coef (:221-224, a2c.py:51-56) w.r.t. the critic variables;
+    policy loss = -mean(Q(s, mean(s))) w.r.t. the actor variables, and only when `sync` (global_step % policy_delay
+    == 0), else its gradient is zero (:199-207).  Returns ((loss, policy_loss, value_loss*coef), grads, aux)."""
+    B = len(batch["state"])
+    invB = F(1) / F(B)
+    loc = P["actor/samples"]
+    x = state_normalize(batch["state"], norm[0], norm[1], 5.0)
+    logits, (h1, h2) = actor_forward(P, x, A, N)
+    k, a_opt = mean_action(logits, loc, tanh_mode=True)
+    xa = np.concatenate([x, a_opt], -1).astype(F)
+    q_pi, acts_pi = q_forward(P, "q", xa)
+    xh = np.concatenate([x, np.asarray(batch["action"], F)], -1).astype(F)
+    q1r, acts1r = q_forward(P, "q", xh)
+    q2r, acts2r = q_forward(P, "twin_q", xh)
+    x2 = state_normalize(batch["state_"], norm_t[0], norm_t[1], 5.0)
+    logits2, _ = actor_forward(PT, x2, A, N)
+    _, a2 = mean_action(logits2, PT["actor/samples"], tanh_mode=True)
+    a2 = np.clip((a2 + F(target_noise) * np.asarray(noise_t, F)).astype(F), F(lb), F(ub))
+    xa2 = np.concatenate([x2, a2], -1).astype(F)
+    v2 = np.minimum(q_forward(PT, "q", xa2)[0], q_forward(PT, "twin_q", xa2)[0])
+    q_target = (np.asarray(batch["reward"], F) + F(gamma) * np.asarray(batch["not_terminal"], F) * v2).astype(F)
+    value_loss = ((q1r - q_target) ** 2 + (q2r - q_target) ** 2).mean(dtype=F) * F(value_loss_coef)
+    policy_loss = -q_pi.mean(dtype=F)
+    G = {}
+    _q_backward(P, "q", xh, acts1r, (F(2) * (q1r - q_target) * F(value_loss_coef) * invB).astype(F), G)
+    _q_backward(P, "twin_q", xh, acts2r, (F(2) * (q2r - q_target) * F(value_loss_coef) * invB).astype(F), G)
+    if sync:
+        dxa = _q_backward(P, "q", xa, acts_pi, np.full(B, -invB, F))
+        dlogits, dloc = deterministic_action_bwd(logits, loc, dxa[:, -A:])
+        dlogits = dlogits.reshape(B, A * N)
+        G["actor/samples"] = dloc
+        dh2, G["actor/fc_policy/weight"], G["actor/fc_policy/bias"] = _fc_bwd(h2, P["actor/fc_policy/weight"], None, dlogits, False)
+        dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True)
+        _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True)
+    else:
+        for n in TD3_ACTOR:
+            G[n] = np.zeros_like(P[n])
+    G["actor/samples_std"] = np.zeros_like(P["actor/samples_std"])        # fixed_sigma: not a trainable variable
+    aux = {"a_opt": a_opt, "k": k, "q_target": q_target, "q_pi": q_pi, "a2": a2}
+    return (F(policy_loss + value_loss), F(policy_loss), F(value_loss)), G, aux
+
+
+class TD3State:
+    def __init__(self, rng, S=197, A=36, N=35, hidden=(1024, 512), policy_delay=2, act_noise=0.1):
+        self.S, self.A, self.N, self.policy_delay = S, A, N, policy_delay
+        self.P = init_td3_params(rng, S, A, N, hidden, act_noise=act_noise)
+        self.PT = {k: v.copy() for k, v in self.P.items()}                   # hard sync at init (ddpg.py:110-121)
+        self.m = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.P.items()}
+        self.bp_c, self.bp_a = [F(0.9), F(0.999)], [F(0.9), F(0.999)]
+        self.norm_mean, self.norm_std = np.zeros(S, F), np.ones(S, F)
+        self.norm_mean_t, self.norm_std_t = np.zeros(S, F), np.ones(S, F)
+        self.global_step = 0
+
+
+def td3_learner_step(st, batch, noise_t, lr_c=1e-4, lr_a=1e-4, clip_norm=1.0, tau=0.005, gamma=0.95):
+    """Single-worker TD3-PFPN update: gradients (policy gradient only on sync steps), ONE joint global-norm clip, critic
+    Adam then actor Adam (base_worker.py:33-45, :97-118), normaliser EMA, then on sync steps the soft update of EVERY
+    target variable incl. the normaliser statistics (ddpg.py:97-109).  `sync` uses the step counter BEFORE this apply:
+    the tensor is evaluated once per run and the loss needs it before the optimiser increments the counter."""
+    sync = st.global_step % st.policy_delay == 0 if st.policy_delay > 1 else True
+    losses, G, aux = td3_grads(st.P, st.PT, (st.norm_mean, st.norm_std), (st.norm_mean_t, st.norm_std_t), batch, noise_t,
+                               st.A, st.N, sync, gamma)
+    trainable_a = [n for n in TD3_ACTOR if n != "actor/samples_std"]
+    names = TD3_CRITIC + trainable_a
+    clipped, _ = clip_by_global_norm([np.asarray(G[n], F) for n in names], clip_norm)
+    new_mean, new_std = state_norm_update(batch["state"], st.norm_mean, st.norm_std, st.global_step)
+    for n, g in zip(names, clipped):
+        bp, lr = (st.bp_c, lr_c) if n in TD3_CRITIC else (st.bp_a, lr_a)
+        st.P[n], st.m[n], st.v[n] = tf_adam(st.P[n], g.reshape(st.P[n].shape), st.m[n], st.v[n], bp[0], bp[1], lr)
+    st.bp_c = [F(st.bp_c[0] * F(0.9)), F(st.bp_c[1] * F(0.999))]
+    st.bp_a = [F(st.bp_a[0] * F(0.9)), F(st.bp_a[1] * F(0.999))]
+    st.norm_mean, st.norm_std = new_mean, new_std
+    st.global_step += 1
+    if sync:
+        t = F(tau)
+        for n in st.PT:
+            st.PT[n] = ((F(1) - t) * st.PT[n] + t * st.P[n]).astype(F)
+        st.norm_mean_t = ((F(1) - t) * st.norm_mean_t + t * st.norm_mean).astype(F)
+        st.norm_std_t = ((F(1) - t) * st.norm_std_t + t * st.norm_std).astype(F)
+    return losses, aux
+
+
 def vtrace(logp_target, logp_behavior, value, reward, not_terminal, E, gamma, rho_clip=1.0, pg_rho_clip=1.0,
            seq_len=None):
     """reference networks/actor_critic/vtrace.py:101-180.  Inputs flat [E*T] in episode-major order

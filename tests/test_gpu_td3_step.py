@@ -1,0 +1,105 @@
+"""GPU parity of the TD3-PFPN learner step (reference networks/actor_critic/ddpg.py) vs the NumPy oracle:
+deterministic particle action with its custom gradient, twin critics, the full target network with its own actor and
+normaliser statistics, the policy-delay gate and the delayed soft update."""
+import numpy as np
+import pytest
+import torch
+
+from _parity import close_scaled
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+NET_OPTS = dict(common_net_shape=[], critic_net_shape=[1024, 512], actor_net_shape=[1024, 512],
+                value_loss_coef=0.5, gamma=0.95, normalize_state=True, clip_state=5.0,
+                normalize_value=False, clip_value=None, normalize_advantage=False, clip_advantage=None,
+                particles=35, resample=-1, resample_interval=12000)
+
+
+def make_net(dev, trainable=True, S=197, A=36, seed=7, **kw):
+    from pfpn_amd.networks import ParticleFilteringDDPGNetwork
+    net = ParticleFilteringDDPGNetwork(trainable=trainable, state_shape=[S], action_shape=[A],
+                                       action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
+                                       device=dev, seed=seed, **dict(NET_OPTS, **kw))
+    net.init()
+    return net
+
+
+@pytest.mark.parametrize("B", [16, 256])
+def test_td3_step_matches_oracle(oracle, dev, B):
+    from pfpn_amd.models import SyncReplicasApplier
+    S, A, N = 197, 36, 35
+    net = make_net(dev)
+    for op in net.init_ops:
+        op()
+    opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                    {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    st = oracle.TD3State(np.random.default_rng(0), S, A, N)
+    for k, v in net.variables().items():
+        st.P[k] = v.detach().cpu().numpy().reshape(st.P[k].shape).copy()
+    st.PT = {k: v.copy() for k, v in st.P.items()}
+    # the fixed-width tanh grid (act_noise -> init_sigma, fixed_sigma) of the network == the oracle's
+    o_loc, o_ls = oracle.init_particles(A, N, tanh_mode=True, init_sigma=0.1)
+    np.testing.assert_array_equal(st.P["actor/samples"], o_loc)
+    np.testing.assert_array_equal(st.P["actor/samples_std"], o_ls)
+    rng = np.random.default_rng(B)
+    for it in range(4):                                   # steps 0 and 2 carry the policy gradient and the soft update
+        batch = {"state": (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F),
+                 "action": np.tanh(rng.normal(0, 1, (B, A))).astype(F),
+                 "reward": rng.random(B).astype(F),
+                 "not_terminal": (rng.random(B) < 0.9).astype(F),
+                 "state_": (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F)}
+        noise_t = rng.normal(0, 1, (B, A)).astype(F)
+        sync = st.global_step % 2 == 0
+        (l_ref, pl_ref, vl_ref), G_ref, aux = oracle.td3_grads(
+            st.P, st.PT, (st.norm_mean, st.norm_std), (st.norm_mean_t, st.norm_std_t), batch, noise_t, A, N, sync)
+        oracle.td3_learner_step(st, batch, noise_t)
+        args = [net._to_dev(batch[k]) for k in ("state", "action", "reward", "not_terminal", "state_")]
+        loss3 = net.compute_gradients(*args, noise={"target": torch.from_numpy(noise_t).to(dev)}).cpu().numpy()
+        assert net._sync_now == sync
+        assert np.array_equal(net.last["k"].cpu().numpy(), aux["k"]), "argmax particle indices must be bit-exact"
+        close_scaled(net.last["a_opt"].cpu().numpy(), aux["a_opt"], 1e-6, "deterministic action")
+        close_scaled(net.last["a2"].cpu().numpy(), aux["a2"], 1e-5, "smoothed target action")
+        close_scaled(loss3, [l_ref, pl_ref, vl_ref], 2e-5, "losses", floor=1.0)
+        G = net.gradients()
+        for name, g_ref in G_ref.items():
+            g_ref = np.asarray(g_ref, F)
+            close_scaled(G[name].cpu().numpy(), g_ref, 2e-4, "grad " + name, floor=1e-30,
+                         flips=max(8, g_ref.size // 500))          # ReLU6 mask bits that round the other way
+            if not sync and name.startswith("actor"):
+                assert not G[name].any()
+        opt.apply(net)
+        for name, v in net.variables().items():
+            close_scaled(v.cpu().numpy(), st.P[name], 3e-6, name, floor=1.0, flips=max(8, st.P[name].size // 500))
+        for name, v in net.target_variables().items():
+            close_scaled(v.cpu().numpy(), st.PT[name], 3e-7, "target " + name, floor=1.0, flips=max(8, v.numel() // 500))
+        close_scaled(net.state_normalizer.mean.cpu().numpy(), st.norm_mean, 1e-5, "norm mean", floor=1.0)
+        close_scaled(net.target_norm[0].cpu().numpy(), st.norm_mean_t, 1e-5, "target norm mean", floor=1.0)
+        close_scaled(net.target_norm[1].cpu().numpy(), st.norm_std_t, 1e-5, "target norm std", floor=1.0)
+    assert net.global_step == 4
+    assert not torch.equal(net.target_store.flat, net.store.flat[:net.target_store.flat.numel()])
+
+
+def test_td3_api_surface(dev):
+    """run() -> [action] inside the action box, exploring when trainable and deterministic when not; train() with host
+    arrays returns the reference's loss tuple; unbuilt options raise."""
+    from pfpn_amd.models import SyncReplicasApplier
+    net = make_net(dev)
+    opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                    {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    rng = np.random.default_rng(0)
+    s = rng.normal(0, 1, 197).astype(F)
+    a1, a2 = net.run(None, s)[0], net.run(None, s)[0]
+    assert a1.shape == (36,) and np.all(np.abs(a1) <= 1) and not np.array_equal(a1, a2)       # exploration noise
+    B = 64
+    loss, extra = net.train(None, opt, ["global_step"], rng.normal(0, 1, (B, 197)).astype(F),
+                            np.tanh(rng.normal(0, 1, (B, 36))).astype(F), rng.random(B).astype(F),
+                            np.ones(B, F), rng.normal(0, 1, (B, 197)).astype(F))
+    assert extra == [1] and loss[1] is None and all(np.isfinite([loss[0], loss[2], loss[3]]))
+    ev = make_net(dev, trainable=False)
+    e1, e2 = ev.run(None, s)[0], ev.run(None, s)[0]
+    assert np.array_equal(e1, e2) and np.all(np.abs(e1) < 1)
+    with pytest.raises(NotImplementedError):
+        make_net(dev, ou_noise=True)
+    with pytest.raises(NotImplementedError):
+        make_net(dev, twin_q=False)

@@ -329,3 +329,77 @@ def test_torch_cpu_step_is_the_oracle_step(oracle):
             # from zero moments Adam's first steps are ~lr * sign(g): entries with |g| ~ 1e-7 amplify rounding
             np.testing.assert_allclose(ts.P[k].detach().numpy().reshape(st.P[k].shape), st.P[k], rtol=0, atol=1e-5)
         np.testing.assert_allclose(ts.mean.numpy(), st.norm_mean, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("sync", [True, False])
+def test_td3_grads_match_autograd(oracle, sync):
+    """oracle.td3_grads (hand-written backward through the deterministic particle action) vs float64 torch autograd of
+    the same graph with the reference's custom gradient of `mean()` (utils.py:205-221), the target network's own actor
+    (ddpg.py:201-219) and the policy-delay gate (ddpg.py:199-207)."""
+    rng = np.random.default_rng(8)
+    S, A, N, B = 11, 3, 35, 9
+    st = oracle.TD3State(rng, S, A, N, hidden=(16, 8))
+    for k in st.P:
+        if k.endswith("weight"):
+            st.P[k] = (st.P[k] * 30).astype(np.float32)
+    st.PT = {k: (v * 1.05).astype(np.float32) if k.endswith("weight") else v.copy() for k, v in st.P.items()}
+    batch = {"state": rng.normal(0, 1, (B, S)).astype(np.float32), "action": np.tanh(rng.normal(0, 1, (B, A))).astype(np.float32),
+             "reward": rng.random(B).astype(np.float32), "not_terminal": (rng.random(B) < 0.8).astype(np.float32),
+             "state_": rng.normal(0, 1, (B, S)).astype(np.float32)}
+    noise_t = rng.normal(0, 1, (B, A)).astype(np.float32)
+    norm = (st.norm_mean, st.norm_std)
+    (loss, pl, vl), G, aux = oracle.td3_grads(st.P, st.PT, norm, norm, batch, noise_t, A, N, sync)
+
+    T = lambda v, g=False: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=g)
+    P = {k: T(v, True) for k, v in st.P.items()}
+    PT = {k: T(v) for k, v in st.PT.items()}
+    relu6 = lambda t: torch.clamp(t, 0, 6)
+
+    def actor(Pd, x):
+        h = relu6(x @ Pd["actor/fc1/weight"] + Pd["actor/fc1/bias"])
+        h = relu6(h @ Pd["actor/fc2/weight"] + Pd["actor/fc2/bias"])
+        return (h @ Pd["actor/fc_policy/weight"] + Pd["actor/fc_policy/bias"]).view(-1, A, N)
+
+    def qnet(Pd, q, xa):
+        h = relu6(xa @ Pd["critic/%s/fc1/weight" % q] + Pd["critic/%s/fc1/bias" % q])
+        h = relu6(h @ Pd["critic/%s/fc2/weight" % q] + Pd["critic/%s/fc2/bias" % q])
+        return (h @ Pd["critic/%s/fc3/weight" % q] + Pd["critic/%s/fc3/bias" % q])[:, 0]
+
+    def mean_action(Pd, logits):
+        w = torch.softmax(logits, -1)
+        p = torch.tanh(Pd["actor/samples"]).unsqueeze(0)                       # [1,A,N]
+        m = torch.nn.functional.one_hot(w.argmax(-1), N).double()
+
+        class Mask(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, w, p):
+                y = m * p
+                ctx.save_for_backward((p - y.sum(-1, keepdim=True)).detach())
+                return y
+            @staticmethod
+            def backward(ctx, dy):
+                return ctx.saved_tensors[0] * dy, (m * dy).sum(0, keepdim=True)
+        return Mask.apply(w, p).sum(-1)
+
+    x, x2 = T(batch["state"]).clamp(-5, 5), T(batch["state_"]).clamp(-5, 5)
+    a_opt = mean_action(P, actor(P, x))
+    q_pi = qnet(P, "q", torch.cat([x, a_opt], -1))
+    xh = torch.cat([x, T(batch["action"])], -1)
+    q1r, q2r = qnet(P, "q", xh), qnet(P, "twin_q", xh)
+    with torch.no_grad():
+        a2 = (mean_action(PT, actor(PT, x2)) + 0.2 * T(noise_t)).clamp(-1, 1)
+        xa2 = torch.cat([x2, a2], -1)
+        qt = T(batch["reward"]) + 0.95 * T(batch["not_terminal"]) * torch.minimum(qnet(PT, "q", xa2), qnet(PT, "twin_q", xa2))
+    value_loss = 0.5 * ((q1r - qt) ** 2 + (q2r - qt) ** 2).mean()
+    policy_loss = -q_pi.mean()
+    np.testing.assert_allclose([pl, vl], [policy_loss.item(), value_loss.item()], rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(aux["a_opt"], a_opt.detach().numpy(), rtol=1e-5, atol=1e-6)
+    crit = [k for k in P if k.startswith("critic")]
+    act = [k for k in P if k.startswith("actor") and k != "actor/samples_std"]
+    gc = torch.autograd.grad(value_loss, [P[k] for k in crit], retain_graph=True)
+    ga = torch.autograd.grad(policy_loss, [P[k] for k in act])
+    for k, g in list(zip(crit, gc)) + list(zip(act, ga)):
+        ref = g.numpy() if (sync or k in crit) else np.zeros_like(g.numpy())
+        got = np.asarray(G[k]).reshape(ref.shape)
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-4 * (np.abs(g.numpy()).max() + 1e-12), err_msg=k)
+    assert not np.any(G["actor/samples_std"])                                  # fixed_sigma
