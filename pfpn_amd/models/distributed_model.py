@@ -122,6 +122,7 @@ class AbstractDistributedWorker(object):
         self.is_chief, self.is_evaluator = _is_chief, _is_evaluator
         self.seed, self.on_policy = _seed, _on_policy
         self.max_samples, self.render = _max_samples, render
+        self.log_dir = _log_dir
         self.batch_size, self.unroll_length, self.opt_epochs = batch_size, unroll_length, opt_epochs
         # episodic training: the learner gets whole zero-padded rollout segments plus their lengths (V-trace)
         self.episodic_training = episodic_training

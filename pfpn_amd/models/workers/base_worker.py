@@ -53,6 +53,15 @@ def actor_critic_worker_wrapper(base_distributed_worker_class):
             if nan is None and now <= self.log_interval_time + self.last_notify_time:
                 return
             _, policy_entropy, policy_loss, value_loss = nan if nan is not None else losses[-1][0]
+            if self.log_dir:              # TensorBoard scalars under the reference's tags (actor_critic.py:132-184)
+                if self.logger is None:
+                    from ...summary import Summary
+                    self.logger = Summary(self.log_dir)
+                self.logger.add_scalar("loss/value_loss", value_loss, self.global_step)
+                self.logger.add_scalar("loss/policy_loss", policy_loss, self.global_step)
+                if policy_entropy is not None:
+                    self.logger.add_scalar("loss/policy_entropy", policy_entropy, self.global_step)
+                self.logger.flush()
             print("[TRAIN] Step: {}; Value Loss: {:.4f}; Policy Loss: {:.4f}; Policy Entropy: {:.4f}; "
                   "Worker: {}; {}".format(self.global_step, value_loss, policy_loss,
                                           0.0 if policy_entropy is None else policy_entropy, self.name,

@@ -87,3 +87,24 @@ def test_write_read_roundtrip(tmp_path):
     open(p2, "wb").write(blob)
     h2, e2 = ck.read_index(p2)
     assert list(e2) == list(entries) and all(e2[k].encode() == entries[k].encode() for k in entries)
+
+
+def test_tensorboard_event_file_round_trip(tmp_path):
+    """pfpn_amd/summary.py writes the TFRecord / Event / Summary wire format of the reference's `Summary` writer
+    (models/utils.py:28-54): scalars and 1000-bin histograms read back with intact checksums."""
+    from pfpn_amd.summary import Summary, read_events
+    w = Summary(str(tmp_path))
+    rng = np.random.default_rng(0)
+    vals = rng.normal(0, 1, 5000).astype(np.float32)
+    w.add_scalar("loss/value_loss", 0.25, 7)
+    w.add_histogram("model/advantage", vals, 7)
+    w.add_summaries({"loss": {"policy_loss": np.float32(-1.5)}, "model": {"value": vals[:64]}}, 8)
+    w.close()
+    ev = read_events(w.path)
+    assert [(s, t) for s, t, _ in ev] == [(7, "loss/value_loss"), (7, "model/advantage"), (8, "loss/policy_loss"),
+                                          (8, "model/value")]
+    assert ev[0][2] == 0.25 and ev[2][2] == -1.5
+    h = ev[1][2]
+    counts, edges = np.histogram(vals.astype(np.float64), bins=1000)
+    assert h["num"] == 5000 and np.array_equal(h["bucket"], counts) and np.allclose(h["bucket_limit"], edges[1:])
+    assert h["min"] == vals.min() and h["max"] == vals.max() and abs(h["sum"] - vals.astype(np.float64).sum()) < 1e-9
