@@ -331,14 +331,40 @@ def main():
                 fn(); fn()
                 torch.cuda.synchronize()
                 e0.record()
-                for _ in range(10):
+                for _ in range(30):
                     fn()
                 e1.record()
                 torch.cuda.synchronize()
-                u = e0.elapsed_time(e1) * 1e3 / 10
+                u = e0.elapsed_time(e1) * 1e3 / 30
                 res[name] = {"kernel": "k_mix_wide<1,%s> (+reduce)" % name.upper(), "us_per_launch": u,
                              "algorithmic_bytes": nbytes, "achieved": nbytes / u / 1e3, "unit": "GB/s",
                              "peak": HBM_PEAK_GBS, "frac": nbytes / u / 1e3 / HBM_PEAK_GBS}
+            # the PPO composition at this shape: forward -> loss head on [B] -> backward (3L: the row log-prob couples
+            # all 128 segments of a row and neither a 128-KiB row plus the 393-KB bank nor 1 GiB of logits stays on chip
+            # between the two passes)
+            s_lp_old = kernels.logprob_fwd(sl, sx, sloc, sls).clone()
+            s_stats = kernels.adv_stats(sg)
+            s_out = {"logp": torch.empty(sB, device=dev), "dlogits": torch.empty(sB, sA * sN, device=dev),
+                     "dloc": torch.empty(sA, sN, device=dev), "dlogstd": torch.empty(sA, sN, device=dev),
+                     "dvalue": torch.empty(sB, device=dev), "loss3": torch.empty(3, device=dev)}
+            s_v = torch.zeros(sB, device=dev)
+
+            def ppo_composed():
+                kernels.ppo_mixture_fwd_bwd(sl, sx, sloc, sls, s_lp_old, sg, s_v, s_v, s_stats, out=s_out)
+            ppo_composed(); ppo_composed()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                ppo_composed()
+            e1.record()
+            torch.cuda.synchronize()
+            u = e0.elapsed_time(e1) * 1e3 / 10
+            nb = 3 * L_ + 2 * X_ + 8 * V_ + 3 * P_
+            res["ppo"] = {"kernel": "k_mix_wide<FWD> + k_row_sum + k_ppo_loss + k_mix_wide<BWD> (+reduce)",
+                          "us_per_launch": u, "algorithmic_bytes": nb, "achieved": nb / u / 1e3, "unit": "GB/s",
+                          "peak": HBM_PEAK_GBS, "frac": nb / u / 1e3 / HBM_PEAK_GBS,
+                          "note": "3L composition; a fused 2L pass needs a row (128 KiB) AND the [A,N] bank (393 KB) on one CU"}
+            del s_out
             out["roofline_stress"] = {"shape": [sB, sA, sN], "bound": "hbm", **res}
             del sl, sx, sg
         except Exception as ex:      # never fail the headline line on the auxiliary measurement
@@ -456,6 +482,44 @@ def main():
                 del snet, sopt, sstep
             except Exception as e:
                 out["sac_step"] = {"error": repr(e)}
+        # ---- config5_step: BASELINE.json config 5 as a learner step on ONE GPU's shard (8192 rows over 8 GPUs = 1024 rows
+        # per GPU): 128 action dims x 256 particles, head 512 -> 32768, eager launches
+        if extras:
+            try:
+                cA, cN, cB = 128, 256, 1024
+                copts = dict(NET_OPTS, particles=cN)
+                cnet = ParticleFilteringClipPPONetwork(trainable=True, state_shape=[S], action_shape=[cA],
+                                                       action_lower_bound=-np.ones(cA), action_upper_bound=np.ones(cA),
+                                                       device=dev, seed=SEED, **copts)
+                cnet.init()
+                copt = SyncReplicasApplier(cnet, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+                crng = np.random.default_rng(SEED + 5)
+                ct = {"state": torch.from_numpy((crng.normal(0, 1, (cB, S)) * 2 + 0.3).astype(np.float32)).to(dev),
+                      "action": torch.from_numpy(crng.uniform(-1, 1, (cB, cA)).astype(np.float32)).to(dev),
+                      "advantage": torch.from_numpy(crng.normal(0, 1, cB).astype(np.float32)).to(dev)}
+                with torch.no_grad():
+                    cp, _, chc = cnet._forward(ct["state"])
+                    c_lp = cp.log_prob(ct["action"]).clone()
+                    c_v = cnet._value(chc).clone()
+                for _ in range(5):
+                    cnet.train_device(copt, ct["state"], ct["action"], c_v, c_lp, ct["advantage"])
+                torch.cuda.synchronize()
+                t_c = time.perf_counter()
+                for _ in range(30):
+                    cnet.train_device(copt, ct["state"], ct["action"], c_v, c_lp, ct["advantage"])
+                torch.cuda.synchronize()
+                cms = (time.perf_counter() - t_c) / 30 * 1e3
+                cl3 = cnet.train_out["loss3"].cpu().numpy()
+                mac = S * 2048 + 2 * 1024 * 512 + 512 * cA * cN
+                flops = 2.0 * cB * (mac + S * 2048 + 2 * 2 * 1024 * 512 + 2 * 512 * cA * cN)
+                out["config5_step"] = {"workload": "128 action dims x 256 particles, %d rows (one GPU's shard of the 8192-row "
+                                                   "batch over 8 GPUs), head 512 -> 32768" % cB,
+                                       "ms_per_step": cms, "steps_per_s": 1e3 / cms, "gemm_flops": flops,
+                                       "gemm_tflops_if_all_time_were_gemm": flops / (cms * 1e-3) / 1e12,
+                                       "finite_loss": bool(np.all(np.isfinite(cl3)))}
+                del cnet, copt
+            except Exception as e:
+                out["config5_step"] = {"error": repr(e)}
         if extras:
             out["cpu_baseline"] = cpu_baseline()
             rs = out["cpu_baseline"].get("runs", {}).get("reference_schedule", {})

@@ -66,8 +66,9 @@ def logprob_fwd(logits, x, loc, logstd, tanh_mode=False, want_pmix=False):
     return (logp, pmix) if want_pmix else logp
 
 
-def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False):
-    """-> dlogits [B,A,N], dloc [A,N], dlogstd [A,N] (, dx [B,A])."""
+def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, out=None):
+    """-> dlogits [B,A,N], dloc [A,N], dlogstd [A,N] (, dx [B,A]).  `out`: dict with preallocated `dlogits`, `dloc`,
+    `dlogstd` to write into (no 1-GiB temporaries at the 128 x 256 shape)."""
     lib = _lib.load()
     A, N = loc.shape
     B = x.shape[0]
@@ -75,9 +76,13 @@ def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False):
     px = _f32(x, B, A, name="x")
     ploc, pls = _f32(loc, A, N, name="loc"), _f32(logstd, A, N, name="logstd")
     pg = _f32(dlogp, B, name="dlogp")
-    dlogits = torch.empty(B, A, N, dtype=torch.float32, device=x.device)
-    dloc = torch.empty(A, N, dtype=torch.float32, device=x.device)
-    dlogstd = torch.empty(A, N, dtype=torch.float32, device=x.device)
+    if out is not None:
+        dlogits, dloc, dlogstd = out["dlogits"].view(B, A, N), out["dloc"], out["dlogstd"]
+        _f32(dlogits, B, A, N, name="dlogits"); _f32(dloc, A, N, name="dloc"); _f32(dlogstd, A, N, name="dlogstd")
+    else:
+        dlogits = torch.empty(B, A, N, dtype=torch.float32, device=x.device)
+        dloc = torch.empty(A, N, dtype=torch.float32, device=x.device)
+        dlogstd = torch.empty(A, N, dtype=torch.float32, device=x.device)
     dx = torch.empty(B, A, dtype=torch.float32, device=x.device) if want_dx else None
     ws, wsn = _mix_ws(B, A, N, x.device)
     _lib.check(lib.pfpn_logprob_bwd(pl, px, ploc, pls, pg, B, A, N, int(tanh_mode), dlogits.data_ptr(),
@@ -143,11 +148,12 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
     if rc == 1 and B >= 1 and finalize:
         # shape outside the fused kernel's coverage (N > 64, no template instance, A*N % 4 != 0): the
         # documented composition of the three HIP entry points (include/pfpn_hip.h)
+        # (the row log-prob couples all A segments of a row; at N >= 64 a row and the [A,N] bank no longer fit on one
+        # CU, so the second pass over the logits is structural: 3L of traffic)
         out["logp"].copy_(logprob_fwd(logits, action, loc, logstd))
         dlogp, dvalue, loss3 = ppo_loss(out["logp"], logp_old, adv, value, value_old, stats, clip_eps, value_coef)
-        dl, dloc, dls = logprob_bwd(logits, action, loc, logstd, dlogp)
-        out["dlogits"].view(B, A * N).copy_(dl.view(B, A * N))
-        out["dloc"].copy_(dloc); out["dlogstd"].copy_(dls); out["dvalue"].copy_(dvalue); out["loss3"].copy_(loss3)
+        logprob_bwd(logits, action, loc, logstd, dlogp, out=out)          # straight into the caller's buffers
+        out["dvalue"].copy_(dvalue); out["loss3"].copy_(loss3)
         if dbias is not None:
             act_bwd_bias_grad(None, out["dlogits"].view(B, A * N), dbias.view(1, -1), relu6=False)
         return out

@@ -256,3 +256,40 @@ def test_global_norm_from_the_reduction_launch(dev, monkeypatch, B):
         assert torch.equal(opts[0].beta_pow, opts[1].beta_pow)
         torch.testing.assert_close(nets[0].store.flat, nets[1].store.flat, rtol=1e-5, atol=2e-8)   # Adam amplifies the 1e-7 relative norm difference on near-zero parameters
         assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+
+
+def test_config5_shaped_learner_step_matches_oracle(oracle, dev):
+    """BASELINE.json config 5 as a LEARNER STEP (128 action dims x 256 particles: head 512 -> 32768): the PPO network at
+    that shape takes the composed path (wide forward -> loss head -> wide backward, the fused kernel covers N <= 64) and
+    matches the oracle's step -- log-prob, losses, every gradient, parameters."""
+    from pfpn_amd.models import SyncReplicasApplier
+    A, N, B = 128, 256, 64
+    net = make_net(dev, A=A, particles=N)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    st = oracle.DPPOState(np.random.default_rng(0), 197, A, N)
+    sync_oracle_state(oracle, net, st)
+    assert st.P["actor/fc_policy/weight"].shape == (512, A * N)
+    rng = np.random.default_rng(5)
+    for it in range(2):
+        batch = make_batch(rng, B, A=A)
+        batch["action"] = rng.uniform(-1.0, 1.0, (B, A)).astype(F)        # inside the grid: sigma = 2/255
+        for _ in range(50):
+            x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
+            bad = near_kink_rows(st.P, x)
+            if not bad.any():
+                break
+            batch["state"][bad] = make_batch(rng, int(bad.sum()), A=A)["state"]
+        logits, _ = oracle.actor_forward(st.P, x, A, N)
+        lp, _ = oracle.mixture_log_prob(logits, batch["action"], st.P["actor/samples"], st.P["actor/samples_std"])
+        batch["log_prob"] = away_from_clip(lp, (lp + rng.normal(0, 0.1, B)).astype(F))
+        (l_ref, pl_ref, vl_ref), G_ref, aux = oracle.dppo_grads(st.P, st.norm_mean, st.norm_std, batch, A, N)
+        oracle.dppo_learner_step(st, [batch])
+        loss, _ = net.train(None, opt, [], batch["state"], batch["action"], batch["value"], batch["log_prob"],
+                            batch["advantage"])
+        np.testing.assert_allclose(net.train_out["logp"].cpu().numpy(), aux["logp"], rtol=1e-5, atol=0)
+        close_scaled([loss[0], loss[2]], [l_ref, pl_ref], 1e-5, "loss", floor=1.0)
+        G = net.gradients()
+        for name, g_ref in G_ref.items():
+            close_scaled(G[name].cpu().numpy(), g_ref, 2e-4, "grad " + name)
+        for name, v in net.variables().items():
+            close_scaled(v.cpu().numpy(), st.P[name], 2e-6, name, floor=1.0)
