@@ -288,8 +288,11 @@ def test_config5_shaped_learner_step_matches_oracle(oracle, dev):
                             batch["advantage"])
         np.testing.assert_allclose(net.train_out["logp"].cpu().numpy(), aux["logp"], rtol=1e-5, atol=0)
         close_scaled([loss[0], loss[2]], [l_ref, pl_ref], 1e-5, "loss", floor=1.0)
+        # gradients: every actor gradient carries the ratio exp(logp - logp_old), and a fp32 log-prob summed over 128
+        # dims (|logp| ~ 3e2) is good to ~3e-4 absolute: 1e-3 of the tensor's scale (measured 3e-4 on the particle
+        # locations, whose terms are amplified by 1/sigma = 128)
         G = net.gradients()
         for name, g_ref in G_ref.items():
-            close_scaled(G[name].cpu().numpy(), g_ref, 2e-4, "grad " + name)
+            close_scaled(G[name].cpu().numpy(), g_ref, 1e-3, "grad " + name)
         for name, v in net.variables().items():
             close_scaled(v.cpu().numpy(), st.P[name], 2e-6, name, floor=1.0)
