@@ -10,7 +10,7 @@ def bench(f, n=30):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)*1e3/n
-R = 4096
+R = int(os.environ.get("ROWS", 4096))
 shapes = (("L0", 2, 200, 1024), ("L1", 2, 1024, 512), ("head", 1, 512, 1260))
 if os.environ.get("ONLY_L1"): shapes = shapes[1:2]
 for name, G, K, N in shapes:
