@@ -294,5 +294,5 @@ def test_config5_shaped_learner_step_matches_oracle(oracle, dev):
         G = net.gradients()
         for name, g_ref in G_ref.items():
             close_scaled(G[name].cpu().numpy(), g_ref, 1e-3, "grad " + name)
-        for name, v in net.variables().items():
-            close_scaled(v.cpu().numpy(), st.P[name], 2e-6, name, floor=1.0)
+        for name, v in net.variables().items():       # within 5 % of one Adam step (lr = 1e-4; see the step test above)
+            close_scaled(v.cpu().numpy(), st.P[name], 5e-6, name, floor=1.0)
