@@ -180,7 +180,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define PFPN_STAMP(id_) do { } while (0)      /* build with -DPFPN_ENABLE_STAMPS for tools/stamp_probe.py */
 #endif
 
-// MAXT: launch bound.  704 threads (9 compute + 2 loader waves -> 3 waves/SIMD -> 168 VGPRs) covers the tile
+// MAXT: launch bound.  768 threads (9 compute + 2 loader + 1 row wave -> 3 waves/SIMD -> 168 VGPRs) covers the tile
 // of A = 36; the generic bound of 1024 caps the allocation at 128 VGPRs.
 template <int N, int MODE, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_mix_packed(
@@ -203,12 +203,18 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     extern __shared__ float4 smem4[];
     const int AN = A * N;
     const int nseg = R * A;                               // segments per full tile
-    const int nwaves = (blockDim.x >> 6) - PACK_NL;       // compute waves
+    // ROW WAVE (forward / PPO modes): one extra wave -- the block's last -- owns the row stage of every tile: it waits for
+    // the segment log-probs of a tile's rows, sums them, runs the loss head and publishes d loss / d logp per row.  Before,
+    // every compute wave ran that stage for the rows it touches (~100 VALU per wave and tile, a quarter of the loop's
+    // instructions, on the SIMD that is VALU-issue bound); now the compute waves only wait for a counter and read one float,
+    // and the row wave works while they are in the next tile's forward.
+    constexpr int NRW = (MODE != MODE_BWD) ? 1 : 0;
+    const int nwaves = (blockDim.x >> 6) - PACK_NL - NRW; // compute waves
     const int TS = nwaves * SLICE;                        // floats per plane (>= R*AN)
     const int XS = (nseg + 63) & ~63;                     // floats per action-value plane
     // LDS map (floats):  [P][TS] tiles | [P][XS] action values | [P][64] row scalars | [4][nseg] segment log p
-    //                    | [2][R] row counters | [P] ready | [P] freed | [1] bank_done | [2*nwaves] loss partials
-    //                    | [3][AN] particle bank
+    //                    | [2][R] row counters | [P] ready | [P] freed | [1] bank_done | [2] gdone | [2*nwaves] (unused)
+    //                    | [2][R] row gradients | [3][AN] particle bank
     float* tile = reinterpret_cast<float*>(smem4);
     float* xpl = tile + (size_t)P * TS;
     float* rpl = xpl + P * XS;                            // [P][4][16]: adv, logp_old, value, value_old (PPO) | dlogp (BWD)
@@ -216,9 +222,11 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     int* cnt = reinterpret_cast<int*>(segbuf + 4 * nseg);
     int* ready = cnt + 2 * R;
     int* freed = ready + P;
-    int* bank_done = freed + P;                           // compute waves that have written their share of the bank
-    float* lossbuf = reinterpret_cast<float*>(bank_done + 1);
-    float* bank = lossbuf + 2 * nwaves;                   // [3][AN]: loc | isc2 | 64 - ct2   (see below)
+    int* bank_done = freed + P;                           // (kept in the map; the start-up barrier publishes the bank)
+    int* gdone = bank_done + 1;                           // [2]: tiles of this parity whose row stage is complete
+    float* lossbuf = reinterpret_cast<float*>(gdone + 2);
+    float* gbuf = lossbuf + 2 * nwaves;                   // [2][R]: d loss / d logp of the rows of tile k (parity k & 1)
+    float* bank = gbuf + 2 * R;                           // [3][AN]: loc | isc2 | 64 - ct2   (see below)
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave index as a scalar: uniform control flow
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
     int q = 0, g = 0, sidx = 0, r = 0, a = 0, s_lo = 0, s_hi = -1, r_lo = 0, r_hi = -1;
     bool seg_lane = false;
     // =========================== loader waves ================================================
-    if (wave >= nwaves) {
+    if (wave >= nwaves && wave < nwaves + PACK_NL) {
         const int l = wave - nwaves;
         PFPN_STAMP(1);
         // per-tile DMA items: tile chunks of 64 float4 | action-value chunks of 64 floats | one row-scalar piece
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         // priority: the loaders share SIMDs 1 and 2 with compute waves that are busy with the table transform
         __builtin_amdgcn_s_setprio(3);
         if (T > 0) issue_tile();
-        for (int i = t - nwaves * 64; i < 2 * R + 2 * P + 1; i += PACK_NL * 64) cnt[i] = 0;   // cnt, ready, freed, bank_done
+        for (int i = t - nwaves * 64; i < 2 * R + 2 * P + 3; i += PACK_NL * 64) cnt[i] = 0;   // cnt, ready, freed, bank_done, gdone
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         while (signalled < T) {
             bool can = issued < T && issued - signalled < dmax;
@@ -354,6 +362,8 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                 __builtin_amdgcn_s_sleep(2);               // ring full and nothing of mine in flight
             }
         }
+    } else if (wave >= nwaves) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // row wave: nothing to prepare
     } else {
         // index arithmetic of the compute waves (divisions by the run-time A), also ahead of the barrier
         q = lane >> 2; g = lane & 3;
@@ -420,11 +430,6 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             b_loc[i] = bank[a * N + n];
             b_isc[i] = bank[AN + a * N + n];
             b_ct[i] = bank[2 * AN + a * N + n];
-        }
-        float adv_mean = 0.f, adv_rstd = 1.f, adv_lo = -INFINITY, adv_hi = INFINITY;
-        if (MODE == MODE_PPO) {
-            adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1];
-            adv_lo = ppo.adv_stats[2]; adv_hi = ppo.adv_stats[3];
         }
         PFPN_STAMP(1);
 
@@ -548,69 +553,17 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
             if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1); }
             if (k < 4) PFPN_STAMP(4 + k * 6);
 
-            // ---- row stage of this tile ----------------------------------------------------------
+            // ---- row stage of this tile: done by the row wave; wait for it and pick up my row's gradient ---------
             float my_g = 0.f;                               // d loss / d logp of my row
             if (MODE == MODE_BWD) {
                 if (active) my_g = rpl[slot * 64 + r];
             } else {
-                const int rr_l = r_lo + lane;
-                if (rr_l <= r_hi && rr_l < rows) {
-                    const int target = A * ((k >> 1) + 1);
-                    while (lds_counter(&cnt[(k & 1) * R + rr_l]) < target) __builtin_amdgcn_s_sleep(1);
-                }
+                // (forward mode waits too: it keeps the compute waves within two tiles of the row wave, which is what
+                // the four segment-log-p buffers allow)
+                while (lds_counter(&gdone[k & 1]) < (k >> 1) + 1) __builtin_amdgcn_s_sleep(1);
                 asm volatile("" ::: "memory");
                 if (k < 4) PFPN_STAMP(5 + k * 6);
-                // 16-lane group j sums row r_lo+j's A segment log-probs and runs its loss head; every wave
-                // touching a row forms the identical sum (same lanes, same order).  A wave touches <= 4 rows
-                // (A >= 4, see plan_packed).
-                const int kq = lane >> 4, jl = lane & 15;
-                const int rk = r_lo + kq;
-                const bool rk_ok = rk <= r_hi && rk < rows;
-                float sacc = 0.f;
-                if (rk_ok)
-                    for (int i = jl; i < A; i += 16) sacc += sb[rk * A + i];
-                sacc = quad_sum(sacc);
-                sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
-                sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
-                // the rotation steps associate differently per lane: every lane takes its group's lane 0
-                const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
-                const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
-                const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
-                const float u3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
-                const float s = kq == 0 ? u0 : kq == 1 ? u1 : kq == 2 ? u2 : u3;
-                const int b = row0 + rk;
-                const bool owner = rk_ok && jl == 0 && (rk * A) / PACK_WSEG == wave;   // wave holding the row's first segment
-                float gval = 0.f;
-                if (MODE == MODE_PPO) {
-                    const int rkc = min(rk, R - 1);
-                    const float* rs = rpl + slot * 64;
-                    const float adv = rs[rkc], lpo = rs[16 + rkc], val_b = rs[32 + rkc], vold_b = rs[48 + rkc];
-                    const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
-                    // v_exp_f32 on (s - lpo) * log2 e: |s - lpo| is O(0.1-1), so the product's rounding is far below the
-                    // instruction's own 1 ulp; libm's expf costs ~25 VALU slots in a stage every wave runs for every tile
-                    const float ratio = __builtin_amdgcn_exp2f((s - lpo) * PFPN_LOG2E);
-                    const float sur = ratio * nadv;
-                    const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
-                    const float csur = cr * nadv;
-                    // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
-                    // clip_by_value passes where lo <= ratio <= hi.
-                    const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
-                    gval = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-                    if (owner) {
-                        pol_sum += fminf(sur, csur);
-                        const float dvv = val_b - (adv + vold_b);
-                        val_sum += dvv * dvv;
-                        ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
-                        if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
-                    }
-                }
-                if (owner) logp_out[b] = s;
-                const float g0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 0));
-                const float g1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 16));
-                const float g2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 32));
-                const float g3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gval), 48));
-                const int rel = r - r_lo;
-                my_g = rel == 0 ? g0 : rel == 1 ? g1 : rel == 2 ? g2 : g3;
+                if (MODE == MODE_PPO && active) my_g = gbuf[(k & 1) * R + r];
             }
             if (k < 4) PFPN_STAMP(6 + k * 6);
 
@@ -688,6 +641,77 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
         }
     }
 
+    // =========================== row wave ====================================================
+    if (NRW && wave == nwaves + PACK_NL) {
+        float adv_mean = 0.f, adv_rstd = 1.f, adv_lo = -INFINITY, adv_hi = INFINITY;
+        if (MODE == MODE_PPO) {
+            adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1];
+            adv_lo = ppo.adv_stats[2]; adv_hi = ppo.adv_stats[3];
+        }
+        const int kq = lane >> 4, jl = lane & 15;
+        int slot = 0;
+        for (int k = 0; k < T; ++k) {
+            const int tileid = tile0 + k * tstep;
+            const int row0 = tileid * R;
+            const int rows = min(R, B - row0);
+            const float* sb = segbuf + (k & 3) * nseg;
+            // every row of the tile has all its A segment log-probs (lane j waits for row j; R <= 16)
+            if (lane < rows) {
+                const int target = A * ((k >> 1) + 1);
+                while (lds_counter(&cnt[(k & 1) * R + lane]) < target) __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            // 16-lane group j sums row pg+j's A segment log-probs (fixed lanes, fixed order: reproducible) and runs its
+            // loss head; four rows per pass
+            for (int pg = 0; pg < rows; pg += 4) {
+                const int rk = pg + kq;
+                const bool rk_ok = rk < rows;
+                float sacc = 0.f;
+                if (rk_ok)
+                    for (int i = jl; i < A; i += 16) sacc += sb[rk * A + i];
+                sacc = quad_sum(sacc);
+                sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
+                sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
+                // the rotation steps associate differently per lane: every lane takes its group's lane 0
+                const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
+                const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
+                const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
+                const float u3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
+                const float s = kq == 0 ? u0 : kq == 1 ? u1 : kq == 2 ? u2 : u3;
+                const int b = row0 + rk;
+                const bool owner = rk_ok && jl == 0;
+                if (MODE == MODE_PPO) {
+                    const int rkc = min(rk, R - 1);
+                    const float* rs = rpl + slot * 64;
+                    const float adv = rs[rkc], lpo = rs[16 + rkc], val_b = rs[32 + rkc], vold_b = rs[48 + rkc];
+                    const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
+                    // v_exp_f32 on (s - lpo) * log2 e: |s - lpo| is O(0.1-1), so the product's rounding is far below the
+                    // instruction's own 1 ulp
+                    const float ratio = __builtin_amdgcn_exp2f((s - lpo) * PFPN_LOG2E);
+                    const float sur = ratio * nadv;
+                    const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
+                    const float csur = cr * nadv;
+                    // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
+                    // clip_by_value passes where lo <= ratio <= hi.
+                    const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+                    if (owner) {
+                        gbuf[(k & 1) * R + rk] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+                        pol_sum += fminf(sur, csur);
+                        const float dvv = val_b - (adv + vold_b);
+                        val_sum += dvv * dvv;
+                        ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                        if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
+                    }
+                }
+                if (owner) logp_out[b] = s;
+            }
+            // a wave's LDS operations execute in issue order: the gradients are visible to whoever sees the counter
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(&gdone[k & 1], 1);
+            if (++slot == P) slot = 0;
+        }
+    }
+
     if (MODE == MODE_FWD) return;
     PFPN_STAMP(40);
     // ---- block partials: dloc / dlogstd (/ dlogits column sums) summed over the R segments that share an
@@ -711,21 +735,17 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
                     if (nq == 3) lsb[TS + sidx * N + g + PACK_G * i] = acc_db[i];
                 }
         }
-        // the waves' loss sums ride behind the same barrier (no third one): summed in wave order by one lane of the
-        // last wave, which has nothing else to do
-        if (MODE == MODE_PPO) {
-            pol_sum = wave_sum_dpp(pol_sum);              // held by the 4 group-leading lanes
-            val_sum = wave_sum_dpp(val_sum);
-            if (lane == 0 && wave < nwaves) { lossbuf[wave] = pol_sum; lossbuf[nwaves + wave] = val_sum; }
-        }
         tail_barrier();
         PFPN_STAMP(46);
-        if (t == (int)blockDim.x - 64) {
-            float ps = 0.f, vs = 0.f;
-            if (MODE == MODE_PPO)
-                for (int i = 0; i < nwaves; ++i) { ps += lossbuf[i]; vs += lossbuf[nwaves + i]; }
-            slab[nq * AN + 0] = ps;
-            slab[nq * AN + 1] = vs;
+        // loss sums: the row wave holds them (lanes 0, 16, 32, 48: the row groups' leaders, rows in tile order)
+        if (NRW) {
+            if (wave == nwaves + PACK_NL) {
+                const float ps = wave_sum_dpp(pol_sum), vs = wave_sum_dpp(val_sum);      // lane 63 = total
+                if (lane == 63) { slab[nq * AN + 0] = ps; slab[nq * AN + 1] = vs; }
+            }
+        } else if (t == (int)blockDim.x - 64) {
+            slab[nq * AN + 0] = 0.f;
+            slab[nq * AN + 1] = 0.f;
         }
         // column sums over the R rows of the tile, in row order.  Up to TQ outputs per thread per round with all of
         // their LDS reads issued before the first add (one LDS round trip per round instead of one per output).
@@ -1209,13 +1229,13 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     // block stays <= 12 compute waves and <= 16 rows (A=36: R=4, 9 waves, every lane busy)
     const int R0 = PACK_WSEG / gcd_i(A, PACK_WSEG);
     const int W0 = R0 * A / PACK_WSEG;
-    if (W0 > 14 || R0 > 16) return pl;
+    if (W0 > 13 || R0 > 16) return pl;            // compute + 2 loader + 1 row wave <= 16 waves
     int k = 12 / W0;
     if (k < 1) k = 1;
     while (k > 1 && R0 * k > 16) --k;
     int R = R0 * k;
     static const int env_rows = getenv("PFPN_MIX_ROWS") ? atoi(getenv("PFPN_MIX_ROWS")) : 0;   // tuning knob
-    if (env_rows > 0 && env_rows <= 16 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 14) R = env_rows;
+    if (env_rows > 0 && env_rows <= 16 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 13) R = env_rows;
     if (R > B) R = B;                                   // small batches: one partial tile
     const int waves = (R * A + PACK_WSEG - 1) / PACK_WSEG;      // compute waves
     pl.R = R;
@@ -1228,7 +1248,7 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     if (env_p >= pmin && env_p <= 8) P = env_p;
     size_t small = 0;
     for (;; --P) {
-        small = (size_t)(4 * R * A + 2 * R + 2 * P + 2 * waves + 16 + 3 * AN) * 4;
+        small = (size_t)(4 * R * A + 2 * R + 2 * P + 2 * waves + 2 * R + 24 + 3 * AN) * 4;   // + gdone, gbuf [2][R]
         if (P * plane + small <= PACK_MAX_LDS || P <= pmin) break;
     }
     pl.P = P;
@@ -1240,7 +1260,7 @@ static PackPlan plan_packed(int B, int A, int N, const void* logits, const void*
     if (env_pcu > 0) per_cu = env_pcu;
     const int cap = cu_count() * per_cu;
     pl.grid = ntiles < cap ? ntiles : cap;
-    pl.ok = pl.lds <= PACK_MAX_LDS && waves <= 14 && R <= 16;
+    pl.ok = pl.lds <= PACK_MAX_LDS && waves <= 13 && R <= 16;
     return pl;
 }
 
@@ -1256,15 +1276,16 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PACK_MAX_LDS);        \
             big_lds_ok = true;                                                                              \
         }                                                                                                   \
-        hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(pl.threads), pl.lds, st, logits, x, \
+        hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(threads), pl.lds, st, logits, x, \
                            loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.P, pl.ntiles / pl.grid,            \
                            pl.ntiles % pl.grid, logp, pmix, dlogits, dx, partial, ppo);                     \
     } while (0)
 #define PFPN_LAUNCH_PACKED(NN)                                                  \
     do {                                                                        \
-        if (pl.threads <= 704) PFPN_LAUNCH_PACKED_T(NN, 704);                   \
+        if (threads <= 768) PFPN_LAUNCH_PACKED_T(NN, 768);                      \
         else PFPN_LAUNCH_PACKED_T(NN, PACK_BLOCK);                              \
     } while (0)
+    const int threads = pl.threads + (MODE != MODE_BWD ? 64 : 0);       // + the row wave (forward / PPO modes)
     switch (N) {
         case 35: PFPN_LAUNCH_PACKED(35); break;
         case 50: PFPN_LAUNCH_PACKED(50); break;
