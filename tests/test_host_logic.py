@@ -316,3 +316,31 @@ def test_evaluator_plays_whole_episodes_past_max_iterations(oracle):
     w.after_episode = after_episode
     w.work(None, max_iterations=100)
     assert episodes == [50, 50]
+
+
+def test_polling_evaluator_follows_new_checkpoints(oracle, monkeypatch, capsys):
+    """DistributedModel.evaluate (reference distributed_model.py:446-496): wait for a checkpoint newer than the last one
+    evaluated, restore it, average n episodes, print one [PERFORM] line per checkpoint; stop once the condition fails
+    and nothing new has appeared."""
+    from pfpn_amd import checkpoint
+    from pfpn_amd.models import DPPOWorker, SyncModel
+    net = StubNet(oracle, trainable=False)
+    model = SyncModel(lambda **kw: DPPOWorker(lr_critic=1e-4, lr_actor=1e-4, norm_clip=1.0, opt_epochs=1, batch_size=32,
+                                              unroll_length=128, **kw),
+                      lambda name, render: SyntheticDeepMimicEnv(episode_length=50, seed=3),
+                      lambda env, trainable: net, checkpoint_dir="unused", seed=3)
+    seen = iter([None, "ckpt/model.ckpt-10", "ckpt/model.ckpt-10", "ckpt/model.ckpt-10", "ckpt/model.ckpt-20"])
+    state = {"last": None, "polls": 0}
+
+    def latest(directory):
+        state["polls"] += 1
+        state["last"] = next(seen, state["last"])
+        return state["last"]
+    restored = []
+    monkeypatch.setattr(checkpoint, "latest_checkpoint", latest)
+    monkeypatch.setattr(SyncModel, "restore", lambda self, worker, prefix=None: restored.append(prefix) or prefix)
+    worker = model.evaluate(n=2, evaluation_cond=lambda: state["polls"] < 8, poll_seconds=0.0)
+    assert restored == ["ckpt/model.ckpt-10", "ckpt/model.ckpt-20"]          # each new checkpoint exactly once
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("[PERFORM]")]
+    assert len(lines) == 2 and "Life Time: 50.0" in lines[0]                  # 2 averaged episodes of 50 steps each
+    assert worker.request_stop and state["polls"] >= 8
