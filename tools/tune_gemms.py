@@ -1,7 +1,9 @@
 """Offline GEMM selection for the learner step: run the step under PyTorch TunableOp with a generous budget, write the
 chosen hipBLASLt / rocBLAS solutions to a CSV, then time the step with exactly that file loaded and tuning OFF.
-Usage (GPU box): python tools/tune_gemms.py <out.csv> [iterations] ; the result is committed as
-pfpn_amd/tuned/tunableop_gfx950.csv and loaded by bench.py (pfpn_amd/tuning.py)."""
+Usage (GPU box): python tools/tune_gemms.py <out.csv> [iterations] [base.csv] ; the result is committed as
+pfpn_amd/tuned/tunableop_gfx950.csv and loaded by bench.py (pfpn_amd/tuning.py).  With `base.csv` the selections already in
+that file are kept and only the shapes it lacks are tuned (round 2: the 512 / 2048-row shards of the strong-scaling run and
+the 128 x 256 head of BASELINE.json config 5)."""
 import os, sys, time
 import numpy as np, torch
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -13,6 +15,8 @@ torch.cuda.tunable.tuning_enable(True)
 torch.cuda.tunable.set_max_tuning_duration(200)
 torch.cuda.tunable.set_max_tuning_iterations(iters)
 torch.cuda.tunable.set_filename(out)
+if len(sys.argv) > 3:
+    assert torch.cuda.tunable.read_file(sys.argv[3]), "base selection rejected (validators differ?)"
 from test_gpu_dppo_step import make_net, make_batch
 from test_gpu_sac_step import make_net as make_sac
 from pfpn_amd.models import SyncReplicasApplier
@@ -32,10 +36,20 @@ def dppo(B):
 net, opt, args = dppo(4096)
 for _ in range(3):
     net.train_device(opt, *args)
-for B in (32, 64, 256, 1024):                      # minibatch sizes of the shipped settings / SAC replay batches
+for B in (32, 64, 256, 512, 1024, 2048):           # minibatch sizes of the shipped settings / SAC replay batches / DP shards
     n2, o2, a2 = dppo(B)
     for _ in range(2):
         n2.train_device(o2, *a2)
+# BASELINE.json config 5 (128 action dims x 256 particles): one GPU's 1024-row shard
+from pfpn_amd.networks import ParticleFilteringClipPPONetwork
+import test_gpu_dppo_step as tds
+c5 = tds.make_net(dev, A=128, particles=256)
+c5o = SyncReplicasApplier(c5, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+c5b = make_batch(rng, 1024, A=128); c5b["log_prob"] = np.full(1024, -300.0, np.float32)
+c5a = [torch.from_numpy(c5b[k]).to(dev) for k in ("state", "action", "value", "log_prob", "advantage")]
+for _ in range(2):
+    c5.train_device(c5o, *c5a)
+del c5, c5o, c5a
 # rollout inference (one state per call, and a pool of environments per call)
 for E in (1, 8, 64):
     st = torch.randn(E, 197, device=dev)
