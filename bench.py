@@ -246,19 +246,36 @@ def main():
         reps = 200
 
         def time_fused(finalize):
-            for _ in range(10):
+            """device time per launch: 20 launches captured in one hipGraph and replayed 10 times between two HIP events on
+            the replay stream.  (Eager back-to-back launches measure the HOST: one call of the Python wrapper costs
+            ~16 us, more than the kernel since round 2.)"""
+            def call():
                 kernels.ppo_mixture_fwd_bwd(logits, action, net.loc, net.logstd, logp_old, adv, net.value_buf, value_old,
                                             stats, 0.2, 0.5, out=net.train_out, dbias=net.store.g("actor/fc_policy/bias"),
                                             finalize=finalize)
+            for _ in range(5):
+                call()
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            per_graph, replays = 20, reps // 20
+            with torch.cuda.stream(side):
+                call()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(per_graph):
+                        call()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
             ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ea.record()
-            for _ in range(reps):
-                kernels.ppo_mixture_fwd_bwd(logits, action, net.loc, net.logstd, logp_old, adv, net.value_buf, value_old,
-                                            stats, 0.2, 0.5, out=net.train_out, dbias=net.store.g("actor/fc_policy/bias"),
-                                            finalize=finalize)
+            for _ in range(replays):
+                g.replay()
             eb.record()
             torch.cuda.synchronize()
-            return ea.elapsed_time(eb) * 1e3 / reps
+            return ea.elapsed_time(eb) * 1e3 / (per_graph * replays)
 
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         # the dominant kernel alone (its launch back to back, the slab finalize skipped) -- the number rocprofv3's
@@ -309,11 +326,13 @@ def main():
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source, "algorithmic_bytes": ab, "us_per_launch": us, "launches_timed": reps,
                            "us_in_step_event_pairs": us_in_step, "us_with_slab_finalize_launch": us_op,
-                           "note": "us_per_launch: HIP events around 200 back-to-back launches of the kernel alone (in "
+                           "note": "us_per_launch: HIP events around 200 launches of the kernel alone, replayed from a hipGraph "
+                                   "so that the host's launch rate is out of the measurement (in "
                                    "the step its slab sums are finished by the single deferred reduce launch); "
                                    "us_in_step_event_pairs: an event pair around each call inside 100 eager learner "
                                    "steps (includes the dispatch gap); "
-                                   "42 MB per launch: start-up and VALU-issue bound at this size (DESIGN.md section 4); "
+                                   "42 MB per launch: four tiles per block -- start-up, tail and one VALU-issue-bound SIMD "
+                                   "(DESIGN.md section 4); "
                                    "the 1 GiB shape of BASELINE.json config 5 is in roofline_stress"}
         # the same mixture math on the 1 GiB stress shape (BASELINE.json config 5, one GPU's shard)
         try:
