@@ -785,6 +785,577 @@ __global__ __launch_bounds__(MAXT) void k_mix_packed(
 }
 
 // ---------------------------------------------------------------------------------------
+// tile path ("dims x rows" lanes; loader / compute / row / storer waves around an LDS ring)
+//
+// Same ring as above -- LDS-DMA loader waves stream R = 4-row tiles into P planes laid out as in HBM -- with three
+// changes that came out of the phase stamps of the wave-sliced kernel (profiles/r02_mix_packed_stamps.txt):
+//  * LANE MAP.  Compute wave w owns action dims [4w, 4w+4) of ALL four rows of a tile: lane = 16 d + 4 r + g
+//    (d dim, r row, g particle quarter).  The four lanes that hold the same (a, n) set for the four rows then sit in
+//    one 16-lane DPP row, 4 lanes apart: the batch sums (dloc, dlogstd, fc_policy bias gradient) are finished with two
+//    row_ror DPP adds per value and leave straight from registers -- the old tail (stage 27 values per lane through
+//    LDS, two block barriers, column sums: 4.4 k cycles after the SLOWEST wave arrived) is gone; no barrier follows
+//    the start-up one.
+//  * STORER waves copy a finished plane LDS -> HBM (whole 1-KiB wave stores, line-aligned whatever the wave count;
+//    the 2,240-B wave slices split 128-B lines: 1.07x traffic).  The compute waves, the critical path, no longer spend
+//    ~600-800 cycles per tile reading their slice back and storing it.
+//  * START-UP.  The first tile's DMAs are issued by every non-compute wave at once (the two loaders alone needed
+//    ~2,300 cycles to get 24 DMAs out), the loaders run on into tile 1, and the start-up barrier publishes tile 0, the
+//    particle bank and the zeroed counters together.
+// ---------------------------------------------------------------------------------------
+constexpr int TK_R = 4;                              // rows per tile
+constexpr int TK_NL = 2;                             // loader waves
+constexpr int TK_NS = 2;                             // storer waves (modes that write dlogits)
+
+template <int N, int MODE>
+__global__ __launch_bounds__(1024) void k_mix_tile(
+    const float* __restrict__ logits, const float* __restrict__ x,
+    const float* __restrict__ loc, const float* __restrict__ logstd,
+    const float* __restrict__ dlogp_in,      // MODE_BWD: [B]
+    int B, int A, int tanh_mode, int P,      // P: LDS planes in the ring
+    int tbase, int trem,                     // tiles per block = tbase (+1 for the first trem blocks)
+    float* __restrict__ logp_out,            // [B]   (FWD, PPO)
+    float* __restrict__ pmix_out,            // [B,A] optional
+    float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
+    float* __restrict__ dx_out,              // [B,A] optional (BWD)
+    float* __restrict__ partial,             // [grid][nq*A*N + 4] (BWD, PPO)
+    PpoArgs ppo)
+{
+    constexpr int R = TK_R;
+    constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
+    constexpr int NPK = (NP - 1) / 2;                     // particle pairs that always exist (packed fp32 math)
+    constexpr int NRW = (MODE != MODE_BWD) ? 1 : 0;       // row wave
+    constexpr int NS = (MODE != MODE_FWD) ? TK_NS : 0;    // storer waves
+    extern __shared__ float4 smem4[];
+    const int AN = A * N;
+    const int nseg = R * A;                               // segments per full tile
+    const int NC = (A + 3) >> 2;                          // compute waves
+    const int TS = R * AN;                                // floats per plane
+    const int XS = (nseg + 63) & ~63;                     // floats per action-value plane
+    // LDS map (floats):  [P][TS] tiles | [P][XS] action values | [P][64] row scalars | [4][nseg] segment log p
+    //                    | ints: [2][R] row counters | [P] ready | [P] freed | [P] bdone | [2] gdone
+    //                    | [2][R] row gradients | [3][AN] particle bank
+    float* tile = reinterpret_cast<float*>(smem4);
+    float* xpl = tile + (size_t)P * TS;
+    float* rpl = xpl + P * XS;                            // [P][4][16]: adv, logp_old, value, value_old (PPO) | dlogp (BWD)
+    float* segbuf = rpl + P * 64;
+    int* cnt = reinterpret_cast<int*>(segbuf + 4 * nseg);
+    int* ready = cnt + 2 * R;
+    int* freed = ready + P;
+    int* bdone = freed + P;                               // compute waves done with the backward of the tile in this plane
+    int* gdone = bdone + P;                               // [2]: tiles of this parity whose row stage is complete
+    float* gbuf = reinterpret_cast<float*>(gdone + 2);    // [2][R]: d loss / d logp of the rows of tile k (parity k & 1)
+    float* bank = gbuf + 2 * R;                           // [3][AN]: loc | isc2 | 64 - ct2
+
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int nwv = (int)(blockDim.x >> 6);               // all waves
+#ifdef PFPN_ENABLE_STAMPS
+    unsigned long long* stamps = g_stamps;
+#endif
+    PFPN_STAMP(0);
+    const int T = tbase + ((int)blockIdx.x < trem ? 1 : 0);                    // my tiles: a contiguous run
+    const int tile0 = (int)blockIdx.x * tbase + min((int)blockIdx.x, trem);
+
+    // per-tile DMA items: tile chunks of 64 float4 | action-value chunks of 64 floats | one row-scalar piece
+    const int nct = (R * AN / 4 + 63) >> 6;
+    const int ncx = (nseg + 63) >> 6;
+    const int nrs = (MODE == MODE_FWD) ? 0 : 1;
+    const int M = nct + ncx + nrs;
+    const unsigned tile_b = (unsigned)(uintptr_t)tile, xpl_b = (unsigned)(uintptr_t)xpl, rpl_b = (unsigned)(uintptr_t)rpl;
+    // one item of tile `kt` (block-local number) into plane `slot`; short tiles clamp their addresses, never skip
+    auto issue_item = [&](int kt, int it_, int slot) __attribute__((always_inline)) {
+        const int row0 = (tile0 + kt) * R, rows = min(R, B - row0);
+        if (it_ < nct) {
+            const int nv4 = rows * AN / 4;
+            const int i4 = it_ * 64 + lane;
+            if (i4 < R * AN / 4)                               // never past the plane
+                dma16(reinterpret_cast<const float4*>(logits + (size_t)row0 * AN) + min(i4, nv4 - 1),
+                      __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + it_ * 1024)));
+        } else if (it_ < nct + ncx) {
+            const int c = it_ - nct;
+            const int i = c * 64 + lane;
+            dma4(x + (size_t)row0 * A + min(i, rows * A - 1),
+                 __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + c * 64) * 4)));
+        } else {
+            // lane j -> array j/16, row j%16
+            const int arr = lane >> 4, rw = min(lane & 15, rows - 1);
+            const float* src;
+            if (MODE == MODE_PPO)
+                src = (arr == 0 ? ppo.adv : arr == 1 ? ppo.logp_old : arr == 2 ? ppo.value : ppo.value_old) + row0 + rw;
+            else
+                src = dlogp_in + row0 + rw;
+            dma4(src, __builtin_amdgcn_readfirstlane(rpl_b + (unsigned)(slot * 64 * 4)));
+        }
+    };
+
+    // Start-up.  Compute wave w needs the particle tables of ITS four dims only (<= 4 N consecutive elements): it
+    // loads them itself (<= BKU per lane, coalesced), transforms them and passes them to its lanes through its own
+    // corner of the LDS bank -- no other wave is involved, so the bank costs no block-wide wait.
+    constexpr int BKU = (4 * N + 63) / 64;                                    // table elements per lane
+    float bank_ls[BKU], bank_lc[BKU];
+    if (wave < NC) {
+        const int e0 = wave * 4 * N, ne = min(4, A - wave * 4) * N;
+#pragma unroll
+        for (int u = 0; u < BKU; ++u) {
+            const int i = e0 + min(lane + 64 * u, ne - 1);
+            bank_ls[u] = logstd[i];
+            bank_lc[u] = loc[i];
+        }
+    } else if (T > 0) {
+        // every other wave: its share of the first tile, at raised priority (these waves share SIMDs with compute
+        // waves that are about to run the table transform).  Full tile: pointer bumps only.
+        __builtin_amdgcn_s_setprio(3);
+        const int sw = wave - NC, nsv = nwv - NC;
+        const int rows0 = min(R, B - tile0 * R);
+        if (rows0 == R) {
+            const char* gp = reinterpret_cast<const char*>(logits + (size_t)tile0 * R * AN) + (size_t)(sw * 64 + lane) * 16;
+            unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(sw * 1024));
+            int c = sw;
+            for (; c < nct - 1; c += nsv) {
+                dma16(gp, lb);
+                gp += nsv * 1024;
+                lb += nsv * 1024;
+            }
+            if (c == nct - 1 && c * 64 + lane < R * AN / 4) dma16(gp, lb);
+            for (int it_ = nct + ((sw - nct) % nsv + nsv) % nsv; it_ < M; it_ += nsv) issue_item(0, it_, 0);
+        } else {
+            for (int it_ = sw; it_ < M; it_ += nsv) issue_item(0, it_, 0);
+        }
+        PFPN_STAMP(3);
+    }
+
+    // =========================== loader waves ================================================
+    if (wave >= NC && wave < NC + TK_NL) {
+        const int l = wave - NC;
+        const int Q = (M - l + TK_NL - 1) / TK_NL;         // my DMAs per tile from tile 1 on (constant)
+        int dmax = PACK_DEPTH;                             // tiles a loader keeps in flight
+        while (dmax > 1 && (dmax - 1) * Q > 63) --dmax;
+        if (dmax > P) dmax = P;
+        const int nfree = (MODE == MODE_FWD) ? NC : NS;    // who hands a plane back
+        int issued = (T > 0) ? 1 : 0, signalled = issued;  // tile 0: issued above, published by the start-up barrier
+        int slot_i = (P > 1) ? 1 : 0, wrap_i = (P > 1) ? 0 : 1, slot_s = slot_i;
+        if (T == 0) { slot_i = 0; wrap_i = 0; slot_s = 0; }
+        auto issue_tile = [&]() __attribute__((always_inline)) {
+            const int row0 = (tile0 + issued) * R, rows = min(R, B - row0);
+            const int slot = slot_i;
+            if (rows == R) {
+                // full tile: per-DMA overhead is a pointer bump (a wave issues at most one instruction per ~4 cycles)
+                const char* gp = reinterpret_cast<const char*>(logits + (size_t)row0 * AN) + (size_t)(l * 64 + lane) * 16;
+                unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + l * 1024));
+                int c = l;
+                for (; c < nct - 1; c += TK_NL) {
+                    dma16(gp, lb);
+                    gp += TK_NL * 1024;
+                    lb += TK_NL * 1024;
+                }
+                if (c == nct - 1 && c * 64 + lane < R * AN / 4) dma16(gp, lb);       // last chunk: partial (never empty)
+                for (int it_ = nct + ((l - nct) % TK_NL + TK_NL) % TK_NL; it_ < M; it_ += TK_NL) issue_item(issued, it_, slot);
+            } else {
+                for (int it_ = l; it_ < M; it_ += TK_NL) issue_item(issued, it_, slot);
+            }
+            ++issued;
+            if (++slot_i == P) { slot_i = 0; ++wrap_i; }
+        };
+        // run on into tile 1 (a fresh plane when P > 1), then zero the counters and meet the block
+        bool t1 = false;
+        if (T > 1 && P > 1 && dmax > 1) { issue_tile(); t1 = true; }
+        for (int i = t - NC * 64; i < 2 * R + 3 * P + 2; i += TK_NL * 64)
+            cnt[i] = (i == 2 * R && T > 0) ? TK_NL : 0;    // ready[0] = landed (cnt, ready, freed, bdone, gdone)
+        // my share of tile 0 has landed when only tile 1's DMAs are outstanding (in-order counter)
+        if (t1) wait_vmcnt(Q); else wait_vmcnt(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        PFPN_STAMP(4);
+        while (signalled < T) {
+            bool can = issued < T && issued - signalled < dmax;
+            if (can && wrap_i > 0)                         // plane still in use?
+                can = lds_counter(&freed[slot_i]) >= nfree * wrap_i;
+            if (can) {
+                issue_tile();
+            } else if (issued > signalled) {
+                wait_vmcnt(Q * (issued - signalled - 1));  // oldest unsignalled tile: everything after it may stay in flight
+                if (lane == 0) atomicAdd(&ready[slot_s], 1);
+                ++signalled;
+                if (++slot_s == P) slot_s = 0;
+                if (signalled <= 4) PFPN_STAMP(4 + (signalled - 1) * 6);
+            } else {
+                __builtin_amdgcn_s_sleep(2);               // ring full and nothing of mine in flight
+            }
+        }
+        return;
+    }
+
+    // =========================== row wave ====================================================
+    if (NRW && wave == NC + TK_NL) {
+        float pol_sum = 0.f, val_sum = 0.f;
+        float adv_mean = 0.f, adv_rstd = 1.f, adv_lo = -INFINITY, adv_hi = INFINITY;
+        if (MODE == MODE_PPO) {                            // (loads in flight across the start-up wait)
+            adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1];
+            adv_lo = ppo.adv_stats[2]; adv_hi = ppo.adv_stats[3];
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // (stays at raised priority: every compute wave waits for this wave's few instructions once per tile)
+        const int kq = lane >> 4, jl = lane & 15;
+        int slot = 0;
+        for (int k = 0; k < T; ++k) {
+            const int row0 = (tile0 + k) * R;
+            const int rows = min(R, B - row0);
+            const float* sb = segbuf + (k & 3) * nseg;
+            // every row of the tile has all its A segment log-probs (lane j waits for row j)
+            if (lane < rows) {
+                const int target = A * ((k >> 1) + 1);
+                while (lds_counter(&cnt[(k & 1) * R + lane]) < target) { }
+            }
+            asm volatile("" ::: "memory");
+            // 16-lane group kq sums row kq's A segment log-probs (fixed lanes, fixed order: reproducible) and runs its
+            // loss head
+            const int rk = kq;
+            const bool rk_ok = rk < rows;
+            float sacc = 0.f;
+            if (rk_ok)
+                for (int i = jl; i < A; i += 16) sacc += sb[rk * A + i];
+            sacc = quad_sum(sacc);
+            sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
+            sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
+            // the rotation steps associate differently per lane: every lane takes its group's lane 0
+            const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
+            const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
+            const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
+            const float u3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
+            const float s = kq == 0 ? u0 : kq == 1 ? u1 : kq == 2 ? u2 : u3;
+            const int b = row0 + rk;
+            const bool owner = rk_ok && jl == 0;
+            if (MODE == MODE_PPO) {
+                const float* rs = rpl + slot * 64;
+                const float adv = rs[rk], lpo = rs[16 + rk], val_b = rs[32 + rk], vold_b = rs[48 + rk];
+                const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
+                // v_exp_f32 on (s - lpo) * log2 e: |s - lpo| is O(0.1-1), so the product's rounding is far below the
+                // instruction's own 1 ulp
+                const float ratio = __builtin_amdgcn_exp2f((s - lpo) * PFPN_LOG2E);
+                const float sur = ratio * nadv;
+                const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
+                const float csur = cr * nadv;
+                // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
+                // clip_by_value passes where lo <= ratio <= hi.
+                const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+                if (owner) {
+                    gbuf[(k & 1) * R + rk] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+                    pol_sum += fminf(sur, csur);
+                    const float dvv = val_b - (adv + vold_b);
+                    val_sum += dvv * dvv;
+                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                    if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
+                }
+            }
+            if (owner) logp_out[b] = s;
+            // a wave's LDS operations execute in issue order: the gradients are visible to whoever sees the counter
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(&gdone[k & 1], 1);
+            if (k < 4) PFPN_STAMP(5 + k * 6);
+            if (++slot == P) slot = 0;
+        }
+        if (MODE == MODE_PPO) {
+            // loss sums (lanes 0, 16, 32, 48 hold them: rows in tile order)
+            const int nq = ppo.want_db ? 3 : 2;
+            float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
+            const float ps = wave_sum_dpp(pol_sum), vs = wave_sum_dpp(val_sum);      // lane 63 = total
+            if (lane == 63) { slab[nq * AN + 0] = ps; slab[nq * AN + 1] = vs; }
+        }
+        return;
+    }
+
+    // =========================== storer waves ================================================
+    if (NS && wave >= NC + TK_NL + NRW) {
+        const int s_ = wave - (NC + TK_NL + NRW);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        constexpr int SU = 4;                              // float4 per lane in flight
+        int slot = 0, lap = 0;
+        for (int k = 0; k < T; ++k) {
+            const int row0 = (tile0 + k) * R, rows = min(R, B - row0);
+            const int nv4 = rows * AN / 4;
+            while (lds_counter(&bdone[slot]) < NC * (lap + 1)) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            const float4* src = reinterpret_cast<const float4*>(tile + (size_t)slot * TS);
+            float4* dst = reinterpret_cast<float4*>(dlogits + (size_t)row0 * AN);
+            for (int c0 = s_; c0 * 64 < nv4; c0 += SU * NS) {
+                float4 v[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i4 = (c0 + u * NS) * 64 + lane;
+                    v[u] = src[min(i4, nv4 - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i4 = (c0 + u * NS) * 64 + lane;
+                    if (i4 < nv4) dst[i4] = v[u];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of the plane have returned
+            if (lane == 0) atomicAdd(&freed[slot], 1);
+            if (k < 4) PFPN_STAMP(8 + k * 6);
+            if (++slot == P) { slot = 0; ++lap; }
+        }
+        return;
+    }
+
+    // =========================== compute waves ===============================================
+    // lane = 16 d + 4 r + g: dim 4*wave + d, row r of the tile, particles g, g+4, ...
+    const int d = lane >> 4, r = (lane >> 2) & 3, g = lane & 3;
+    const int a_raw = wave * 4 + d;
+    const bool dim_ok = a_raw < A;
+    const int a = dim_ok ? a_raw : A - 1;                  // clamped: addresses stay inside the plane
+    const int sidx = r * A + a;                            // segment slot in the tile
+    const int ndw = min(4, A - wave * 4);                  // my dims (per row)
+    float* seg0 = tile + sidx * N + g;
+    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
+    float b_loc[NP], b_isc[NP], b_ct[NP];
+    float acc_loc[NP], acc_ls[NP], acc_db[NP];
+    {
+        // The tables of my wave's dims, transformed once per wave:
+        //   scale = exp(logstd), cterm = 0.5log(2pi)+log(scale) as the reference graph computes them, pre-scaled
+        //   to base 2:  z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale
+        //   +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
+        //   down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
+        const int e0 = wave * 4 * N, ne = ndw * N;
+#pragma unroll
+        for (int u = 0; u < BKU; ++u) {
+            const int j = lane + 64 * u;
+            if (j < ne) {
+                const float sc = expf(bank_ls[u]);
+                bank[e0 + j] = bank_lc[u];
+                bank[AN + e0 + j] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
+                bank[2 * AN + e0 + j] = 64.0f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+            }
+        }
+        PFPN_STAMP(43);
+        // same wave wrote what it now reads: a wave's LDS operations execute in issue order
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int n = min(g + PACK_G * i, N - 1);
+            b_loc[i] = bank[a * N + n];
+            b_isc[i] = bank[AN + a * N + n];
+            b_ct[i] = bank[2 * AN + a * N + n];
+            acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile 0 landed, counters zeroed
+        PFPN_STAMP(42);
+    }
+    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
+    PFPN_STAMP(1);
+
+    // tile k of this block lives in plane k % P; (slot, lap) = (k % P, k / P) are carried as counters
+    auto wait_ready = [&](int slot, int lap) __attribute__((always_inline)) {
+        const int target = TK_NL * (lap + 1);
+        while (lds_counter(&ready[slot]) < target) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    // forward of tile k: softmax numerators stay in the plane, per-segment log p is published to
+    // segbuf[k mod 4] and the row arrival counters of that parity are bumped.
+    auto forward = [&](int k, int slot, float& p_o, float& inv_o) __attribute__((always_inline)) {
+        const int row0 = (tile0 + k) * R;
+        const int rows = min(R, B - row0);
+        const bool active = dim_ok && r < rows;
+        float* seg = seg0 + slot * TS;
+        // four log-p buffers: a wave that has run ahead writes tile k+2's (and, one iteration later, k+3's)
+        // values while the row wave may still be summing tile k's; it cannot reach k+4 before the row wave
+        // has finished k+2
+        float* sb = segbuf + (k & 3) * nseg;
+        float inv_sum = 0.f, p = 0.f;
+        if (active) {
+            const float xval = xpl[slot * XS + sidx];
+            // particles in pairs (2k, 2k+1): v_pk_mul/add/fma_f32 give two results per issue slot; the last one or
+            // two particles -- the only ones that may not exist -- stay scalar.  The maximum is taken on l*log2(e).
+            v2f lp2[NPK > 0 ? NPK : 1];
+            float lpt[NP - 2 * NPK];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) {
+                lp2[k] = (v2f){seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]} * PFPN_LOG2E;
+                mx = fmaxf(fmaxf(lp2[k].x, lp2[k].y), mx);
+            }
+#pragma unroll
+            for (int i = 2 * NPK; i < NP; ++i) {
+                lpt[i - 2 * NPK] = 0.f;
+                if (i < NP - 1 || last_ok) {
+                    lpt[i - 2 * NPK] = seg[PACK_G * i] * PFPN_LOG2E;
+                    mx = fmaxf(mx, lpt[i - 2 * NPK]);
+                }
+            }
+            mx = quad_max(mx);
+            v2f s2 = {0.f, 0.f}, n2 = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NPK; ++k) {
+                // raw v_exp_f32 twice per particle: softmax numerator, and numerator * Normal.prob * 2^64 in one go
+                const v2f le = lp2[k] - mx;
+                const v2f z = (xval - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * (v2f){b_isc[2 * k], b_isc[2 * k + 1]};
+                const v2f arg = le + __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
+                const v2f en = {__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
+                if (MODE != MODE_FWD) { seg[PACK_G * 2 * k] = en.x; seg[PACK_G * (2 * k + 1)] = en.y; }
+                s2 += en;
+                n2 += (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+            }
+            float sum = s2.x + s2.y, num = n2.x + n2.y;
+#pragma unroll
+            for (int i = 2 * NPK; i < NP; ++i) {
+                if (i < NP - 1 || last_ok) {
+                    const float le = lpt[i - 2 * NPK] - mx;
+                    const float zq = (xval - b_loc[i]) * b_isc[i];
+                    const float en = __builtin_amdgcn_exp2f(le);
+                    if (MODE != MODE_FWD) seg[PACK_G * i] = en;
+                    sum += en;
+                    num += __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
+                }
+            }
+            sum = quad_sum(sum);
+            num = quad_sum(num);
+            inv_sum = __builtin_amdgcn_rcpf(sum);
+            p = (num * two_m64) * inv_sum;
+            if (p < 1.401298464324817e-45f) p = 0.f;   // below the smallest fp32 denormal: the reference's p is 0
+            if (g == 0) {
+                float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;      // v_log_f32 is log2
+                if (tanh_mode) lp -= tanh_log_det(xval);
+                if (pmix_out) pmix_out[(size_t)row0 * A + sidx] = p;
+                sb[sidx] = lp;
+            }
+        }
+        p_o = p; inv_o = inv_sum;
+        if (MODE != MODE_BWD) {
+            // publish: my dims of every live row have arrived.  segbuf and cnt both live in LDS, and a wave's LDS
+            // operations are executed in issue order, so the ds_write of log p is visible to whoever observes the
+            // later ds_add.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < rows) atomicAdd(&cnt[(k & 1) * R + lane], ndw);
+        }
+        if (MODE == MODE_FWD) {
+            // forward mode never stores the plane: it is free as soon as my reads of it are done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) atomicAdd(&freed[slot], 1);
+        }
+    };
+
+    float p = 0.f, inv_sum = 0.f, p1 = 0.f, inv1 = 0.f;
+    if (T > 0) forward(0, 0, p, inv_sum);                  // tile 0: published by the start-up barrier
+    PFPN_STAMP(2);
+
+    int slot = 0, slot_n = (P > 1) ? 1 : 0, lap_n = (P > 1) ? 0 : 1;       // plane of tile k | plane and lap of tile k+1
+    for (int k = 0; k < T; ++k) {
+        const int row0 = (tile0 + k) * R;
+        const int rows = min(R, B - row0);
+        float* seg = seg0 + slot * TS;
+        const bool active = dim_ok && r < rows;
+        if (k < 4) PFPN_STAMP(3 + k * 6);
+
+        // ---- forward of the next tile --------------------------------------------------------
+        if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1); }
+        if (k < 4) PFPN_STAMP(4 + k * 6);
+
+        // ---- row stage of this tile: done by the row wave; wait for it and pick up my row's gradient ---------
+        float my_g = 0.f;                               // d loss / d logp of my row
+        if (MODE == MODE_BWD) {
+            if (active) my_g = rpl[slot * 64 + r];
+        } else {
+            // (forward mode waits too: it keeps the compute waves within two tiles of the row wave, which is what
+            // the four segment-log-p buffers allow)
+            while (lds_counter(&gdone[k & 1]) < (k >> 1) + 1) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            if (MODE == MODE_PPO && active) my_g = gbuf[(k & 1) * R + r];
+        }
+        if (k < 4) PFPN_STAMP(6 + k * 6);
+
+        if (MODE != MODE_FWD) {
+            // ---- backward on my quarter (dlogits overwrite the LDS slot) -----------------------
+            if (active) {
+                const float xv = xpl[slot * XS + sidx];
+                const float q_ = guard_finite(my_g * __builtin_amdgcn_rcpf(p));
+                const float qs = q_ * inv_sum;
+                const float qp = qs * p;
+                const float qs64 = qs * two_m64;
+                float dxa = 0.f;
+                v2f dx2 = {0.f, 0.f};
+                // e*phi is re-formed from the numerator kept in LDS (one v_exp) instead of being held in registers
+                // across the next tile's forward.  Pairs of particles, as in the forward.
+#pragma unroll
+                for (int k = 0; k < NPK; ++k) {
+                    const v2f en = {seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]};
+                    const v2f isc = {b_isc[2 * k], b_isc[2 * k + 1]};
+                    const v2f z = (xv - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * isc;            // z / c
+                    const v2f g2 = __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
+                    const v2f tt = (en * (v2f){__builtin_amdgcn_exp2f(g2.x), __builtin_amdgcn_exp2f(g2.y)}) * qs64;   // q * w_n * phi_n
+                    const v2f dlg = __builtin_elementwise_fma(-en, (v2f){qp, qp}, tt);            // q * w_n * (phi_n - p)
+                    seg[PACK_G * 2 * k] = dlg.x; seg[PACK_G * (2 * k + 1)] = dlg.y;
+                    if (MODE == MODE_PPO) { acc_db[2 * k] += dlg.x; acc_db[2 * k + 1] += dlg.y; }   // fc_policy bias gradient
+                    const v2f al = __builtin_elementwise_fma(tt, z, (v2f){acc_loc[2 * k], acc_loc[2 * k + 1]});     // scaled by isc*c in the tail
+                    acc_loc[2 * k] = al.x; acc_loc[2 * k + 1] = al.y;
+                    const v2f as = __builtin_elementwise_fma(
+                        tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}),
+                        (v2f){acc_ls[2 * k], acc_ls[2 * k + 1]});                                 // tt*(z^2 - 1)
+                    acc_ls[2 * k] = as.x; acc_ls[2 * k + 1] = as.y;
+                    if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, isc * PFPN_2LN2, dx2);     // isc*c = isc2*2ln2
+                }
+#pragma unroll
+                for (int i = 2 * NPK; i < NP; ++i) {
+                    if (i < NP - 1 || last_ok) {
+                        const float en = seg[PACK_G * i];
+                        const float zq = (xv - b_loc[i]) * b_isc[i];
+                        const float tt = qs64 * (en * __builtin_amdgcn_exp2f(fmaf(-zq, zq, b_ct[i])));
+                        const float dlg = fmaf(-en, qp, tt);
+                        seg[PACK_G * i] = dlg;
+                        if (MODE == MODE_PPO) acc_db[i] += dlg;
+                        acc_loc[i] = fmaf(tt, zq, acc_loc[i]);
+                        acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);
+                        if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);
+                    }
+                }
+                dxa += dx2.x + dx2.y;
+                if (dx_out) {
+                    dxa = quad_sum(dxa);
+                    if (g == 0) {
+                        float dd = -dxa;
+                        if (tanh_mode) dd += my_g * 2.f * tanhf(xv);
+                        dx_out[(size_t)row0 * A + sidx] = dd;
+                    }
+                }
+            }
+            if (k < 4) PFPN_STAMP(7 + k * 6);
+            // ---- the plane now holds my part of dlogits: hand it to the storer waves ----------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my ds_writes are done (in-order LDS)
+            if (lane == 0) atomicAdd(&bdone[slot], 1);
+        }
+        p = p1; inv_sum = inv1;
+        slot = slot_n;
+        if (++slot_n == P) { slot_n = 0; ++lap_n; }
+    }
+
+    if (MODE == MODE_FWD) return;
+    PFPN_STAMP(40);
+    // ---- block partials: dloc / dlogstd (/ dlogits column sums).  The four rows of a tile that share my (a, n) set
+    //      are the lanes 4, 8, 12 further on in my 16-lane DPP row: two row_ror adds, ((r0 + r3) + (r2 + r1)) in the
+    //      row-0 lanes, which store.  All lanes run the DPP steps (idle lanes hold zeros).  Slab layout [nq*AN + 4]
+    //      per block, as before.
+    const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
+    float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
+    const bool writer = dim_ok && r == 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        float v0 = acc_loc[i] * (b_isc[i] * PFPN_2LN2);     // dloc *= c/scale
+        float v1 = acc_ls[i];
+        float v2 = acc_db[i];
+        v0 += dpp_shift<0x124, 0xf>(v0, 0.f); v0 += dpp_shift<0x128, 0xf>(v0, 0.f);
+        v1 += dpp_shift<0x124, 0xf>(v1, 0.f); v1 += dpp_shift<0x128, 0xf>(v1, 0.f);
+        if (MODE == MODE_PPO) { v2 += dpp_shift<0x124, 0xf>(v2, 0.f); v2 += dpp_shift<0x128, 0xf>(v2, 0.f); }
+        if (writer && (i < NP - 1 || last_ok)) {
+            const int col = a * N + g + PACK_G * i;
+            slab[col] = v0;
+            slab[AN + col] = v1;
+            if (nq == 3) slab[2 * AN + col] = v2;
+        }
+    }
+    if (!NRW && wave == 0 && lane == 0) { slab[nq * AN + 0] = 0.f; slab[nq * AN + 1] = 0.f; }
+    PFPN_STAMP(41);
+}
+
+// ---------------------------------------------------------------------------------------
 // wave path (any N): wave (a, chunk c) walks rows b = c, c+C, ...
 // ---------------------------------------------------------------------------------------
 template <int MODE>
@@ -1300,6 +1871,86 @@ static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float*
 
 static bool packed_has(int N) { return N == 35 || N == 50 || N == 16 || N == 8; }
 
+// tile kernel (k_mix_tile): R = 4 rows per tile, 4 action dims per compute wave
+static PackPlan plan_tile(int B, int A, int N, const void* logits, const void* dlogits) {
+    PackPlan pl{};
+    pl.ok = false;
+    if (N > 64 || N < 1 || A < 1 || B < 1) return pl;
+    const int AN = A * N;
+    if ((AN % 4) || ((uintptr_t)logits % 16) || (dlogits && (uintptr_t)dlogits % 16)) return pl;
+    const int NC = (A + 3) / 4;
+    if (NC + TK_NL + 1 + TK_NS > 16) return pl;         // compute + loader + row + storer waves in one block
+    const int R = TK_R;
+    pl.R = R;
+    pl.threads = NC * 64;                               // compute waves; the launcher adds the service waves of the mode
+    const size_t plane = (size_t)(R * AN + ((R * A + 63) & ~63) + 64) * 4;
+    const int pmin = dlogits ? 3 : 2;
+    int P = 4;
+    static const int env_p = getenv("PFPN_MIX_PLANES") ? atoi(getenv("PFPN_MIX_PLANES")) : 0;     // tuning knob
+    if (env_p >= pmin && env_p <= 8) P = env_p;
+    size_t small = 0;
+    for (;; --P) {
+        small = (size_t)(4 * R * A + (2 * R + 3 * P + 2) + 2 * R + 8 + 3 * AN) * 4;
+        if (P * plane + small <= PACK_MAX_LDS || P <= pmin) break;
+    }
+    pl.P = P;
+    pl.lds = P * plane + small;
+    const int ntiles = (B + R - 1) / R;
+    pl.ntiles = ntiles;
+    const int cap = cu_count();                         // one block per CU
+    pl.grid = ntiles < cap ? ntiles : cap;
+    pl.ok = pl.lds <= PACK_MAX_LDS;
+    return pl;
+}
+
+template <int MODE>
+static int launch_tile(int N, const PackPlan& pl, hipStream_t st, const float* logits, const float* x,
+                       const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
+                       float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
+    const int threads = pl.threads + 64 * (TK_NL + (MODE != MODE_BWD ? 1 : 0) + (MODE != MODE_FWD ? TK_NS : 0));
+#define PFPN_LAUNCH_TILE(NN)                                                                                \
+    do {                                                                                                    \
+        static bool big_lds_ok = false;          /* > 64 KB of dynamic LDS needs a one-time opt-in */         \
+        if (pl.lds > 64 * 1024 && !big_lds_ok) {                                                            \
+            (void)hipFuncSetAttribute((const void*)&k_mix_tile<NN, MODE>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PACK_MAX_LDS);        \
+            big_lds_ok = true;                                                                              \
+        }                                                                                                   \
+        hipLaunchKernelGGL((k_mix_tile<NN, MODE>), dim3(pl.grid), dim3(threads), pl.lds, st, logits, x,      \
+                           loc, logstd, dlogp, B, A, tanh_mode, pl.P, pl.ntiles / pl.grid,                  \
+                           pl.ntiles % pl.grid, logp, pmix, dlogits, dx, partial, ppo);                     \
+    } while (0)
+    switch (N) {
+        case 35: PFPN_LAUNCH_TILE(35); break;
+        case 50: PFPN_LAUNCH_TILE(50); break;
+        case 16: PFPN_LAUNCH_TILE(16); break;
+        case 8: PFPN_LAUNCH_TILE(8); break;
+        default: return -1;
+    }
+#undef PFPN_LAUNCH_TILE
+    return 0;
+}
+
+// A/B switch for this round's measurements: PFPN_MIX_TILE=0 takes the wave-sliced kernel (k_mix_packed)
+static bool use_tile() { static const int v = getenv("PFPN_MIX_TILE") ? atoi(getenv("PFPN_MIX_TILE")) : 1; return v != 0; }
+static PackPlan plan_mix(int B, int A, int N, const void* logits, const void* dlogits) {
+    if (use_tile()) {
+        PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+        if (pl.ok) return pl;
+    }
+    return plan_packed(B, A, N, logits, dlogits);
+}
+template <int MODE>
+static int launch_mix(int N, const PackPlan& pl, hipStream_t st, const float* logits, const float* x,
+                      const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
+                      float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
+    if (use_tile() && plan_tile(B, A, N, logits, dlogits).ok)
+        return launch_tile<MODE>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, logp, pmix, dlogits, dx,
+                                 partial, ppo);
+    return launch_packed<MODE>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, logp, pmix, dlogits, dx,
+                               partial, ppo);
+}
+
 // wide path: float4 per lane, up to 4 float4s per lane (N <= 1024)
 static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
     return N >= 64 && N % 4 == 0 && N <= 1024 && ((uintptr_t)logits % 16 == 0) &&
@@ -1349,10 +2000,10 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
     if (!logits || !x || !loc || !logstd || !logp || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipStream_t st = (hipStream_t)stream;
-    PackPlan pl = plan_packed(B, A, N, logits, nullptr);
+    PackPlan pl = plan_mix(B, A, N, logits, nullptr);
     if (pl.ok && packed_has(N)) {
         PpoArgs none{};
-        launch_packed<MODE_FWD>(N, pl, st, logits, x, loc, logstd, nullptr, B, A, tanh_mode, logp, pmix,
+        launch_mix<MODE_FWD>(N, pl, st, logits, x, loc, logstd, nullptr, B, A, tanh_mode, logp, pmix,
                                 nullptr, nullptr, nullptr, none);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
@@ -1411,11 +2062,11 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     }
     if (!workspace) return PFPN_ERR_WORKSPACE;
     float* partial = (float*)workspace;
-    PackPlan pl = plan_packed(B, A, N, logits, dlogits);
+    PackPlan pl = plan_mix(B, A, N, logits, dlogits);
     if (pl.ok && packed_has(N)) {
         if (workspace_bytes < (size_t)pl.grid * (2 * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
         PpoArgs none{};
-        launch_packed<MODE_BWD>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, nullptr, nullptr,
+        launch_mix<MODE_BWD>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, nullptr, nullptr,
                                 dlogits, dx, partial, none);
         PFPN_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, pl.grid,
@@ -1470,7 +2121,7 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
 int pfpn_ppo_mixture_slabs(int B, int A, int N, int want_dbias, const float* logits, const float* dlogits,
                            int* nslab, int* stride) {
     if (!nslab || !stride || !logits || !dlogits || B < 1 || A < 1 || N < 1) return PFPN_ERR_ARG;
-    PackPlan pl = plan_packed(B, A, N, logits, dlogits);
+    PackPlan pl = plan_mix(B, A, N, logits, dlogits);
     if (!(pl.ok && packed_has(N))) return PFPN_ERR_ARG;
     *nslab = pl.grid;
     *stride = (want_dbias ? 3 : 2) * A * N + 4;
@@ -1490,7 +2141,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     if (!workspace) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int AN = A * N;
-    PackPlan pl = plan_packed(B, A, N, logits, dlogits);
+    PackPlan pl = plan_mix(B, A, N, logits, dlogits);
     if (!(pl.ok && packed_has(N))) return PFPN_ERR_ARG;   // caller falls back to fwd + ppo_loss + bwd
     const int nq = dbias ? 3 : 2;
     if (workspace_bytes < (size_t)pl.grid * (nq * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
@@ -1499,7 +2150,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     pa.inv_B = 1.0f / (float)B; pa.clip_lo = 1.0f - clip_eps; pa.clip_hi = 1.0f + clip_eps;
     pa.value_coef = value_coef; pa.dvalue = dvalue; pa.ratio_out = nullptr; pa.want_db = dbias ? 1 : 0;
     float* partial = (float*)workspace;
-    launch_packed<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
+    launch_mix<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
                             nullptr, partial, pa);
     PFPN_CHECK_LAUNCH();
     if (!loss3) return PFPN_OK;          // diagnostic: slabs left unreduced (times the main kernel alone, bench.py)

@@ -1,9 +1,11 @@
+"""In-kernel phase stamps (s_memtime) of block 0 of k_mix_tile<35,PPO> at 4096 x 36 x 35.
+Needs the diagnostic build: rm -rf pfpn_amd/build && PFPN_BUILD_STAMPS=1 python -m pfpn_amd.build"""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pfpn_amd import kernels, _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
-B, A, N = 4096, 36, 35
+B, A, N = int(os.environ.get("PB", 4096)), 36, 35
 g = torch.Generator(device=dev); g.manual_seed(0)
 logits = torch.randn(B, A*N, device=dev, generator=g)
 x = (torch.rand(B, A, device=dev, generator=g)*2.2-1.1)
@@ -21,34 +23,24 @@ kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st, out=
 torch.cuda.synchronize()
 lib.pfpn_debug_stamps(None)
 s = buf.cpu().numpy().reshape(16, 64)
-names = {0:"start",1:"bank done",2:"barrier0"}
+NC = 9
+t0 = s[:14, 0][s[:14, 0] > 0].min()
+def d(w, k): return int(s[w, k] - t0) if s[w, k] else -1
+print("cycles since block start (s_memtime)")
+print("compute waves: start | bank written | past barrier | bank in regs | fwd(0) done | loop end | slabs out")
+for w in range(NC):
+    print("   w%-2d %6d %6d %6d %6d %6d %6d %6d" % (w, d(w, 0), d(w, 43), d(w, 42), d(w, 1), d(w, 2), d(w, 40), d(w, 41)))
 for it in range(4):
-    for k,nm in enumerate(["top","fwd done","wait done","row done","bwd done","staged next"]):
-        names[3+it*6+k] = "t%d %s" % (it, nm)
-names[40]="loop end"; names[41]="slab done"; names[42]="past barrier"; names[43]="bank written"; names[44]="bank complete"
-t0 = s[:9,0].min()
-for w in (0, 4, 8):
-    print("wave", w)
-    prev = None
-    for k in sorted(names):
-        if s[w,k] == 0: continue
-        dt = (s[w,k]-t0)/100.0   # s_memtime: 100 MHz ticks? print raw delta
-        print("   %-14s %8d ticks  (+%d)" % (names[k], s[w,k]-t0, (s[w,k]-prev) if prev else 0))
-        prev = s[w,k]
-
-print("\nper-wave timeline (ticks since block start): top | fwd done | wait done | bwd done | staged next")
-for it in range(4):
-    print("tile", it)
-    for w in range(9):
-        base = 3 + it * 6
-        print("   w%d  top %6d  fwd %6d  wait %6d  row %6d  bwd %6d  staged %6d" % (
-            w, s[w, base] - t0, s[w, base + 1] - t0, s[w, base + 2] - t0, s[w, base + 3] - t0, s[w, base + 4] - t0,
-            (s[w, base + 5] - t0) if s[w, base + 5] else -1))
-
-print("loader waves: tile k issued / landed (ticks)")
-for w in (9, 10):
-    print("   w%d " % w + "  ".join("t%d issued %6d landed %6d" % (k, s[w, 3 + k * 6] - t0, s[w, 4 + k * 6] - t0) for k in range(4)))
-
-print("tail: " + "  ".join("w%d loop end %d all arrived %d staged %d slabs out %d done %d" % (w, s[w,40]-t0, s[w,45]-t0, s[w,46]-t0, s[w,47]-t0, s[w,41]-t0) for w in (0,8,9)))
-print("start-up: " + "  ".join("w%d barrier %d written %d complete %d regs %d" % (w, s[w,42]-t0, s[w,43]-t0, s[w,44]-t0, s[w,1]-t0) for w in (0,4,8)))
-print("starts: " + "  ".join("w%d s0 %d s1 %d s2 %d" % (w, s[w,0]-t0, s[w,1]-t0, (s[w,2]-t0) if s[w,2] else -1) for w in (0,4,8,9,10)))
+    print("tile %d: top | fwd(k+1) done | row gradient seen | bwd done" % it)
+    for w in range(NC):
+        b = 3 + it * 6
+        print("   w%-2d %6d %6d %6d %6d" % (w, d(w, b), d(w, b + 1), d(w, b + 3), d(w, b + 4)))
+print("loader waves: start | tile-0 share issued | past barrier | tiles 1.. landed")
+for w in (NC, NC + 1):
+    print("   w%-2d %6d %6d %6d   " % (w, d(w, 0), d(w, 3), d(w, 4)) + " ".join("%6d" % d(w, 4 + k * 6) for k in range(1, 4)))
+w = NC + 2
+print("row wave: start | tile-0 share issued | row stage of tile k done")
+print("   w%-2d %6d %6d   " % (w, d(w, 0), d(w, 3)) + " ".join("%6d" % d(w, 5 + k * 6) for k in range(4)))
+print("storer waves: start | tile-0 share issued | tile k stores issued")
+for w in (NC + 3, NC + 4):
+    print("   w%-2d %6d %6d   " % (w, d(w, 0), d(w, 3)) + " ".join("%6d" % d(w, 8 + k * 6) for k in range(4)))
