@@ -27,6 +27,7 @@ namespace pfpn {
 enum { MODE_FWD = 0, MODE_BWD = 1, MODE_PPO = 2 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));     // packed-fp32 operand (v_pk_*_f32)
+typedef float f4v __attribute__((ext_vector_type(4)));
 
 struct PpoArgs {
     const float* logp_old;   // [B]
@@ -832,19 +833,21 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     const int TS = R * AN;                                // floats per plane
     const int XS = (nseg + 63) & ~63;                     // floats per action-value plane
     // LDS map (floats):  [P][TS] tiles | [P][XS] action values | [P][64] row scalars | [4][nseg] segment log p
-    //                    | ints: [2][R] row counters | [P] ready | [P] freed | [P] bdone | [2] gdone
-    //                    | [2][R] row gradients | [3][AN] particle bank
+    //                    | [4][R] row results (64-bit: tile number + 1 | d loss / d logp) | ints: [4][R] row counters
+    //                    | [P] ready | [P] freed | [P] bdone | [3][AN] particle bank
     float* tile = reinterpret_cast<float*>(smem4);
     float* xpl = tile + (size_t)P * TS;
     float* rpl = xpl + P * XS;                            // [P][4][16]: adv, logp_old, value, value_old (PPO) | dlogp (BWD)
     float* segbuf = rpl + P * 64;
-    int* cnt = reinterpret_cast<int*>(segbuf + 4 * nseg);
-    int* ready = cnt + 2 * R;
+    // row results: ONE 8-byte LDS word per row and tile (set k & 3) carries {k + 1, d loss / d logp}: a compute wave
+    // polls the word of its row and has the gradient the moment it sees the tile number -- no separate "done" counter
+    // behind a second LDS round trip
+    unsigned long long* gslot = reinterpret_cast<unsigned long long*>(segbuf + 4 * nseg);     // (8-byte aligned: all terms even)
+    int* cnt = reinterpret_cast<int*>(gslot + 4 * R);     // [4][R]: segment log-probs of row r of tile k that have arrived (set k & 3)
+    int* ready = cnt + 4 * R;
     int* freed = ready + P;
     int* bdone = freed + P;                               // compute waves done with the backward of the tile in this plane
-    int* gdone = bdone + P;                               // [2]: tiles of this parity whose row stage is complete
-    float* gbuf = reinterpret_cast<float*>(gdone + 2);    // [2][R]: d loss / d logp of the rows of tile k (parity k & 1)
-    float* bank = gbuf + 2 * R;                           // [3][AN]: loc | isc2 | 64 - ct2
+    float* bank = reinterpret_cast<float*>(bdone + P);    // [3][AN]: loc | isc2 | 64 - ct2
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
@@ -959,8 +962,8 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         // run on into tile 1 (a fresh plane when P > 1), then zero the counters and meet the block
         bool t1 = false;
         if (T > 1 && P > 1 && dmax > 1) { issue_tile(); t1 = true; }
-        for (int i = t - NC * 64; i < 2 * R + 3 * P + 2; i += TK_NL * 64)
-            cnt[i] = (i == 2 * R && T > 0) ? TK_NL : 0;    // ready[0] = landed (cnt, ready, freed, bdone, gdone)
+        for (int i = t - NC * 64; i < 12 * R + 3 * P; i += TK_NL * 64)        // gslot (8 R ints), cnt, ready, freed, bdone
+            reinterpret_cast<int*>(gslot)[i] = (i == 12 * R && T > 0) ? TK_NL : 0;    // ready[0] = landed
         // my share of tile 0 has landed when only tile 1's DMAs are outstanding (in-order counter)
         if (t1) wait_vmcnt(Q); else wait_vmcnt(0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -995,39 +998,48 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // (stays at raised priority: every compute wave waits for this wave's few instructions once per tile)
         const int kq = lane >> 4, jl = lane & 15;
-        int slot = 0;
+        int slot = 0, lap = 0;
         for (int k = 0; k < T; ++k) {
             const int row0 = (tile0 + k) * R;
             const int rows = min(R, B - row0);
             const float* sb = segbuf + (k & 3) * nseg;
+            const int rk = kq;                             // 16-lane group kq owns row kq
+            const bool rk_ok = rk < rows;
+            const int b = row0 + rk;
+            const bool owner = rk_ok && jl == 0;
+            // the row's scalars arrive with the tile: everything that does not need the log-prob happens before the
+            // wait for the forward passes
+            float adv = 0.f, lpo = 0.f, nadv = 0.f, dvv = 0.f;
+            if (MODE == MODE_PPO) {
+                while (lds_counter(&ready[slot]) < TK_NL * (lap + 1)) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                const float* rs = rpl + slot * 64;
+                adv = rs[rk]; lpo = rs[16 + rk];
+                const float val_b = rs[32 + rk], vold_b = rs[48 + rk];
+                nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
+                dvv = val_b - (adv + vold_b);
+                if (owner) {
+                    val_sum += dvv * dvv;
+                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                }
+            }
             // every row of the tile has all its A segment log-probs (lane j waits for row j)
             if (lane < rows) {
-                const int target = A * ((k >> 1) + 1);
-                while (lds_counter(&cnt[(k & 1) * R + lane]) < target) { }
+                const int target = A * ((k >> 2) + 1);
+                while (lds_counter(&cnt[(k & 3) * R + lane]) < target) { }
             }
             asm volatile("" ::: "memory");
-            // 16-lane group kq sums row kq's A segment log-probs (fixed lanes, fixed order: reproducible) and runs its
-            // loss head
-            const int rk = kq;
-            const bool rk_ok = rk < rows;
+            // the group sums its row's A segment log-probs (fixed lanes, fixed order: reproducible); the rotation steps
+            // associate differently per lane, so only the group's lane 0 -- the owner -- uses the sum
             float sacc = 0.f;
             if (rk_ok)
                 for (int i = jl; i < A; i += 16) sacc += sb[rk * A + i];
             sacc = quad_sum(sacc);
             sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
             sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
-            // the rotation steps associate differently per lane: every lane takes its group's lane 0
-            const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
-            const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
-            const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
-            const float u3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
-            const float s = kq == 0 ? u0 : kq == 1 ? u1 : kq == 2 ? u2 : u3;
-            const int b = row0 + rk;
-            const bool owner = rk_ok && jl == 0;
+            const float s = sacc;
+            float grad = 0.f;
             if (MODE == MODE_PPO) {
-                const float* rs = rpl + slot * 64;
-                const float adv = rs[rk], lpo = rs[16 + rk], val_b = rs[32 + rk], vold_b = rs[48 + rk];
-                const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
                 // v_exp_f32 on (s - lpo) * log2 e: |s - lpo| is O(0.1-1), so the product's rounding is far below the
                 // instruction's own 1 ulp
                 const float ratio = __builtin_amdgcn_exp2f((s - lpo) * PFPN_LOG2E);
@@ -1037,21 +1049,20 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
                 // clip_by_value passes where lo <= ratio <= hi.
                 const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+                grad = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
                 if (owner) {
-                    gbuf[(k & 1) * R + rk] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
                     pol_sum += fminf(sur, csur);
-                    const float dvv = val_b - (adv + vold_b);
-                    val_sum += dvv * dvv;
-                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
                     if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
                 }
             }
-            if (owner) logp_out[b] = s;
-            // a wave's LDS operations execute in issue order: the gradients are visible to whoever sees the counter
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) atomicAdd(&gdone[k & 1], 1);
+            if (owner) {
+                __hip_atomic_store(&gslot[(k & 3) * R + rk],
+                                   ((unsigned long long)__float_as_uint(grad) << 32) | (unsigned)(k + 1),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                logp_out[b] = s;
+            }
             if (k < 4) PFPN_STAMP(5 + k * 6);
-            if (++slot == P) slot = 0;
+            if (++slot == P) { slot = 0; ++lap; }
         }
         if (MODE == MODE_PPO) {
             // loss sums (lanes 0, 16, 32, 48 hold them: rows in tile order)
@@ -1068,27 +1079,27 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         const int s_ = wave - (NC + TK_NL + NRW);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_s_setprio(0);
-        constexpr int SU = 4;                              // float4 per lane in flight
+        constexpr int SU = 5;                              // float4 per lane and round: all reads of a round, then its stores
         int slot = 0, lap = 0;
         for (int k = 0; k < T; ++k) {
             const int row0 = (tile0 + k) * R, rows = min(R, B - row0);
             const int nv4 = rows * AN / 4;
             while (lds_counter(&bdone[slot]) < NC * (lap + 1)) __builtin_amdgcn_s_sleep(1);
             asm volatile("" ::: "memory");
-            const float4* src = reinterpret_cast<const float4*>(tile + (size_t)slot * TS);
-            float4* dst = reinterpret_cast<float4*>(dlogits + (size_t)row0 * AN);
+            const f4v* src = reinterpret_cast<const f4v*>(tile + (size_t)slot * TS);
+            f4v* dst = reinterpret_cast<f4v*>(dlogits + (size_t)row0 * AN);
             for (int c0 = s_; c0 * 64 < nv4; c0 += SU * NS) {
-                float4 v[SU];
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int i4 = (c0 + u * NS) * 64 + lane;
-                    v[u] = src[min(i4, nv4 - 1)];
-                }
-#pragma unroll
-                for (int u = 0; u < SU; ++u) {
-                    const int i4 = (c0 + u * NS) * 64 + lane;
-                    if (i4 < nv4) dst[i4] = v[u];
-                }
+                // SU clamped, unconditional LDS reads in one round trip, then the stores.  The empty asm ties the five
+                // values together: hipcc otherwise pairs each read with its store (one LDS round trip per KiB).
+                const int i0 = c0 * 64 + lane, i1 = i0 + NS * 64, i2 = i1 + NS * 64, i3 = i2 + NS * 64, i4 = i3 + NS * 64;
+                f4v v0 = src[min(i0, nv4 - 1)], v1 = src[min(i1, nv4 - 1)], v2 = src[min(i2, nv4 - 1)],
+                    v3 = src[min(i3, nv4 - 1)], v4 = src[min(i4, nv4 - 1)];
+                asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
+                if (i0 < nv4) dst[i0] = v0;
+                if (i1 < nv4) dst[i1] = v1;
+                if (i2 < nv4) dst[i2] = v2;
+                if (i3 < nv4) dst[i3] = v3;
+                if (i4 < nv4) dst[i4] = v4;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of the plane have returned
             if (lane == 0) atomicAdd(&freed[slot], 1);
@@ -1221,11 +1232,11 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         }
         p_o = p; inv_o = inv_sum;
         if (MODE != MODE_BWD) {
-            // publish: my dims of every live row have arrived.  segbuf and cnt both live in LDS, and a wave's LDS
-            // operations are executed in issue order, so the ds_write of log p is visible to whoever observes the
-            // later ds_add.
+            // publish: my dims of every live row have arrived.  The wait orders the ds_write of log p before the
+            // ds_add that announces it (the order in which the LDS unit retires a wave's plain writes and its atomics
+            // is not something to rely on).
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < rows) atomicAdd(&cnt[(k & 1) * R + lane], ndw);
+            if (lane < rows) atomicAdd(&cnt[(k & 3) * R + lane], ndw);
         }
         if (MODE == MODE_FWD) {
             // forward mode never stores the plane: it is free as soon as my reads of it are done
@@ -1257,9 +1268,13 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         } else {
             // (forward mode waits too: it keeps the compute waves within two tiles of the row wave, which is what
             // the four segment-log-p buffers allow)
-            while (lds_counter(&gdone[k & 1]) < (k >> 1) + 1) __builtin_amdgcn_s_sleep(1);
+            const unsigned long long* gs = &gslot[(k & 3) * R + (r < rows ? r : 0)];
+            unsigned long long gv;
+            do {
+                gv = __hip_atomic_load(gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } while ((unsigned)gv != (unsigned)(k + 1));
             asm volatile("" ::: "memory");
-            if (MODE == MODE_PPO && active) my_g = gbuf[(k & 1) * R + r];
+            if (MODE == MODE_PPO && active) my_g = __uint_as_float((unsigned)(gv >> 32));
         }
         if (k < 4) PFPN_STAMP(6 + k * 6);
 
@@ -1460,7 +1475,6 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 #ifndef PFPN_WIDE_NT
 #define PFPN_WIDE_NT 0
 #endif
-typedef float f4v __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ float4 ld4_stream(const float* p) {
     if (NT) {
@@ -1890,7 +1904,7 @@ static PackPlan plan_tile(int B, int A, int N, const void* logits, const void* d
     if (env_p >= pmin && env_p <= 8) P = env_p;
     size_t small = 0;
     for (;; --P) {
-        small = (size_t)(4 * R * A + (2 * R + 3 * P + 2) + 2 * R + 8 + 3 * AN) * 4;
+        small = (size_t)(4 * R * A + (12 * R + 3 * P) + 8 + 3 * AN) * 4;
         if (P * plane + small <= PACK_MAX_LDS || P <= pmin) break;
     }
     pl.P = P;

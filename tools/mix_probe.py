@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pfpn_amd import kernels, _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
-B, A, N = int(os.environ.get("PB", 4096)), 36, 35
+B, A, N = int(os.environ.get("PB", 4096)), int(os.environ.get("PA", 36)), 35
 g = torch.Generator(device=dev); g.manual_seed(0)
 logits = torch.randn(B, A*N, device=dev, generator=g)
 x = (torch.rand(B, A, device=dev, generator=g)*2.2-1.1)

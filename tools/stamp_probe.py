@@ -5,7 +5,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from pfpn_amd import kernels, _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
-B, A, N = int(os.environ.get("PB", 4096)), 36, 35
+B, A, N = int(os.environ.get("PB", 4096)), int(os.environ.get("PA", 36)), 35
 g = torch.Generator(device=dev); g.manual_seed(0)
 logits = torch.randn(B, A*N, device=dev, generator=g)
 x = (torch.rand(B, A, device=dev, generator=g)*2.2-1.1)
@@ -23,7 +23,7 @@ kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, adv, v, vo, st, out=
 torch.cuda.synchronize()
 lib.pfpn_debug_stamps(None)
 s = buf.cpu().numpy().reshape(16, 64)
-NC = 9
+NC = (A + 3) // 4
 t0 = s[:14, 0][s[:14, 0] > 0].min()
 def d(w, k): return int(s[w, k] - t0) if s[w, k] else -1
 print("cycles since block start (s_memtime)")
