@@ -316,13 +316,13 @@ def main():
         for rnd in ("r02", "r01"):     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE)
             try:
                 with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
-                    traffic = json.load(f)["kernels"]["k_mix_packed<35,PPO>"]["traffic_bytes"]
+                    traffic = json.load(f)["kernels"]["k_mix_tile<35,PPO>"]["traffic_bytes"]
                 traffic_source = "profiles/%s_pmc_traffic.json: separate rocprofv3 --pmc passes of round %s over this " \
                                  "command (tools/pmc_traffic.py), NOT measured in this run" % (rnd, rnd[1:])
                 break
             except Exception:
                 pass
-        out["roofline"] = {"kernel": "k_mix_packed<35,PPO>", "bound": "hbm", "achieved": ach,
+        out["roofline"] = {"kernel": "k_mix_tile<35,PPO>", "bound": "hbm", "achieved": ach,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": traffic_source, "algorithmic_bytes": ab, "us_per_launch": us, "launches_timed": reps,
                            "us_in_step_event_pairs": us_in_step, "us_with_slab_finalize_launch": us_op,
@@ -331,8 +331,9 @@ def main():
                                    "the step its slab sums are finished by the single deferred reduce launch); "
                                    "us_in_step_event_pairs: an event pair around each call inside 100 eager learner "
                                    "steps (includes the dispatch gap); "
-                                   "42 MB per launch: four tiles per block -- start-up, tail and one VALU-issue-bound SIMD "
-                                   "(DESIGN.md section 4); "
+                                   "42 MB per launch, four tiles per block: ~5 k cycles until the first tile has landed, "
+                                   "~3.6 k per tile on the SIMD that hosts three of the nine compute waves, the last plane "
+                                   "stored ~2 k after the last backward (DESIGN.md section 4); "
                                    "the 1 GiB shape of BASELINE.json config 5 is in roofline_stress"}
         # the same mixture math on the 1 GiB stress shape (BASELINE.json config 5, one GPU's shard)
         try:

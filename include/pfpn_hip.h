@@ -36,8 +36,8 @@ extern "C" {
 
 /* library / ABI version, and a cheap "is the device code loadable" probe (no compute). */
 int pfpn_abi_version(void);
-/* diagnostic only: device buffer (16*64 uint64) receiving s_memtime phase stamps of block 0 of the packed
- * mixture kernel; NULL (default) disables stamping. */
+/* diagnostic only: device buffer (16*64 uint64) receiving s_memtime phase stamps of block 0 of the tile
+ * mixture kernel (k_mix_tile); NULL (default) disables stamping. */
 int pfpn_debug_stamps(void* device_buffer);
 
 /* ---- mixture log-prob (K1/K2) ------------------------------------------------------------ */
@@ -73,8 +73,8 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
  * dbias [A*N] (optional, may be NULL: column sums of dlogits = the fc_policy bias gradient, a2c.py:541-554),
  * loss3 = {loss, policy_loss, value_loss*coef} (NULL: the per-block partial sums are left unreduced in the workspace --
  * dloc/dlogstd/dbias/loss3 are then NOT written; used by bench.py to time the main kernel alone).
- * Returns PFPN_ERR_ARG for shapes the packed path
- * does not cover (N > 64 or no template instance): compose fwd + pfpn_ppo_loss + bwd instead. */
+ * Returns PFPN_ERR_ARG for shapes the tile kernel
+ * does not cover (N > 64, A > 44 or no template instance): compose fwd + pfpn_ppo_loss + bwd instead. */
 int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const float* loc, const float* logstd,
                              const float* logp_old, const float* adv, const float* value,
                              const float* value_old, const float* adv_stats,
@@ -270,7 +270,7 @@ int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v
 int pfpn_state_moment_chunks(int B);
 /* Slab geometry of pfpn_ppo_mixture_fwd_bwd called with loss3 = NULL (same arguments): nslab slabs of `stride`
  * floats laid out [dloc A*N | dlogstd A*N | (dbias A*N) | policy-loss, value-loss, pad, pad].  PFPN_ERR_ARG when the
- * packed path does not cover the shape. */
+ * tile kernel does not cover the shape. */
 int pfpn_ppo_mixture_slabs(int B, int A, int N, int want_dbias, const float* logits, const float* dlogits,
                            int* nslab, int* stride);
 

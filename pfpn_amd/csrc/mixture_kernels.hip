@@ -7,12 +7,13 @@
 // actor_critic.py:151-156).
 //
 // Three data paths (chosen by shape in the C entry points at the end of this file):
-//  * "packed" (4 <= A, N <= 64, A*N % 4 == 0; templated on N: the shipped N=35, the default N=50, 16, 8):
-//    a loader/consumer ring -- LDS-DMA loader waves stream 4-row tiles into LDS planes, compute waves
-//    own 16-segment slices (4 lanes per segment) and run forward, row stage, loss head and backward
-//    out of LDS and registers.  Because a block owns complete rows, the row-level log-prob, the PPO
-//    ratio/clip and the backward run in ONE pass: logits are read from HBM once and dlogits written
-//    once (2L traffic instead of 3L).  See the block comment above k_mix_packed.
+//  * "tile" (N <= 64, A <= 44, A*N % 4 == 0; templated on N: the shipped N=35, the default N=50, 16, 8):
+//    an LDS ring -- LDS-DMA loader waves stream 4-row tiles into LDS planes, compute waves own four action
+//    dims of the tile's four rows (4 lanes per segment) and run forward and backward out of LDS and
+//    registers, a row wave runs the row stage and the loss head, storer waves copy finished planes back.
+//    Because a block owns complete rows, the row-level log-prob, the PPO ratio/clip and the backward run in
+//    ONE pass: logits are read from HBM once and dlogits written once (2L traffic instead of 3L).  See the
+//    block comment above k_mix_tile.
 //  * "wide" (N >= 64, N % 4 == 0: the 128 x 256 stress shape): one wavefront per segment, float4 per
 //    lane straight from HBM, 4 rows reduced together by a transposing DPP butterfly.
 //  * "wave" (any shape): one 64-lane wavefront owns one segment, lanes stride the particles; a
@@ -44,40 +45,8 @@ struct PpoArgs {
 };
 
 constexpr int PACK_G = 4;                            // lanes per (row, action-dim) segment
-constexpr int PACK_BLOCK = 1024;                     // generic launch bound; actual block = (compute + loader waves)*64
-constexpr int PACK_WSEG = 64 / PACK_G;               // 16 segments per wave
-constexpr size_t PACK_MAX_LDS = 150 * 1024;         // dynamic LDS the packed kernel may ask for (160 KB per CU)
+constexpr size_t PACK_MAX_LDS = 150 * 1024;         // dynamic LDS the tile kernel may ask for (160 KB per CU)
 
-// ---------------------------------------------------------------------------------------
-// packed path ("wave-sliced", loader/consumer ring)
-//
-// A tile is Rt whole batch rows = Rt*A segments, laid out in an LDS plane exactly as in HBM.
-//
-// * LOADER waves (PACK_NL of them, no arithmetic) move tiles HBM -> LDS with LDS-DMA
-//   (`global_load_lds_dwordx4`: 1 KiB per wave-instruction, no VGPR destination), several tiles
-//   ahead, into a ring of P planes; with them ride the tile's action values and per-row scalars.
-//   A loader's instruction stream is nothing but DMAs, so its `s_waitcnt vmcnt(n)` can be counted
-//   exactly: it keeps up to 63 DMAs in flight and bumps the plane's `ready` counter when the OLDEST
-//   tile has landed.  This is what fills the memory pipeline: the bytes in flight per CU are no longer
-//   limited by the VGPRs of the computing waves (one tile ahead = 20 KB per CU measured ~2.6 TB/s
-//   chip-wide; by Little's law 6 TB/s at ~3 us loaded latency needs ~70 KB per CU in flight).
-// * COMPUTE wave w owns the 16 consecutive segments [16w, 16w+16) of every tile -- a contiguous
-//   64*N-byte slice of the plane that it transforms in place (logits -> softmax numerators -> dlogits)
-//   and stores back itself: no block barrier in steady state, and NO global load (hence no vmcnt wait)
-//   anywhere in its loop.  4 lanes share a segment (particles g, g+4, ...); their softmax/mixture
-//   reductions are two quad-permute DPP steps.  The particle bank of a lane's (a, n) set is constant
-//   across tiles (same slot -> same action dim), so it lives in registers.
-// * The only cross-wave dependency is the row log-prob (a row's A segments span 2-4 waves): waves
-//   publish per-segment log p to LDS and bump a per-row arrival counter (monotonic, never reset).
-//   The loop is software-pipelined -- forward(t+1) | row stage(t) | backward(t) | store(t) -- so a wave
-//   asks for a row's log-prob a whole forward pass after it published its own part.
-// * When a compute wave has read its dlogits slice back out of the plane it bumps the plane's `freed`
-//   counter; the loaders reuse a plane once all compute waves have.
-// ---------------------------------------------------------------------------------------
-#ifndef PACK_NLOAD
-#define PACK_NLOAD 2
-#endif
-constexpr int PACK_NL = PACK_NLOAD;                  // loader waves per block
 #ifndef PACK_DEPTH
 #define PACK_DEPTH 2                                 // tiles a loader keeps in flight
 #endif
@@ -181,627 +150,40 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define PFPN_STAMP(id_) do { } while (0)      /* build with -DPFPN_ENABLE_STAMPS for tools/stamp_probe.py */
 #endif
 
-// MAXT: launch bound.  768 threads (9 compute + 2 loader + 1 row wave -> 3 waves/SIMD -> 168 VGPRs) covers the tile
-// of A = 36; the generic bound of 1024 caps the allocation at 128 VGPRs.
-template <int N, int MODE, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_mix_packed(
-    const float* __restrict__ logits, const float* __restrict__ x,
-    const float* __restrict__ loc, const float* __restrict__ logstd,
-    const float* __restrict__ dlogp_in,      // MODE_BWD: [B]
-    int B, int A, int R, int tanh_mode, int P,           // P: LDS planes in the ring
-    int tbase, int trem,                     // tiles per block = tbase (+1 for the first trem blocks): no device division
-    float* __restrict__ logp_out,            // [B]   (FWD, PPO)
-    float* __restrict__ pmix_out,            // [B,A] optional
-    float* __restrict__ dlogits,             // [B,A,N] (BWD, PPO)
-    float* __restrict__ dx_out,              // [B,A] optional (BWD)
-    float* __restrict__ partial,             // [grid][nq*A*N + 4] (BWD, PPO)
-    PpoArgs ppo)
-{
-    constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
-    constexpr int NPK = (NP - 1) / 2;                     // particle pairs that always exist (packed fp32 math)
-    constexpr int SLICE = PACK_WSEG * N;                  // floats per wave slice (16 segments)
-    constexpr int NV = (SLICE / 4 + 63) / 64;             // float4 per lane per slice (3 for N=35)
-    extern __shared__ float4 smem4[];
-    const int AN = A * N;
-    const int nseg = R * A;                               // segments per full tile
-    // ROW WAVE (forward / PPO modes): one extra wave -- the block's last -- owns the row stage of every tile: it waits for
-    // the segment log-probs of a tile's rows, sums them, runs the loss head and publishes d loss / d logp per row.  Before,
-    // every compute wave ran that stage for the rows it touches (~100 VALU per wave and tile, a quarter of the loop's
-    // instructions, on the SIMD that is VALU-issue bound); now the compute waves only wait for a counter and read one float,
-    // and the row wave works while they are in the next tile's forward.
-    constexpr int NRW = (MODE != MODE_BWD) ? 1 : 0;
-    const int nwaves = (blockDim.x >> 6) - PACK_NL - NRW; // compute waves
-    const int TS = nwaves * SLICE;                        // floats per plane (>= R*AN)
-    const int XS = (nseg + 63) & ~63;                     // floats per action-value plane
-    // LDS map (floats):  [P][TS] tiles | [P][XS] action values | [P][64] row scalars | [4][nseg] segment log p
-    //                    | [2][R] row counters | [P] ready | [P] freed | [1] bank_done | [2] gdone | [2*nwaves] (unused)
-    //                    | [2][R] row gradients | [3][AN] particle bank
-    float* tile = reinterpret_cast<float*>(smem4);
-    float* xpl = tile + (size_t)P * TS;
-    float* rpl = xpl + P * XS;                            // [P][4][16]: adv, logp_old, value, value_old (PPO) | dlogp (BWD)
-    float* segbuf = rpl + P * 64;
-    int* cnt = reinterpret_cast<int*>(segbuf + 4 * nseg);
-    int* ready = cnt + 2 * R;
-    int* freed = ready + P;
-    int* bank_done = freed + P;                           // (kept in the map; the start-up barrier publishes the bank)
-    int* gdone = bank_done + 1;                           // [2]: tiles of this parity whose row stage is complete
-    float* lossbuf = reinterpret_cast<float*>(gdone + 2);
-    float* gbuf = lossbuf + 2 * nwaves;                   // [2][R]: d loss / d logp of the rows of tile k (parity k & 1)
-    float* bank = gbuf + 2 * R;                           // [3][AN]: loc | isc2 | 64 - ct2   (see below)
-
-    const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;   // wave index as a scalar: uniform control flow
-#ifdef PFPN_ENABLE_STAMPS
-    unsigned long long* stamps = g_stamps;
-#endif
-    PFPN_STAMP(0);
-    const int gs = (int)gridDim.x;
-    const int T = tbase + ((int)blockIdx.x < trem ? 1 : 0);                    // my tiles
-    // which ones: a CONTIGUOUS run (tile0, +1, ...): a block then touches one or two pages of each tensor instead of T
-    // pages ~B/T rows apart.  PFPN_MIX_INTERLEAVE builds the older blockIdx, +grid, +2 grid, ... order for A/B runs.
-#ifdef PFPN_MIX_INTERLEAVE
-    const int tile0 = (int)blockIdx.x, tstep = gs;
-#else
-    const int tile0 = (int)blockIdx.x * tbase + min((int)blockIdx.x, trem), tstep = 1;
-#endif
-
-    // Start-up order (what the in-kernel stamps showed: 9,000 of a block's 36,000 cycles went by before the first
-    // tile's forward): every wave FIRST puts its long-latency requests in flight -- the loaders the DMAs of the first
-    // tiles, the compute waves the loads of the [A,N] particle tables -- and only then the block zeroes its counters
-    // and meets at the one start-up barrier.  The barrier is the raw s_barrier behind an LDS-only wait: a
-    // __syncthreads() fence would also wait for the DMAs / loads just issued (vmcnt(0)).
-    constexpr int BKU = 4;                                                    // table elements per thread and round
-    float bank_ls[BKU], bank_lc[BKU];
-    if (wave < nwaves) {
-#pragma unroll
-        for (int u = 0; u < BKU; ++u) {
-            const int i = min(t + u * nwaves * 64, AN - 1);
-            bank_ls[u] = logstd[i];
-            bank_lc[u] = loc[i];
-        }
-    }
-
-    int q = 0, g = 0, sidx = 0, r = 0, a = 0, s_lo = 0, s_hi = -1, r_lo = 0, r_hi = -1;
-    bool seg_lane = false;
-    // =========================== loader waves ================================================
-    if (wave >= nwaves && wave < nwaves + PACK_NL) {
-        const int l = wave - nwaves;
-        PFPN_STAMP(1);
-        // per-tile DMA items: tile chunks of 64 float4 | action-value chunks of 64 floats | one row-scalar piece
-        const int cap4 = TS >> 2;                          // float4 capacity of a plane
-        const int nct = (R * AN / 4 + 63) >> 6;            // tile chunks (R*AN % 4 == 0 on this path)
-        const int ncx = (nseg + 63) >> 6;
-        const int nrs = (MODE == MODE_FWD) ? 0 : 1;
-        const int M = nct + ncx + nrs;
-        const int Q = (M - l + PACK_NL - 1) / PACK_NL;     // my DMAs per tile (constant: short tiles clamp, never skip)
-        // tiles I keep in flight: two.  A compute pass over a tile takes about twice as long as the memory system
-        // needs to deliver one, so more only queues requests in front of the tile that is needed next (the first
-        // tile of a cold start lands ~1000 + 120 ticks per KB requested per CU); vmcnt immediate <= 63 caps it too.
-        int dmax = PACK_DEPTH;
-        while (dmax > 1 && (dmax - 1) * Q > 63) --dmax;
-        if (dmax > P) dmax = P;
-        const unsigned tile_b = (unsigned)(uintptr_t)tile, xpl_b = (unsigned)(uintptr_t)xpl,
-                       rpl_b = (unsigned)(uintptr_t)rpl;
-        int issued = 0, signalled = 0;
-        int slot_i = 0, wrap_i = 0, slot_s = 0;            // issued % P, issued / P, signalled % P without dividing
-        // all DMAs of tile number `issued` of this block into plane `slot_i`
-        auto issue_tile = [&]() __attribute__((always_inline)) {
-            const int tid = tile0 + issued * tstep;
-            const int row0 = tid * R, rows = min(R, B - row0);
-            const int slot = slot_i;
-            const int nv4 = rows * AN / 4;             // valid float4 of this tile
-            const float4* g4 = reinterpret_cast<const float4*>(logits + (size_t)row0 * AN);
-            // item i (tile chunks, then action-value chunks, then the row scalars) belongs to loader i % NL.
-            // A wave issues at most one instruction per ~4 cycles, so the full-tile path below keeps the
-            // per-DMA overhead to a pointer bump (measured: 250 -> ~50 cycles per DMA).
-            if (rows == R) {
-                const char* gp = reinterpret_cast<const char*>(g4) + (size_t)(l * 64 + lane) * 16;
-                unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + l * 1024));
-                int c = l;
-                for (; c < nct - 1; c += PACK_NL) {
-                    dma16(gp, lb);
-                    gp += PACK_NL * 1024;
-                    lb += PACK_NL * 1024;
-                }
-                if (c == nct - 1 && c * 64 + lane < nv4) dma16(gp, lb);        // last chunk: partial (never empty)
-                int cx = ((l - nct) % PACK_NL + PACK_NL) % PACK_NL;
-                for (; cx < ncx; cx += PACK_NL) {
-                    const int i = cx * 64 + lane;
-                    dma4(x + (size_t)row0 * A + min(i, nseg - 1),
-                         __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + cx * 64) * 4)));
-                }
-            } else {
-                for (int it_ = l; it_ < nct + ncx; it_ += PACK_NL) {
-                    if (it_ < nct) {
-                        const int i4 = it_ * 64 + lane;
-                        if (i4 < cap4)                 // never past the plane; short tiles re-read their last float4
-                            dma16(g4 + min(i4, nv4 - 1),
-                                  __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(slot * TS * 4 + it_ * 1024)));
-                    } else {
-                        const int c = it_ - nct;
-                        const int i = c * 64 + lane;
-                        dma4(x + (size_t)row0 * A + min(i, rows * A - 1),
-                             __builtin_amdgcn_readfirstlane(xpl_b + (unsigned)((slot * XS + c * 64) * 4)));
-                    }
-                }
-            }
-            if (nrs && (nct + ncx) % PACK_NL == l) {
-                // lane j -> array j/16, row j%16 (R <= 16)
-                const int arr = lane >> 4, rw = min(lane & 15, rows - 1);
-                const float* src;
-                if (MODE == MODE_PPO)
-                    src = (arr == 0 ? ppo.adv : arr == 1 ? ppo.logp_old : arr == 2 ? ppo.value : ppo.value_old) +
-                          row0 + rw;
-                else
-                    src = dlogp_in + row0 + rw;
-                dma4(src, __builtin_amdgcn_readfirstlane(rpl_b + (unsigned)(slot * 64 * 4)));
-            }
-            ++issued;
-            if (++slot_i == P) { slot_i = 0; ++wrap_i; }
-            if (issued <= 4) PFPN_STAMP(3 + (issued - 1) * 6);
-        };
-        // the first tile goes out before anything else happens in the block (fresh plane: no `freed` check), at raised
-        // priority: the loaders share SIMDs 1 and 2 with compute waves that are busy with the table transform
-        __builtin_amdgcn_s_setprio(3);
-        if (T > 0) issue_tile();
-        for (int i = t - nwaves * 64; i < 2 * R + 2 * P + 3; i += PACK_NL * 64) cnt[i] = 0;   // cnt, ready, freed, bank_done, gdone
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        while (signalled < T) {
-            bool can = issued < T && issued - signalled < dmax;
-            if (can && wrap_i > 0)                         // plane still being read by the compute waves?
-                can = lds_counter(&freed[slot_i]) >= nwaves * wrap_i;
-            if (can) {
-                issue_tile();
-            } else if (issued > signalled) {
-                // oldest unsignalled tile: everything issued after it may stay in flight
-                wait_vmcnt(Q * (issued - signalled - 1));
-                if (lane == 0) atomicAdd(&ready[slot_s], 1);
-                ++signalled;
-                if (++slot_s == P) slot_s = 0;
-                if (signalled <= 4) PFPN_STAMP(4 + (signalled - 1) * 6);
-            } else {
-                __builtin_amdgcn_s_sleep(2);               // ring full and nothing of mine in flight
-            }
-        }
-    } else if (wave >= nwaves) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // row wave: nothing to prepare
-    } else {
-        // index arithmetic of the compute waves (divisions by the run-time A), also ahead of the barrier
-        q = lane >> 2; g = lane & 3;
-        sidx = wave * PACK_WSEG + q;                      // segment slot in the tile
-        seg_lane = sidx < nseg;
-        r = seg_lane ? sidx / A : 0;
-        a = seg_lane ? sidx - r * A : 0;
-        s_lo = wave * PACK_WSEG; s_hi = min(nseg, s_lo + PACK_WSEG) - 1;           // inclusive
-        r_lo = s_lo / A; r_hi = (s_hi >= s_lo) ? s_hi / A : r_lo - 1;              // rows this wave touches
-        // The [A,N] tables are tiny, but read per lane they are ~20 scattered lines per wave-instruction x 18
-        // instructions x every wave of every CU, all on the same few L2 lines: measured ~3 us of queueing in
-        // front of the first tile's loads.  So: each element is transformed ONCE per block (coalesced loads,
-        // a quarter of the exp/log work) into LDS, and the lanes pick their (a, n) set from there.
-        //   scale = exp(logstd), cterm = 0.5log(2pi)+log(scale) as the reference graph computes them, pre-scaled
-        //   to base 2:  z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale
-        //   +64: e*phi is formed as ONE exp2 of (softmax exponent + Gaussian exponent + 64), so products
-        //   down to 2^-190 stay normal; the 2^-64 is taken back after the segment sum.
-        // All of it happens BEFORE the start-up barrier -- the ~2,500 cycles of expf / logf run while the first
-        // tile's DMAs are in flight, and the barrier itself publishes the bank (no separate counter to spin on).
-        for (int i0 = t; i0 < AN; i0 += BKU * nwaves * 64) {
-            float ls[BKU], lc[BKU];
-#pragma unroll
-            for (int u = 0; u < BKU; ++u) {                // one round trip for up to four elements per thread
-                if (i0 == t) { ls[u] = bank_ls[u]; lc[u] = bank_lc[u]; continue; }      // in flight since the kernel's first instructions
-                const int i = min(i0 + u * nwaves * 64, AN - 1);
-                ls[u] = logstd[i];
-                lc[u] = loc[i];
-            }
-#pragma unroll
-            for (int u = 0; u < BKU; ++u) {
-                const int i = i0 + u * nwaves * 64;
-                if (i < AN) {
-                    const float sc = expf(ls[u]);
-                    bank[i] = lc[u];
-                    bank[AN + i] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
-                    bank[2 * AN + i] = 64.0f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
-                }
-            }
-        }
-        PFPN_STAMP(43);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // counters zeroed (loaders), bank complete
-        PFPN_STAMP(42);
-    }
-
-    float* slice0 = tile + wave * SLICE;
-    float* seg0 = slice0 + q * N + g;                     // == tile + sidx*N + g
-    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
-
-    // =========================== compute waves ===============================================
-    // particle bank of my (a, n) set -> registers.  scale = exp(logstd), cterm = 0.5log(2pi)+log(scale)
-    // as the reference graph computes them, pre-scaled to base 2:
-    //   z' = (x - loc) * isc2,  phi = exp2(-z'^2 - ct2),  isc2 = sqrt(0.5 log2 e)/scale, ct2 = cterm*log2 e
-    float b_loc[NP], b_isc[NP], b_ct[NP];
-    float acc_loc[NP], acc_ls[NP], acc_db[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) { b_loc[i] = 0.f; b_isc[i] = 0.f; b_ct[i] = 0.f; acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f; }
-    const float two_m64 = 5.421010862427522e-20f;      // 2^-64
-    float pol_sum = 0.f, val_sum = 0.f;
-    if (wave < nwaves) {
-        PFPN_STAMP(44);
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int n = min(g + PACK_G * i, N - 1);
-            b_loc[i] = bank[a * N + n];
-            b_isc[i] = bank[AN + a * N + n];
-            b_ct[i] = bank[2 * AN + a * N + n];
-        }
-        PFPN_STAMP(1);
-
-        // tile k of this block lives in plane k % P; wait until both loaders have landed their part
-        // (slot, lap) = (k % P, k / P) are carried as counters: P is a run-time value and a scalar division costs
-        // ~100 cycles each time
-        auto wait_ready = [&](int slot, int lap) __attribute__((always_inline)) {
-            const int target = PACK_NL * (lap + 1);
-            while (lds_counter(&ready[slot]) < target) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-        };
-        // forward of tile k: softmax numerators stay in the plane, per-segment log p is published to
-        // segbuf[k mod 4] and the row arrival counters of that parity are bumped.
-        auto forward = [&](int k, int slot, float& p_o, float& inv_o) __attribute__((always_inline)) {
-            const int tid = tile0 + k * tstep;
-            const int row0 = tid * R;
-            const int rows = min(R, B - row0);
-            const int nact = rows * A;                     // active segments in this tile
-            const bool active = seg_lane && sidx < nact;
-            float* seg = seg0 + slot * TS;
-            // four log-p buffers: a wave that has run ahead writes tile k+2's (and, one iteration later, k+3's)
-            // values while a neighbour may still be summing tile k's; it cannot reach k+4 before that neighbour
-            // has published k+2, which in the neighbour's program order follows its reads of tile k
-            float* sb = segbuf + (k & 3) * nseg;
-            float inv_sum = 0.f, p = 0.f;
-            if (active) {
-                const float xval = xpl[slot * XS + sidx];
-                // particles in pairs (2k, 2k+1): v_pk_mul/add/fma_f32 give two results per issue slot (this loop is
-                // VALU-issue bound on the SIMD that hosts three of the nine waves); the last one or two particles
-                // -- the only ones that may not exist -- stay scalar.  The maximum is taken on l*log2(e).
-                v2f lp2[NPK > 0 ? NPK : 1];
-                float lpt[NP - 2 * NPK];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < NPK; ++k) {
-                    lp2[k] = (v2f){seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]} * PFPN_LOG2E;
-                    mx = fmaxf(fmaxf(lp2[k].x, lp2[k].y), mx);
-                }
-#pragma unroll
-                for (int i = 2 * NPK; i < NP; ++i) {
-                    lpt[i - 2 * NPK] = 0.f;
-                    if (i < NP - 1 || last_ok) {
-                        lpt[i - 2 * NPK] = seg[PACK_G * i] * PFPN_LOG2E;
-                        mx = fmaxf(mx, lpt[i - 2 * NPK]);
-                    }
-                }
-                mx = quad_max(mx);
-                v2f s2 = {0.f, 0.f}, n2 = {0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < NPK; ++k) {
-                    // raw v_exp_f32 twice per particle: softmax numerator, and numerator * Normal.prob * 2^64 in one go
-                    const v2f le = lp2[k] - mx;
-                    const v2f z = (xval - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * (v2f){b_isc[2 * k], b_isc[2 * k + 1]};
-                    const v2f arg = le + __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
-                    const v2f en = {__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
-                    if (MODE != MODE_FWD) { seg[PACK_G * 2 * k] = en.x; seg[PACK_G * (2 * k + 1)] = en.y; }
-                    s2 += en;
-                    n2 += (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-                }
-                float sum = s2.x + s2.y, num = n2.x + n2.y;
-#pragma unroll
-                for (int i = 2 * NPK; i < NP; ++i) {
-                    if (i < NP - 1 || last_ok) {
-                        const float le = lpt[i - 2 * NPK] - mx;
-                        const float zq = (xval - b_loc[i]) * b_isc[i];
-                        const float en = __builtin_amdgcn_exp2f(le);
-                        if (MODE != MODE_FWD) seg[PACK_G * i] = en;
-                        sum += en;
-                        num += __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
-                    }
-                }
-                sum = quad_sum(sum);
-                num = quad_sum(num);
-                inv_sum = __builtin_amdgcn_rcpf(sum);
-                p = (num * two_m64) * inv_sum;
-                if (p < 1.401298464324817e-45f) p = 0.f;   // below the smallest fp32 denormal: the reference's p is 0
-                if (g == 0) {
-                    float lp = __builtin_amdgcn_logf(p) * 0.6931471805599453f;      // v_log_f32 is log2
-                    if (tanh_mode) lp -= tanh_log_det(xval);
-                    if (pmix_out) pmix_out[(size_t)row0 * A + sidx] = p;
-                    sb[sidx] = lp;
-                }
-            }
-            p_o = p; inv_o = inv_sum;
-            if (MODE != MODE_BWD) {
-                // publish: my segments of each touched row have arrived.  segbuf and cnt both live in LDS, and a
-                // wave's LDS operations are executed in issue order by the one LDS unit of the CU, so the ds_write
-                // of log p is visible to whoever observes the later ds_add: a compiler barrier is all that is needed.
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const int rr_l = r_lo + lane;
-                if (rr_l <= r_hi && rr_l < rows) {
-                    const int n_r = min(min((rr_l + 1) * A, s_hi + 1), nact) - max(rr_l * A, s_lo);
-                    if (n_r > 0) atomicAdd(&cnt[(k & 1) * R + rr_l], n_r);
-                }
-            }
-            if (MODE == MODE_FWD) {
-                // forward mode never stores the plane: it is free as soon as my reads of it are done
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) atomicAdd(&freed[slot], 1);
-            }
-        };
-
-        float p = 0.f, inv_sum = 0.f, p1 = 0.f, inv1 = 0.f;
-        if (T > 0) { wait_ready(0, 0); forward(0, 0, p, inv_sum); }
-        PFPN_STAMP(2);
-
-        int slot = 0, slot_n = (P > 1) ? 1 : 0, lap_n = (P > 1) ? 0 : 1;       // plane of tile k | plane and lap of tile k+1
-        for (int k = 0; k < T; ++k) {
-            const int tileid = tile0 + k * tstep;
-            const int row0 = tileid * R;
-            const int rows = min(R, B - row0);
-            const int nact = rows * A;                     // active segments in this tile
-            const int nfl = max(0, min(nact * N - s_lo * N, SLICE));   // valid floats in my slice
-            float* sb = segbuf + (k & 3) * nseg;
-            float* slice = slice0 + slot * TS;
-            float* seg = seg0 + slot * TS;
-            const bool active = seg_lane && sidx < nact;
-            if (k < 4) PFPN_STAMP(3 + k * 6);
-
-            // ---- forward of the next tile --------------------------------------------------------
-            if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1); }
-            if (k < 4) PFPN_STAMP(4 + k * 6);
-
-            // ---- row stage of this tile: done by the row wave; wait for it and pick up my row's gradient ---------
-            float my_g = 0.f;                               // d loss / d logp of my row
-            if (MODE == MODE_BWD) {
-                if (active) my_g = rpl[slot * 64 + r];
-            } else {
-                // (forward mode waits too: it keeps the compute waves within two tiles of the row wave, which is what
-                // the four segment-log-p buffers allow)
-                while (lds_counter(&gdone[k & 1]) < (k >> 1) + 1) __builtin_amdgcn_s_sleep(1);
-                asm volatile("" ::: "memory");
-                if (k < 4) PFPN_STAMP(5 + k * 6);
-                if (MODE == MODE_PPO && active) my_g = gbuf[(k & 1) * R + r];
-            }
-            if (k < 4) PFPN_STAMP(6 + k * 6);
-
-            if (MODE != MODE_FWD) {
-                // ---- backward on my quarter (dlogits overwrite the LDS slot) -----------------------
-                if (active) {
-                    const float xv = xpl[slot * XS + sidx];
-                    const float q_ = guard_finite(my_g * __builtin_amdgcn_rcpf(p));
-                    const float qs = q_ * inv_sum;
-                    const float qp = qs * p;
-                    const float qs64 = qs * two_m64;
-                    float dxa = 0.f;
-                    v2f dx2 = {0.f, 0.f};
-                    // e*phi is re-formed from the numerator kept in LDS (one v_exp) instead of being held in registers
-                    // across the next tile's forward and the row stage.  Pairs of particles, as in the forward.
-#pragma unroll
-                    for (int k = 0; k < NPK; ++k) {
-                        const v2f en = {seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]};
-                        const v2f isc = {b_isc[2 * k], b_isc[2 * k + 1]};
-                        const v2f z = (xv - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * isc;            // z / c
-                        const v2f g2 = __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
-                        const v2f tt = (en * (v2f){__builtin_amdgcn_exp2f(g2.x), __builtin_amdgcn_exp2f(g2.y)}) * qs64;   // q * w_n * phi_n
-                        const v2f dlg = __builtin_elementwise_fma(-en, (v2f){qp, qp}, tt);            // q * w_n * (phi_n - p)
-                        seg[PACK_G * 2 * k] = dlg.x; seg[PACK_G * (2 * k + 1)] = dlg.y;
-                        if (MODE == MODE_PPO) { acc_db[2 * k] += dlg.x; acc_db[2 * k + 1] += dlg.y; }   // fc_policy bias gradient
-                        const v2f al = __builtin_elementwise_fma(tt, z, (v2f){acc_loc[2 * k], acc_loc[2 * k + 1]});     // scaled by isc*c in the tail
-                        acc_loc[2 * k] = al.x; acc_loc[2 * k + 1] = al.y;
-                        const v2f as = __builtin_elementwise_fma(
-                            tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}),
-                            (v2f){acc_ls[2 * k], acc_ls[2 * k + 1]});                                 // tt*(z^2 - 1)
-                        acc_ls[2 * k] = as.x; acc_ls[2 * k + 1] = as.y;
-                        if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, isc * PFPN_2LN2, dx2);     // isc*c = isc2*2ln2
-                    }
-#pragma unroll
-                    for (int i = 2 * NPK; i < NP; ++i) {
-                        if (i < NP - 1 || last_ok) {
-                            const float en = seg[PACK_G * i];
-                            const float zq = (xv - b_loc[i]) * b_isc[i];
-                            const float tt = qs64 * (en * __builtin_amdgcn_exp2f(fmaf(-zq, zq, b_ct[i])));
-                            const float dlg = fmaf(-en, qp, tt);
-                            seg[PACK_G * i] = dlg;
-                            if (MODE == MODE_PPO) acc_db[i] += dlg;
-                            acc_loc[i] = fmaf(tt, zq, acc_loc[i]);
-                            acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);
-                            if (dx_out) dxa = fmaf(tt * zq, b_isc[i] * PFPN_2LN2, dxa);
-                        }
-                    }
-                    dxa += dx2.x + dx2.y;
-                    if (dx_out) {
-                        dxa = quad_sum(dxa);
-                        if (g == 0) {
-                            float d = -dxa;
-                            if (tanh_mode) d += my_g * 2.f * tanhf(xv);
-                            dx_out[(size_t)row0 * A + sidx] = d;
-                        }
-                    }
-                }
-                if (k < 4) PFPN_STAMP(7 + k * 6);
-                // ---- my slice of dlogits -> HBM (same wave wrote it: in-order LDS, no barrier), then the plane
-                //      is the loaders' again.  The stores are never waited for inside the loop.
-                float* gdst = dlogits + (size_t)row0 * AN + (size_t)s_lo * N;
-                const int nv = nfl >> 2;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    const int i = lane + 64 * j;
-                    if (i < nv) reinterpret_cast<float4*>(gdst)[i] = reinterpret_cast<const float4*>(slice)[i];
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my ds_reads of the plane have returned
-                if (lane == 0) atomicAdd(&freed[slot], 1);
-                if (k < 4) PFPN_STAMP(8 + k * 6);
-            }
-            p = p1; inv_sum = inv1;
-            slot = slot_n;
-            if (++slot_n == P) { slot_n = 0; ++lap_n; }
-        }
-    }
-
-    // =========================== row wave ====================================================
-    if (NRW && wave == nwaves + PACK_NL) {
-        float adv_mean = 0.f, adv_rstd = 1.f, adv_lo = -INFINITY, adv_hi = INFINITY;
-        if (MODE == MODE_PPO) {
-            adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1];
-            adv_lo = ppo.adv_stats[2]; adv_hi = ppo.adv_stats[3];
-        }
-        const int kq = lane >> 4, jl = lane & 15;
-        int slot = 0;
-        for (int k = 0; k < T; ++k) {
-            const int tileid = tile0 + k * tstep;
-            const int row0 = tileid * R;
-            const int rows = min(R, B - row0);
-            const float* sb = segbuf + (k & 3) * nseg;
-            // every row of the tile has all its A segment log-probs (lane j waits for row j; R <= 16)
-            if (lane < rows) {
-                const int target = A * ((k >> 1) + 1);
-                while (lds_counter(&cnt[(k & 1) * R + lane]) < target) __builtin_amdgcn_s_sleep(1);
-            }
-            asm volatile("" ::: "memory");
-            // 16-lane group j sums row pg+j's A segment log-probs (fixed lanes, fixed order: reproducible) and runs its
-            // loss head; four rows per pass
-            for (int pg = 0; pg < rows; pg += 4) {
-                const int rk = pg + kq;
-                const bool rk_ok = rk < rows;
-                float sacc = 0.f;
-                if (rk_ok)
-                    for (int i = jl; i < A; i += 16) sacc += sb[rk * A + i];
-                sacc = quad_sum(sacc);
-                sacc += dpp_shift<0x124, 0xf>(sacc, 0.f);             // row_ror:4
-                sacc += dpp_shift<0x128, 0xf>(sacc, 0.f);             // row_ror:8
-                // the rotation steps associate differently per lane: every lane takes its group's lane 0
-                const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 0));
-                const float u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 16));
-                const float u2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 32));
-                const float u3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sacc), 48));
-                const float s = kq == 0 ? u0 : kq == 1 ? u1 : kq == 2 ? u2 : u3;
-                const int b = row0 + rk;
-                const bool owner = rk_ok && jl == 0;
-                if (MODE == MODE_PPO) {
-                    const int rkc = min(rk, R - 1);
-                    const float* rs = rpl + slot * 64;
-                    const float adv = rs[rkc], lpo = rs[16 + rkc], val_b = rs[32 + rkc], vold_b = rs[48 + rkc];
-                    const float nadv = clip_adv((adv - adv_mean) * adv_rstd, adv_lo, adv_hi);
-                    // v_exp_f32 on (s - lpo) * log2 e: |s - lpo| is O(0.1-1), so the product's rounding is far below the
-                    // instruction's own 1 ulp
-                    const float ratio = __builtin_amdgcn_exp2f((s - lpo) * PFPN_LOG2E);
-                    const float sur = ratio * nadv;
-                    const float cr = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo);
-                    const float csur = cr * nadv;
-                    // grad of -mean(min(sur, csur)): tf.minimum routes to `sur` where sur <= csur,
-                    // clip_by_value passes where lo <= ratio <= hi.
-                    const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
-                    if (owner) {
-                        gbuf[(k & 1) * R + rk] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-                        pol_sum += fminf(sur, csur);
-                        const float dvv = val_b - (adv + vold_b);
-                        val_sum += dvv * dvv;
-                        ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
-                        if (ppo.ratio_out) ppo.ratio_out[b] = ratio;
-                    }
-                }
-                if (owner) logp_out[b] = s;
-            }
-            // a wave's LDS operations execute in issue order: the gradients are visible to whoever sees the counter
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) atomicAdd(&gdone[k & 1], 1);
-            if (++slot == P) slot = 0;
-        }
-    }
-
-    if (MODE == MODE_FWD) return;
-    PFPN_STAMP(40);
-    // ---- block partials: dloc / dlogstd (/ dlogits column sums) summed over the R segments that share an
-    //      action dim, in row order; loss sums in wave order.  Slab layout [nq*AN + 4] per block.
-    //      The ring's first three planes are free now: all sums are staged in one pass.
-    // raw barriers behind an LDS-only wait: __syncthreads()'s fence would first drain the last tile's dlogits stores
-    // (vmcnt(0): ~2,000-3,000 cycles), which nothing below depends on
-    auto tail_barrier = []() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
-    float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
-    {
-        float* lsb = tile + TS;
-        tail_barrier();
-        PFPN_STAMP(45);
-        if (seg_lane) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i)
-                if (i < NP - 1 || last_ok) {
-                    seg0[PACK_G * i] = acc_loc[i] * (b_isc[i] * PFPN_2LN2);      // dloc *= c/scale
-                    lsb[sidx * N + g + PACK_G * i] = acc_ls[i];
-                    if (nq == 3) lsb[TS + sidx * N + g + PACK_G * i] = acc_db[i];
-                }
-        }
-        tail_barrier();
-        PFPN_STAMP(46);
-        // loss sums: the row wave holds them (lanes 0, 16, 32, 48: the row groups' leaders, rows in tile order)
-        if (NRW) {
-            if (wave == nwaves + PACK_NL) {
-                const float ps = wave_sum_dpp(pol_sum), vs = wave_sum_dpp(val_sum);      // lane 63 = total
-                if (lane == 63) { slab[nq * AN + 0] = ps; slab[nq * AN + 1] = vs; }
-            }
-        } else if (t == (int)blockDim.x - 64) {
-            slab[nq * AN + 0] = 0.f;
-            slab[nq * AN + 1] = 0.f;
-        }
-        // column sums over the R rows of the tile, in row order.  Up to TQ outputs per thread per round with all of
-        // their LDS reads issued before the first add (one LDS round trip per round instead of one per output).
-        constexpr int TQ = 6;
-        const int total = nq * AN, bd = (int)blockDim.x;
-        for (int base = t; base < total; base += TQ * bd) {
-            float v[TQ][4];
-            if (R == 4) {
-#pragma unroll
-                for (int k = 0; k < TQ; ++k) {
-                    const int idx = min(base + k * bd, total - 1);
-                    const int which = idx >= 2 * AN ? 2 : idx >= AN ? 1 : 0;
-                    const float* src = (which == 0 ? tile : lsb + (which - 1) * TS) + (idx - which * AN);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) v[k][rr] = src[rr * AN];
-                }
-#pragma unroll
-                for (int k = 0; k < TQ; ++k) {
-                    const int idx = base + k * bd;
-                    if (idx < total) slab[idx] = (((0.f + v[k][0]) + v[k][1]) + v[k][2]) + v[k][3];
-                }
-            } else {
-                for (int k = 0; k < TQ; ++k) {
-                    const int idx = base + k * bd;
-                    if (idx >= total) break;
-                    const int which = idx >= 2 * AN ? 2 : idx >= AN ? 1 : 0;
-                    const float* src = (which == 0 ? tile : lsb + (which - 1) * TS) + (idx - which * AN);
-                    float s_ = 0.f;
-                    for (int rr = 0; rr < R; ++rr) s_ += src[rr * AN];
-                    slab[idx] = s_;
-                }
-            }
-        }
-    }
-    PFPN_STAMP(47);
-    PFPN_STAMP(41);
-}
-
 // ---------------------------------------------------------------------------------------
-// tile path ("dims x rows" lanes; loader / compute / row / storer waves around an LDS ring)
+// tile path: loader / compute / row / storer waves around an LDS ring
 //
-// Same ring as above -- LDS-DMA loader waves stream R = 4-row tiles into P planes laid out as in HBM -- with three
-// changes that came out of the phase stamps of the wave-sliced kernel (profiles/r02_mix_packed_stamps.txt):
-//  * LANE MAP.  Compute wave w owns action dims [4w, 4w+4) of ALL four rows of a tile: lane = 16 d + 4 r + g
-//    (d dim, r row, g particle quarter).  The four lanes that hold the same (a, n) set for the four rows then sit in
-//    one 16-lane DPP row, 4 lanes apart: the batch sums (dloc, dlogstd, fc_policy bias gradient) are finished with two
-//    row_ror DPP adds per value and leave straight from registers -- the old tail (stage 27 values per lane through
-//    LDS, two block barriers, column sums: 4.4 k cycles after the SLOWEST wave arrived) is gone; no barrier follows
-//    the start-up one.
-//  * STORER waves copy a finished plane LDS -> HBM (whole 1-KiB wave stores, line-aligned whatever the wave count;
-//    the 2,240-B wave slices split 128-B lines: 1.07x traffic).  The compute waves, the critical path, no longer spend
-//    ~600-800 cycles per tile reading their slice back and storing it.
-//  * START-UP.  The first tile's DMAs are issued by every non-compute wave at once (the two loaders alone needed
-//    ~2,300 cycles to get 24 DMAs out), the loaders run on into tile 1, and the start-up barrier publishes tile 0, the
-//    particle bank and the zeroed counters together.
+// A tile is R = 4 whole batch rows, laid out in an LDS plane exactly as in HBM; a block walks a contiguous run
+// of tiles through a ring of P planes.  One block per CU, one start-up barrier, no other block-wide wait.
+//
+// * LOADER waves (no arithmetic) move tiles HBM -> LDS with LDS-DMA (`global_load_lds_dwordx4`: 1 KiB per
+//   wave-instruction, no VGPR destination), together with the tile's action values and per-row scalars.  A loader's
+//   instruction stream is nothing but DMAs, so its `s_waitcnt vmcnt(n)` is counted exactly: it keeps two tiles in
+//   flight and bumps the plane's `ready` counter when the OLDEST has landed.  The bytes in flight per CU are not
+//   limited by the VGPRs of the computing waves (one tile ahead in registers = 20 KB per CU measured ~2.6 TB/s
+//   chip-wide).
+// * COMPUTE wave w owns action dims [4w, 4w+4) of ALL four rows of every tile: lane = 16 d + 4 r + g (d dim, r row,
+//   g particle quarter; particles g, g+4, ...).  It transforms its part of the plane in place (logits -> softmax
+//   numerators -> dlogits): no global load, hence no vmcnt wait, anywhere in its loop.  The 4 lanes of a segment
+//   reduce with two quad-permute DPP steps.  The particle bank of a lane's (a, n) set is tile-invariant and lives
+//   in registers.  The four lanes that hold the same (a, n) set for the four rows sit in one 16-lane DPP row, 4 lanes
+//   apart, so the batch sums (dloc, dlogstd, fc_policy bias gradient) are finished after the last tile with two
+//   row_ror DPP adds per value and leave straight from registers as the block's slab (fixed order: bitwise
+//   reproducible, no float atomics, no LDS staging, no barrier).
+// * The ROW wave owns the only cross-wave dependency, the row log-prob: compute waves publish per-segment log p
+//   and bump a per-row arrival counter; the row wave sums a row's A values in a fixed order, runs the loss head and
+//   publishes {tile number, d loss / d logp} as ONE 8-byte LDS word per row, which the compute waves poll: the
+//   gradient arrives with the flag.  The loop is software-pipelined -- forward(k+1) | wait row(k) | backward(k) -- so
+//   the row stage of tile k overlaps the forward of tile k+1.
+// * STORER waves (modes that write dlogits) copy a plane whose backward is complete LDS -> HBM: whole 1-KiB wave
+//   stores, line-aligned whatever the wave count (wave-sized slices of 2,240 B split 128-B lines: 1.07x traffic),
+//   non-temporal, then hand the plane back to the loaders.
+// * START-UP: nothing of the first tile goes through the loaders -- see the comment in the kernel.
+//
+// What the phase stamps of block 0 (tools/stamp_probe.py) say at 4096 x 36 x 35 (4 tiles per block): ~1,500 cycles
+// until the kernel arguments are there, tile 0 landed at ~4,900 (one cold 5 MB burst from 256 CUs), ~3,600 cycles per
+// tile -- set by the third compute wave of SIMD 0 (nine compute waves on four SIMDs), whose forward takes 2,000-2,200
+// cycles against 1,400 for a SIMD's first wave -- and the last plane stored ~2,000 cycles after the last backward.
 // ---------------------------------------------------------------------------------------
 constexpr int TK_R = 4;                              // rows per tile
 constexpr int TK_NL = 2;                             // loader waves
@@ -891,41 +273,46 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         }
     };
 
-    // Start-up.  Compute wave w needs the particle tables of ITS four dims only (<= 4 N consecutive elements): it
-    // loads them itself (<= BKU per lane, coalesced), transforms them and passes them to its lanes through its own
-    // corner of the LDS bank -- no other wave is involved, so the bank costs no block-wide wait.
+    // Start-up.  Nothing of the first tile goes through the loaders: compute wave w fetches what IT needs -- the
+    // particle tables of its four dims (<= 4 N consecutive elements, <= BKU per lane), its action values, and its own
+    // four row pieces of tile 0 by LDS-DMA -- in its first instructions, so the first forward pass waits for one HBM
+    // round trip and for no other wave (before: every service wave issued a share of tile 0 and the block met at a
+    // barrier ~5,000 cycles in).  The one block barrier only publishes the zeroed counters and comes early.
     constexpr int BKU = (4 * N + 63) / 64;                                    // table elements per lane
     float bank_ls[BKU], bank_lc[BKU];
+    float x0 = 0.f, g0 = 0.f;                                                 // tile 0: my action value, my row's dlogp (BWD)
     if (wave < NC) {
-        const int e0 = wave * 4 * N, ne = min(4, A - wave * 4) * N;
+        const int ndw_ = min(4, A - wave * 4);
+        const int e0 = wave * 4 * N, ne = ndw_ * N;
 #pragma unroll
         for (int u = 0; u < BKU; ++u) {
             const int i = e0 + min(lane + 64 * u, ne - 1);
             bank_ls[u] = logstd[i];
             bank_lc[u] = loc[i];
         }
-    } else if (T > 0) {
-        // every other wave: its share of the first tile, at raised priority (these waves share SIMDs with compute
-        // waves that are about to run the table transform).  Full tile: pointer bumps only.
-        __builtin_amdgcn_s_setprio(3);
-        const int sw = wave - NC, nsv = nwv - NC;
-        const int rows0 = min(R, B - tile0 * R);
-        if (rows0 == R) {
-            const char* gp = reinterpret_cast<const char*>(logits + (size_t)tile0 * R * AN) + (size_t)(sw * 64 + lane) * 16;
-            unsigned lb = __builtin_amdgcn_readfirstlane(tile_b + (unsigned)(sw * 1024));
-            int c = sw;
-            for (; c < nct - 1; c += nsv) {
-                dma16(gp, lb);
-                gp += nsv * 1024;
-                lb += nsv * 1024;
+        if (T > 0) {
+            const int row0 = tile0 * R, rows0 = min(R, B - row0);
+            const int r_ = (lane >> 2) & 3, a_ = min(wave * 4 + (lane >> 4), A - 1);
+            if (r_ < rows0) {
+                x0 = x[(size_t)(row0 + r_) * A + a_];
+                if (MODE == MODE_BWD) g0 = dlogp_in[row0 + r_];
             }
-            if (c == nct - 1 && c * 64 + lane < R * AN / 4) dma16(gp, lb);
-            for (int it_ = nct + ((sw - nct) % nsv + nsv) % nsv; it_ < M; it_ += nsv) issue_item(0, it_, 0);
-        } else {
-            for (int it_ = sw; it_ < M; it_ += nsv) issue_item(0, it_, 0);
+            // my piece of row rr: ndw N floats = ndw N / 4 float4 (AN % 4 == 0 makes every piece whole), one DMA each
+            const int nf4 = ne >> 2;
+            for (int rr = 0; rr < rows0; ++rr)
+                if (lane < nf4)
+                    dma16(reinterpret_cast<const float4*>(logits + (size_t)(row0 + rr) * AN + e0) + lane,
+                          __builtin_amdgcn_readfirstlane(tile_b + (unsigned)((rr * AN + e0) * 4)));
         }
-        PFPN_STAMP(3);
+    } else if (NRW && wave == NC + TK_NL) {
+        if (MODE == MODE_PPO && T > 0) issue_item(0, nct + ncx, 0);           // row wave: tile 0's row scalars
+    } else if (wave == NC) {
+        // first loader: zero gslot (8 R ints), cnt, ready, freed, bdone; ready[0] = landed (tile 0 is the compute waves')
+        for (int i = lane; i < 12 * R + 3 * P; i += 64)
+            reinterpret_cast<int*>(gslot)[i] = (i == 12 * R && T > 0) ? TK_NL : 0;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PFPN_STAMP(42);
 
     // =========================== loader waves ================================================
     if (wave >= NC && wave < NC + TK_NL) {
@@ -935,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         while (dmax > 1 && (dmax - 1) * Q > 63) --dmax;
         if (dmax > P) dmax = P;
         const int nfree = (MODE == MODE_FWD) ? NC : NS;    // who hands a plane back
-        int issued = (T > 0) ? 1 : 0, signalled = issued;  // tile 0: issued above, published by the start-up barrier
+        int issued = (T > 0) ? 1 : 0, signalled = issued;  // tile 0 is fetched by the compute waves themselves
         int slot_i = (P > 1) ? 1 : 0, wrap_i = (P > 1) ? 0 : 1, slot_s = slot_i;
         if (T == 0) { slot_i = 0; wrap_i = 0; slot_s = 0; }
         auto issue_tile = [&]() __attribute__((always_inline)) {
@@ -959,15 +346,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
             ++issued;
             if (++slot_i == P) { slot_i = 0; ++wrap_i; }
         };
-        // run on into tile 1 (a fresh plane when P > 1), then zero the counters and meet the block
-        bool t1 = false;
-        if (T > 1 && P > 1 && dmax > 1) { issue_tile(); t1 = true; }
-        for (int i = t - NC * 64; i < 12 * R + 3 * P; i += TK_NL * 64)        // gslot (8 R ints), cnt, ready, freed, bdone
-            reinterpret_cast<int*>(gslot)[i] = (i == 12 * R && T > 0) ? TK_NL : 0;    // ready[0] = landed
-        // my share of tile 0 has landed when only tile 1's DMAs are outstanding (in-order counter)
-        if (t1) wait_vmcnt(Q); else wait_vmcnt(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        PFPN_STAMP(4);
+        __builtin_amdgcn_s_setprio(3);                     // (loaders share SIMDs with compute waves)
         while (signalled < T) {
             bool can = issued < T && issued - signalled < dmax;
             if (can && wrap_i > 0)                         // plane still in use?
@@ -995,8 +374,8 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
             adv_mean = ppo.adv_stats[0]; adv_rstd = ppo.adv_stats[1];
             adv_lo = ppo.adv_stats[2]; adv_hi = ppo.adv_stats[3];
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // (stays at raised priority: every compute wave waits for this wave's few instructions once per tile)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile 0's row scalars (my own DMA)
+        __builtin_amdgcn_s_setprio(3);     // every compute wave waits for this wave's few instructions once per tile
         const int kq = lane >> 4, jl = lane & 15;
         int slot = 0, lap = 0;
         for (int k = 0; k < T; ++k) {
@@ -1077,8 +456,6 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     // =========================== storer waves ================================================
     if (NS && wave >= NC + TK_NL + NRW) {
         const int s_ = wave - (NC + TK_NL + NRW);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_s_setprio(0);
         constexpr int SU = 5;                              // float4 per lane and round: all reads of a round, then its stores
         int slot = 0, lap = 0;
         for (int k = 0; k < T; ++k) {
@@ -1095,11 +472,14 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 f4v v0 = src[min(i0, nv4 - 1)], v1 = src[min(i1, nv4 - 1)], v2 = src[min(i2, nv4 - 1)],
                     v3 = src[min(i3, nv4 - 1)], v4 = src[min(i4, nv4 - 1)];
                 asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
-                if (i0 < nv4) dst[i0] = v0;
-                if (i1 < nv4) dst[i1] = v1;
-                if (i2 < nv4) dst[i2] = v2;
-                if (i3 < nv4) dst[i3] = v3;
-                if (i4 < nv4) dst[i4] = v4;
+                // non-temporal: the 20 MB of dlogits are not left dirty in L2 for the end-of-kernel write-back
+                // (measured 13.8 -> 12.6 us per launch, and the step gains too although its next kernels read dlogits;
+                // nt on the scattered slab stores cost +3 us, nt on the DMA loads changed nothing)
+                if (i0 < nv4) __builtin_nontemporal_store(v0, &dst[i0]);
+                if (i1 < nv4) __builtin_nontemporal_store(v1, &dst[i1]);
+                if (i2 < nv4) __builtin_nontemporal_store(v2, &dst[i2]);
+                if (i3 < nv4) __builtin_nontemporal_store(v3, &dst[i3]);
+                if (i4 < nv4) __builtin_nontemporal_store(v4, &dst[i4]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my reads of the plane have returned
             if (lane == 0) atomicAdd(&freed[slot], 1);
@@ -1149,8 +529,11 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
             b_ct[i] = bank[2 * AN + a * N + n];
             acc_loc[i] = 0.f; acc_ls[i] = 0.f; acc_db[i] = 0.f;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile 0 landed, counters zeroed
-        PFPN_STAMP(42);
+        // tile 0: my action values (and, backward mode, my rows' dlogp -- every wave writes the same four values) into
+        // the planes the later tiles' DMAs fill; then my row pieces must have landed
+        if (T > 0 && dim_ok && g == 0 && tile0 * R + r < B) xpl[sidx] = x0;
+        if (MODE == MODE_BWD && T > 0 && d == 0 && g == 0 && tile0 * R + r < B) rpl[r] = g0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     const float two_m64 = 5.421010862427522e-20f;      // 2^-64
     PFPN_STAMP(1);
@@ -1785,8 +1168,6 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // ---------------------------------------------------------------------------------------
 struct PackPlan { int R; int grid; int threads; size_t lds; int P; bool ok; int ntiles; };
 
-static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
-
 // compute units of the current device (MI355X: 256); asked once
 static int cu_count() {
     static int n = 0;
@@ -1801,89 +1182,7 @@ static int cu_count() {
     return n;
 }
 
-static PackPlan plan_packed(int B, int A, int N, const void* logits, const void* dlogits) {
-    PackPlan pl{};
-    pl.ok = false;
-    // A >= 4: the 16 consecutive segments of a wave then span at most 4 rows (one 16-lane group per row
-    // in the row stage); narrower action spaces take the wave kernel
-    if (N > 64 || N < 1 || A < 4 || B < 1) return pl;
-    const int AN = A * N;
-    // the kernel streams float4 slices / 1 KiB DMA pieces only; unaligned shapes take the wave kernel
-    if ((AN % 4) || ((uintptr_t)logits % 16) || (dlogits && (uintptr_t)dlogits % 16)) return pl;
-    // rows per tile: the smallest R0 with R0*A a multiple of 16 segments (full waves), repeated while the
-    // block stays <= 12 compute waves and <= 16 rows (A=36: R=4, 9 waves, every lane busy)
-    const int R0 = PACK_WSEG / gcd_i(A, PACK_WSEG);
-    const int W0 = R0 * A / PACK_WSEG;
-    if (W0 > 13 || R0 > 16) return pl;            // compute + 2 loader + 1 row wave <= 16 waves
-    int k = 12 / W0;
-    if (k < 1) k = 1;
-    while (k > 1 && R0 * k > 16) --k;
-    int R = R0 * k;
-    static const int env_rows = getenv("PFPN_MIX_ROWS") ? atoi(getenv("PFPN_MIX_ROWS")) : 0;   // tuning knob
-    if (env_rows > 0 && env_rows <= 16 && (env_rows * A + PACK_WSEG - 1) / PACK_WSEG <= 13) R = env_rows;
-    if (R > B) R = B;                                   // small batches: one partial tile
-    const int waves = (R * A + PACK_WSEG - 1) / PACK_WSEG;      // compute waves
-    pl.R = R;
-    pl.threads = (waves + PACK_NL) * 64;
-    // LDS ring: P planes of (tile + action values + row scalars), then the small arrays (see the kernel's map)
-    const size_t plane = (size_t)waves * PACK_WSEG * N * 4 + (size_t)(((R * A + 63) & ~63) + 64) * 4;
-    const int pmin = dlogits ? 3 : 2;
-    int P = 4;
-    static const int env_p = getenv("PFPN_MIX_PLANES") ? atoi(getenv("PFPN_MIX_PLANES")) : 0;     // tuning knob
-    if (env_p >= pmin && env_p <= 8) P = env_p;
-    size_t small = 0;
-    for (;; --P) {
-        small = (size_t)(4 * R * A + 2 * R + 2 * P + 2 * waves + 2 * R + 24 + 3 * AN) * 4;   // + gdone, gbuf [2][R]
-        if (P * plane + small <= PACK_MAX_LDS || P <= pmin) break;
-    }
-    pl.P = P;
-    pl.lds = P * plane + small;
-    const int ntiles = (B + R - 1) / R;
-    pl.ntiles = ntiles;
-    int per_cu = 1;                                     // one block (compute + loader waves) per CU
-    static const int env_pcu = getenv("PFPN_MIX_PER_CU") ? atoi(getenv("PFPN_MIX_PER_CU")) : 0;   // tuning knob
-    if (env_pcu > 0) per_cu = env_pcu;
-    const int cap = cu_count() * per_cu;
-    pl.grid = ntiles < cap ? ntiles : cap;
-    pl.ok = pl.lds <= PACK_MAX_LDS && waves <= 13 && R <= 16;
-    return pl;
-}
-
-template <int MODE>
-static int launch_packed(int N, const PackPlan& pl, hipStream_t st, const float* logits, const float* x,
-                         const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
-                         float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
-#define PFPN_LAUNCH_PACKED_T(NN, TT)                                                                        \
-    do {                                                                                                    \
-        static bool big_lds_ok = false;          /* > 64 KB of dynamic LDS needs a one-time opt-in */         \
-        if (pl.lds > 64 * 1024 && !big_lds_ok) {                                                            \
-            (void)hipFuncSetAttribute((const void*)&k_mix_packed<NN, MODE, TT>,                              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PACK_MAX_LDS);        \
-            big_lds_ok = true;                                                                              \
-        }                                                                                                   \
-        hipLaunchKernelGGL((k_mix_packed<NN, MODE, TT>), dim3(pl.grid), dim3(threads), pl.lds, st, logits, x, \
-                           loc, logstd, dlogp, B, A, pl.R, tanh_mode, pl.P, pl.ntiles / pl.grid,            \
-                           pl.ntiles % pl.grid, logp, pmix, dlogits, dx, partial, ppo);                     \
-    } while (0)
-#define PFPN_LAUNCH_PACKED(NN)                                                  \
-    do {                                                                        \
-        if (threads <= 768) PFPN_LAUNCH_PACKED_T(NN, 768);                      \
-        else PFPN_LAUNCH_PACKED_T(NN, PACK_BLOCK);                              \
-    } while (0)
-    const int threads = pl.threads + (MODE != MODE_BWD ? 64 : 0);       // + the row wave (forward / PPO modes)
-    switch (N) {
-        case 35: PFPN_LAUNCH_PACKED(35); break;
-        case 50: PFPN_LAUNCH_PACKED(50); break;
-        case 16: PFPN_LAUNCH_PACKED(16); break;
-        case 8: PFPN_LAUNCH_PACKED(8); break;
-        default: return -1;
-    }
-#undef PFPN_LAUNCH_PACKED
-#undef PFPN_LAUNCH_PACKED_T
-    return 0;
-}
-
-static bool packed_has(int N) { return N == 35 || N == 50 || N == 16 || N == 8; }
+static bool tile_has(int N) { return N == 35 || N == 50 || N == 16 || N == 8; }
 
 // tile kernel (k_mix_tile): R = 4 rows per tile, 4 action dims per compute wave
 static PackPlan plan_tile(int B, int A, int N, const void* logits, const void* dlogits) {
@@ -1945,26 +1244,6 @@ static int launch_tile(int N, const PackPlan& pl, hipStream_t st, const float* l
     return 0;
 }
 
-// A/B switch for this round's measurements: PFPN_MIX_TILE=0 takes the wave-sliced kernel (k_mix_packed)
-static bool use_tile() { static const int v = getenv("PFPN_MIX_TILE") ? atoi(getenv("PFPN_MIX_TILE")) : 1; return v != 0; }
-static PackPlan plan_mix(int B, int A, int N, const void* logits, const void* dlogits) {
-    if (use_tile()) {
-        PackPlan pl = plan_tile(B, A, N, logits, dlogits);
-        if (pl.ok) return pl;
-    }
-    return plan_packed(B, A, N, logits, dlogits);
-}
-template <int MODE>
-static int launch_mix(int N, const PackPlan& pl, hipStream_t st, const float* logits, const float* x,
-                      const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
-                      float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
-    if (use_tile() && plan_tile(B, A, N, logits, dlogits).ok)
-        return launch_tile<MODE>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, logp, pmix, dlogits, dx,
-                                 partial, ppo);
-    return launch_packed<MODE>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, logp, pmix, dlogits, dx,
-                               partial, ppo);
-}
-
 // wide path: float4 per lane, up to 4 float4s per lane (N <= 1024)
 static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
     return N >= 64 && N % 4 == 0 && N <= 1024 && ((uintptr_t)logits % 16 == 0) &&
@@ -2001,7 +1280,7 @@ int pfpn_debug_stamps(void* device_buffer) {
 }
 
 size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
-    // slabs: packed path <= 1024 blocks x (2AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]
+    // slabs: tile path <= 1024 blocks x (3AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]
     const size_t AN = (size_t)A * N;
     const size_t slabs = (N <= 64 ? (size_t)1024 : (size_t)64) * (3 * AN + 4);
     return (slabs + (size_t)B * A + 64) * sizeof(float);
@@ -2014,10 +1293,10 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
     if (!logits || !x || !loc || !logstd || !logp || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipStream_t st = (hipStream_t)stream;
-    PackPlan pl = plan_mix(B, A, N, logits, nullptr);
-    if (pl.ok && packed_has(N)) {
+    PackPlan pl = plan_tile(B, A, N, logits, nullptr);
+    if (pl.ok && tile_has(N)) {
         PpoArgs none{};
-        launch_mix<MODE_FWD>(N, pl, st, logits, x, loc, logstd, nullptr, B, A, tanh_mode, logp, pmix,
+        launch_tile<MODE_FWD>(N, pl, st, logits, x, loc, logstd, nullptr, B, A, tanh_mode, logp, pmix,
                                 nullptr, nullptr, nullptr, none);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
@@ -2076,11 +1355,11 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     }
     if (!workspace) return PFPN_ERR_WORKSPACE;
     float* partial = (float*)workspace;
-    PackPlan pl = plan_mix(B, A, N, logits, dlogits);
-    if (pl.ok && packed_has(N)) {
+    PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+    if (pl.ok && tile_has(N)) {
         if (workspace_bytes < (size_t)pl.grid * (2 * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
         PpoArgs none{};
-        launch_mix<MODE_BWD>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, nullptr, nullptr,
+        launch_tile<MODE_BWD>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, nullptr, nullptr,
                                 dlogits, dx, partial, none);
         PFPN_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, pl.grid,
@@ -2135,8 +1414,8 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
 int pfpn_ppo_mixture_slabs(int B, int A, int N, int want_dbias, const float* logits, const float* dlogits,
                            int* nslab, int* stride) {
     if (!nslab || !stride || !logits || !dlogits || B < 1 || A < 1 || N < 1) return PFPN_ERR_ARG;
-    PackPlan pl = plan_mix(B, A, N, logits, dlogits);
-    if (!(pl.ok && packed_has(N))) return PFPN_ERR_ARG;
+    PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+    if (!(pl.ok && tile_has(N))) return PFPN_ERR_ARG;
     *nslab = pl.grid;
     *stride = (want_dbias ? 3 : 2) * A * N + 4;
     return PFPN_OK;
@@ -2155,8 +1434,8 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     if (!workspace) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int AN = A * N;
-    PackPlan pl = plan_mix(B, A, N, logits, dlogits);
-    if (!(pl.ok && packed_has(N))) return PFPN_ERR_ARG;   // caller falls back to fwd + ppo_loss + bwd
+    PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+    if (!(pl.ok && tile_has(N))) return PFPN_ERR_ARG;   // caller falls back to fwd + ppo_loss + bwd
     const int nq = dbias ? 3 : 2;
     if (workspace_bytes < (size_t)pl.grid * (nq * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
     PpoArgs pa{};
@@ -2164,7 +1443,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     pa.inv_B = 1.0f / (float)B; pa.clip_lo = 1.0f - clip_eps; pa.clip_hi = 1.0f + clip_eps;
     pa.value_coef = value_coef; pa.dvalue = dvalue; pa.ratio_out = nullptr; pa.want_db = dbias ? 1 : 0;
     float* partial = (float*)workspace;
-    launch_mix<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
+    launch_tile<MODE_PPO>(N, pl, st, logits, action, loc, logstd, nullptr, B, A, 0, logp, nullptr, dlogits,
                             nullptr, partial, pa);
     PFPN_CHECK_LAUNCH();
     if (!loss3) return PFPN_OK;          // diagnostic: slabs left unreduced (times the main kernel alone, bench.py)

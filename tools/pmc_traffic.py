@@ -10,10 +10,10 @@ def collect(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"k_mix_packed<(\d+), (\d+)", r["Kernel_Name"])
+        m = re.search(r"k_mix_tile<(\d+), (\d+)", r["Kernel_Name"])
         if m:
             mode = {0: "FWD", 1: "BWD", 2: "PPO"}[int(m.group(2))]
-            acc["k_mix_packed<%s,%s>" % (m.group(1), mode)].append(float(r["Counter_Value"]))
+            acc["k_mix_tile<%s,%s>" % (m.group(1), mode)].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 

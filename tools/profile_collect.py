@@ -2,7 +2,7 @@
   <tag>_bench_kernel_stats.csv  per-kernel stats table of the eager step
   <tag>_step_timeline.txt       one learner step of the default run, kernel by kernel
   <tag>_pmc_traffic.json        HBM bytes per launch of the packed / wide mixture kernels (FETCH_SIZE x2 + WRITE_SIZE)
-  <tag>_mix_packed_sq.json      SQ counters of k_mix_packed<35,PPO>: the measured VALU-issue share
+  <tag>_mix_tile_sq.json      SQ counters of k_mix_tile<35,PPO>: the measured VALU-issue share
   <tag>_bench_line.json         the bench JSON line
 usage: python tools/profile_collect.py <raw dir> <out dir> <tag>"""
 import csv, glob, json, os, re, subprocess, sys
@@ -33,10 +33,10 @@ def counters(path):
         return acc
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        m = re.search(r"k_mix_packed<(\d+), (\d+)", k)
+        m = re.search(r"k_mix_tile<(\d+), (\d+)", k)
         name = None
         if m:
-            name = "k_mix_packed<%s,%s>" % (m.group(1), {0: "FWD", 1: "BWD", 2: "PPO"}[int(m.group(2))])
+            name = "k_mix_tile<%s,%s>" % (m.group(1), {0: "FWD", 1: "BWD", 2: "PPO"}[int(m.group(2))])
         else:
             m = re.search(r"k_mix_wide<(\d+), (\d+)", k)
             if m:
@@ -66,7 +66,7 @@ sq = {}
 for d in ("sq1", "sq2"):
     for k, cs in counters(one(d + "/**/*counter_collection.csv")).items():
         sq.setdefault(k, {}).update({c: mean(v) for c, v in cs.items()})
-k = "k_mix_packed<35,PPO>"
+k = "k_mix_tile<35,PPO>"
 if k in sq:
     c = sq[k]
     waves, simds = c.get("SQ_WAVES", 0), 256 * 4
@@ -82,7 +82,7 @@ if k in sq:
             },
             "note": "SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md); 1024 SIMDs; the "
                     "SIMD that hosts three of the nine compute waves carries 3 / 2.25 of the average VALU issue"}
-    json.dump(note, open(os.path.join(out, tag + "_mix_packed_sq.json"), "w"), indent=1)
+    json.dump(note, open(os.path.join(out, tag + "_mix_tile_sq.json"), "w"), indent=1)
 bl = os.path.join(raw, "bench.log")
 if os.path.exists(bl):
     lines = [l for l in open(bl).read().splitlines() if l.startswith("{")]
