@@ -385,6 +385,24 @@ def main():
                           "peak": HBM_PEAK_GBS, "frac": nb / u / 1e3 / HBM_PEAK_GBS,
                           "note": "3L composition; a fused 2L pass needs a row (128 KiB) AND the [A,N] bank (393 KB) on one CU"}
             del s_out
+            # this box's read+write roof in the same run: a device copy of the 1 GiB logits (the backward kernel streams
+            # the same 2L; the forward is bounded by its two v_exp_f32 per particle, tools/bw_probe8.hip)
+            s_cp = torch.empty_like(sl)
+            s_cp.copy_(sl); s_cp.copy_(sl)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                s_cp.copy_(sl)
+            e1.record()
+            torch.cuda.synchronize()
+            u = e0.elapsed_time(e1) * 1e3 / 10
+            res["device_copy"] = {"kernel": "torch copy_ of the same logits (read L + write L)", "us_per_launch": u,
+                                  "algorithmic_bytes": 2 * L_, "achieved": 2 * L_ / u / 1e3, "unit": "GB/s",
+                                  "peak": HBM_PEAK_GBS, "frac": 2 * L_ / u / 1e3 / HBM_PEAK_GBS}
+            del s_cp
+            res["note"] = ("bwd streams 2L at the box's copy rate (device_copy); fwd is bound by its arithmetic -- two "
+                           "v_exp_f32 per particle: with the rows already in LDS (LDS-DMA ring, tools/bw_probe8.hip) the same "
+                           "math takes ~203 us, while the bare stream runs at 0.74-0.79 of the roof")
             out["roofline_stress"] = {"shape": [sB, sA, sN], "bound": "hbm", **res}
             del sl, sx, sg
         except Exception as ex:      # never fail the headline line on the auxiliary measurement
