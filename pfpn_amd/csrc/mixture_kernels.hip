@@ -458,7 +458,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         const int s_ = wave - (NC + TK_NL + NRW);
         constexpr int SU = 5;                              // float4 per lane and round: all reads of a round, then its stores
         int slot = 0, lap = 0;
-        for (int k = 0; k < T; ++k) {
+        for (int k = 0; k + 1 < T; ++k) {                  // (the block's last tile is stored by the compute waves)
             const int row0 = (tile0 + k) * R, rows = min(R, B - row0);
             const int nv4 = rows * AN / 4;
             while (lds_counter(&bdone[slot]) < NC * (lap + 1)) __builtin_amdgcn_s_sleep(1);
@@ -546,7 +546,8 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     };
     // forward of tile k: softmax numerators stay in the plane, per-segment log p is published to
     // segbuf[k mod 4] and the row arrival counters of that parity are bumped.
-    auto forward = [&](int k, int slot, float& p_o, float& inv_o) __attribute__((always_inline)) {
+    auto forward = [&](int k, int slot, float& p_o, float& inv_o, v2f (&ef2_o)[NPK > 0 ? NPK : 1], float (&eft_o)[NP - 2 * NPK])
+        __attribute__((always_inline)) {
         const int row0 = (tile0 + k) * R;
         const int rows = min(R, B - row0);
         const bool active = dim_ok && r < rows;
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 const v2f en = {__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
                 if (MODE != MODE_FWD) { seg[PACK_G * 2 * k] = en.x; seg[PACK_G * (2 * k + 1)] = en.y; }
                 s2 += en;
-                n2 += (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                ef2_o[k] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                n2 += ef2_o[k];
             }
             float sum = s2.x + s2.y, num = n2.x + n2.y;
 #pragma unroll
@@ -598,7 +600,8 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                     const float en = __builtin_amdgcn_exp2f(le);
                     if (MODE != MODE_FWD) seg[PACK_G * i] = en;
                     sum += en;
-                    num += __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
+                    eft_o[i - 2 * NPK] = __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
+                    num += eft_o[i - 2 * NPK];
                 }
             }
             sum = quad_sum(sum);
@@ -628,8 +631,17 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         }
     };
 
+    // e_n * phi_n * 2^64 of my particles (the forward's numerator terms) stay in registers until the tile's backward:
+    // 9 VGPRs per tile in flight instead of a v_exp_f32 per particle to re-form them (the compute waves are VALU-bound,
+    // and 28 of their ~190 VALU instructions per tile were quarter-rate transcendentals)
+    v2f ef2[NPK > 0 ? NPK : 1], ef2n[NPK > 0 ? NPK : 1];
+    float eft[NP - 2 * NPK], eftn[NP - 2 * NPK];
+#pragma unroll
+    for (int i = 0; i < (NPK > 0 ? NPK : 1); ++i) { ef2[i] = (v2f){0.f, 0.f}; ef2n[i] = (v2f){0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < NP - 2 * NPK; ++i) { eft[i] = 0.f; eftn[i] = 0.f; }
     float p = 0.f, inv_sum = 0.f, p1 = 0.f, inv1 = 0.f;
-    if (T > 0) forward(0, 0, p, inv_sum);                  // tile 0: published by the start-up barrier
+    if (T > 0) forward(0, 0, p, inv_sum, ef2, eft);        // tile 0: fetched by this wave itself
     PFPN_STAMP(2);
 
     int slot = 0, slot_n = (P > 1) ? 1 : 0, lap_n = (P > 1) ? 0 : 1;       // plane of tile k | plane and lap of tile k+1
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         if (k < 4) PFPN_STAMP(3 + k * 6);
 
         // ---- forward of the next tile --------------------------------------------------------
-        if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1); }
+        if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1, ef2n, eftn); }
         if (k < 4) PFPN_STAMP(4 + k * 6);
 
         // ---- row stage of this tile: done by the row wave; wait for it and pick up my row's gradient ---------
@@ -671,15 +683,13 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 const float qs64 = qs * two_m64;
                 float dxa = 0.f;
                 v2f dx2 = {0.f, 0.f};
-                // e*phi is re-formed from the numerator kept in LDS (one v_exp) instead of being held in registers
-                // across the next tile's forward.  Pairs of particles, as in the forward.
+                // pairs of particles, as in the forward
 #pragma unroll
                 for (int k = 0; k < NPK; ++k) {
                     const v2f en = {seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]};
                     const v2f isc = {b_isc[2 * k], b_isc[2 * k + 1]};
                     const v2f z = (xv - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * isc;            // z / c
-                    const v2f g2 = __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
-                    const v2f tt = (en * (v2f){__builtin_amdgcn_exp2f(g2.x), __builtin_amdgcn_exp2f(g2.y)}) * qs64;   // q * w_n * phi_n
+                    const v2f tt = ef2[k] * qs64;                                                  // q * w_n * phi_n
                     const v2f dlg = __builtin_elementwise_fma(-en, (v2f){qp, qp}, tt);            // q * w_n * (phi_n - p)
                     seg[PACK_G * 2 * k] = dlg.x; seg[PACK_G * (2 * k + 1)] = dlg.y;
                     if (MODE == MODE_PPO) { acc_db[2 * k] += dlg.x; acc_db[2 * k + 1] += dlg.y; }   // fc_policy bias gradient
@@ -696,7 +706,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                     if (i < NP - 1 || last_ok) {
                         const float en = seg[PACK_G * i];
                         const float zq = (xv - b_loc[i]) * b_isc[i];
-                        const float tt = qs64 * (en * __builtin_amdgcn_exp2f(fmaf(-zq, zq, b_ct[i])));
+                        const float tt = qs64 * eft[i - 2 * NPK];
                         const float dlg = fmaf(-en, qp, tt);
                         seg[PACK_G * i] = dlg;
                         if (MODE == MODE_PPO) acc_db[i] += dlg;
@@ -716,11 +726,33 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 }
             }
             if (k < 4) PFPN_STAMP(7 + k * 6);
-            // ---- the plane now holds my part of dlogits: hand it to the storer waves ----------------
+            // ---- the plane now holds my part of dlogits: hand it to the storer waves -- except for the block's LAST
+            //      tile, whose pieces every compute wave stores itself the moment its own backward is done: the storers
+            //      would start on it only when the slowest wave has finished, with the whole block waiting (~2,000 cycles
+            //      of the kernel's tail).  Four row pieces of ndw N floats, one float4 per lane, non-temporal.
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my ds_writes are done (in-order LDS)
-            if (lane == 0) atomicAdd(&bdone[slot], 1);
+            if (k + 1 < T) {
+                if (lane == 0) atomicAdd(&bdone[slot], 1);
+            } else {
+                const int nf4 = (ndw * N) >> 2;
+                const f4v* src = reinterpret_cast<const f4v*>(tile + (size_t)slot * TS + wave * 4 * N) + lane;
+                f4v* dst = reinterpret_cast<f4v*>(dlogits + (size_t)row0 * AN + wave * 4 * N) + lane;
+                if (lane < nf4) {
+                    f4v v[R];
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) v[rr] = src[(size_t)min(rr, rows - 1) * (AN >> 2)];
+                    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr)
+                        if (rr < rows) __builtin_nontemporal_store(v[rr], &dst[(size_t)rr * (AN >> 2)]);
+                }
+            }
         }
         p = p1; inv_sum = inv1;
+#pragma unroll
+        for (int i = 0; i < (NPK > 0 ? NPK : 1); ++i) ef2[i] = ef2n[i];
+#pragma unroll
+        for (int i = 0; i < NP - 2 * NPK; ++i) eft[i] = eftn[i];
         slot = slot_n;
         if (++slot_n == P) { slot_n = 0; ++lap_n; }
     }
@@ -728,12 +760,14 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     if (MODE == MODE_FWD) return;
     PFPN_STAMP(40);
     // ---- block partials: dloc / dlogstd (/ dlogits column sums).  The four rows of a tile that share my (a, n) set
-    //      are the lanes 4, 8, 12 further on in my 16-lane DPP row: two row_ror adds, ((r0 + r3) + (r2 + r1)) in the
-    //      row-0 lanes, which store.  All lanes run the DPP steps (idle lanes hold zeros).  Slab layout [nq*AN + 4]
-    //      per block, as before.
+    //      are the lanes 4, 8, 12 further on in my 16-lane DPP row: two row_ror adds leave a total in each of the four
+    //      (with its own, fixed association order).  The row-q lane stores quantity q (0 dloc, 1 dlogstd, 2 column
+    //      sums): one store instruction per particle instead of three.  All lanes run the DPP steps (idle lanes hold
+    //      zeros).  Slab layout [nq*AN + 4] per block.
     const int nq = (MODE == MODE_PPO && ppo.want_db) ? 3 : 2;
     float* slab = partial + (size_t)blockIdx.x * (nq * AN + 4);
-    const bool writer = dim_ok && r == 0;
+    const bool writer = dim_ok && r < nq;
+    float* my_slab = slab + r * AN + a * N + g;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         float v0 = acc_loc[i] * (b_isc[i] * PFPN_2LN2);     // dloc *= c/scale
@@ -742,12 +776,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         v0 += dpp_shift<0x124, 0xf>(v0, 0.f); v0 += dpp_shift<0x128, 0xf>(v0, 0.f);
         v1 += dpp_shift<0x124, 0xf>(v1, 0.f); v1 += dpp_shift<0x128, 0xf>(v1, 0.f);
         if (MODE == MODE_PPO) { v2 += dpp_shift<0x124, 0xf>(v2, 0.f); v2 += dpp_shift<0x128, 0xf>(v2, 0.f); }
-        if (writer && (i < NP - 1 || last_ok)) {
-            const int col = a * N + g + PACK_G * i;
-            slab[col] = v0;
-            slab[AN + col] = v1;
-            if (nq == 3) slab[2 * AN + col] = v2;
-        }
+        if (writer && (i < NP - 1 || last_ok)) my_slab[PACK_G * i] = r == 0 ? v0 : r == 1 ? v1 : v2;
     }
     if (!NRW && wave == 0 && lane == 0) { slab[nq * AN + 0] = 0.f; slab[nq * AN + 1] = 0.f; }
     PFPN_STAMP(41);
