@@ -1,8 +1,10 @@
 """Turn the raw rocprofv3 outputs of tools/profile_round.sh into the small files committed under profiles/:
   <tag>_bench_kernel_stats.csv  per-kernel stats table of the eager step
   <tag>_step_timeline.txt       one learner step of the default run, kernel by kernel
-  <tag>_pmc_traffic.json        HBM bytes per launch of the packed / wide mixture kernels (FETCH_SIZE x2 + WRITE_SIZE)
-  <tag>_mix_tile_sq.json      SQ counters of k_mix_tile<35,PPO>: the measured VALU-issue share
+  <tag>_pmc_traffic.json        HBM bytes per launch of the tile / wide mixture kernels (FETCH_SIZE x2 + WRITE_SIZE)
+  <tag>_mix_tile_sq.json        SQ counters of k_mix_tile<35,PPO>: the measured VALU-issue share
+  <tag>_mix_tile_stamps.txt     in-kernel phase stamps of block 0 (tools/stamp_probe.py, stamped build)
+  <tag>_mix_probe_kernel_durations.json   rocprofv3 kernel-trace durations of the probe's mixture kernels (begin to end)
   <tag>_bench_line.json         the bench JSON line
 usage: python tools/profile_collect.py <raw dir> <out dir> <tag>"""
 import csv, glob, json, os, re, subprocess, sys
@@ -89,3 +91,17 @@ if os.path.exists(bl):
     if lines:
         open(os.path.join(out, tag + "_bench_line.json"), "w").write(lines[-1] + "\n")
 print("collected into", out, sorted(os.listdir(out)))
+
+sp = os.path.join(raw, "stamps.txt")
+if os.path.exists(sp):
+    open(os.path.join(out, tag + "_mix_tile_stamps.txt"), "w").write(open(sp).read())
+pt = one("probe_trace/**/*kernel_trace.csv")
+if pt:
+    dur = defaultdict(list)
+    for r in csv.DictReader(open(pt)):
+        k = r["Kernel_Name"]
+        if "k_mix_tile" in k or "k_finalize" in k:
+            dur[re.sub(r"\(.*", "", k.replace("void pfpn::", ""))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    json.dump({"note": "rocprofv3 --kernel-trace of tools/mix_probe.py (4096x36x35): kernel begin-to-end in us, all launches",
+               "kernels": {k: {"launches": len(v), "mean_us": mean(v), "min_us": min(v), "max_us": max(v)} for k, v in dur.items()}},
+              open(os.path.join(out, tag + "_mix_probe_kernel_durations.json"), "w"), indent=1)

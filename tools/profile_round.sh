@@ -1,18 +1,27 @@
 #!/bin/bash
 # Round profile set (run on the GPU box from the repo root): per-kernel stats of the eager step, one step's timeline
-# of the default (hipGraph, tuned GEMMs) run, HBM traffic and SQ counters of the packed mixture kernel.
+# of the default (hipGraph, tuned GEMMs) run, HBM traffic and SQ counters of the mixture tile kernel, the bench line,
+# and (last: it rebuilds the library with -DPFPN_ENABLE_STAMPS) the in-kernel phase stamps.
 # Outputs under gpurun_out/prof/ ; tools/profile_collect.py turns them into the files committed under profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
+TAG=${1:-r02}
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-tune --no-graph > $O/stats.log 2>&1
+echo "stats done" > $O/progress.log
 rocprofv3 --kernel-trace --output-format csv -d $O/timeline -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/timeline.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/probe_trace -- python3 tools/mix_probe.py > $O/probe_trace.log 2>&1
+echo "traces done" >> $O/progress.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 tools/mix_probe.py > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 tools/mix_probe.py > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY --output-format csv -d $O/sq1 -- python3 tools/mix_probe.py > $O/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC --output-format csv -d $O/sq2 -- python3 tools/mix_probe.py > $O/sq2.log 2>&1
+echo "mix pmc done" >> $O/progress.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/sfetch -- python3 tools/stress_probe.py > $O/sfetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/swrite -- python3 tools/stress_probe.py > $O/swrite.log 2>&1
+echo "stress pmc done" >> $O/progress.log
 python3 bench.py > $O/bench.log 2>&1
-python3 tools/profile_collect.py $O gpurun_out/prof_summary r02 > $O/collect.log 2>&1
+echo "bench done" >> $O/progress.log
+rm -rf pfpn_amd/build && PFPN_BUILD_STAMPS=1 python3 -m pfpn_amd.build > $O/stamp_build.log 2>&1 && python3 tools/stamp_probe.py 2>&1 | grep -v amdgpu.ids > $O/stamps.txt
+python3 tools/profile_collect.py $O gpurun_out/prof_summary $TAG > $O/collect.log 2>&1
 tail -3 $O/collect.log
