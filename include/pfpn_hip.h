@@ -335,6 +335,10 @@ int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, con
                   const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
                   float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
                   float* dlog_alpha, float* loss3, void* stream);
+/* The three critic inputs of a SAC step in one launch -- sac.py:108-121 (tf.concat([state, action], -1) for Q(s, a_pi),
+ * Q(s, action_hist) and the target Q'(s', a')): x, x_next [B,S] normalised states, a_* [B,A]; outputs [B,S+A]. */
+int pfpn_sac_q_inputs(const float* x, const float* x_next, const float* a_pi, const float* a_hist, const float* a_next,
+                      int B, int S, int A, float* xa_pi, float* xa_hist, float* xa_next, void* stream);
 /* SAC soft target update -- sac.py:67-73. */
 int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream);
 

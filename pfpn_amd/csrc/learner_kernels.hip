@@ -1182,6 +1182,26 @@ static inline int stream_grid(size_t n_items) {
     return (int)g;
 }
 
+// The three critic inputs of a SAC step -- concat([state, action]) for (s, a_pi), (s, a_hist), (s', a') (reference
+// networks/actor_critic/sac.py:108-121, three tf.concat) -- in ONE launch: three 5-us launches of a latency-bound step.
+__global__ __launch_bounds__(256) void k_sac_q_inputs(const float* __restrict__ x, const float* __restrict__ x_next,
+                                                      const float* __restrict__ a_pi, const float* __restrict__ a_hist,
+                                                      const float* __restrict__ a_next, int B, int S, int A,
+                                                      float* __restrict__ xa_pi, float* __restrict__ xa_hist,
+                                                      float* __restrict__ xa_next) {
+    const int W = S + A;
+    const long long per = (long long)B * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * per) return;
+    const int which = (int)(i / per);
+    const long long j = i - which * per;
+    const int b = (int)(j / W), c = (int)(j - (long long)b * W);
+    const float* xs = which == 2 ? x_next : x;
+    const float* as = which == 0 ? a_pi : which == 1 ? a_hist : a_next;
+    float* dst = which == 0 ? xa_pi : which == 1 ? xa_hist : xa_next;
+    dst[j] = c < S ? xs[(size_t)b * S + c] : as[(size_t)b * A + (c - S)];
+}
+
 }  // namespace pfpn
 
 using namespace pfpn;
@@ -1658,6 +1678,18 @@ int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, con
     hipLaunchKernelGGL(k_sac_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, q_pi, q_run, q_tgt, logp, logp_t,
                        reward, not_terminal, log_alpha, B, gamma, value_coef, target_entropy, dq_pi, dq_run, dlogp,
                        dlog_alpha, loss3);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_sac_q_inputs(const float* x, const float* x_next, const float* a_pi, const float* a_hist, const float* a_next,
+                      int B, int S, int A, float* xa_pi, float* xa_hist, float* xa_next, void* stream) {
+    PFPN_BEGIN();
+    if (!x || !x_next || !a_pi || !a_hist || !a_next || !xa_pi || !xa_hist || !xa_next || B < 1 || S < 1 || A < 1)
+        return PFPN_ERR_ARG;
+    const long long n = 3LL * B * (S + A);
+    hipLaunchKernelGGL(k_sac_q_inputs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_next,
+                       a_pi, a_hist, a_next, B, S, A, xa_pi, xa_hist, xa_next);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -727,6 +727,16 @@ def sac_loss(q_pi, q_run, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, 
     return out
 
 
+def sac_q_inputs(x, x_next, a_pi, a_hist, a_next, xa_pi, xa_hist, xa_next):
+    """the three concat([state, action]) critic inputs of a SAC step, one launch."""
+    lib = _lib.load()
+    B, S = x.shape
+    A = a_pi.shape[1]
+    _lib.check(lib.pfpn_sac_q_inputs(_f32(x, B, S), _f32(x_next, B, S), _f32(a_pi, B, A), _f32(a_hist, B, A),
+                                     _f32(a_next, B, A), B, S, A, _f32(xa_pi, B, S + A), _f32(xa_hist, B, S + A),
+                                     _f32(xa_next, B, S + A), _stream()), "pfpn_sac_q_inputs")
+
+
 # --------------------------------------------------------------------------------------- #
 # dense layers on the hand-written fp32 MFMA GEMM (fused epilogues)                         #
 # --------------------------------------------------------------------------------------- #

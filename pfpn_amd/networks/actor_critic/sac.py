@@ -137,6 +137,7 @@ def sac_network_wrapper(base_class):
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
             self.logits = f(B, AN)
             self.logits2 = f(B, AN)
+            self.dlogits = f(B, AN)
             self.xn2 = f(B, self.S)
             self.xa, self.xh, self.xa2 = f(B, self.S + A), f(B, self.S + A), f(B, self.S + A)
             self.q_pi, self.q_run, self.q_tgt = f(2, B), f(2, B), f(2, B)
@@ -237,8 +238,7 @@ def sac_network_wrapper(base_class):
             logp2 = kernels.logprob_fwd(self.logits2, s2, loc, logstd, True)
             self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
             # Q inputs
-            for buf, xs, act in ((self.xa, x, a), (self.xh, x, action), (self.xa2, x2, a2)):
-                torch.cat((xs, act), dim=1, out=buf)
+            kernels.sac_q_inputs(x, x2, a, action, a2, self.xa, self.xh, self.xa2)
             hq_pi = self._q_forward(self.xa, 0, self.q_pi, fold=fold)
             hq_run = self._q_forward(self.xh, 1, self.q_run, fold=fold)
             self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
@@ -251,8 +251,8 @@ def sac_network_wrapper(base_class):
                 # both heads' backward inside the trunks' last-layer passes; bias-gradient sums become jobs
                 self.q_stack.backward(self.dh_run, slot=1, need_dw=True, deferred=deferred,
                                       value=(-1, self.q_w3, out["dq_run"], gw3, gb3))
-                dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True, deferred=deferred,
-                                            value=(-1, self.q_w3, out["dq_pi"], None, None))
+                da = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=(S, S + A), deferred=deferred,
+                                           value=(-1, self.q_w3, out["dq_pi"], None, None))
             else:
                 for g in range(2):
                     kernels.value_head_bwd(hq_run[g], self.q_w3[g], out["dq_run"][g], self.dh_run[g], gw3[g],
@@ -262,14 +262,15 @@ def sac_network_wrapper(base_class):
                 for g in range(2):
                     kernels.value_head_bwd(hq_pi[g], self.q_w3[g], out["dq_pi"][g], self.dh_pi[g], self.scratch_w3,
                                            self.scratch_b3, relu6=True)
-                dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True)
-            da = dxa[:, S:].contiguous()
-            dlogits, dloc, dlogstd, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True)
+                da = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=(S, S + A))
+            # the particle-grid gradients land straight in the flat gradient buffer: log-prob backward writes them, the
+            # reparameterised-sample backward adds its part in place
+            dloc, dlogstd = st.g("actor/samples"), st.g("actor/samples_std")
+            dlogits, _, _, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True,
+                                                     out={"dlogits": self.dlogits, "dloc": dloc, "dlogstd": dlogstd})
             dlogits = dlogits.view(B, -1)
             kernels.rsample_bwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"], da, dxs,
                                 dlogits, dloc, dlogstd)
-            st.g("actor/samples").copy_(dloc)
-            st.g("actor/samples_std").copy_(dlogstd)
             torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
             gpb = st.g("actor/fc_policy/bias")
             if fold:

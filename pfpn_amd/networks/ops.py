@@ -304,14 +304,17 @@ class DenseStack:
                     if need_dw:
                         on_dw_stream(lambda: torch.mm(xt, d2d, out=gw))
                     if need_dx:
-                        dx = torch.mm(d2d, w.t())
+                        # need_dx = (c0, c1): the gradient w.r.t. input columns [c0, c1) only (SAC: the action part)
+                        wx = w if need_dx is True else w[need_dx[0]:need_dx[1]]
+                        dx = torch.mm(d2d, wx.t())
                 else:
                     if need_dw:
                         on_dw_stream(lambda: [torch.mm(xt, d[g], out=gw[g]) for g in range(self.G)])
                     if need_dx:
-                        dx = torch.mm(d[0], w[0].t())
+                        rows = slice(None) if need_dx is True else slice(need_dx[0], need_dx[1])
+                        dx = torch.mm(d[0], w[0][rows].t())
                         for g in range(1, self.G):
-                            dx.addmm_(d[g], w[g].t())
+                            dx.addmm_(d[g], w[g][rows].t())
             else:
                 if need_dw:
                     on_dw_stream(lambda: torch.bmm(act[i - 1].transpose(1, 2), d, out=gw))
