@@ -214,8 +214,7 @@ def ddpg_network_wrapper(base_class):
             _, a2 = kernels.mean_action(self.logits2, self.target_store["actor/samples"], True)
             a2 = self.explore(a2, self.target_noise, noise["target"])
             self.last = {"a_opt": a_opt, "k": k, "a2": a2}
-            for buf, xs, act in ((self.xa, x, a_opt), (self.xh, x, action), (self.xa2, x2, a2)):
-                torch.cat((xs, act), dim=1, out=buf)
+            kernels.sac_q_inputs(x, x2, a_opt, action, a2, self.xa, self.xh, self.xa2)     # three concats, one launch
             hq_pi = self._q_forward(self.xa, 0, self.q_pi)
             self.q_pi[1].copy_(self.q_pi[0])              # the policy loss uses Q alone: min(Q, Q) routes to row 0
             hq_run = self._q_forward(self.xh, 1, self.q_run)
@@ -238,8 +237,7 @@ def ddpg_network_wrapper(base_class):
             kernels.value_head_bwd(hq_pi[0], w3[0], out["dq_pi"][0], self.dh_pi[0], self.scratch_w3, self.scratch_b3,
                                    relu6=True)
             self.dh_pi[1].zero_()
-            dxa = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=True)
-            da = dxa[:, S:].contiguous()
+            da = self.q_stack.backward(self.dh_pi, slot=0, need_dw=False, need_dx=(S, S + A))    # action columns only
             dloc = st.g("actor/samples")
             self.dlogits.zero_(); dloc.zero_(); self.scr_ls.zero_()
             kernels.rsample_bwd(self.logits, self.loc, self.logstd, self.zero_noise, self.zero_noise, da, self.zero_ba,
