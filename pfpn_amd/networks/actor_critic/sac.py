@@ -246,7 +246,8 @@ def sac_network_wrapper(base_class):
                                    self.log_alpha, self.gamma, self.value_loss_coef, -float(A), self.sac_out)
             # critic gradients (value loss through Q(s, action_hist))
             gw3, gb3 = st.g("critic/q1+critic/q2|fc3/weight"), st.g("critic/q1+critic/q2|fc3/bias")
-            gb3.zero_()
+            if not fold:
+                gb3.zero_()        # (folded: the reduction jobs assign [g, 0]; the padding of the fresh buffer stays zero)
             if fold:
                 # both heads' backward inside the trunks' last-layer passes; bias-gradient sums become jobs
                 self.q_stack.backward(self.dh_run, slot=1, need_dw=True, deferred=deferred,
