@@ -657,6 +657,11 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         float* seg = seg0 + slot * TS;
         const bool active = dim_ok && r < rows;
         if (k < 4) PFPN_STAMP(3 + k * 6);
+        {   // ... and the three generations trade priorities tile by tile, so that none stays the block's laggard:
+            // 15.9 -> 15.3-15.4 us with finalize, backward 14.8 -> 14.5 (A/B on one box, tools/mix_var.sh)
+            const int pr = ((wave >> 2) + 2 * k) % 3;
+            if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+        }
 
         // ---- forward of the next tile --------------------------------------------------------
         if (k + 1 < T) { wait_ready(slot_n, lap_n); forward(k + 1, slot_n, p1, inv1, ef2n, eftn); }
