@@ -331,9 +331,9 @@ def main():
                                    "the step its slab sums are finished by the single deferred reduce launch); "
                                    "us_in_step_event_pairs: an event pair around each call inside 100 eager learner "
                                    "steps (includes the dispatch gap); "
-                                   "42 MB per launch, four tiles per block: ~5 k cycles until the first tile has landed, "
-                                   "~3.6 k per tile on the SIMD that hosts three of the nine compute waves, the last plane "
-                                   "stored ~2 k after the last backward (DESIGN.md section 4); "
+                                   "42 MB per launch, four tiles per block (~22 k cycles): ~5 k until the first tile has landed, ~3 k "
+                                   "per tile -- VALU issue on the SIMD that hosts three of the nine compute waves -- and "
+                                   "~2 k of tail (DESIGN.md section 4); rocprofv3 adds ~0.5 us to a traced kernel; "
                                    "the 1 GiB shape of BASELINE.json config 5 is in roofline_stress"}
         # the same mixture math on the 1 GiB stress shape (BASELINE.json config 5, one GPU's shard)
         try:
