@@ -121,6 +121,10 @@ int pfpn_gumbel_from_uniform(float* u, size_t n, void* stream);
 /* The four noise tensors of one SAC learner step (utils.py:156-161 for s and s') from uniforms u [4][n] in [0,1), in place:
  * rows 0, 1 -> Gumbel noise as above; rows 2, 3 -> a Box-Muller pair of independent N(0,1) draws. */
 int pfpn_sac_noise_from_uniform(float* u, size_t n, void* stream);
+/* The same four tensors drawn on the device in one launch: element i of buf [4][n] takes its four uniforms from the
+ * Philox4x32-10 block {counter = (i, offset), key = seed} (the role of tf.random.uniform / tf.random.normal behind
+ * utils.py:156-161; the stream itself cannot match TensorFlow's and is the caller's to choose: a new `offset` per step). */
+int pfpn_sac_noise_fill(float* buf, size_t n, uint64_t seed, uint64_t offset, void* stream);
 
 /* SAC reparameterised sample (K4) -- utils.py:156-186.  gumbel [B,A*N] = -log(-log u), eps [B,A*N]:
  * k = argmax(logits+gumbel), s_out = p_k = loc+exp(logstd)*eps, a_out = tanh(p_k).

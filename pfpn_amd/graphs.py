@@ -14,7 +14,10 @@ from . import kernels
 def refill_noise(noise, generator):
     """fresh draws into static noise buffers, same distributions as MixtureGaussianDistribution.make_noise /
     the SAC network's make_train_noise (u_cat: U[0,1) float64; gumbel*: -log(-log U(tiny,1)); others: N(0,1))."""
-    if "_buf" in noise:                       # SAC learner step: one uniform fill + one transform launch for all four
+    if getattr(noise, "refill", None) is not None:      # SAC learner step: one launch draws all four tensors
+        noise.refill(noise["_buf"])
+        return
+    if "_buf" in noise:                       # (a buffer of the older kind: one uniform fill + one transform launch)
         kernels.sac_noise_from_uniform_(noise["_buf"].uniform_(generator=generator))
         return
     for k, t in noise.items():

@@ -328,6 +328,17 @@ def gumbel_from_uniform_(u):
     return u
 
 
+def sac_noise_fill_(buf, seed, offset):
+    """buf [4, ...]: rows 0,1 <- Gumbel(0,1), rows 2,3 <- N(0,1), drawn on the device (Philox4x32-10 keyed by `seed`,
+    block counter (element, `offset`)) -- one launch, no uniform fill."""
+    lib = _lib.load()
+    if buf.shape[0] != 4:
+        raise ValueError("buf must be [4, ...]")
+    _lib.check(lib.pfpn_sac_noise_fill(_f32(buf), buf.numel() // 4, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                       int(offset) & 0xFFFFFFFFFFFFFFFF, _stream()), "pfpn_sac_noise_fill")
+    return buf
+
+
 def sac_noise_from_uniform_(buf):
     """buf [4, ...] uniforms in [0,1) -> rows 0,1 Gumbel(0,1), rows 2,3 N(0,1) (Box-Muller pair), in place, one launch."""
     lib = _lib.load()

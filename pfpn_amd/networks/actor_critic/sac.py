@@ -22,6 +22,11 @@ from .a2c import ParticleFilteringA2CNetwork
 __all__ = ["ParticleFilteringSACNetwork"]
 
 
+class _TrainNoise(dict):
+    """the SAC step's noise tensors by name; `refill(buf)` (set by the network) redraws all of them in one launch"""
+    refill = None
+
+
 def sac_network_wrapper(base_class):
     class AbstractSACNetwork(base_class):
         def __init__(self, alpha=0.2, tau=0.005, **kwargs):
@@ -206,11 +211,19 @@ def sac_network_wrapper(base_class):
             return [] if ok else None
 
         def make_train_noise(self, B):
-            """the step's four draws (Gumbel + normal for s and for s') from ONE uniform fill and ONE transform launch;
-            `_buf` is the backing buffer (graphs.refill_noise redraws through it)."""
+            """the step's four draws (Gumbel + normal for s and for s') from ONE launch; `_buf` is the backing buffer; the
+            dict's `refill` attribute redraws into it (graphs.refill_noise)."""
             AN = self.n_actions * self.particles
-            buf = kernels.sac_noise_from_uniform_(torch.rand(4, B, AN, device=self.device, generator=self.rng))
-            return {"gumbel": buf[0], "gumbel_": buf[1], "eps": buf[2], "eps_": buf[3], "_buf": buf}
+            buf = self._draw_train_noise(torch.empty(4, B, AN, dtype=torch.float32, device=self.device))
+            noise = _TrainNoise({"gumbel": buf[0], "gumbel_": buf[1], "eps": buf[2], "eps_": buf[3], "_buf": buf})
+            noise.refill = self._draw_train_noise
+            return noise
+
+        def _draw_train_noise(self, buf):
+            """fresh draws into buf [4, B, A*N] in ONE launch: a Philox block per element, keyed by the network generator's
+            seed, counted by the number of draws so far (no uniform fill + transform pass)."""
+            self._noise_draws = getattr(self, "_noise_draws", 0) + 1
+            return kernels.sac_noise_fill_(buf, self.rng.initial_seed(), self._noise_draws)
 
         def compute_gradients(self, state, action, reward, not_terminal, state_, noise=None):
             B, S, A = state.shape[0], self.S, self.n_actions

@@ -190,3 +190,31 @@ def test_sac_noise_transform_distributions(dev):
         assert abs(z[r].mean().item()) < 3e-3 and abs(z[r].var().item() - 1.0) < 5e-3
         assert abs((z[r] ** 4).mean().item() - 3.0) < 5e-2                      # kurtosis of a normal
     assert abs((z[2] * z[3]).mean().item()) < 3e-3                                # the pair is uncorrelated
+
+
+def test_sac_noise_fill_philox(dev):
+    """pfpn_sac_noise_fill: one launch draws the step's four noise tensors from Philox4x32-10 blocks.  Known answer of the
+    generator (Random123's kat vector: counter 0, key 0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8), distributions, streams."""
+    from pfpn_amd import kernels
+    n = 2048 * 1260
+    z = kernels.sac_noise_fill_(torch.empty(4, n, device=dev), 0, 0)
+    assert torch.isfinite(z).all()
+    r = [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    u = [np.float32((x >> 8) * 2.0 ** -24) for x in r]
+    first = z[:, 0].cpu().numpy()
+    np.testing.assert_allclose(first[0], -np.log(-np.log(u[0])), rtol=1e-5)
+    np.testing.assert_allclose(first[1], -np.log(-np.log(u[1])), rtol=1e-5)
+    rr = np.sqrt(-2.0 * np.log(np.float64(u[2])))
+    np.testing.assert_allclose(first[2], rr * np.cos(2 * np.pi * np.float64(u[3])), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(first[3], rr * np.sin(2 * np.pi * np.float64(u[3])), rtol=2e-5, atol=1e-6)
+    for row in (0, 1):
+        assert abs(z[row].mean().item() - 0.5772157) < 5e-3 and abs(z[row].var().item() - np.pi ** 2 / 6) < 2e-2
+    for row in (2, 3):
+        assert abs(z[row].mean().item()) < 3e-3 and abs(z[row].var().item() - 1.0) < 5e-3
+        assert abs((z[row] ** 4).mean().item() - 3.0) < 5e-2
+    assert abs((z[2] * z[3]).mean().item()) < 3e-3 and abs((z[0] * z[1]).mean().item() - 0.5772157 ** 2) < 5e-3
+    # same (seed, offset) -> same draws; another offset or seed -> another stream
+    assert torch.equal(z, kernels.sac_noise_fill_(torch.empty(4, n, device=dev), 0, 0))
+    for seed, off in ((0, 1), (1, 0), (1 << 40, 0), (0, 1 << 33)):
+        z2 = kernels.sac_noise_fill_(torch.empty(4, n, device=dev), seed, off)
+        assert not torch.equal(z2, z) and abs((z2[2] * z[2]).mean().item()) < 3e-3
