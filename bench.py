@@ -335,6 +335,52 @@ def main():
                                    "per tile -- VALU issue on the SIMD that hosts three of the nine compute waves -- and "
                                    "~2 k of tail (DESIGN.md section 4); rocprofv3 adds ~0.5 us to a traced kernel; "
                                    "the 1 GiB shape of BASELINE.json config 5 is in roofline_stress"}
+        # the SAME kernel on four and sixteen times the rows (same A x N): how much of the 0.46 at 4096 rows is the fixed cost
+        # of a block's start-up and tail (four tiles per block at 4096 rows, 16 / 64 at these sizes)
+        try:
+            scaled = {}
+            for rows_ in (16384, 65536):
+                gq = torch.Generator(device=dev); gq.manual_seed(3)
+                lq = torch.randn(rows_, A * NP, device=dev, generator=gq)
+                xq = torch.rand(rows_, A, device=dev, generator=gq) * 2.2 - 1.1
+                lpq = kernels.logprob_fwd(lq, xq, net.loc, net.logstd).clone()
+                aq = torch.randn(rows_, device=dev, generator=gq)
+                vq = torch.randn(rows_, device=dev, generator=gq)
+                sq_ = kernels.adv_stats(aq)
+                oq = kernels.ppo_mixture_fwd_bwd(lq, xq, net.loc, net.logstd, lpq, aq, vq, vq, sq_, finalize=False)
+
+                def callq():
+                    kernels.ppo_mixture_fwd_bwd(lq, xq, net.loc, net.logstd, lpq, aq, vq, vq, sq_, out=oq, finalize=False)
+                for _ in range(3):
+                    callq()
+                torch.cuda.synchronize()
+                sideq = torch.cuda.Stream()
+                sideq.wait_stream(torch.cuda.current_stream())
+                gqr = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(sideq):
+                    callq()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(gqr, stream=sideq):
+                        for _ in range(10):
+                            callq()
+                torch.cuda.synchronize()
+                gqr.replay()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(5):
+                    gqr.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                uq = e0.elapsed_time(e1) * 1e3 / 50
+                abq = algorithmic_bytes_fused(rows_)
+                scaled[str(rows_)] = {"us_per_launch": uq, "algorithmic_bytes": abq, "achieved": abq / uq / 1e3, "unit": "GB/s",
+                                      "frac": abq / uq / 1e3 / HBM_PEAK_GBS}
+                del lq, xq, oq, gqr
+            out["roofline_more_rows"] = {"kernel": "k_mix_tile<35,PPO>", "bound": "hbm", "peak": HBM_PEAK_GBS, "rows": scaled,
+                                         "note": "the roofline kernel on 4x / 16x the metric's rows (same 36 x 35 mixture): the "
+                                                 "block's start-up and tail are paid once per launch"}
+        except Exception as ex:
+            out["roofline_more_rows"] = {"error": repr(ex)}
         # the same mixture math on the 1 GiB stress shape (BASELINE.json config 5, one GPU's shard)
         try:
             sB, sA, sN = 8192, 128, 256

@@ -26,7 +26,9 @@ SHAPES = [(1, 36, 35), (5, 36, 35), (7, 36, 35), (8, 36, 35), (64, 36, 35), (257
           (33, 6, 50), (19, 36, 16), (40, 3, 8), (9, 5, 35), (3, 1, 35),
           (17, 36, 23), (6, 4, 100), (5, 3, 256), (4, 7, 64), (3, 2, 2),
           # more tiles per block than LDS planes (the loader ring wraps), ragged last tiles
-          (6001, 36, 35), (20003, 8, 16), (9001, 12, 8), (5000, 4, 50), (1030, 20, 35)]
+          (6001, 36, 35), (20003, 8, 16), (9001, 12, 8), (5000, 4, 50), (1030, 20, 35),
+          # the tile kernel's widest block (A = 44: 11 compute waves) and the first shape beyond it (wave kernel)
+          (13, 44, 8), (7, 48, 16), (3, 1, 8)]
 
 
 @pytest.mark.parametrize("B,A,N", SHAPES)
