@@ -338,6 +338,8 @@ def main():
         # the SAME kernel on four and sixteen times the rows (same A x N): how much of the 0.46 at 4096 rows is the fixed cost
         # of a block's start-up and tail (four tiles per block at 4096 rows, 16 / 64 at these sizes)
         try:
+            if args.no_cpu_baseline:         # profiling runs: keep the kernel statistics to the headline shape
+                raise RuntimeError("skipped with --no-cpu-baseline")
             scaled = {}
             for rows_ in (16384, 65536):
                 gq = torch.Generator(device=dev); gq.manual_seed(3)
