@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpfpn_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-Wno-unused-result", "-I" + os.path.join(HERE, "..", "include")]
-FLAGS += os.environ.get("PFPN_EXTRA_FLAGS", "").split()      # tuning experiments (-DPACK_DEPTH=3 ...)
+FLAGS += os.environ.get("PFPN_EXTRA_FLAGS", "").split()      # tuning experiments (-DTK_DEPTH=3 ...)
 if os.environ.get("PFPN_BUILD_STAMPS"):       # diagnostic build for tools/stamp_probe.py (remove build/ first)
     FLAGS.append("-DPFPN_ENABLE_STAMPS")
 

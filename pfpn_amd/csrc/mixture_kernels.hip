@@ -44,11 +44,11 @@ struct PpoArgs {
     int want_db;             // also emit column sums of dlogits (fc_policy bias gradient) into the slab
 };
 
-constexpr int PACK_G = 4;                            // lanes per (row, action-dim) segment
-constexpr size_t PACK_MAX_LDS = 150 * 1024;         // dynamic LDS the tile kernel may ask for (160 KB per CU)
+constexpr int TK_G = 4;                              // lanes per (row, action-dim) segment
+constexpr size_t TK_MAX_LDS = 150 * 1024;            // dynamic LDS the tile kernel may ask for (160 KB per CU)
 
-#ifndef PACK_DEPTH
-#define PACK_DEPTH 2                                 // tiles a loader keeps in flight
+#ifndef TK_DEPTH
+#define TK_DEPTH 2                                   // tiles a loader keeps in flight
 #endif
 
 // LDS-DMA of one wave-instruction: lane i's 16 (or 4) bytes at `gsrc` land at lds_byte + 16*i (4*i).
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     PpoArgs ppo)
 {
     constexpr int R = TK_R;
-    constexpr int NP = (N + PACK_G - 1) / PACK_G;         // particles per lane (9 for N=35)
+    constexpr int NP = (N + TK_G - 1) / TK_G;             // particles per lane (9 for N=35)
     constexpr int NPK = (NP - 1) / 2;                     // particle pairs that always exist (packed fp32 math)
     constexpr int NRW = (MODE != MODE_BWD) ? 1 : 0;       // row wave
     constexpr int NS = (MODE != MODE_FWD) ? TK_NS : 0;    // storer waves
@@ -233,7 +233,6 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
 
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int nwv = (int)(blockDim.x >> 6);               // all waves
 #ifdef PFPN_ENABLE_STAMPS
     unsigned long long* stamps = g_stamps;
 #endif
@@ -276,8 +275,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     // Start-up.  Nothing of the first tile goes through the loaders: compute wave w fetches what IT needs -- the
     // particle tables of its four dims (<= 4 N consecutive elements, <= BKU per lane), its action values, and its own
     // four row pieces of tile 0 by LDS-DMA -- in its first instructions, so the first forward pass waits for one HBM
-    // round trip and for no other wave (before: every service wave issued a share of tile 0 and the block met at a
-    // barrier ~5,000 cycles in).  The one block barrier only publishes the zeroed counters and comes early.
+    // round trip and for no other wave.  The one block barrier only publishes the zeroed counters and comes early.
     constexpr int BKU = (4 * N + 63) / 64;                                    // table elements per lane
     float bank_ls[BKU], bank_lc[BKU];
     float x0 = 0.f, g0 = 0.f;                                                 // tile 0: my action value, my row's dlogp (BWD)
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     if (wave >= NC && wave < NC + TK_NL) {
         const int l = wave - NC;
         const int Q = (M - l + TK_NL - 1) / TK_NL;         // my DMAs per tile from tile 1 on (constant)
-        int dmax = PACK_DEPTH;                             // tiles a loader keeps in flight
+        int dmax = TK_DEPTH;                               // tiles a loader keeps in flight
         while (dmax > 1 && (dmax - 1) * Q > 63) --dmax;
         if (dmax > P) dmax = P;
         const int nfree = (MODE == MODE_FWD) ? NC : NS;    // who hands a plane back
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
     const int sidx = r * A + a;                            // segment slot in the tile
     const int ndw = min(4, A - wave * 4);                  // my dims (per row)
     float* seg0 = tile + sidx * N + g;
-    const bool last_ok = (g + PACK_G * (NP - 1)) < N;     // does my NP-th particle exist?
+    const bool last_ok = (g + TK_G * (NP - 1)) < N;       // does my NP-th particle exist?
     float b_loc[NP], b_isc[NP], b_ct[NP];
     float acc_loc[NP], acc_ls[NP], acc_db[NP];
     {
@@ -523,7 +521,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int n = min(g + PACK_G * i, N - 1);
+            const int n = min(g + TK_G * i, N - 1);
             b_loc[i] = bank[a * N + n];
             b_isc[i] = bank[AN + a * N + n];
             b_ct[i] = bank[2 * AN + a * N + n];
@@ -572,14 +570,14 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
             float mx = -INFINITY;
 #pragma unroll
             for (int k = 0; k < NPK; ++k) {
-                lp2[k] = (v2f){seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]} * PFPN_LOG2E;
+                lp2[k] = (v2f){seg[TK_G * 2 * k], seg[TK_G * (2 * k + 1)]} * PFPN_LOG2E;
                 mx = fmaxf(fmaxf(lp2[k].x, lp2[k].y), mx);
             }
 #pragma unroll
             for (int i = 2 * NPK; i < NP; ++i) {
                 lpt[i - 2 * NPK] = 0.f;
                 if (i < NP - 1 || last_ok) {
-                    lpt[i - 2 * NPK] = seg[PACK_G * i] * PFPN_LOG2E;
+                    lpt[i - 2 * NPK] = seg[TK_G * i] * PFPN_LOG2E;
                     mx = fmaxf(mx, lpt[i - 2 * NPK]);
                 }
             }
@@ -592,7 +590,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 const v2f z = (xval - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * (v2f){b_isc[2 * k], b_isc[2 * k + 1]};
                 const v2f arg = le + __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
                 const v2f en = {__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
-                if (MODE != MODE_FWD) { seg[PACK_G * 2 * k] = en.x; seg[PACK_G * (2 * k + 1)] = en.y; }
+                if (MODE != MODE_FWD) { seg[TK_G * 2 * k] = en.x; seg[TK_G * (2 * k + 1)] = en.y; }
                 s2 += en;
                 ef2_o[k] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
                 n2 += ef2_o[k];
@@ -604,7 +602,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                     const float le = lpt[i - 2 * NPK] - mx;
                     const float zq = (xval - b_loc[i]) * b_isc[i];
                     const float en = __builtin_amdgcn_exp2f(le);
-                    if (MODE != MODE_FWD) seg[PACK_G * i] = en;
+                    if (MODE != MODE_FWD) seg[TK_G * i] = en;
                     sum += en;
                     eft_o[i - 2 * NPK] = __builtin_amdgcn_exp2f(le + fmaf(-zq, zq, b_ct[i]));
                     num += eft_o[i - 2 * NPK];
@@ -697,12 +695,12 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 // pairs of particles, as in the forward
 #pragma unroll
                 for (int k = 0; k < NPK; ++k) {
-                    const v2f en = {seg[PACK_G * 2 * k], seg[PACK_G * (2 * k + 1)]};
+                    const v2f en = {seg[TK_G * 2 * k], seg[TK_G * (2 * k + 1)]};
                     const v2f isc = {b_isc[2 * k], b_isc[2 * k + 1]};
                     const v2f z = (xv - (v2f){b_loc[2 * k], b_loc[2 * k + 1]}) * isc;            // z / c
                     const v2f tt = ef2[k] * qs64;                                                  // q * w_n * phi_n
                     const v2f dlg = __builtin_elementwise_fma(-en, (v2f){qp, qp}, tt);            // q * w_n * (phi_n - p)
-                    seg[PACK_G * 2 * k] = dlg.x; seg[PACK_G * (2 * k + 1)] = dlg.y;
+                    seg[TK_G * 2 * k] = dlg.x; seg[TK_G * (2 * k + 1)] = dlg.y;
                     if (MODE == MODE_PPO) { acc_db[2 * k] += dlg.x; acc_db[2 * k + 1] += dlg.y; }   // fc_policy bias gradient
                     const v2f al = __builtin_elementwise_fma(tt, z, (v2f){acc_loc[2 * k], acc_loc[2 * k + 1]});     // scaled by isc*c in the tail
                     acc_loc[2 * k] = al.x; acc_loc[2 * k + 1] = al.y;
@@ -715,11 +713,11 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
 #pragma unroll
                 for (int i = 2 * NPK; i < NP; ++i) {
                     if (i < NP - 1 || last_ok) {
-                        const float en = seg[PACK_G * i];
+                        const float en = seg[TK_G * i];
                         const float zq = (xv - b_loc[i]) * b_isc[i];
                         const float tt = qs64 * eft[i - 2 * NPK];
                         const float dlg = fmaf(-en, qp, tt);
-                        seg[PACK_G * i] = dlg;
+                        seg[TK_G * i] = dlg;
                         if (MODE == MODE_PPO) acc_db[i] += dlg;
                         acc_loc[i] = fmaf(tt, zq, acc_loc[i]);
                         acc_ls[i] = fmaf(tt, fmaf(zq * zq, PFPN_2LN2, -1.f), acc_ls[i]);
@@ -787,7 +785,7 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
         v0 += dpp_shift<0x124, 0xf>(v0, 0.f); v0 += dpp_shift<0x128, 0xf>(v0, 0.f);
         v1 += dpp_shift<0x124, 0xf>(v1, 0.f); v1 += dpp_shift<0x128, 0xf>(v1, 0.f);
         if (MODE == MODE_PPO) { v2 += dpp_shift<0x124, 0xf>(v2, 0.f); v2 += dpp_shift<0x128, 0xf>(v2, 0.f); }
-        if (writer && (i < NP - 1 || last_ok)) my_slab[PACK_G * i] = r == 0 ? v0 : r == 1 ? v1 : v2;
+        if (writer && (i < NP - 1 || last_ok)) my_slab[TK_G * i] = r == 0 ? v0 : r == 1 ? v1 : v2;
     }
     if (!NRW && wave == 0 && lane == 0) { slab[nq * AN + 0] = 0.f; slab[nq * AN + 1] = 0.f; }
     PFPN_STAMP(41);
@@ -1206,7 +1204,7 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // ---------------------------------------------------------------------------------------
 // host-side launch helpers
 // ---------------------------------------------------------------------------------------
-struct PackPlan { int R; int grid; int threads; size_t lds; int P; bool ok; int ntiles; };
+struct TilePlan { int R; int grid; int threads; size_t lds; int P; bool ok; int ntiles; };
 
 // compute units of the current device (MI355X: 256); asked once
 static int cu_count() {
@@ -1225,8 +1223,8 @@ static int cu_count() {
 static bool tile_has(int N) { return N == 35 || N == 50 || N == 16 || N == 8; }
 
 // tile kernel (k_mix_tile): R = 4 rows per tile, 4 action dims per compute wave
-static PackPlan plan_tile(int B, int A, int N, const void* logits, const void* dlogits) {
-    PackPlan pl{};
+static TilePlan plan_tile(int B, int A, int N, const void* logits, const void* dlogits) {
+    TilePlan pl{};
     pl.ok = false;
     if (N > 64 || N < 1 || A < 1 || B < 1) return pl;
     const int AN = A * N;
@@ -1244,7 +1242,7 @@ static PackPlan plan_tile(int B, int A, int N, const void* logits, const void* d
     size_t small = 0;
     for (;; --P) {
         small = (size_t)(4 * R * A + (12 * R + 3 * P) + 8 + 3 * AN) * 4;
-        if (P * plane + small <= PACK_MAX_LDS || P <= pmin) break;
+        if (P * plane + small <= TK_MAX_LDS || P <= pmin) break;
     }
     pl.P = P;
     pl.lds = P * plane + small;
@@ -1252,12 +1250,12 @@ static PackPlan plan_tile(int B, int A, int N, const void* logits, const void* d
     pl.ntiles = ntiles;
     const int cap = cu_count();                         // one block per CU
     pl.grid = ntiles < cap ? ntiles : cap;
-    pl.ok = pl.lds <= PACK_MAX_LDS;
+    pl.ok = pl.lds <= TK_MAX_LDS;
     return pl;
 }
 
 template <int MODE>
-static int launch_tile(int N, const PackPlan& pl, hipStream_t st, const float* logits, const float* x,
+static int launch_tile(int N, const TilePlan& pl, hipStream_t st, const float* logits, const float* x,
                        const float* loc, const float* logstd, const float* dlogp, int B, int A, int tanh_mode,
                        float* logp, float* pmix, float* dlogits, float* dx, float* partial, PpoArgs ppo) {
     const int threads = pl.threads + 64 * (TK_NL + (MODE != MODE_BWD ? 1 : 0) + (MODE != MODE_FWD ? TK_NS : 0));
@@ -1266,7 +1264,7 @@ static int launch_tile(int N, const PackPlan& pl, hipStream_t st, const float* l
         static bool big_lds_ok = false;          /* > 64 KB of dynamic LDS needs a one-time opt-in */         \
         if (pl.lds > 64 * 1024 && !big_lds_ok) {                                                            \
             (void)hipFuncSetAttribute((const void*)&k_mix_tile<NN, MODE>,                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PACK_MAX_LDS);        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_MAX_LDS);        \
             big_lds_ok = true;                                                                              \
         }                                                                                                   \
         hipLaunchKernelGGL((k_mix_tile<NN, MODE>), dim3(pl.grid), dim3(threads), pl.lds, st, logits, x,      \
@@ -1333,7 +1331,7 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
     if (!logits || !x || !loc || !logstd || !logp || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipStream_t st = (hipStream_t)stream;
-    PackPlan pl = plan_tile(B, A, N, logits, nullptr);
+    TilePlan pl = plan_tile(B, A, N, logits, nullptr);
     if (pl.ok && tile_has(N)) {
         PpoArgs none{};
         launch_tile<MODE_FWD>(N, pl, st, logits, x, loc, logstd, nullptr, B, A, tanh_mode, logp, pmix,
@@ -1395,7 +1393,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     }
     if (!workspace) return PFPN_ERR_WORKSPACE;
     float* partial = (float*)workspace;
-    PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+    TilePlan pl = plan_tile(B, A, N, logits, dlogits);
     if (pl.ok && tile_has(N)) {
         if (workspace_bytes < (size_t)pl.grid * (2 * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
         PpoArgs none{};
@@ -1454,7 +1452,7 @@ int pfpn_adv_stats(const float* adv, int B, int normalize, float* stats, void* s
 int pfpn_ppo_mixture_slabs(int B, int A, int N, int want_dbias, const float* logits, const float* dlogits,
                            int* nslab, int* stride) {
     if (!nslab || !stride || !logits || !dlogits || B < 1 || A < 1 || N < 1) return PFPN_ERR_ARG;
-    PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+    TilePlan pl = plan_tile(B, A, N, logits, dlogits);
     if (!(pl.ok && tile_has(N))) return PFPN_ERR_ARG;
     *nslab = pl.grid;
     *stride = (want_dbias ? 3 : 2) * A * N + 4;
@@ -1474,7 +1472,7 @@ int pfpn_ppo_mixture_fwd_bwd(const float* logits, const float* action, const flo
     if (!workspace) return PFPN_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int AN = A * N;
-    PackPlan pl = plan_tile(B, A, N, logits, dlogits);
+    TilePlan pl = plan_tile(B, A, N, logits, dlogits);
     if (!(pl.ok && tile_has(N))) return PFPN_ERR_ARG;   // caller falls back to fwd + ppo_loss + bwd
     const int nq = dbias ? 3 : 2;
     if (workspace_bytes < (size_t)pl.grid * (nq * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;

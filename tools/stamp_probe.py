@@ -35,12 +35,12 @@ for it in range(4):
     for w in range(NC):
         b = 3 + it * 6
         print("   w%-2d %6d %6d %6d %6d" % (w, d(w, b), d(w, b + 1), d(w, b + 3), d(w, b + 4)))
-print("loader waves: start | tile-0 share issued | past barrier | tiles 1.. landed")
+print("loader waves: start | past barrier | tiles 1.. landed")
 for w in (NC, NC + 1):
-    print("   w%-2d %6d %6d %6d   " % (w, d(w, 0), d(w, 3), d(w, 4)) + " ".join("%6d" % d(w, 4 + k * 6) for k in range(1, 4)))
+    print("   w%-2d %6d %6d   " % (w, d(w, 0), d(w, 42)) + " ".join("%6d" % d(w, 4 + k * 6) for k in range(1, 4)))
 w = NC + 2
-print("row wave: start | tile-0 share issued | row stage of tile k done")
-print("   w%-2d %6d %6d   " % (w, d(w, 0), d(w, 3)) + " ".join("%6d" % d(w, 5 + k * 6) for k in range(4)))
-print("storer waves: start | tile-0 share issued | tile k stores issued")
+print("row wave: start | row result of tile k published")
+print("   w%-2d %6d   " % (w, d(w, 0)) + " ".join("%6d" % d(w, 5 + k * 6) for k in range(4)))
+print("storer waves: start | tile k stored (the block's last tile is stored by the compute waves)")
 for w in (NC + 3, NC + 4):
-    print("   w%-2d %6d %6d   " % (w, d(w, 0), d(w, 3)) + " ".join("%6d" % d(w, 8 + k * 6) for k in range(4)))
+    print("   w%-2d %6d   " % (w, d(w, 0)) + " ".join("%6d" % d(w, 8 + k * 6) for k in range(4)))
