@@ -38,11 +38,28 @@ __global__ __launch_bounds__(256) void k_gae(const float* __restrict__ reward, c
         }
         __syncthreads();
         if (threadIdx.x == 0) {
+            // the recurrence is sequential by definition (the reference's Python loop, float64 accumulator: same order,
+            // same bits); what need not be sequential are the LDS accesses -- 16 deltas per round trip instead of one
+            // dependent LDS read per step (27 -> ~6 us for 512 steps)
             double acc = carry;
-            for (int t = hi - 1; t >= lo; --t) {
+            int t = hi - 1 - lo;                              // index into delta
+            for (; t >= 15; t -= 16) {
+                float d[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) d[j] = delta[t - j];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const double m = gae_gamma * acc;
+                    acc = (double)d[j] + m;
+                    d[j] = (float)acc;
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) delta[t - j] = d[j];
+            }
+            for (; t >= 0; --t) {
                 const double m = gae_gamma * acc;
-                acc = (double)delta[t - lo] + m;
-                delta[t - lo] = (float)acc;
+                acc = (double)delta[t] + m;
+                delta[t] = (float)acc;
             }
             carry = acc;
         }
