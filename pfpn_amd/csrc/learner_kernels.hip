@@ -105,28 +105,35 @@ __global__ __launch_bounds__(1024) void k_ppo_loss(
 
 // ---------------------------------------------------------------------------------------
 // V-trace (reference networks/actor_critic/vtrace.py:101-180).  E episodes of T steps, data flat in
-// episode-major order (index e*T + t, the order the workers feed: vtrace.py:16-37).  One thread per
-// episode walks its T steps backwards exactly as the reference's reverse tf.scan does, in fp32 and in
-// the graph's operation order:
+// episode-major order (index e*T + t, the order the workers feed: vtrace.py:16-37).  Every episode's T steps are
+// walked backwards exactly as the reference's reverse tf.scan does, in fp32 and in the graph's operation order:
 //   rho = exp(lp_target - lp_behaviour); v_rho = min(rho_clip, rho); c = min(1, rho); disc = gamma*not_terminal
 //   value_t1[t] = value[t+1], and value[t] itself at the last step / at t = seq_len-1 (concat_bootstrap_value)
 //   a[t] = v_rho*((r + disc*value_t1) - value) + (disc'*c)*a[t+1],  disc' = 0 at t = seq_len-1;  vs = a + value
 //   pg_adv[t] = pg_rho*((r + disc*vs_t1) - value), vs_t1 = vs[t+1] (value[t] at the last step / episode end)
 // Clips <= 0 mean "None" (no clipping).  mask[t] = t < seq_len (all ones without seq_len).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_vtrace(const float* __restrict__ lp_t, const float* __restrict__ lp_b,
-                                               const float* __restrict__ value, const float* __restrict__ reward,
-                                               const float* __restrict__ not_terminal,
-                                               const int* __restrict__ seq_len, int E, int T, float gamma,
-                                               float rho_clip, float pg_rho_clip, float* __restrict__ vs,
-                                               float* __restrict__ pg_adv, float* __restrict__ mask) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// One WAVE per episode (round 2; before: one thread per episode, five dependent global loads per step -- 20-30 us for 64
+// steps): the lanes take 64 consecutive steps, everything that does not depend on the recurrence (ratio, clips, discounts,
+// the temporal difference, the coefficient of a[t+1]) is computed once per step in parallel from coalesced loads, and only
+// a[t] = td[t] + k[t] * a[t+1] walks the lanes from 63 down to 0 on wave-uniform values -- the same fp32 multiply and add per
+// step, in the same order, as the serial loop (and as the reference's reverse tf.scan).
+__global__ __launch_bounds__(256) void k_vtrace(const float* __restrict__ lp_t, const float* __restrict__ lp_b,
+                                                const float* __restrict__ value, const float* __restrict__ reward,
+                                                const float* __restrict__ not_terminal,
+                                                const int* __restrict__ seq_len, int E, int T, float gamma,
+                                                float rho_clip, float pg_rho_clip, float* __restrict__ vs,
+                                                float* __restrict__ pg_adv, float* __restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int e = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (e >= E) return;
     const int end = seq_len ? seq_len[e] - 1 : -1;           // episodic_end_idx within the episode
     const size_t base = (size_t)e * T;
-    float a_next = 0.f, vs_next = 0.f;
-    for (int t = T - 1; t >= 0; --t) {
-        const size_t i = base + t;
+    float a_next = 0.f, vs_next = 0.f;                       // a[t+1], vs[t+1] of the chunk handled before (later in time)
+    for (int hi = T; hi > 0; hi -= 64) {
+        const int t = hi - 64 + lane;                        // my step (may be < 0 in the first, ragged chunk)
+        const bool live = t >= 0;
+        const size_t i = base + (live ? t : 0);
         const float v = value[i], r = reward[i];
         const float rho = expf(lp_t[i] - lp_b[i]);
         const float v_rho = rho_clip > 0.f ? fminf(rho_clip, rho) : rho;
@@ -134,17 +141,32 @@ __global__ __launch_bounds__(64) void k_vtrace(const float* __restrict__ lp_t, c
         const float c = fminf(1.0f, rho);
         const float disc = gamma * not_terminal[i];
         const bool boot = (t == T - 1) || (t == end);
-        const float v_t1 = boot ? v : value[i + 1];
+        const float v_t1 = (boot || !live) ? v : value[i + 1];
         const float td = v_rho * ((r + disc * v_t1) - v);
         const float dsc = (t == end) ? 0.f : disc;
-        const float a = td + (dsc * c) * a_next;
+        const float kc = dsc * c;
+        // the recurrence, lane 63 (latest step) first
+        float a = 0.f;
+        for (int j = 63; j >= 0; --j) {
+            if (hi - 64 + j < 0) break;                      // (wave-uniform)
+            const float td_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(td), j));
+            const float kc_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kc), j));
+            a_next = td_j + kc_j * a_next;
+            if (lane == j) a = a_next;
+        }
         const float vs_t = a + v;
-        const float vs_t1 = boot ? v : vs_next;
-        vs[i] = vs_t;
-        pg_adv[i] = pg_rho * ((r + disc * vs_t1) - v);
-        if (mask) mask[i] = (!seq_len || t <= end) ? 1.f : 0.f;
-        a_next = a;
-        vs_next = vs_t;
+        // vs[t+1]: my right neighbour's, or the previous chunk's first step for lane 63
+        float vs_r = __shfl_down(vs_t, 1, 64);
+        if (lane == 63) vs_r = vs_next;
+        const float vs_t1 = boot ? v : vs_r;
+        if (live) {
+            vs[i] = vs_t;
+            pg_adv[i] = pg_rho * ((r + disc * vs_t1) - v);
+            if (mask) mask[i] = (!seq_len || t <= end) ? 1.f : 0.f;
+        }
+        // the chunk's first live step feeds the next (earlier) chunk
+        const int first = max(0, 64 - hi);
+        vs_next = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs_t), first));
     }
 }
 
@@ -1255,7 +1277,7 @@ int pfpn_vtrace(const float* logp_target, const float* logp_behavior, const floa
     if (!logp_target || !logp_behavior || !value || !reward || !not_terminal || !vs || !pg_adv || E < 0 || T < 1)
         return PFPN_ERR_ARG;
     if (E == 0) return PFPN_OK;
-    hipLaunchKernelGGL(k_vtrace, dim3((E + 63) / 64), dim3(64), 0, (hipStream_t)stream, logp_target, logp_behavior,
+    hipLaunchKernelGGL(k_vtrace, dim3((E + 3) / 4), dim3(256), 0, (hipStream_t)stream, logp_target, logp_behavior,
                        value, reward, not_terminal, (const int*)seq_len, E, T, gamma, rho_clip, pg_rho_clip, vs,
                        pg_adv, mask);
     PFPN_CHECK_LAUNCH();

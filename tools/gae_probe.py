@@ -23,3 +23,10 @@ for E, T in ((8, 512), (64, 64), (1, 4096), (1, 512), (512, 8)):
     adv = kernels.gae(r, v, off, 0.95, 0.95 * 0.95)
     t = timeit(lambda: kernels.gae(r, v, off, 0.95, 0.95 * 0.95))
     print("k_gae  %3d sequences x %4d steps (%5d transitions): %6.2f us" % (E, T, E * T, t))
+for E, T in ((16, 64), (64, 64), (8, 512)):
+    n = E * T
+    lt, lb, v, r = (torch.randn(n, device=dev) * 0.1 for _ in range(4))
+    nt = torch.ones(n, device=dev)
+    kernels.vtrace(lt, lb, v, r, nt, E, 0.95)
+    t = timeit(lambda: kernels.vtrace(lt, lb, v, r, nt, E, 0.95))
+    print("k_vtrace %3d sequences x %4d steps (%5d transitions): %6.2f us" % (E, T, n, t))
