@@ -221,9 +221,11 @@ def sac_network_wrapper(base_class):
 
         def _draw_train_noise(self, buf):
             """fresh draws into buf [4, B, A*N] in ONE launch: a Philox block per element, keyed by the network generator's
-            seed, counted by the number of draws so far (no uniform fill + transform pass)."""
+            seed, counted by the learner step and the number of draws so far (no uniform fill + transform pass)."""
             self._noise_draws = getattr(self, "_noise_draws", 0) + 1
-            return kernels.sac_noise_fill_(buf, self.rng.initial_seed(), self._noise_draws)
+            # (the learner step count restored from a checkpoint is part of the counter: a resumed run does not replay
+            # the draws of the run's beginning)
+            return kernels.sac_noise_fill_(buf, self.rng.initial_seed(), (int(self.global_step) << 24) + self._noise_draws)
 
         def compute_gradients(self, state, action, reward, not_terminal, state_, noise=None):
             B, S, A = state.shape[0], self.S, self.n_actions
