@@ -188,14 +188,21 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         torch.addmm(self.policy_bias, ha, self.policy_weight, out=self.logits)
         return self.logits
 
-    def _forward(self, state, x=None):
+    def _forward(self, state, x=None, with_value=False):
         """state [B,S] device tensor -> (policy distribution, actor hidden, critic hidden).
-        `x`: the already normalised state (when the caller launched the normaliser itself)."""
+        `x`: the already normalised state (when the caller launched the normaliser itself).
+        `with_value`: also leave the critic's value in `self.value_buf`, evaluated inside the merged trunk's last epilogue
+        (same bits as `_value`, one launch less); `self._value_folded` says whether that happened."""
         B = state.shape[0]
         self._ensure_buffers(B)
         if x is None:
             x = self._normalize(state)
-        ha, hc = self._trunks_forward(x)
+        self._value_folded = bool(with_value and self.trunk is not None)      # (B % 4 != 0: the stack launches the head itself)
+        if self._value_folded:
+            ha, hc = self._trunks_forward(x, value_head=(self.store["critic/fc3/weight"].view(-1),
+                                                          self.store["critic/fc3/bias"], self.value_buf))
+        else:
+            ha, hc = self._trunks_forward(x)
         logits = self._policy_logits(ha)
         policy = MixtureGaussianDistribution(logits, self.loc, self.logstd, self.normalize_policy_output_)
         return policy, ha, hc
@@ -352,7 +359,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         sample + log-prob + value + activation statistics.  Returns device tensors
         (action [E,A], log_prob [E] or None, value [E] or None)."""
         st = self._to_dev(states).view(-1, self.S)
-        policy, ha, hc = self._forward(st)
+        policy, ha, hc = self._forward(st, with_value=self.trainable)
         upd = running_update and self.trainable and self.max_active is not None
         mx, sm = (self.max_active, self.sum_active) if upd else (None, None)
         logp = None
@@ -368,7 +375,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             if upd:
                 kernels.active_stats(policy.logits, mx, sm)
         self.policy = policy
-        value = self._value(hc) if self.trainable else None
+        value = (self.value_buf if self._value_folded else self._value(hc)) if self.trainable else None
         return action, logp, value
 
     def run_one(self, state):
