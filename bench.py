@@ -487,17 +487,15 @@ def main():
                 rp, _, rhc = net._forward(rt[0])
                 r_lp = rp.log_prob(rt[1]).clone()
                 r_v = net._value(rhc).clone()
-            rstep = graphs.GraphedLearnerStep(net, opt, rt[0], rt[1], r_v, r_lp, rt[2])
-            for _ in range(10):
-                rstep()
+            rrun, rlaunch = make_stepper(net, opt, (rt[0], rt[1], r_v, r_lp, rt[2]))      # K steps per replay, like the headline
+            rrun(16)
             torch.cuda.synchronize()
             tr = time.perf_counter()
-            for _ in range(200):
-                rstep()
+            rrun(208)
             torch.cuda.synchronize()
-            rus = (time.perf_counter() - tr) / 200 * 1e6
+            rus = (time.perf_counter() - tr) / 208 * 1e6
             out["reference_schedule"] = {"global_batch": 256, "steps_per_4096_transitions": 16, "us_per_step": rus,
-                                         "transitions_per_s": 256 / (rus * 1e-6),
+                                         "transitions_per_s": 256 / (rus * 1e-6), "launch": rlaunch,
                                          "note": "the headline step consumes 4096 transitions per step: %.0f transitions/s"
                                                  % (B * out["value"])}
         except Exception as e:          # informational only
