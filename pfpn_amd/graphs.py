@@ -40,8 +40,13 @@ class GraphedLearnerStep(object):
     ~10 us between them, K steps per replay pay that once.  The host part of every step (step counter, resample tick)
     runs after the replay, so a K-step replay is only legal while no resample falls inside it: `can_replay()`."""
 
-    def __init__(self, net, optimizer, *inputs, warmup=3, noise=None, steps_per_replay=1, input_sets=None):
+    def __init__(self, net, optimizer, *inputs, warmup=3, noise=None, steps_per_replay=1, input_sets=None,
+                 gather_from=None):
+        """`gather_from` = (columns, rows [K, B] int64, losses [K, 3]), all static device tensors: step k of a replay
+        first gathers rows[k] of the staged rollout `columns` into its input set (the minibatch slicing of a training
+        round, inside the graph) and leaves its loss3 in losses[k]."""
         self.net, self.opt = net, optimizer
+        self.gather_from = gather_from
         # data parallel: the step is captured as TWO graphs around the bucket all-reduce (everything up to the
         # per-replica clip | Adam + statistics); the collective itself is enqueued between the two replays, so the
         # capture never contains an RCCL call and the host enqueues 3 things per step instead of ~25
@@ -76,11 +81,15 @@ class GraphedLearnerStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=s):      # same stream as the warm-up: per-stream workspaces exist
             for k in range(self.K):
+                if gather_from is not None:
+                    kernels.gather_columns(list(gather_from[0]), list(self.input_sets[k]), gather_from[1][k])
                 self.loss3 = net.compute_gradients(*self._args(k))
                 if self.split:
                     optimizer.pre_reduce(net)
                 else:
                     optimizer.apply_device(net)
+                if gather_from is not None:
+                    gather_from[2][k].copy_(self.loss3)
         if self.split:
             self.graph_post = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_post, stream=s):
@@ -124,6 +133,7 @@ class GraphedLearnerStep(object):
         if self.noise is not None:
             refill_noise(self.noise, self.net.rng)
         self.graph.replay()
+        self.replays = getattr(self, "replays", 0) + 1
         if self.split:
             self.opt.reduce(self.net)
             self.graph_post.replay()

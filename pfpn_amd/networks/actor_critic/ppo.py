@@ -105,6 +105,35 @@ def clip_ppo_network_wrapper(a2c_base_class):
             loss3 = self.graphed_train(optimizer, args)
             return self._report(loss3, ops)
 
+        ROUND_STEPS_PER_REPLAY = 8
+
+        def _round_graph(self, optimizer, cols, B, K):
+            """K consecutive minibatch steps of a training round as ONE hipGraph (pfpn_amd/graphs.py; consecutive
+            one-step replays leave ~10 us of idle GPU between them).  Built once the one-step graph of this minibatch
+            size exists (the first steps of a run stay eager, as in graphed_train); the staged rollout lives in static
+            device columns the graph's gathers read, so a round of another size gets its own graph (at most two are
+            kept).  PFPN_GRAPH_ROUND=0: one-step replays only."""
+            if (B, id(optimizer)) not in self._train_graphs or os.environ.get("PFPN_GRAPH_ROUND", "1") == "0":
+                return None
+            n = cols[0].shape[0]
+            key = (B, n, K, id(optimizer))
+            rg = self._round_graphs.get(key) if hasattr(self, "_round_graphs") else None
+            if rg is None:
+                if not hasattr(self, "_round_graphs"):
+                    self._round_graphs = {}
+                if len(self._round_graphs) >= 2:
+                    return None
+                from ...graphs import GraphedLearnerStep
+                stage = [torch.empty_like(c) for c in cols]
+                rows = torch.zeros(K, B, dtype=torch.int64, device=self.device)
+                losses = torch.zeros(K, 3, dtype=torch.float32, device=self.device)
+                sets = [tuple(c[:B].clone() for c in cols) for _ in range(K)]      # sane inputs for the warm-up steps
+                rg = self._round_graphs[key] = GraphedLearnerStep(self, optimizer, steps_per_replay=K, input_sets=sets,
+                                                                  gather_from=(stage, rows, losses))
+            for dst, src in zip(rg.gather_from[0], cols):
+                dst.copy_(src, non_blocking=True)
+            return rg
+
         def train_round(self, sess_or_optimizer, ops, names, columns, plan):
             """A whole training round in one call (pfpn_amd/models/distributed_model.py: flat_train): `columns` are the
             rollout's host arrays by name (`names` = the learner's argument order), `plan` the row ids of every learner
@@ -119,11 +148,27 @@ def clip_ppo_network_wrapper(a2c_base_class):
             cols[2:] = [c.view(-1) for c in cols[2:]]
             rows = torch.from_numpy(np.concatenate(plan).astype(np.int64)).to(self.device)
             losses = torch.empty(len(plan), 3, dtype=torch.float32, device=self.device)
-            steps, pos = [], 0
-            for i, ids in enumerate(plan):
+            steps, pos, i = [], 0, 0
+            B0, K = len(plan[0]), self.ROUND_STEPS_PER_REPLAY
+            rg = self._round_graph(optimizer, cols, B0, K) if len(plan) >= K else None
+            if rg is not None:
+                cols = rg.gather_from[0]                    # the staged rollout the graph's gathers read
+            while i < len(plan):
+                if rg is not None and i + K <= len(plan) and all(len(p) == B0 for p in plan[i:i + K]):
+                    if rg.can_replay():
+                        # K minibatch steps per replay: their gathers read the staged rollout inside the graph
+                        rg.gather_from[1].copy_(rows[pos:pos + K * B0].view(K, B0))
+                        rg()
+                        losses[i:i + K].copy_(rg.gather_from[2])
+                        steps.extend(range(self.global_step - K + 1, self.global_step + 1))
+                        pos += K * B0
+                        i += K
+                        continue
+                ids = plan[i]
                 losses[i].copy_(self.graphed_train(optimizer, cols, rows=rows[pos:pos + len(ids)]))
                 pos += len(ids)
                 steps.append(self.global_step)
+                i += 1
             host = losses.cpu().numpy()
             wanted = list(ops) if hasattr(ops, "__len__") else ([ops] if ops else [])
             return [((float(l[0]), None, float(l[1]), float(l[2])),

@@ -103,10 +103,12 @@ def test_graphed_rollout_matches_eager(dev):
         net.run(None, st[0])
 
 
-def test_staged_training_round_matches_stepwise_training(dev):
+@pytest.mark.parametrize("n,rounds", [(200, 2), (256, 3)])
+def test_staged_training_round_matches_stepwise_training(dev, n, rounds):
     """`train_round` (rollout staged once, device-side minibatch gathers into the captured step, one loss read) gives
     the bits of per-minibatch `train()` calls on the same plan, across the switch from eager steps to hipGraph replays,
-    a ragged last minibatch and a resample tick."""
+    a ragged last minibatch (n = 200), resample ticks, and -- with uniform minibatches (n = 256) -- replays of EIGHT
+    steps per graph whose gathers run inside the graph, falling back to one-step replays around a tick."""
     import numpy as np
     import torch
     from pfpn_amd.models import SyncReplicasApplier
@@ -115,22 +117,26 @@ def test_staged_training_round_matches_stepwise_training(dev):
     names = ["state", "action", "value", "log_prob", "advantage"]
     rng = np.random.default_rng(5)
     nets = [make_net(dev, seed=11, resample_interval=13) for _ in range(2)]
-    opts = [SyncReplicasApplier(n, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1) for n in nets]
-    for rnd in range(2):
-        n = 200                                             # 6 minibatches of 32 + one of 8, two epochs
+    opts = [SyncReplicasApplier(n_, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1) for n_ in nets]
+    per_round = 2 * ((n + 31) // 32)                        # two epochs of 32-row minibatches (n = 200: 6 + one of 8)
+    for rnd in range(rounds):
         b = make_batch(rng, n)
         b["log_prob"] = rng.normal(-38, 0.3, n).astype(np.float32)
         plan = minibatch_plan(n, 32, 2, np.random.RandomState(rnd))
         cols = {k: b[k] for k in names}
         out_round = nets[0].train_round(opts[0], ["global_step"], names, cols, plan)
         out_steps = [nets[1].train(None, opts[1], ["global_step"], *[cols[k][rows] for k in names]) for rows in plan]
-        assert len(out_round) == len(plan) == 14
+        assert len(out_round) == len(plan) == per_round
         for (l0, e0), (l1, e1) in zip(out_round, out_steps):
             assert l0 == l1 and e0 == e1
         assert torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
         assert torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
-    assert nets[0].global_step == 28 and nets[0].train_flag == nets[1].train_flag == 2      # ticks at 13 and 26
+    assert nets[0].global_step == rounds * per_round
+    assert nets[0].train_flag == nets[1].train_flag == rounds * per_round % 13          # steps since the last tick (every 13)
     assert len(nets[0]._train_graphs) >= 1                  # the round really ran on captured steps
+    if n == 256:
+        (rg,) = nets[0]._round_graphs.values()              # rounds 2 and 3 replayed eight steps at a time
+        assert rg.K == 8 and rg.replays >= 2
 
 
 def test_gather_columns_kernel(dev):

@@ -25,7 +25,8 @@ for B in (32, 256, 4096):
         print("net.train(), %4d-row minibatch, %s: %.3f ms/step -> %.0f steps/s" % (B, "hipGraph" if mode == "1" else "eager   ", t * 1e3, 1 / t))
 # the reference schedule: one worker's 512-step unroll, 16 minibatches of 32 (deepmimic_dppo_base.py:6-12)
 os.environ["PFPN_GRAPH_TRAIN"] = "1"
-for n, bs in ((512, 32), (4096, 256)):
+for n, bs, rnd in ((512, 32, "1"), (512, 32, "0"), (4096, 256, "1"), (4096, 256, "0")):
+    os.environ["PFPN_GRAPH_ROUND"] = rnd            # 1: eight minibatch steps per graph replay, 0: one
     net = make_net(dev, seed=1, resample_interval=10 ** 9)
     opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
     b = make_batch(rng, n); b["log_prob"] = np.full(n, -40.0, np.float32)
@@ -36,5 +37,5 @@ for n, bs in ((512, 32), (4096, 256)):
     R_ = 20
     for _ in range(R_): net.train_round(opt, [], names, cols, minibatch_plan(n, bs, 1, r))
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / (R_ * (n // bs))
-    print("train_round(), %d rows in %d-row minibatches: %.3f ms/step -> %.0f steps/s, %.0f transitions/s"
-          % (n, bs, t * 1e3, 1 / t, bs / t))
+    print("train_round(), %d rows in %d-row minibatches, %s steps per replay: %.3f ms/step -> %.0f steps/s, %.0f transitions/s"
+          % (n, bs, "8" if rnd == "1" else "1", t * 1e3, 1 / t, bs / t))
