@@ -270,7 +270,8 @@ int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, flo
 int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                            const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                            float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,
-                           float* step_counter, const float* sq_partial, int n_partials, void* stream);
+                           float* step_counter, const float* sq_partial, int n_partials, float* soft_target,
+                           long long soft_off, long long soft_len, float soft_tau, void* stream);
 int pfpn_state_moment_chunks(int B);
 /* Slab geometry of pfpn_ppo_mixture_fwd_bwd called with loss3 = NULL (same arguments): nslab slabs of `stride`
  * floats laid out [dloc A*N | dlogstd A*N | (dbias A*N) | policy-loss, value-loss, pad, pad].  PFPN_ERR_ARG when the
@@ -324,13 +325,17 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
  * with beta_pow it also rotates the Adam powers exactly as pfpn_clip_adam's first launch does), then -- after the
  * caller's all-reduce (sum) -- pfpn_adam_groups applies TF-Adam with grad_mul = 1/W, using the "used" pair of
  * beta_pow, and bumps step_counter (1 launch); scale_buf[0..scale_n) *= scale_mul in the same launch (the replicated
- * statistics in the bucket tail: sums -> replica means, sync_model.py:37-46; scale_n = 0: none). */
+ * statistics in the bucket tail: sums -> replica means, sync_model.py:37-46; scale_n = 0: none).
+ * soft_target != NULL (pfpn_adam_groups, pfpn_clip_adam_prenorm): the SAC soft target update (sac.py:67-73) of the
+ * parameters [soft_off, soft_off + soft_len) happens in the same launch, on the values Adam just wrote:
+ * soft_target[i] <- (1 - soft_tau) soft_target[i] + soft_tau params[soft_off + i] (pfpn_soft_update's arithmetic). */
 int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm_scale, float* beta_pow, int n_groups,
                             float beta1, float beta2, void* workspace, size_t workspace_bytes, void* stream);
 int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                      const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                      float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter,
-                     float* scale_buf, size_t scale_n, float scale_mul, void* stream);
+                     float* scale_buf, size_t scale_n, float scale_mul, float* soft_target, long long soft_off,
+                     long long soft_len, float soft_tau, void* stream);
 /* SAC loss head -- sac.py:123-139 (vf_target, q_target) and :160-173 (Q and policy losses).
  * q_pi, q_run, q_tgt are [2,B] (Q1 row then Q2 row): Q(s, a_pi), Q(s, action_hist), Q'(s', a').
  * Outputs dq_pi [2,B] (d policy_loss/dQ through tf.minimum), dq_run [2,B] (d value_loss/dQ),

@@ -715,7 +715,9 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
                                                    const float* __restrict__ partial, int nblk, float clip_norm,
                                                    float grad_mul, float* __restrict__ norm_scale,
                                                    float* __restrict__ step, float* __restrict__ scale_buf = nullptr,
-                                                   size_t scale_n = 0, float scale_mul = 1.f) {
+                                                   size_t scale_n = 0, float scale_mul = 1.f,
+                                                   float* __restrict__ soft_t = nullptr, size_t soft_o4 = 0,
+                                                   size_t soft_n4 = 0, float tau = 0.f) {
     __shared__ float red[4];
     // data parallel: the replicated statistics behind the gradients in the all-reduce bucket turn from sums into
     // replica means here (sync_model.py:37-46 push_weights) instead of in a launch of their own
@@ -754,6 +756,16 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
             reinterpret_cast<float4*>(p)[o4 + i] = pp;
             reinterpret_cast<float4*>(m)[o4 + i] = mm;
             reinterpret_cast<float4*>(v)[o4 + i] = vv;
+            // SAC soft target update (sac.py:67-73) of the parameters just written: t <- (1-tau) t + tau p, k_soft_update's
+            // arithmetic, for the floats [4 soft_o4, 4 (soft_o4 + soft_n4)) of the buffer (soft_t holds their targets)
+            const size_t e = o4 + i - soft_o4;
+            if (soft_t && o4 + i >= soft_o4 && e < soft_n4) {
+                const float omt = 1.f - tau;
+                float4 t = reinterpret_cast<float4*>(soft_t)[e];
+                t.x = omt * t.x + tau * pp.x; t.y = omt * t.y + tau * pp.y;
+                t.z = omt * t.z + tau * pp.z; t.w = omt * t.w + tau * pp.w;
+                reinterpret_cast<float4*>(soft_t)[e] = t;
+            }
         }
     }
 }
@@ -1625,10 +1637,14 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
 int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                            const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                            float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,
-                           float* step_counter, const float* sq_partial, int n_partials, void* stream) {
+                           float* step_counter, const float* sq_partial, int n_partials, float* soft_target,
+                           long long soft_off, long long soft_len, float soft_tau, void* stream) {
     PFPN_BEGIN();
     if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || !sq_partial || n < 1 ||
         n_groups < 1 || n_groups > 4 || n_partials < 1)
+        return PFPN_ERR_ARG;
+    if (soft_target && (soft_off < 0 || soft_len < 0 || (soft_off & 3) || (soft_len & 3) ||
+                        (size_t)(soft_off + soft_len) > n || ((uintptr_t)soft_target & 15)))
         return PFPN_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
     AdamGroups gr{};
@@ -1643,7 +1659,8 @@ int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v
     }
     hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
                        v, gr, beta1, beta2, eps, beta_pow, sq_partial, n_partials, clip_norm, 1.0f, norm_scale,
-                       step_counter);
+                       step_counter, (float*)nullptr, (size_t)0, 1.f, soft_target, (size_t)soft_off >> 2,
+                       (size_t)soft_len >> 2, soft_tau);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
@@ -1683,10 +1700,14 @@ int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, flo
 int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                      const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                      float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter,
-                     float* scale_buf, size_t scale_n, float scale_mul, void* stream) {
+                     float* scale_buf, size_t scale_n, float scale_mul, float* soft_target, long long soft_off,
+                     long long soft_len, float soft_tau, void* stream) {
     PFPN_BEGIN();
     if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || n < 1 || n_groups < 1 ||
         n_groups > 4 || (scale_n > 0 && !scale_buf))
+        return PFPN_ERR_ARG;
+    if (soft_target && (soft_off < 0 || soft_len < 0 || (soft_off & 3) || (soft_len & 3) ||
+                        (size_t)(soft_off + soft_len) > n || ((uintptr_t)soft_target & 15)))
         return PFPN_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
     AdamGroups gr{};
@@ -1701,7 +1722,8 @@ int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size
     }
     hipLaunchKernelGGL(k_clip_adam, dim3(stream_grid(longest >> 2)), dim3(256), 0, (hipStream_t)stream, params, grads, m,
                        v, gr, beta1, beta2, eps, beta_pow, (const float*)nullptr, 0, 0.f, grad_mul, (float*)nullptr,
-                       step_counter, scale_buf, scale_n, scale_mul);
+                       step_counter, scale_buf, scale_n, scale_mul, soft_target, (size_t)soft_off >> 2,
+                       (size_t)soft_len >> 2, soft_tau);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -638,8 +638,16 @@ def tf_adam(params, grads, m, v, beta_pow, lr, beta1=0.9, beta2=0.999, eps=1e-8,
                "pfpn_tf_adam")
 
 
+def _soft_args(soft):
+    """soft = (target_flat, off, len, tau) or None -> the four trailing C arguments"""
+    if soft is None:
+        return None, 0, 0, 0.0
+    t, off, ln, tau = soft
+    return _f32(t), int(off), int(ln), float(tau)
+
+
 def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, clip_norm, norm_scale, beta1=0.9,
-              beta2=0.999, eps=1e-8, step_counter=None, prenorm=None):
+              beta2=0.999, eps=1e-8, step_counter=None, prenorm=None, soft=None):
     """One-replica optimiser step in two launches (global-norm clip folded into TF-Adam).  group_* are ctypes
     arrays (host); beta_pow is [G,4] (see include/pfpn_hip.h).
     prenorm = (partial, count) from reduce_jobs(norm=...): the norm's partial sums exist and the powers are rotated
@@ -653,8 +661,11 @@ def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, cli
                                               ctypes.addressof(group_lr), float(beta1), float(beta2), float(eps),
                                               _f32(beta_pow, G, 4), float(clip_norm), _f32(norm_scale, 2),
                                               _f32(step_counter, 1) if step_counter is not None else None,
-                                              _f32(prenorm[0]), int(prenorm[1]), _stream()), "pfpn_clip_adam_prenorm")
+                                              _f32(prenorm[0]), int(prenorm[1]), *_soft_args(soft), _stream()),
+                   "pfpn_clip_adam_prenorm")
         return
+    if soft is not None:
+        raise ValueError("the soft target update rides on the one-launch optimiser (prenorm) only")
     ws, wsn = _learn_ws(1, 1, params.device)
     _lib.check(lib.pfpn_clip_adam(_f32(params), _f32(grads), _f32(m), _f32(v), n, G, ctypes.addressof(group_off),
                                   ctypes.addressof(group_len), ctypes.addressof(group_lr), float(beta1), float(beta2),
@@ -680,7 +691,7 @@ def clip_scale_inplace(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0
 
 
 def adam_groups(params, grads, m, v, group_off, group_len, group_lr, beta_pow, grad_mul=1.0, beta1=0.9, beta2=0.999,
-                eps=1e-8, step_counter=None, scale=None, scale_mul=1.0):
+                eps=1e-8, step_counter=None, scale=None, scale_mul=1.0, soft=None):
     """TF-Adam of every parameter group in one launch, on the powers pfpn_clip_scale_inplace / pfpn_clip_adam rotated.
     `scale` (a float tensor): multiplied by `scale_mul` in the same launch (bucket-tail statistics -> replica means)."""
     lib = _lib.load()
@@ -690,8 +701,8 @@ def adam_groups(params, grads, m, v, group_off, group_len, group_lr, beta_pow, g
                                     float(beta1), float(beta2), float(eps), _f32(beta_pow, G, 4), float(grad_mul),
                                     _f32(step_counter, 1) if step_counter is not None else None,
                                     _f32(scale) if scale is not None else None,
-                                    scale.numel() if scale is not None else 0, float(scale_mul), _stream()),
-               "pfpn_adam_groups")
+                                    scale.numel() if scale is not None else 0, float(scale_mul), *_soft_args(soft),
+                                    _stream()), "pfpn_adam_groups")
 
 
 def gather_columns(srcs, dsts, rows):

@@ -71,6 +71,14 @@ class SyncReplicasApplier(object):
                 and os.environ.get("PFPN_FUSED_NORM", "1") != "0":
             net._norm_hook = {"partial": torch.zeros(4096, dtype=torch.float32, device=st.device),
                               "beta_pow": self.beta_pow, "beta1": beta1, "beta2": beta2}
+        # SAC: the soft target update (a train op after the apply, sac.py:67-73) becomes part of the optimiser's device
+        # work -- inside the Adam launch where that is one launch, else right behind it -- instead of a launch of its own
+        # after every graph replay
+        self._soft_net = hasattr(net, "soft_update_args") and (net.sync_target_net_soft in net.train_ops or
+                                                               getattr(net, "_soft_by_optimizer", False))
+        if self._soft_net and not getattr(net, "_soft_by_optimizer", False):
+            net.train_ops.remove(net.sync_target_net_soft)
+            net._soft_by_optimizer = True
         if self.exchange and hasattr(net, "adopt_tail_statistics"):
             net.adopt_tail_statistics()        # replicated statistics live in the all-reduce bucket from now on
 
@@ -95,11 +103,15 @@ class SyncReplicasApplier(object):
             self.post_reduce(net)
             return
         net.join_side_stream()
+        soft = net.soft_update_args() if self._soft_net else None
         if self._fused_ok():
             # clip + every group's Adam + power / step-counter advance in one launch (two without the norm hook)
+            pre = self._prenorm(net)
             kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
-                              step_counter=net.step_dev, prenorm=self._prenorm(net))
+                              step_counter=net.step_dev, prenorm=pre, soft=soft if pre is not None else None)
+            if soft is not None and pre is None:
+                net.sync_target_net_soft()
             net.unpack_synced_stats(st.tail, 1.0)
             return
         fused_scale = None
@@ -108,6 +120,8 @@ class SyncReplicasApplier(object):
             kernels.clip_by_global_norm(st.grad, self.norm_clip, self.norm_scale, apply=False)
             fused_scale = self.norm_scale
         self._adam_groups_unfused(net, fused_scale, 1.0)
+        if soft is not None:
+            net.sync_target_net_soft()
         net.unpack_synced_stats(st.tail, 1.0)
 
     def pre_reduce(self, net):
@@ -124,15 +138,18 @@ class SyncReplicasApplier(object):
     def post_reduce(self, net):
         """Adam on the all-reduced sum with 1/W folded in; the statistics tail becomes the replica mean."""
         st, W = net.store, self.world
+        soft = net.soft_update_args() if self._soft_net else None
         if self._fused_ok():
             in_tail = getattr(net, "_stats_in_tail", False) and st.tail.numel() > 0
             kernels.adam_groups(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                                 1.0 / W, self.beta1, self.beta2, self.epsilon, step_counter=net.step_dev,
-                                scale=st.tail if in_tail else None, scale_mul=1.0 / W)
+                                scale=st.tail if in_tail else None, scale_mul=1.0 / W, soft=soft)
             if not in_tail:
                 net.unpack_synced_stats(st.tail, 1.0 / W)
             return
         self._adam_groups_unfused(net, None, 1.0 / W)
+        if soft is not None:
+            net.sync_target_net_soft()
         net.unpack_synced_stats(st.tail, 1.0 / W)
 
     def _adam_groups_unfused(self, net, fused_scale, grad_mul):

@@ -34,6 +34,7 @@ def sac_network_wrapper(base_class):
                 kwargs["normalize_policy_output"] = True          # sac.py:15-16
             super().__init__(**kwargs)
             self.alpha = alpha       # replaced by exp(log_alpha) for the trainable net (sac.py:36-39)
+            self.batch_actor = os.environ.get("PFPN_SAC_BATCH_ACTOR", "1") != "0"
             self.tau = tau
             self.reward, self.not_terminal = "reward", "not_terminal"
 
@@ -136,14 +137,22 @@ def sac_network_wrapper(base_class):
             off, ln = self.critic_span
             kernels.soft_update(self.target_store.flat[:ln], self.store.flat[off:off + ln], self.tau)
 
+        def soft_update_args(self):
+            """(target values, offset, length, tau) of the soft update over the flat parameter buffer: what the optimiser's
+            Adam launch needs to do the update itself (kernels.clip_adam / adam_groups `soft=`)."""
+            off, ln = self.critic_span
+            return self.target_store.flat[:ln], off, ln, self.tau
+
         # -- buffers ----------------------------------------------------------------------------------
         def _alloc_policy_buffers(self, B):
             dev, A, AN = self.device, self.n_actions, self.n_actions * self.particles
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-            self.logits = f(B, AN)
-            self.logits2 = f(B, AN)
+            # s and s' share one buffer each ([2B, .]: first half s, second half s'): the actor is evaluated on both in
+            # ONE pass of 2B rows (compute_gradients); the halves are what the rest of the step names x / x2, logits / logits2
+            self.xn_both, self.logits_both = f(2 * B, self.S), f(2 * B, AN)
+            self.xn, self.xn2 = self.xn_both[:B], self.xn_both[B:]
+            self.logits, self.logits2 = self.logits_both[:B], self.logits_both[B:]
             self.dlogits = f(B, AN)
-            self.xn2 = f(B, self.S)
             self.xa, self.xh, self.xa2 = f(B, self.S + A), f(B, self.S + A), f(B, self.S + A)
             self.q_pi, self.q_run, self.q_tgt = f(2, B), f(2, B), f(2, B)
             hc = self.critic_net_shape[-1]
@@ -243,14 +252,29 @@ def sac_network_wrapper(base_class):
                 x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
                 self.update_state_normalizer(state)        # side stream, joined in the optimiser
             fold = deferred is not None
-            # eval actor on s, shared actor on s' (sac.py:141-153)
-            ha = self._actor_logits(x, 0, self.logits, masks=fold)
-            self._actor_logits(x2, 1, self.logits2)
             loc, logstd = self.loc, self.logstd
-            a, s_, k = kernels.rsample_fwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"])
-            logp = kernels.logprob_fwd(self.logits, s_, loc, logstd, True)
-            a2, s2, _ = kernels.rsample_fwd(self.logits2, loc, logstd, noise["gumbel_"], noise["eps_"])
-            logp2 = kernels.logprob_fwd(self.logits2, s2, loc, logstd, True)
+            nb = noise.get("_buf")
+            both = fold and self.batch_actor and nb is not None and nb.is_contiguous() and \
+                tuple(nb.shape) == (4, B, A * self.particles) and x.data_ptr() == self.xn_both.data_ptr()
+            actor_slot = 0
+            if both:
+                # eval actor on s and the shared actor on s' (sac.py:141-153) are the same network: ONE pass over the
+                # 2B rows [s; s'] -- trunk, head, reparameterised sample and log-prob are 7 launches instead of 14; the
+                # backward runs over the first B rows of that pass's activations
+                hb = self._actor_logits(self.xn_both, 0, self.logits_both, masks=True)
+                self.actor_trunk.share_prefix(2 * B, B, 0, 3)
+                actor_slot, ha = 3, hb[:B]
+                ab, sb, kb = kernels.rsample_fwd(self.logits_both, loc, logstd, nb[0:2].view(2 * B, -1),
+                                                 nb[2:4].view(2 * B, -1))
+                lb = kernels.logprob_fwd(self.logits_both, sb, loc, logstd, True)
+                a, s_, k, logp, a2, logp2 = ab[:B], sb[:B], kb[:B], lb[:B], ab[B:], lb[B:]
+            else:
+                ha = self._actor_logits(x, 0, self.logits, masks=fold)
+                self._actor_logits(x2, 1, self.logits2)
+                a, s_, k = kernels.rsample_fwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"])
+                logp = kernels.logprob_fwd(self.logits, s_, loc, logstd, True)
+                a2, s2, _ = kernels.rsample_fwd(self.logits2, loc, logstd, noise["gumbel_"], noise["eps_"])
+                logp2 = kernels.logprob_fwd(self.logits2, s2, loc, logstd, True)
             self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
             # Q inputs
             kernels.sac_q_inputs(x, x2, a, action, a2, self.xa, self.xh, self.xa2)
@@ -295,7 +319,7 @@ def sac_network_wrapper(base_class):
             else:
                 kernels.act_bwd_bias_grad(None, dlogits, gpb, relu6=False)
             torch.mm(dlogits, self.policy_weight.t(), out=self.dha[0])
-            self.actor_trunk.backward(self.dha, slot=0, deferred=deferred)
+            self.actor_trunk.backward(self.dha, slot=actor_slot, deferred=deferred)
             if fold:
                 self._finish_deferred(deferred, allow_norm=not self.fixed_sigma)
             return out["loss3"]

@@ -175,6 +175,24 @@ class DenseStack:
                            "mask": [None] * self.L, "mask_ok": [False] * self.L}
         return self._bufs[key]
 
+    def share_prefix(self, B_big, B_small, slot_big, slot_small):
+        """(one group) register the first `B_small` rows of the activation set (B_big, slot_big) as the set
+        (B_small, slot_small): after ONE forward over B_big rows a backward can run over the leading rows only (SAC: the
+        actor evaluated on [s; s'] in one pass, differentiated through s alone).  Views, no copies; the mask bits of a
+        row-major [rows, H] layer are a prefix too (H / 4 a multiple of 64)."""
+        if self.G != 1:
+            raise ValueError("prefix sharing is built for single-group stacks")
+        big = self._bufs[(B_big, slot_big)]
+        key = (B_small, slot_small)
+        v = self._bufs.get(key)
+        if v is None or v.get("prefix_of") is not big:
+            v = self._bufs[key] = {
+                "act2d": [a[:B_small] for a in big["act2d"]], "act": [a[:, :B_small] for a in big["act"]],
+                "dact2d": [a[:B_small] for a in big["dact2d"]], "dact": [a[:, :B_small] for a in big["dact"]],
+                "x": None, "B": B_small, "ws": None, "mask": big["mask"], "mask_ok": big["mask_ok"], "prefix_of": big}
+        v["x"] = big["x"][:B_small]
+        return v
+
     def _slab_workspaces(self, buf):
         """private partial-sum workspaces (one per layer + one for a folded critic head): their reductions are
         deferred to the step's single `kernels.reduce_jobs` launch, so no two producers may share slabs."""

@@ -5,6 +5,8 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 from test_gpu_sac_step import make_net
 from pfpn_amd.models import SyncReplicasApplier
+from pfpn_amd import tuning
+tuning.enable_tuned_gemms(tune_missing=False)
 dev = torch.device("cuda", 0)
 net = make_net(dev)
 groups = [{"names": net.critic_param_names(), "lr": 1e-4}, {"names": net.actor_param_names(), "lr": 1e-4}]
@@ -27,9 +29,12 @@ for B in (256, 1024, 4096):
 
 from pfpn_amd.graphs import GraphedLearnerStep
 for B in (256, 1024, 4096):
+  for both in ("0", "1", "0", "1"):
+    os.environ["PFPN_SAC_BATCH_ACTOR"] = both       # 1: the actor evaluated once over [s; s'] (2B rows)
     net = make_net(dev)
     opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4}, {"names": net.actor_param_names(), "lr": 1e-4}],
                               norm_clip=1.0, world_size=1)
+    rng = np.random.default_rng(1)
     b = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(np.float32),
                                                rng.uniform(-0.9, 0.9, (B, 36)).astype(np.float32),
                                                rng.normal(0.5, 0.3, B).astype(np.float32),
@@ -38,7 +43,7 @@ for B in (256, 1024, 4096):
     step = GraphedLearnerStep(net, opt, *b, noise=net.make_train_noise(B))
     for _ in range(10): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(100): step()
-    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 100
-    print("SAC-PFPN learner step as one hipGraph, replay batch %4d: %.3f ms/step -> %.0f steps/s (loss %s)" % (
-        B, t * 1e3, 1 / t, step.loss3.cpu().numpy()))
+    for _ in range(200): step()
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 200
+    print("SAC-PFPN learner step as one hipGraph, replay batch %4d, actor passes %s: %.3f ms/step -> %.0f steps/s (loss %s)" % (
+        B, "one (2B rows)" if both == "1" else "two", t * 1e3, 1 / t, step.loss3.cpu().numpy()))
