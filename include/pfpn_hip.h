@@ -170,10 +170,12 @@ int pfpn_gae(const float* reward, const float* value, const int64_t* offsets, in
 
 /* The learner step's prologue in one launch: x = clip((s-mean)/std) as pfpn_state_norm, plus (want_moments) the
  * float64 column moments of s for pfpn_state_norm_ema, plus (adv_stats != NULL) pfpn_adv_stats' {mean, 1/(std+1e-8)}
- * of the advantages.  pfpn_state_norm_ema turns the moments into the EMA update of pfpn_state_norm_update. */
+ * of the advantages.  pfpn_state_norm_ema turns the moments into the EMA update of pfpn_state_norm_update.
+ * s2 != NULL: a second [B,S] batch (SAC's next states, sac.py:141-153) is normalised with the same moments into x2 in
+ * the same launch (it does not enter the moments). */
 int pfpn_state_prologue(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
                         int want_moments, const float* adv, int normalize_adv, float* adv_stats,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        const float* s2, float* x2, void* workspace, size_t workspace_bytes, void* stream);
 int pfpn_state_norm_ema(const void* workspace, int B, int S, const float* step, const float* mean_in,
                         const float* std_in, float* mean_out, float* std_out, void* stream);
 

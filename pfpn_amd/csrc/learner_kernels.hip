@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict_
                                                         const float* __restrict__ std, int B, int S, int chunk_len,
                                                         int C, float clip, float* __restrict__ x,
                                                         double* __restrict__ partial, const float* __restrict__ adv,
-                                                        int normalize_adv, float* __restrict__ adv_stats) {
+                                                        int normalize_adv, float* __restrict__ adv_stats,
+                                                        const float* __restrict__ s2, float* __restrict__ x2) {
     __shared__ double red[2][4][64];
     if ((int)blockIdx.y == C) {                            // the advantage block
         if (blockIdx.x != 0 || !adv_stats) return;
@@ -298,11 +299,12 @@ __global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict_
     if (c < S) {
         const float mc = mean[c], sc = std[c];
         for (int b = b0 + rl; b < b1; b += 16) {
-            float v[4];
+            float v[4], w[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = b + 4 * j;
                 v[j] = r < b1 ? s[(size_t)r * S + c] : 0.f;
+                w[j] = (s2 && r < b1) ? s2[(size_t)r * S + c] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -313,6 +315,11 @@ __global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict_
                     float xn = (v[j] - mc) / sc;                       // actor_critic.py:229-232
                     if (clip > 0.f) xn = fmaxf(fminf(xn, clip), -clip);
                     x[(size_t)r * S + c] = xn;
+                    if (s2) {                                          // a second batch normalised with the same moments
+                        float yn = (w[j] - mc) / sc;                   // (SAC: the next states), k_state_norm's arithmetic
+                        if (clip > 0.f) yn = fmaxf(fminf(yn, clip), -clip);
+                        x2[(size_t)r * S + c] = yn;
+                    }
                 }
             }
         }
@@ -1345,16 +1352,16 @@ int pfpn_state_norm_update(const float* s, int B, int S, const float* step, cons
 
 int pfpn_state_prologue(const float* s, const float* mean, const float* std, int B, int S, float clip, float* x,
                         int want_moments, const float* adv, int normalize_adv, float* adv_stats,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        const float* s2, float* x2, void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
-    if (!s || !mean || !std || !x || B < 1 || S < 1 || (adv_stats && !adv)) return PFPN_ERR_ARG;
+    if (!s || !mean || !std || !x || B < 1 || S < 1 || (adv_stats && !adv) || (s2 && !x2)) return PFPN_ERR_ARG;
     if (want_moments && (!workspace || workspace_bytes < pfpn_learner_workspace_bytes(B, S))) return PFPN_ERR_WORKSPACE;
     int C = row_chunks(B);
     if (C > 256) C = 256;
     const int len = (B + C - 1) / C;
     hipLaunchKernelGGL(k_state_prologue, dim3((S + 63) / 64, C + 1), dim3(256), 0, (hipStream_t)stream, s, mean, std, B,
                        S, len, C, clip, x, want_moments ? (double*)workspace : (double*)nullptr, adv, normalize_adv,
-                       adv_stats);
+                       adv_stats, s2, x2);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

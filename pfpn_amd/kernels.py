@@ -410,7 +410,7 @@ def state_norm_update(s, step, mean, std, mean_out=None, std_out=None):
 
 
 def state_prologue(s, mean, std, clip, out_x, want_moments=True, adv=None, normalize_adv=False, adv_stats=None,
-                   ws=None):
+                   ws=None, s2=None, out_x2=None):
     """x = clip((s-mean)/std) + float64 column moments of s (for state_norm_ema) + advantage moments, one launch.
     `ws`: private uint8 workspace for the moments (deferred EMA: `job_norm_ema`)."""
     lib = _lib.load()
@@ -419,7 +419,9 @@ def state_prologue(s, mean, std, clip, out_x, want_moments=True, adv=None, norma
     _lib.check(lib.pfpn_state_prologue(_f32(s, B, S), _f32(mean, S), _f32(std, S), B, S, float(clip or 0.0),
                                        _f32(out_x, B, S), int(want_moments),
                                        _f32(adv, B) if adv_stats is not None else None, int(normalize_adv),
-                                       _f32(adv_stats, 4) if adv_stats is not None else None, ws, wsn, _stream()),
+                                       _f32(adv_stats, 4) if adv_stats is not None else None,
+                                       _f32(s2, B, S) if s2 is not None else None,
+                                       _f32(out_x2, B, S) if s2 is not None else None, ws, wsn, _stream()),
                "pfpn_state_prologue")
     return out_x
 

@@ -374,13 +374,17 @@ class ActorCriticNetwork(object):
         optimizer.apply(self)
         return loss3
 
-    def prologue(self, state, advantage=None, deferred=None):
+    def prologue(self, state, advantage=None, deferred=None, state2=None, out2=None):
         """First launches of a learner step: x = normalised state, the state-normaliser EMA on this minibatch
         (UPDATE_OPS, reference sync_model.py:123-138) and -- when `advantage` is given -- its normalisation
         moments into self.adv_stats.  With the normaliser on this is two launches (fused prologue + EMA
-        finalisation) instead of four or more."""
+        finalisation) instead of four or more.  `state2` -> `out2` (deferred steps): a second batch normalised with the
+        same moments in the same launch (SAC's next states)."""
         fusable = self.state_normalizer is not None and self.normalize_state and self.trainable and \
             not self.overlap_ema and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+        if state2 is not None and not (fusable and deferred is not None):
+            self.state_normalizer.normalize(state2, self.clip_state or 0.0, out=out2)
+            state2 = None
         if not fusable:
             x = self._normalize(state)
             self.update_state_normalizer(state)
@@ -395,7 +399,7 @@ class ActorCriticNetwork(object):
             # (its result is first read by the NEXT step's prologue)
             kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
                                    self.normalize_advantage, self.adv_stats if advantage is not None else None,
-                                   ws=self.ws_moments)
+                                   ws=self.ws_moments, s2=state2, out_x2=out2)
             mo, so = (nz.mean, nz.std) if in_place else (tail[:S], tail[S:2 * S])
             deferred.append(kernels.job_norm_ema(self.ws_moments, B, S, self.step_dev, nz.mean, nz.std, mo, so))
             return self.xn

@@ -245,8 +245,9 @@ def sac_network_wrapper(base_class):
             noise = noise or self.make_train_noise(B)
             deferred = self._deferred_jobs(B)
             if deferred is not None:
-                x = self.prologue(state, deferred=deferred)      # normalise + moments in one launch, EMA as a job
-                x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
+                # normalise s AND s' + the moments of s in one launch, the EMA as a job
+                x = self.prologue(state, deferred=deferred, state2=state_, out2=self.xn2)
+                x2 = self.xn2
             else:
                 x = self._normalize(state)
                 x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
