@@ -341,11 +341,13 @@ int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size
 /* SAC loss head -- sac.py:123-139 (vf_target, q_target) and :160-173 (Q and policy losses).
  * q_pi, q_run, q_tgt are [2,B] (Q1 row then Q2 row): Q(s, a_pi), Q(s, action_hist), Q'(s', a').
  * Outputs dq_pi [2,B] (d policy_loss/dQ through tf.minimum), dq_run [2,B] (d value_loss/dQ),
- * dlogp [B] (= alpha/B), dlog_alpha [1], loss3 = {loss, policy_loss, value_loss*coef}. */
+ * dlogp [B] (= alpha/B), dlog_alpha [1], loss3 = {loss, policy_loss, value_loss*coef}.
+ * q_ld: row stride of q_pi, q_run, dq_pi, dq_run (0 = B; 2B when Q(s, a_pi) and Q(s, action_hist) are the two halves of
+ * one [2, 2B] evaluation); q_tgt is [2,B] contiguous. */
 int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, const float* logp, const float* logp_t,
                   const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
                   float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
-                  float* dlog_alpha, float* loss3, void* stream);
+                  float* dlog_alpha, float* loss3, int q_ld, void* stream);
 /* The three critic inputs of a SAC step in one launch -- sac.py:108-121 (tf.concat([state, action], -1) for Q(s, a_pi),
  * Q(s, action_hist) and the target Q'(s', a')): x, x_next [B,S] normalised states, a_* [B,A]; outputs [B,S+A]. */
 int pfpn_sac_q_inputs(const float* x, const float* x_next, const float* a_pi, const float* a_hist, const float* a_next,

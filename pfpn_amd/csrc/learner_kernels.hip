@@ -831,7 +831,7 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
     const float* __restrict__ not_terminal, const float* __restrict__ log_alpha, int B, float gamma,
     float value_coef, float target_entropy,
     float* __restrict__ dq_pi, float* __restrict__ dq_run, float* __restrict__ dlogp,
-    float* __restrict__ dlog_alpha, float* __restrict__ loss3)
+    float* __restrict__ dlog_alpha, float* __restrict__ loss3, int ld)      // ld: row stride of q_pi, q_run, dq_pi, dq_run
 {
     __shared__ float red[16];
     const float la = log_alpha[0];
@@ -841,17 +841,17 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float vft = fminf(q_tgt[b], q_tgt[B + b]) - alpha * logp_t[b];
         const float qt = reward[b] + gamma * not_terminal[b] * vft;
-        const float d1 = qt - q_run[b], d2 = qt - q_run[B + b];
+        const float d1 = qt - q_run[b], d2 = qt - q_run[ld + b];
         vs += d1 * d1 + d2 * d2;
         dq_run[b] = -2.f * d1 * value_coef * inv_B;
-        dq_run[B + b] = -2.f * d2 * value_coef * inv_B;
-        const float q1 = q_pi[b], q2 = q_pi[B + b];
+        dq_run[ld + b] = -2.f * d2 * value_coef * inv_B;
+        const float q1 = q_pi[b], q2 = q_pi[ld + b];
         const bool sel1 = q1 <= q2;                       // tf.minimum routes its gradient to x where x <= y
         const float lp = logp[b];
         ps += alpha * lp - fminf(q1, q2) - la * (lp + target_entropy);
         es += lp + target_entropy;
         dq_pi[b] = sel1 ? -inv_B : 0.f;
-        dq_pi[B + b] = sel1 ? 0.f : -inv_B;
+        dq_pi[ld + b] = sel1 ? 0.f : -inv_B;
         dlogp[b] = alpha * inv_B;
     }
     ps = block_sum(ps, red);
@@ -1738,14 +1738,14 @@ int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size
 int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, const float* logp, const float* logp_t,
                   const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
                   float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
-                  float* dlog_alpha, float* loss3, void* stream) {
+                  float* dlog_alpha, float* loss3, int q_ld, void* stream) {
     PFPN_BEGIN();
     if (!q_pi || !q_run || !q_tgt || !logp || !logp_t || !reward || !not_terminal || !log_alpha || !dq_pi ||
-        !dq_run || !dlogp || !dlog_alpha || !loss3 || B < 1)
+        !dq_run || !dlogp || !dlog_alpha || !loss3 || B < 1 || (q_ld != 0 && q_ld < B))
         return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_sac_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, q_pi, q_run, q_tgt, logp, logp_t,
                        reward, not_terminal, log_alpha, B, gamma, value_coef, target_entropy, dq_pi, dq_run, dlogp,
-                       dlog_alpha, loss3);
+                       dlog_alpha, loss3, q_ld ? q_ld : B);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -738,16 +738,29 @@ def soft_update(target, source, tau):
                "pfpn_soft_update")
 
 
+def _f32_rows(t, rows, cols, name="tensor"):
+    """[rows, cols] float32 CUDA view whose rows are contiguous (any row stride >= cols) -> (pointer, row stride)"""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == (rows, cols)
+            and t.stride(1) == 1 and t.stride(0) >= cols):
+        raise ValueError("%s must be a [%d, %d] float32 CUDA view with contiguous rows" % (name, rows, cols))
+    return t.data_ptr(), t.stride(0)
+
+
 def sac_loss(q_pi, q_run, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, gamma, value_coef, target_entropy,
              out):
-    """out: dict(dq_pi [2,B], dq_run [2,B], dlogp [B], dlog_alpha [1], loss3 [3])."""
+    """out: dict(dq_pi [2,B], dq_run [2,B], dlogp [B], dlog_alpha [1], loss3 [3]).  q_pi, q_run, dq_pi, dq_run may be
+    row-strided views with one common row stride (the halves of [2, 2B] buffers)."""
     lib = _lib.load()
     B = logp.shape[0]
-    _lib.check(lib.pfpn_sac_loss(_f32(q_pi, 2, B), _f32(q_run, 2, B), _f32(q_tgt, 2, B), _f32(logp, B),
+    ptrs = [_f32_rows(t, 2, B) for t in (q_pi, q_run, out["dq_pi"], out["dq_run"])]
+    ld = ptrs[0][1]
+    if any(p[1] != ld for p in ptrs):
+        raise ValueError("q_pi, q_run, dq_pi, dq_run must share one row stride")
+    _lib.check(lib.pfpn_sac_loss(ptrs[0][0], ptrs[1][0], _f32(q_tgt, 2, B), _f32(logp, B),
                                  _f32(logp_t, B), _f32(reward, B), _f32(not_terminal, B), _f32(log_alpha),
                                  B, float(gamma), float(value_coef), float(target_entropy),
-                                 _f32(out["dq_pi"], 2, B), _f32(out["dq_run"], 2, B), _f32(out["dlogp"], B),
-                                 _f32(out["dlog_alpha"]), _f32(out["loss3"], 3), _stream()), "pfpn_sac_loss")
+                                 ptrs[2][0], ptrs[3][0], _f32(out["dlogp"], B),
+                                 _f32(out["dlog_alpha"]), _f32(out["loss3"], 3), int(ld), _stream()), "pfpn_sac_loss")
     return out
 
 

@@ -35,6 +35,7 @@ def sac_network_wrapper(base_class):
             super().__init__(**kwargs)
             self.alpha = alpha       # replaced by exp(log_alpha) for the trainable net (sac.py:36-39)
             self.batch_actor = os.environ.get("PFPN_SAC_BATCH_ACTOR", "1") != "0"
+            self.batch_critic = os.environ.get("PFPN_SAC_BATCH_CRITIC", "1") != "0"
             self.tau = tau
             self.reward, self.not_terminal = "reward", "not_terminal"
 
@@ -153,13 +154,22 @@ def sac_network_wrapper(base_class):
             self.xn, self.xn2 = self.xn_both[:B], self.xn_both[B:]
             self.logits, self.logits2 = self.logits_both[:B], self.logits_both[B:]
             self.dlogits = f(B, AN)
-            self.xa, self.xh, self.xa2 = f(B, self.S + A), f(B, self.S + A), f(B, self.S + A)
-            self.q_pi, self.q_run, self.q_tgt = f(2, B), f(2, B), f(2, B)
+            # Q(s, a_pi) and Q(s, action_hist) use the same (live) critic: their inputs, Q values and dL/dQ are the two
+            # halves of [2B]-row buffers, so that the twin trunks can run ONCE over both (compute_gradients)
+            self.xq_both, self.xa2 = f(2 * B, self.S + A), f(B, self.S + A)
+            self.xa, self.xh = self.xq_both[:B], self.xq_both[B:]
+            self.q_both, self.q_tgt = f(2, 2 * B), f(2, B)
+            self.q_pi, self.q_run = self.q_both[:, :B], self.q_both[:, B:]
             hc = self.critic_net_shape[-1]
+            self.dh_both = f(2, 2 * B, hc)
             self.dh_run, self.dh_pi = f(2, B, hc), f(2, B, hc)
             self.dha = f(1, B, self.actor_net_shape[-1])
-            self.sac_out = {"dq_pi": f(2, B), "dq_run": f(2, B), "dlogp": f(B), "dlog_alpha": self.store.g("alpha/log_alpha"),
-                            "loss3": f(3)}
+            self.dq_both = f(2, 2 * B)
+            self.sac_out = {"dq_pi": self.dq_both[:, :B], "dq_run": self.dq_both[:, B:], "dlogp": f(B),
+                            "dlog_alpha": self.store.g("alpha/log_alpha"), "loss3": f(3)}
+            # the two-pass form (PFPN_SAC_BATCH_CRITIC=0, undeferred steps) keeps contiguous [2, B] buffers of its own
+            self.q_pi_c, self.q_run_c = f(2, B), f(2, B)
+            self.sac_out_c = dict(self.sac_out, dq_pi=f(2, B), dq_run=f(2, B))
             self.scratch_w3, self.scratch_b3 = f(hc), f(1)
             self.ws_pbias = kernels.learner_workspace(B, AN, dev)      # private: deferred fc_policy bias gradient
 
@@ -279,16 +289,31 @@ def sac_network_wrapper(base_class):
             self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
             # Q inputs
             kernels.sac_q_inputs(x, x2, a, action, a2, self.xa, self.xh, self.xa2)
-            hq_pi = self._q_forward(self.xa, 0, self.q_pi, fold=fold)
-            hq_run = self._q_forward(self.xh, 1, self.q_run, fold=fold)
+            both_q = fold and self.batch_critic and B % 16 == 0
+            if both_q:
+                # the live critic on [(s, a_pi); (s, action_hist)] in ONE pass of 2B rows (4 launches instead of 8)
+                self._q_forward(self.xq_both, 0, self.q_both, fold=True)
+                q_pi, q_run, sout = self.q_pi, self.q_run, self.sac_out
+            else:
+                q_pi, q_run, sout = self.q_pi_c, self.q_run_c, self.sac_out_c
+                hq_pi = self._q_forward(self.xa, 0, q_pi, fold=fold)
+                hq_run = self._q_forward(self.xh, 1, q_run, fold=fold)
             self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
-            out = kernels.sac_loss(self.q_pi, self.q_run, self.q_tgt, logp, logp2, reward, not_terminal,
-                                   self.log_alpha, self.gamma, self.value_loss_coef, -float(A), self.sac_out)
+            self.last["q_pi"] = q_pi
+            out = kernels.sac_loss(q_pi, q_run, self.q_tgt, logp, logp2, reward, not_terminal,
+                                   self.log_alpha, self.gamma, self.value_loss_coef, -float(A), sout)
             # critic gradients (value loss through Q(s, action_hist))
             gw3, gb3 = st.g("critic/q1+critic/q2|fc3/weight"), st.g("critic/q1+critic/q2|fc3/bias")
             if not fold:
                 gb3.zero_()        # (folded: the reduction jobs assign [g, 0]; the padding of the fresh buffer stays zero)
-            if fold:
+            if both_q:
+                # ONE backward pass over the 2B rows: the value loss reaches the critic's parameters through the second
+                # half (weight / bias / head gradients from rows [B, 2B) only), the policy loss passes through the first
+                # half to the action alone (Q parameters are skipped, sac.py:167): 6 launches instead of 9
+                da = self.q_stack.backward(self.dh_both, slot=0, need_dw=True, need_dx=(S, S + A), deferred=deferred,
+                                           value=(-1, self.q_w3, self.dq_both, gw3, gb3),
+                                           dw_rows=(B, 2 * B), dx_rows=(0, B))
+            elif fold:
                 # both heads' backward inside the trunks' last-layer passes; bias-gradient sums become jobs
                 self.q_stack.backward(self.dh_run, slot=1, need_dw=True, deferred=deferred,
                                       value=(-1, self.q_w3, out["dq_run"], gw3, gb3))

@@ -255,7 +255,8 @@ class DenseStack:
                 kernels.value_head_fwd(act[-1][g], vw.view(-1), vb, out=vout)
         return act[-1]
 
-    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None):
+    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None,
+                 dw_rows=None, dx_rows=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output (the stack's own dact[-1] buffer
         or any contiguous tensor); masked in place.
         `deferred` (a list): the bias-gradient column sums are left as per-chunk partials and a reduce job per
@@ -264,6 +265,11 @@ class DenseStack:
         group's output is folded into the last layer's pass -- dlast[group] is formed as dvalue (x) w, not read.
         group = -1: a head on EVERY group (w [G,H], dvalue [G,B], grad_w [G,H], grad_b [G,1]; twin Q networks).
         With need_dw=False the partial sums are left unreduced (no jobs; grad_w / grad_b may be None).
+        `dw_rows` = (r0, r1) (with `deferred`): only these rows of the batch enter the weight / bias / head gradients --
+        the others are carried through the dX chain alone (SAC: Q(s, a_pi) and Q(s, a_hist) evaluated as ONE batch of 2B
+        rows; the value loss reaches the critic through the second half, the policy loss only passes through the first
+        half to the action).  r0 and r1 must fall on the row chunks of the partial sums.  `dx_rows` = (p0, p1): the
+        rows of the input gradient to return.
         Weight/bias gradients are written into the store's flat gradient buffer (need_dw).
         `dw_stream`: run the weight-gradient GEMMs (independent of the dX chain) on that stream so they
         overlap the next layer's dX GEMM; the caller joins the stream before using the gradients."""
@@ -284,6 +290,10 @@ class DenseStack:
 
         if value is not None and (deferred is None or not self._group_rows(self.L - 1, B)):
             raise ValueError("a folded value head needs deferred reductions on a batched last layer")
+        if dw_rows is not None and (deferred is None or dw_stream is not None):
+            raise ValueError("a row subset for the weight gradients needs deferred reductions on one stream")
+        r0, r1 = dw_rows if dw_rows is not None else (0, B)
+        rsl = slice(r0, r1)
         for i in reversed(range(self.L)):
             w = self.store[self.wn[i]]
             if deferred is not None:
@@ -297,45 +307,52 @@ class DenseStack:
                     cpg = kernels.act_bwd_partial(None, d2d, grows, ws[i], mask=buf["mask"][i])
                 else:
                     cpg = kernels.act_bwd_partial(act2d[i], d2d, grows, ws[i], relu6=True, value=fold)
+                # the partial sums are per chunk of `clen` rows: rows [r0, r1) are the slabs [c0, c0 + nc) of a group
+                clen = (B + cpg - 1) // cpg
+                c0, nc = r0 // clen, (r1 - r0 + clen - 1) // clen
+                if r0 % clen or (r1 % clen and r1 != B):
+                    raise ValueError("dw_rows %s do not fall on the %d-row chunks of the partial sums" % (dw_rows, clen))
                 gb = self.store.g(self.bn[i])
                 if need_dw and grows:
                     for g in range(self.G):
-                        deferred.append(kernels.job_colsum(ws[i], g * cpg * H, cpg, H, H, gb[g]))
+                        deferred.append(kernels.job_colsum(ws[i], (g * cpg + c0) * H, nc, H, H, gb[g]))
                 elif need_dw:
-                    deferred.append(kernels.job_colsum(ws[i], 0, cpg, H, H, gb.view(-1)))
+                    deferred.append(kernels.job_colsum(ws[i], c0 * H, nc, H, H, gb.view(-1)))
                 if fold is not None and need_dw:
                     if value[0] < 0:        # a head per group: grad_w [G,H], grad_b [G,>=1], dvalue [G,B]
                         for g in range(self.G):
-                            deferred.append(kernels.job_colsum(ws_value, g * cpg * H, cpg, H, H, value[3][g].view(-1)))
-                            deferred.append(kernels.job_vecsum(value[2][g], value[4][g].view(-1)[:1]))
+                            deferred.append(kernels.job_colsum(ws_value, (g * cpg + c0) * H, nc, H, H,
+                                                               value[3][g].view(-1)))
+                            deferred.append(kernels.job_vecsum(value[2][g][rsl], value[4][g].view(-1)[:1]))
                     else:
-                        deferred.append(kernels.job_colsum(ws_value, 0, cpg, H, H, value[3].view(-1)))
-                        deferred.append(kernels.job_vecsum(value[2], value[4].view(-1)))
+                        deferred.append(kernels.job_colsum(ws_value, c0 * H, nc, H, H, value[3].view(-1)))
+                        deferred.append(kernels.job_vecsum(value[2][rsl], value[4].view(-1)))
             else:
                 kernels.act_bwd_bias_grad(act2d[i], d2d,
                                           self.store.g(self.bn[i]) if need_dw else self._scratch_bias(i),
                                           relu6=True, group_rows=self._group_rows(i, B))
             gw = self.store.g(self.wn[i])
+            psl = slice(None) if dx_rows is None else slice(dx_rows[0], dx_rows[1])
             if i == 0:
-                xt = x.t()
+                xt = x[rsl].t()
                 if self.merged0:
                     if need_dw:
-                        on_dw_stream(lambda: torch.mm(xt, d2d, out=gw))
+                        on_dw_stream(lambda: torch.mm(xt, d2d[rsl], out=gw))
                     if need_dx:
                         # need_dx = (c0, c1): the gradient w.r.t. input columns [c0, c1) only (SAC: the action part)
                         wx = w if need_dx is True else w[need_dx[0]:need_dx[1]]
-                        dx = torch.mm(d2d, wx.t())
+                        dx = torch.mm(d2d[psl], wx.t())
                 else:
                     if need_dw:
-                        on_dw_stream(lambda: [torch.mm(xt, d[g], out=gw[g]) for g in range(self.G)])
+                        on_dw_stream(lambda: [torch.mm(xt, d[g][rsl], out=gw[g]) for g in range(self.G)])
                     if need_dx:
                         rows = slice(None) if need_dx is True else slice(need_dx[0], need_dx[1])
-                        dx = torch.mm(d[0], w[0][rows].t())
+                        dx = torch.mm(d[0][psl], w[0][rows].t())
                         for g in range(1, self.G):
-                            dx.addmm_(d[g], w[g][rows].t())
+                            dx.addmm_(d[g][psl], w[g][rows].t())
             else:
                 if need_dw:
-                    on_dw_stream(lambda: torch.bmm(act[i - 1].transpose(1, 2), d, out=gw))
+                    on_dw_stream(lambda: torch.bmm(act[i - 1][:, rsl].transpose(1, 2), d[:, rsl], out=gw))
                 torch.bmm(d, w.transpose(1, 2), out=dact[i - 1])
                 d, d2d = dact[i - 1], dact2d[i - 1]
         return dx

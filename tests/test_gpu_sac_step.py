@@ -142,6 +142,8 @@ def test_sac_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
     rng = np.random.default_rng(B)
     nets, opts = [], []
     monkeypatch.setenv("PFPN_FUSED_NORM", "0")      # compared bit for bit: keep the norm's summation grouping the same
+    monkeypatch.setenv("PFPN_SAC_BATCH_ACTOR", "0")  # ... and the GEMMs' row counts (the deferred step would run the actor
+    monkeypatch.setenv("PFPN_SAC_BATCH_CRITIC", "0")  # and the live critic once over 2B rows: own test below)
     for _ in range(2):
         net = make_net(dev)
         nets.append(net)
@@ -166,7 +168,49 @@ def test_sac_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
         assert torch.equal(losses[0], losses[2]), it
         assert torch.equal(losses[1], losses[3]), it
         assert torch.equal(nets[0].store.flat, nets[1].store.flat)
-        assert torch.equal(nets[0].q_pi, nets[1].q_pi) and torch.equal(nets[0].q_tgt, nets[1].q_tgt)
+        assert torch.equal(nets[0].last["q_pi"], nets[1].last["q_pi"]) and torch.equal(nets[0].q_tgt, nets[1].q_tgt)
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+
+
+@pytest.mark.parametrize("B", [64, 1024])
+def test_sac_one_pass_over_both_batches_matches_two_passes(dev, monkeypatch, B):
+    """The step that runs the actor once over [s; s'] and the live critic once over [(s, a_pi); (s, action_hist)] (2B-row
+    passes; the critic's parameter gradients from the second half of the rows only) against the step with one pass per
+    input: same particle indices, log-probs / Q values / losses / every gradient / parameters to fp32 GEMM rounding (a
+    2B-row GEMM may sum in another order), identical normaliser statistics."""
+    from pfpn_amd.models import SyncReplicasApplier
+    from _parity import assert_close_mostly
+    rng = np.random.default_rng(B + 7)
+    nets, opts = [], []
+    for i in range(2):
+        monkeypatch.setenv("PFPN_SAC_BATCH_ACTOR", "1" if i == 0 else "0")
+        monkeypatch.setenv("PFPN_SAC_BATCH_CRITIC", "1" if i == 0 else "0")
+        net = make_net(dev)
+        nets.append(net)
+        opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                              {"names": net.actor_param_names(), "lr": 1e-4}],
+                                        norm_clip=1.0, world_size=1))
+    for it in range(2):
+        batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                       rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                       rng.normal(0.5, 0.3, B).astype(F),
+                                                       (rng.uniform(size=B) > 0.05).astype(F),
+                                                       (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
+        noise = nets[0].make_train_noise(B)
+        l3 = [net.compute_gradients(*batch, {k: t.clone() for k, t in noise.items()}).clone() for net in nets]
+        assert (nets[0].actor_trunk._bufs.get((B, 3)) is not None) and nets[1].actor_trunk._bufs.get((B, 3)) is None
+        assert (2 * B, 0) in nets[0].q_stack._bufs and (2 * B, 0) not in nets[1].q_stack._bufs
+        assert torch.equal(nets[0].last["k"], nets[1].last["k"])
+        torch.testing.assert_close(nets[0].last["logp"], nets[1].last["logp"], rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(nets[0].last["q_pi"], nets[1].last["q_pi"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(l3[0], l3[1], rtol=1e-5, atol=1e-5)
+        g0, g1 = nets[0].gradients(), nets[1].gradients()
+        for name in g1:
+            a, b = g0[name].cpu().numpy(), g1[name].cpu().numpy()
+            assert_close_mostly(a, b, rtol=1e-3, atol=1e-5 * (np.abs(b).max() + 1e-30), err_msg=name)
+        for net, opt in zip(nets, opts):
+            opt.apply(net)
+        torch.testing.assert_close(nets[0].store.flat, nets[1].store.flat, rtol=1e-4, atol=2e-6)
         assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
 
 

@@ -31,6 +31,7 @@ from pfpn_amd.graphs import GraphedLearnerStep
 for B in (256, 1024, 4096):
   for both in ("0", "1", "0", "1"):
     os.environ["PFPN_SAC_BATCH_ACTOR"] = both       # 1: the actor evaluated once over [s; s'] (2B rows)
+    os.environ["PFPN_SAC_BATCH_CRITIC"] = both      # 1: the live critic once over [(s, a_pi); (s, action_hist)]
     net = make_net(dev)
     opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4}, {"names": net.actor_param_names(), "lr": 1e-4}],
                               norm_clip=1.0, world_size=1)
@@ -45,5 +46,5 @@ for B in (256, 1024, 4096):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200): step()
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 200
-    print("SAC-PFPN learner step as one hipGraph, replay batch %4d, actor passes %s: %.3f ms/step -> %.0f steps/s (loss %s)" % (
-        B, "one (2B rows)" if both == "1" else "two", t * 1e3, 1 / t, step.loss3.cpu().numpy()))
+    print("SAC-PFPN learner step as one hipGraph, replay batch %4d, actor / live critic %s: %.3f ms/step -> %.0f steps/s (loss %s)" % (
+        B, "one pass over 2B rows" if both == "1" else "one pass per input", t * 1e3, 1 / t, step.loss3.cpu().numpy()))
