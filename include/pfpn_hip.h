@@ -57,8 +57,11 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
  * dx [B,A] optional (needed by SAC where x depends on the parameters). */
 int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, const float* logstd,
                      const float* dlogp, int B, int A, int N, int tanh_mode,
-                     float* dlogits, float* dloc, float* dlogstd, float* dx,
+                     float* dlogits, float* dloc, float* dlogstd, float* dx, int finalize,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* finalize = 0: the per-block partial sums of dloc / dlogstd stay in the workspace (dloc, dlogstd may be NULL) as
+ * *nslab slabs of *stride floats [dloc A*N | dlogstd A*N | ..]; a PFPN_JOB_COLSUM job sums them in the same order. */
+int pfpn_logprob_bwd_slabs(const float* logits, const float* dlogits, int B, int A, int N, int* nslab, int* stride);
 
 /* Advantage moments for normalize_advantage -- reference actor_critic.py:151-156:
  * stats = {mean, 1/(sqrt(population var)+1e-8)}; normalize=0 writes {0,1}.
@@ -134,8 +137,12 @@ int pfpn_rsample_fwd(const float* logits, const float* loc, const float* logstd,
                      void* stream);
 int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
                      const float* eps, const float* da, const float* ds, int B, int A, int N, int accumulate,
-                     float* dlogits, float* dloc, float* dlogstd, void* workspace, size_t workspace_bytes,
+                     float* dlogits, float* dloc, float* dlogstd, int finalize, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* finalize = 0: the parameter-gradient partial sums stay in the workspace: *nslab slabs of *stride floats
+ * [dloc A*N | dlogstd A*N] from *float_offset floats on; the caller adds their slab-order sum (PFPN_JOB_COLSUM's second
+ * slab set) to what pfpn_logprob_bwd contributed. */
+int pfpn_rsample_bwd_slabs(int B, int A, int N, int* nslab, int* stride, long long* float_offset);
 
 /* ---- resample (K5) ------------------------------------------------------------------------ */
 /* ParticleFilteringA2CNetwork.build_resample_ops -- a2c.py:385-474.  topk = 0: the `resample == -1` branch
@@ -235,7 +242,8 @@ int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_r
 
 /* Deferred fixed-order reductions, one launch for up to PFPN_MAX_REDUCE_JOBS jobs (the gradients the reference gets
  * from tf.gradients' BiasAddGrad / Sum nodes, sync_model.py:110-121, and the UPDATE_OPS EMA, utils.py:60-68):
- *   PFPN_JOB_COLSUM   out[i] = sum_{k<nslab} src[k*stride + i], i < n           (float slabs)
+ *   PFPN_JOB_COLSUM   out[i] = sum_{k<nslab} src[k*stride + i], i < n           (float slabs); in0 != NULL: plus a second
+ *                     slab set, + sum_{k<p0} in0[k*p1 + i] (p0 slabs of stride p1, both exact small integers)
  *   PFPN_JOB_VECSUM   out[0] = sum_{i<n} src[i]                                  (nslab = 1)
  *   PFPN_JOB_PPO_LOSS src -> the two loss columns of pfpn_ppo_mixture_fwd_bwd's slabs; out = loss3; p0 = 1/B,
  *                     p1 = value_coef; n = 2

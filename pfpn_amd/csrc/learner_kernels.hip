@@ -1137,7 +1137,9 @@ __global__ __launch_bounds__(1024) void k_reduce_jobs(ReduceJobTable t, NormArgs
     }
     if (q.kind == PFPN_JOB_COLSUM) {                      // out[i] = sum_k src[k*stride + i]       (k_bias_grad_final)
         const int i = blk * 64 + cl;
-        const float s = slab_reduce_1024<false>((const float*)q.src, q.nslab, (size_t)q.stride, i, i < q.n, red);
+        float s = slab_reduce_1024<false>((const float*)q.src, q.nslab, (size_t)q.stride, i, i < q.n, red);
+        if (q.in0)                                          // a second slab set: out = sum(first) + sum(second)
+            s = s + slab_reduce_1024<false>(q.in0, (int)q.p0, (size_t)q.p1, i, i < q.n, red);
         if (kl == 0 && i < q.n) q.out[i] = s;
         if (na.sq_partial && kl == 0) {                    // wave 0 holds the block's 64 outputs
             const float sq = wave_sum((q.norm && i < q.n) ? s * s : 0.f);
@@ -1507,8 +1509,10 @@ static int reduce_jobs_launch(const PfpnReduceJob* jobs, int n_jobs, NormArgs na
         const PfpnReduceJob& q = jobs[j];
         if (!q.src || (!q.out && q.kind != PFPN_JOB_SQSUM) || q.n < 1 || q.nslab < 1) return PFPN_ERR_ARG;
         int nb = 1;
-        if (q.kind == PFPN_JOB_COLSUM) nb = (q.n + 63) / 64;
-        else if (q.kind == PFPN_JOB_NORM_EMA) {
+        if (q.kind == PFPN_JOB_COLSUM) {
+            if (q.in0 && (q.p0 < 1.f || q.p1 < (float)q.n)) return PFPN_ERR_ARG;
+            nb = (q.n + 63) / 64;
+        } else if (q.kind == PFPN_JOB_NORM_EMA) {
             if (!q.out2 || !q.in0 || !q.in1 || !q.in2 || q.stride < 1) return PFPN_ERR_ARG;
             nb = (q.n + 15) / 16;
         } else if (q.kind == PFPN_JOB_SQSUM) {

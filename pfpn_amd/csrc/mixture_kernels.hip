@@ -1379,10 +1379,11 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
 
 int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, const float* logstd,
                      const float* dlogp, int B, int A, int N, int tanh_mode,
-                     float* dlogits, float* dloc, float* dlogstd, float* dx,
+                     float* dlogits, float* dloc, float* dlogstd, float* dx, int finalize,
                      void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
-    if (!logits || !x || !loc || !logstd || !dlogp || !dlogits || !dloc || !dlogstd || B < 0 || A < 1 || N < 1)
+    if (!logits || !x || !loc || !logstd || !dlogp || !dlogits || (finalize && (!dloc || !dlogstd)) || B < 0 || A < 1 ||
+        N < 1 || (!finalize && B == 0))
         return PFPN_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int AN = A * N;
@@ -1400,7 +1401,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         launch_tile<MODE_BWD>(N, pl, st, logits, x, loc, logstd, dlogp, B, A, tanh_mode, nullptr, nullptr,
                                 dlogits, dx, partial, none);
         PFPN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, pl.grid,
+        if (finalize) hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, pl.grid,
                            2 * AN + 4, 2 * AN, dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
@@ -1423,7 +1424,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         else { if (M == 1) PFPN_WIDE_BWD(1, false); else if (M == 2) PFPN_WIDE_BWD(2, false); else PFPN_WIDE_BWD(4, false); }
 #undef PFPN_WIDE_BWD
         PFPN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
+        if (finalize) hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
                            dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;
@@ -1435,9 +1436,22 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     hipLaunchKernelGGL((k_mix_wave<MODE_BWD>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, dlogp,
                        B, A, N, C, tanh_mode, (float*)nullptr, (float*)nullptr, dlogits, dx, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
+    if (finalize) hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
                        dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
     PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+// Slab geometry of pfpn_logprob_bwd(finalize = 0): `nslab` slabs of `stride` floats at the start of its workspace, each
+// [dloc A*N | dlogstd A*N | ...]; the caller sums them in slab order (PFPN_JOB_COLSUM does what k_finalize did).
+int pfpn_logprob_bwd_slabs(const float* logits, const float* dlogits, int B, int A, int N, int* nslab, int* stride) {
+    if (!nslab || !stride || B < 1 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    const int AN = A * N;
+    TilePlan pl = plan_tile(B, A, N, logits, dlogits);
+    if (pl.ok && tile_has(N)) { *nslab = pl.grid; *stride = 2 * AN + 4; return PFPN_OK; }
+    if (wide_ok(A, N, logits, dlogits)) { *nslab = wide_chunks(B, A, true); *stride = 2 * AN; return PFPN_OK; }
+    *nslab = (B < 64) ? B : 64;
+    *stride = 2 * AN;
     return PFPN_OK;
 }
 

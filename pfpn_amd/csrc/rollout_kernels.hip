@@ -724,11 +724,11 @@ int pfpn_rsample_fwd(const float* logits, const float* loc, const float* logstd,
 
 int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
                      const float* eps, const float* da, const float* ds, int B, int A, int N, int accumulate,
-                     float* dlogits, float* dloc, float* dlogstd, void* workspace, size_t workspace_bytes,
-                     void* stream) {
+                     float* dlogits, float* dloc, float* dlogstd, int finalize, void* workspace,
+                     size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
-    if (!logits || !loc || !logstd || !gumbel || !eps || !da || !ds || !dlogits || !dloc || !dlogstd ||
-        B < 0 || A < 1 || N < 1)
+    if (!logits || !loc || !logstd || !gumbel || !eps || !da || !ds || !dlogits || (finalize && (!dloc || !dlogstd)) ||
+        B < 0 || A < 1 || N < 1 || (!finalize && B == 0))
         return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     if (!workspace || workspace_bytes < pfpn_rollout_workspace_bytes(B, A, N)) return PFPN_ERR_WORKSPACE;
@@ -753,9 +753,24 @@ int pfpn_rsample_bwd(const float* logits, const float* loc, const float* logstd,
     hipLaunchKernelGGL(k_rsample_param_partial, dim3((C * A * 64 + 255) / 256), dim3(256), 0, st, kt, gp, gs, B, A, N,
                        C, len, partial);
     PFPN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_param_grad_final, dim3((2 * A * N + 63) / 64), dim3(1024), 0, st, partial, C, A * N,
-                       accumulate, dloc, dlogstd);
-    PFPN_CHECK_LAUNCH();
+    if (finalize) {
+        hipLaunchKernelGGL(k_param_grad_final, dim3((2 * A * N + 63) / 64), dim3(1024), 0, st, partial, C, A * N,
+                           accumulate, dloc, dlogstd);
+        PFPN_CHECK_LAUNCH();
+    }
+    return PFPN_OK;
+}
+
+// Slab geometry of pfpn_rsample_bwd(finalize = 0): `nslab` slabs of `stride` floats [dloc A*N | dlogstd A*N] starting
+// `float_offset` floats into its workspace; the caller adds their fixed-order sum to the particle-grid gradients.
+int pfpn_rsample_bwd_slabs(int B, int A, int N, int* nslab, int* stride, long long* float_offset) {
+    if (!nslab || !stride || !float_offset || B < 1 || A < 1 || N < 1) return PFPN_ERR_ARG;
+    int C = (B + 63) / 64;
+    if (C > 256) C = 256;
+    const int len = (((B + C - 1) / C) + 63) / 64 * 64;
+    *nslab = (B + len - 1) / len;
+    *stride = 2 * A * N;
+    *float_offset = (long long)B * A * 6;
     return PFPN_OK;
 }
 

@@ -66,9 +66,11 @@ def logprob_fwd(logits, x, loc, logstd, tanh_mode=False, want_pmix=False):
     return (logp, pmix) if want_pmix else logp
 
 
-def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, out=None):
+def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, out=None, slabs_ws=None):
     """-> dlogits [B,A,N], dloc [A,N], dlogstd [A,N] (, dx [B,A]).  `out`: dict with preallocated `dlogits`, `dloc`,
-    `dlogstd` to write into (no 1-GiB temporaries at the 128 x 256 shape)."""
+    `dlogstd` to write into (no 1-GiB temporaries at the 128 x 256 shape).
+    `slabs_ws` (a private uint8 workspace, mixture_workspace()): dloc / dlogstd are NOT finalised -- their per-block
+    partial sums stay in it (logprob_bwd_slabs() gives the geometry) for a deferred column-sum job."""
     lib = _lib.load()
     A, N = loc.shape
     B = x.shape[0]
@@ -84,11 +86,36 @@ def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, o
         dloc = torch.empty(A, N, dtype=torch.float32, device=x.device)
         dlogstd = torch.empty(A, N, dtype=torch.float32, device=x.device)
     dx = torch.empty(B, A, dtype=torch.float32, device=x.device) if want_dx else None
-    ws, wsn = _mix_ws(B, A, N, x.device)
+    ws, wsn = _mix_ws(B, A, N, x.device) if slabs_ws is None else (slabs_ws.data_ptr(), slabs_ws.numel())
     _lib.check(lib.pfpn_logprob_bwd(pl, px, ploc, pls, pg, B, A, N, int(tanh_mode), dlogits.data_ptr(),
                                     dloc.data_ptr(), dlogstd.data_ptr(), dx.data_ptr() if want_dx else None,
-                                    ws, wsn, _stream()), "pfpn_logprob_bwd")
+                                    int(slabs_ws is None), ws, wsn, _stream()), "pfpn_logprob_bwd")
     return (dlogits, dloc, dlogstd, dx) if want_dx else (dlogits, dloc, dlogstd)
+
+
+def mixture_workspace(B, A, N, device):
+    """a private workspace of the mixture kernels' size (slabs that must survive until a deferred reduction)"""
+    return torch.empty(int(_lib.load().pfpn_mixture_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
+
+
+def rollout_workspace(B, A, N, device):
+    return torch.empty(int(_lib.load().pfpn_rollout_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
+
+
+def logprob_bwd_slabs(logits, dlogits, B, A, N):
+    """(nslab, stride) of the partial sums logprob_bwd(slabs_ws=...) leaves at the start of its workspace"""
+    n, st = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.load().pfpn_logprob_bwd_slabs(logits.data_ptr(), dlogits.data_ptr(), B, A, N, ctypes.addressof(n),
+                                                  ctypes.addressof(st)), "pfpn_logprob_bwd_slabs")
+    return n.value, st.value
+
+
+def rsample_bwd_slabs(B, A, N):
+    """(nslab, stride, float_offset) of the partial sums rsample_bwd(slabs_ws=...) leaves in its workspace"""
+    n, st, off = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_longlong(0)
+    _lib.check(_lib.load().pfpn_rsample_bwd_slabs(B, A, N, ctypes.addressof(n), ctypes.addressof(st),
+                                                  ctypes.addressof(off)), "pfpn_rsample_bwd_slabs")
+    return n.value, st.value, off.value
 
 
 def new_adv_stats(device, clip=None):
@@ -301,8 +328,9 @@ def rsample_fwd(logits, loc, logstd, gumbel, eps):
     return a, s_, k
 
 
-def rsample_bwd(logits, loc, logstd, gumbel, eps, da, ds, dlogits=None, dloc=None, dlogstd=None):
-    """accumulates into dlogits/dloc/dlogstd when all three are given."""
+def rsample_bwd(logits, loc, logstd, gumbel, eps, da, ds, dlogits=None, dloc=None, dlogstd=None, slabs_ws=None):
+    """accumulates into dlogits/dloc/dlogstd when all three are given.  `slabs_ws` (private, rollout_workspace()): the
+    particle-grid partial sums stay in it instead of being added to dloc / dlogstd (rsample_bwd_slabs())."""
     lib = _lib.load()
     A, N = loc.shape
     B = logits.shape[0]
@@ -312,12 +340,12 @@ def rsample_bwd(logits, loc, logstd, gumbel, eps, da, ds, dlogits=None, dloc=Non
         dlogits = torch.empty(B, A * N, dtype=torch.float32, device=dev)
         dloc = torch.empty(A, N, dtype=torch.float32, device=dev)
         dlogstd = torch.empty(A, N, dtype=torch.float32, device=dev)
-    ws, wsn = _roll_ws(B, A, N, dev)
+    ws, wsn = _roll_ws(B, A, N, dev) if slabs_ws is None else (slabs_ws.data_ptr(), slabs_ws.numel())
     _lib.check(lib.pfpn_rsample_bwd(_f32(logits.view(B, A * N), B, A * N), _f32(loc, A, N), _f32(logstd, A, N),
                                     _f32(gumbel.view(B, A * N), B, A * N), _f32(eps.view(B, A * N), B, A * N),
                                     _f32(da, B, A), _f32(ds, B, A), B, A, N, int(acc),
                                     _f32(dlogits.view(B, A * N), B, A * N), _f32(dloc, A, N), _f32(dlogstd, A, N),
-                                    ws, wsn, _stream()), "pfpn_rsample_bwd")
+                                    int(slabs_ws is None), ws, wsn, _stream()), "pfpn_rsample_bwd")
     return dlogits, dloc, dlogstd
 
 
@@ -544,12 +572,19 @@ JOB_COLSUM, JOB_VECSUM, JOB_PPO_LOSS, JOB_NORM_EMA, JOB_SQSUM = 0, 1, 2, 3, 4
 MAX_REDUCE_JOBS = 32
 
 
-def job_colsum(ws, float_offset, nslab, stride, n, out):
-    """out[i] = sum_k ws_f32[float_offset + k*stride + i], i < n"""
+def job_colsum(ws, float_offset, nslab, stride, n, out, second=None):
+    """out[i] = sum_k ws_f32[float_offset + k*stride + i], i < n.  second = (ws2, float_offset2, nslab2, stride2): plus
+    the slab-order sum of a second slab set (out = sum(first) + sum(second))."""
     if out.numel() < n or ws.numel() < 4 * (float_offset + (nslab - 1) * stride + n):
         raise ValueError("column-sum job outside its buffers")
-    return ReduceJob(JOB_COLSUM, nslab, stride, n, ws.data_ptr() + 4 * float_offset, _f32(out), None, None, None, None,
-                     0.0, 0.0, 0)
+    in0, p0, p1 = None, 0.0, 0.0
+    if second is not None:
+        ws2, off2, nslab2, stride2 = second
+        if ws2.numel() < 4 * (off2 + (nslab2 - 1) * stride2 + n) or nslab2 < 1 or stride2 < n or stride2 >= 1 << 24:
+            raise ValueError("second slab set outside its buffer")
+        in0, p0, p1 = ws2.data_ptr() + 4 * off2, float(nslab2), float(stride2)
+    return ReduceJob(JOB_COLSUM, nslab, stride, n, ws.data_ptr() + 4 * float_offset, _f32(out), None, in0, None, None,
+                     p0, p1, 0)
 
 
 def job_vecsum(vec, out):

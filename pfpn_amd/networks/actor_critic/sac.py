@@ -172,6 +172,10 @@ def sac_network_wrapper(base_class):
             self.sac_out_c = dict(self.sac_out, dq_pi=f(2, B), dq_run=f(2, B))
             self.scratch_w3, self.scratch_b3 = f(hc), f(1)
             self.ws_pbias = kernels.learner_workspace(B, AN, dev)      # private: deferred fc_policy bias gradient
+            # private: the particle-grid partial sums of the log-prob / reparameterised-sample backward wait here for the
+            # step's reduction launch
+            self.ws_mixbwd = kernels.mixture_workspace(B, A, self.particles, dev)
+            self.ws_rsbwd = kernels.rollout_workspace(B, A, self.particles, dev)
 
         # -- rollout ----------------------------------------------------------------------------------
         def _actor_logits(self, x, slot, out, masks=False):
@@ -332,11 +336,21 @@ def sac_network_wrapper(base_class):
             # the particle-grid gradients land straight in the flat gradient buffer: log-prob backward writes them, the
             # reparameterised-sample backward adds its part in place
             dloc, dlogstd = st.g("actor/samples"), st.g("actor/samples_std")
+            wm, wr = (self.ws_mixbwd, self.ws_rsbwd) if fold else (None, None)
             dlogits, _, _, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True,
-                                                     out={"dlogits": self.dlogits, "dloc": dloc, "dlogstd": dlogstd})
+                                                     out={"dlogits": self.dlogits, "dloc": dloc, "dlogstd": dlogstd},
+                                                     slabs_ws=wm)
             dlogits = dlogits.view(B, -1)
             kernels.rsample_bwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"], da, dxs,
-                                dlogits, dloc, dlogstd)
+                                dlogits, dloc, dlogstd, slabs_ws=wr)
+            if fold:
+                # dloc / dlogstd = (slab sum of the log-prob backward) + (slab sum of the sample backward): two jobs of the
+                # reduction launch instead of two finalize launches (same sums, same order)
+                AN = dlogits.shape[1]
+                n1, s1 = kernels.logprob_bwd_slabs(self.logits, self.dlogits, B, A, self.particles)
+                n2, s2, o2 = kernels.rsample_bwd_slabs(B, A, self.particles)
+                deferred.append(kernels.job_colsum(wm, 0, n1, s1, AN, dloc.view(-1), second=(wr, o2, n2, s2)))
+                deferred.append(kernels.job_colsum(wm, AN, n1, s1, AN, dlogstd.view(-1), second=(wr, o2 + AN, n2, s2)))
             torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
             gpb = st.g("actor/fc_policy/bias")
             if fold:
