@@ -293,7 +293,8 @@ def sac_network_wrapper(base_class):
             self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
             # Q inputs
             kernels.sac_q_inputs(x, x2, a, action, a2, self.xa, self.xh, self.xa2)
-            both_q = fold and self.batch_critic and B % 16 == 0
+            # (the second half's rows must start on a row chunk of the partial sums: 16-row chunks up to 8192 rows)
+            both_q = fold and self.batch_critic and B % 16 == 0 and 2 * B <= 8192
             if both_q:
                 # the live critic on [(s, a_pi); (s, action_hist)] in ONE pass of 2B rows (4 launches instead of 8)
                 self._q_forward(self.xq_both, 0, self.q_both, fold=True)
