@@ -23,7 +23,9 @@ def make_net(dev, trainable=True, S=197, A=36, seed=7):
     return net
 
 
-@pytest.mark.parametrize("B,one_buffer", [(16, True), (16, False), (256, True), (1024, True), (1024, False)])
+@pytest.mark.parametrize("B,one_buffer", [(16, True), (16, False), (256, True), (1024, True), (1024, False),
+                                          (40, True),      # rows not on 16-row chunks: one actor pass, two critic passes
+                                          (6, True)])      # rows not a multiple of 4: the undeferred step, one pass per input
 def test_sac_step_matches_oracle(oracle, dev, B, one_buffer):
     """B = 1024 is BASELINE.json config 3 (replay batch).  `one_buffer`: the four noise tensors as the step draws them
     (one [4, B, A*N] buffer: the actor runs ONCE over [s; s']); else four separate tensors (one actor pass per state)."""
@@ -61,7 +63,8 @@ def test_sac_step_matches_oracle(oracle, dev, B, one_buffer):
             dn = {"gumbel": buf[0], "gumbel_": buf[1], "eps": buf[2], "eps_": buf[3], "_buf": buf}
         args = [net._to_dev(batch[k]) for k in ("state", "action", "reward", "not_terminal", "state_")]
         loss3 = net.compute_gradients(*args, noise=dn).cpu().numpy()
-        assert (net.actor_trunk._bufs.get((B, 3)) is not None) == one_buffer        # which path ran
+        assert (net.actor_trunk._bufs.get((B, 3)) is not None) == (one_buffer and B % 4 == 0)        # which path ran
+        assert ((2 * B, 0) in net.q_stack._bufs) == (B % 16 == 0)
         assert np.array_equal(net.last["k"].cpu().numpy(), aux["k"]), "rsample particle indices must be bit-exact"
         np.testing.assert_allclose(net.last["logp"].cpu().numpy(), aux["logp"], rtol=1e-5, atol=2e-4)
         np.testing.assert_allclose(loss3, [l_ref, pl_ref, vl_ref], rtol=2e-4, atol=2e-5)
