@@ -354,7 +354,7 @@ class ActorCriticNetwork(object):
         a third of the time.  Data-parallel steps are captured as two graphs around the RCCL all-reduce, which is
         enqueued between their replays.  PFPN_GRAPH_TRAIN=0 keeps the eager path."""
         B = args[0].shape[0] if rows is None else rows.shape[0]
-        key = (B, id(optimizer))
+        key = (B, id(optimizer)) + tuple(self._graph_phase())
         g = self._train_graphs.get(key)
         if rows is not None:
             if g is not None and make_noise is None:
@@ -373,6 +373,11 @@ class ActorCriticNetwork(object):
         loss3 = self.compute_gradients(*args) if make_noise is None else self.compute_gradients(*args, make_noise())
         optimizer.apply(self)
         return loss3
+
+    def _graph_phase(self):
+        """what distinguishes learner steps of different launch structure at one batch size (each gets its own captured
+        graph): nothing for most networks; TD3: whether this step updates the policy."""
+        return ()
 
     def prologue(self, state, advantage=None, deferred=None, state2=None, out2=None):
         """First launches of a learner step: x = normalised state, the state-normaliser EMA on this minibatch

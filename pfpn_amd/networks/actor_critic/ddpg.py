@@ -202,7 +202,7 @@ def ddpg_network_wrapper(base_class):
             if not self._target_initialised:
                 self.sync_target_net_hard()
             if sync is None:
-                sync = self.global_step % self.policy_delay == 0 if self.policy_delay > 1 else True
+                sync = self._policy_step()
             self._sync_now = bool(sync)
             noise = noise or self.make_train_noise(B)
             x = self._normalize(state)
@@ -254,12 +254,21 @@ def ddpg_network_wrapper(base_class):
             optimizer.apply(self)
             return loss3
 
+        def _policy_step(self):
+            return self.global_step % self.policy_delay == 0 if self.policy_delay > 1 else True
+
+        def _graph_phase(self):
+            return (self._policy_step(),)
+
         def train(self, sess, optimizer, ops, state, action, reward, not_terminal, state_):
-            """reference ddpg.py:232-243 + actor_critic.py:382-404.  Eager launches: consecutive steps differ in
-            structure (policy delay), so the step is not captured into one hipGraph."""
+            """reference ddpg.py:232-243 + actor_critic.py:382-404.  Consecutive steps differ in structure (policy delay):
+            after a few eager steps each of the two kinds is captured into a hipGraph of its own and replayed
+            (graphed_train keys its graphs by _graph_phase)."""
             args = [self._to_dev(a) for a in (state, action, reward, not_terminal, state_)]
             args[0], args[1], args[4] = args[0].view(-1, self.S), args[1].view(-1, self.n_actions), args[4].view(-1, self.S)
-            loss3 = self.train_device(optimizer, *args).cpu().numpy()
+            B = args[0].shape[0]
+            self._sync_now = bool(self._policy_step())     # read by the delayed soft update after a replay
+            loss3 = self.graphed_train(optimizer, args, lambda: self.make_train_noise(B)).cpu().numpy()
             loss = (float(loss3[0]), None, float(loss3[1]), float(loss3[2]))
             extra = []
             for o in (ops if hasattr(ops, "__len__") else ([ops] if ops else [])):

@@ -103,3 +103,59 @@ def test_td3_api_surface(dev):
         make_net(dev, ou_noise=True)
     with pytest.raises(NotImplementedError):
         make_net(dev, twin_q=False)
+
+
+@pytest.mark.parametrize("policy_step", [True, False])
+def test_td3_step_as_graph_matches_eager(dev, policy_step):
+    """Each of the two kinds of TD3 learner step (the policy is updated / the policy-delay step) captured into a hipGraph
+    and replayed == the eager step on the same draws: loss, parameters, Adam slots and target network bit for bit."""
+    from pfpn_amd.graphs import GraphedLearnerStep
+    from pfpn_amd.models import SyncReplicasApplier
+    B = 64
+    rng = np.random.default_rng(3)
+    nets, opts = [], []
+    for _ in range(2):
+        net = make_net(dev)
+        for op in net.init_ops:
+            op()
+        net.global_step = 0 if policy_step else 1          # policy_delay 2: even steps update the policy
+        nets.append(net)
+        opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                              {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1))
+    assert nets[0]._graph_phase() == (policy_step,)
+    batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                   np.tanh(rng.normal(0, 1, (B, 36))).astype(F),
+                                                   rng.random(B).astype(F), (rng.random(B) < 0.9).astype(F),
+                                                   (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
+    g = GraphedLearnerStep(nets[0], opts[0], *[t.clone() for t in batch], noise=nets[0].make_train_noise(B))
+    for it in range(3):
+        nets[0]._sync_now = policy_step                     # what train() sets before a replay
+        l_g = g().clone()
+        noise = {k: t.clone() for k, t in g.noise.items()}
+        l_e = nets[1].compute_gradients(*batch, noise, sync=policy_step).clone()
+        opts[1].apply(nets[1])
+        assert torch.equal(l_g, l_e), it
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.m, nets[1].store.m)
+        assert torch.equal(nets[0].target_store.flat, nets[1].target_store.flat)
+    assert nets[0].global_step == nets[1].global_step == (3 if policy_step else 4)
+
+
+def test_td3_train_captures_one_graph_per_kind_of_step(dev):
+    """net.train() alternates policy-update and policy-delay steps; after the eager warm-up calls each kind replays its own
+    graph, the delayed soft update still fires on policy steps only, losses stay finite."""
+    from pfpn_amd.models import SyncReplicasApplier
+    net = make_net(dev)
+    opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                    {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    rng = np.random.default_rng(1)
+    B = 32
+    data = (rng.normal(0, 1, (B, 197)).astype(F), np.tanh(rng.normal(0, 1, (B, 36))).astype(F), rng.random(B).astype(F),
+            np.ones(B, F), rng.normal(0, 1, (B, 197)).astype(F))
+    tgt = []
+    for it in range(16):
+        before = net.target_store.flat.clone()
+        loss, extra = net.train(None, opt, ["global_step"], *data)
+        assert extra == [it + 1] and all(np.isfinite([loss[0], loss[2], loss[3]]))
+        tgt.append(not torch.equal(before, net.target_store.flat))
+    assert len(net._train_graphs) == 2 and {k[2] for k in net._train_graphs} == {True, False}
+    assert tgt == [it % 2 == 0 for it in range(16)]         # the target moves on policy steps (even global_step) only
