@@ -47,6 +47,24 @@ def test_sac_launcher_end_to_end(dev):
     assert all(np.isfinite(v.detach().cpu().numpy()).all() for v in ev.values())
 
 
+@pytest.mark.parametrize("family", ["a3c", "impala"])
+def test_a2c_and_vtrace_launchers_end_to_end(dev, family):
+    """the A3C and IMPALA settings (synchronous replicas here): rollout on the synthetic environment -> A2C targets /
+    V-trace -> learner steps with the entropy term, finite parameters, the step counters in line."""
+    from pfpn_amd import main
+    st = main.parse(["--env", "DeepMimicWalk-v0", "--seed", "3", "--setting",
+                     "settings.deepmimic.deepmimic_%s_pfpn" % family, "--particles", "35", "--train"])
+    st.max_iterations = 4
+    if family == "impala":
+        st.max_samples = 4 * 4 * 64
+    model = main.build(st)
+    worker = model.start({"worker": []})
+    net = worker.global_net
+    assert worker.global_step >= 4 and net.global_step == worker.global_step
+    assert all(np.isfinite(v.detach().cpu().numpy()).all() for v in net.variables().values())
+    assert all(np.isfinite(g.detach().cpu().numpy()).all() for g in net.gradients().values())
+
+
 def test_batched_rollout_feeds_learner(dev):
     """E environments in host processes, one batched policy call per step, PPO buffers, one step."""
     import numpy as np
