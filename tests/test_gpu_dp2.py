@@ -240,6 +240,34 @@ def _rccl_rank(port, q):
             ok &= bool(torch.allclose(opts[0].norm_scale, opts[1].norm_scale, rtol=2e-6))
             ok &= bool(torch.allclose(nets[0].store.flat, nets[1].store.flat, rtol=1e-5, atol=2e-8))
             ok &= torch.equal(opts[0].beta_pow, opts[1].beta_pow)
+        # SAC on the exchange path: the soft target update rides in the Adam launch of either path (pfpn_adam_groups /
+        # pfpn_clip_adam_prenorm `soft_target`) -- applied exactly once, same bits
+        os.environ["PFPN_FUSED_NORM"] = "0"
+        from test_gpu_sac_step import make_net as make_sac
+        snets = [make_sac(dev) for _ in range(2)]
+        sopts = []
+        for i, n in enumerate(snets):
+            for op in n.init_ops:
+                op()
+            sopts.append(SyncReplicasApplier(n, [{"names": n.critic_param_names(), "lr": 1e-4},
+                                                 {"names": n.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1,
+                                             force_exchange=(i == 0)))
+        ok &= sopts[0].exchange and not sopts[1].exchange and sopts[0]._soft_net and sopts[1]._soft_net
+        SB = 64
+        for it in range(3):
+            sb = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (SB, 197)) * 2).astype(F),
+                                                        rng.uniform(-0.9, 0.9, (SB, 36)).astype(F),
+                                                        rng.normal(0.5, 0.3, SB).astype(F),
+                                                        (rng.uniform(size=SB) > 0.05).astype(F),
+                                                        (rng.normal(0, 1, (SB, 197)) * 2).astype(F))]
+            noise = snets[0].make_train_noise(SB)
+            before = snets[0].target_store.flat.clone()
+            for n, o in zip(snets, sopts):
+                n.compute_gradients(*sb, {k: t.clone() for k, t in noise.items()})
+                o.apply(n)
+            ok &= torch.equal(snets[0].store.flat, snets[1].store.flat)
+            ok &= torch.equal(snets[0].target_store.flat, snets[1].target_store.flat)
+            ok &= not torch.equal(before, snets[0].target_store.flat)
         q.put((0, bool(ok), "", ""))
     except Exception as e:
         import traceback
