@@ -143,16 +143,25 @@ def clip_ppo_network_wrapper(a2c_base_class):
             if self.entropy_beta or not plan:           # the entropy report reads the device every step anyway
                 return [self.train(None, optimizer, ops, *[np.asarray(columns[k])[rows] for k in names])
                         for rows in plan]
-            cols = [self._to_dev(columns[k]) for k in names]
-            cols[0], cols[1] = cols[0].view(-1, self.S), cols[1].view(-1, self.n_actions)
-            cols[2:] = [c.view(-1) for c in cols[2:]]
+            B0, K = len(plan[0]), self.ROUND_STEPS_PER_REPLAY
+            n_rows = len(columns[names[0]])
+            rg = getattr(self, "_round_graphs", {}).get((B0, n_rows, K, id(optimizer))) if len(plan) >= K else None
+            if rg is not None and os.environ.get("PFPN_GRAPH_ROUND", "1") != "0" and \
+                    all(isinstance(columns[k], np.ndarray) for k in names):
+                # the round's graph exists: the host columns go straight into the static columns its gathers read
+                cols = rg.gather_from[0]
+                for dst, k in zip(cols, names):
+                    dst.copy_(torch.from_numpy(np.ascontiguousarray(columns[k], dtype=np.float32)).view(dst.shape))
+            else:
+                cols = [self._to_dev(columns[k]) for k in names]
+                cols[0], cols[1] = cols[0].view(-1, self.S), cols[1].view(-1, self.n_actions)
+                cols[2:] = [c.view(-1) for c in cols[2:]]
+                rg = self._round_graph(optimizer, cols, B0, K) if len(plan) >= K else None
+                if rg is not None:
+                    cols = rg.gather_from[0]                # the staged rollout the graph's gathers read
             rows = torch.from_numpy(np.concatenate(plan).astype(np.int64)).to(self.device)
             losses = torch.empty(len(plan), 3, dtype=torch.float32, device=self.device)
             steps, pos, i = [], 0, 0
-            B0, K = len(plan[0]), self.ROUND_STEPS_PER_REPLAY
-            rg = self._round_graph(optimizer, cols, B0, K) if len(plan) >= K else None
-            if rg is not None:
-                cols = rg.gather_from[0]                    # the staged rollout the graph's gathers read
             while i < len(plan):
                 if rg is not None and i + K <= len(plan) and all(len(p) == B0 for p in plan[i:i + K]):
                     if rg.can_replay():
