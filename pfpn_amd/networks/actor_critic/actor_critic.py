@@ -204,6 +204,12 @@ class ActorCriticNetwork(object):
                 v[k].copy_(torch.as_tensor(np.asarray(arr, dtype=np.float32)).to(self.device).view(v[k].shape))
 
     # forward pieces -------------------------------------------------------------------------------
+    def _share_pins(self):
+        for name in ("trunk", "actor_trunk", "critic_trunk", "q_stack"):
+            st = getattr(self, name, None)
+            if st is not None and hasattr(st, "pinned"):
+                st.pinned = self._buf_pinned
+
     def _ensure_buffers(self, B, pin=False):
         """Activation / gradient buffers for a batch of B rows.  A worker alternates between sizes (B = 1 or E in
         the rollout, the minibatch size in the learner), so each size's buffers are kept: nothing is allocated
@@ -211,6 +217,7 @@ class ActorCriticNetwork(object):
         if self._B == B:
             if pin:
                 self._buf_pinned.add(B)
+                self._share_pins()
             return
         cache = self._buf_cache
         if B in cache:
@@ -232,6 +239,7 @@ class ActorCriticNetwork(object):
                         break
         if pin:
             self._buf_pinned.add(B)
+            self._share_pins()
         self._B = B
 
     def _alloc_policy_buffers(self, B):

@@ -130,6 +130,9 @@ class DenseStack:
         self.first_name_index = first_name_index
         self._bufs = {}
         self._last = None
+        self.pinned = set()       # batch sizes a captured graph points at (the network shares its set): never dropped
+
+    MAX_BUFFER_SETS = 64
 
     def group_view(self, t, layer, g, bias=False):
         """group g's slice of a layer tensor (parameter, gradient or Adam slot) in the reference's shape."""
@@ -170,6 +173,16 @@ class DenseStack:
             return t.view(G * B, H), t
         a = [alloc(i) for i in range(self.L)]
         d = [alloc(i) for i in range(self.L)]
+        if len(self._bufs) > self.MAX_BUFFER_SETS:
+            # ragged batches (episodic V-trace / A2C rounds) would otherwise keep one activation set per size ever seen:
+            # drop the oldest set no graph can point at (a step over B rows may run its stacks over 2B rows: SAC)
+            for old in list(self._bufs):
+                b0 = old[0]
+                if isinstance(b0, int) and old != key and b0 not in self.pinned and \
+                        not (b0 % 2 == 0 and b0 // 2 in self.pinned) and \
+                        not any(v.get("prefix_of") is self._bufs[old] for v in self._bufs.values() if isinstance(v, dict)):
+                    del self._bufs[old]
+                    break
         self._bufs[key] = {"act2d": [t[0] for t in a], "act": [t[1] for t in a],
                            "dact2d": [t[0] for t in d], "dact": [t[1] for t in d], "x": None, "B": B, "ws": None,
                            "mask": [None] * self.L, "mask_ok": [False] * self.L}

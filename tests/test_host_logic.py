@@ -344,3 +344,19 @@ def test_polling_evaluator_follows_new_checkpoints(oracle, monkeypatch, capsys):
     lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("[PERFORM]")]
     assert len(lines) == 2 and "Life Time: 50.0" in lines[0]                  # 2 averaged episodes of 50 steps each
     assert worker.request_stop and state["polls"] >= 8
+
+
+def test_dense_stack_keeps_a_bounded_number_of_activation_sets():
+    """Ragged batches must not keep one activation set per size ever seen; sizes a captured graph points at (and the 2B-row
+    sets of a pinned B) survive."""
+    import torch
+    from pfpn_amd.networks.ops import DenseStack, ParamStore
+    store = ParamStore(torch.device("cpu"))
+    stack = DenseStack(store, ["actor"], 8, [16, 8])
+    store.allocate(with_optimizer=False)
+    stack.pinned = {3}
+    for b in range(1, 200):
+        stack._buffers(b, 0)
+    sizes = {k[0] for k in stack._bufs}
+    assert len(stack._bufs) <= DenseStack.MAX_BUFFER_SETS + 2
+    assert 3 in sizes and 6 in sizes and 199 in sizes and 1 not in sizes
