@@ -348,3 +348,67 @@ def test_relu6_mask_bits_match_activation_reads(dev, rows, H, G):
     assert c1 == c2 and torch.equal(ga, gb)
     n = G * c1 * H
     assert torch.equal(ws1.view(torch.float32)[:n], ws2.view(torch.float32)[:n])
+
+
+def test_prologue_normalises_a_second_batch_with_the_same_moments(dev):
+    """pfpn_state_prologue(s2, x2): the second batch (SAC's next states) comes out as pfpn_state_norm would give it, and
+    neither the first batch's x nor the float64 moments change."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(15)
+    for B, S in ((1024, 197), (33, 7)):
+        s = torch.from_numpy((rng.normal(0, 1, (B, S)) * 3 + 0.5).astype(np.float32)).to(dev)
+        s2 = torch.from_numpy((rng.normal(0, 1, (B, S)) * 2 - 0.3).astype(np.float32)).to(dev)
+        mean = torch.from_numpy(rng.normal(0, 0.3, S).astype(np.float32)).to(dev)
+        std = torch.from_numpy(rng.uniform(0.5, 2, S).astype(np.float32)).to(dev)
+        step = torch.tensor([5.0], device=dev)
+        xa, xb, x2 = torch.empty_like(s), torch.empty_like(s), torch.empty_like(s)
+        kernels.state_prologue(s, mean, std, 5.0, xa, True)
+        ma, sa = torch.empty_like(mean), torch.empty_like(std)
+        kernels.state_norm_ema(B, S, step, mean, std, ma, sa)
+        kernels.state_prologue(s, mean, std, 5.0, xb, True, s2=s2, out_x2=x2)
+        mb, sb = torch.empty_like(mean), torch.empty_like(std)
+        kernels.state_norm_ema(B, S, step, mean, std, mb, sb)
+        assert torch.equal(xa, xb) and torch.equal(ma, mb) and torch.equal(sa, sb)
+        assert torch.equal(x2, kernels.state_norm(s2, mean, std, 5.0))
+
+
+def test_soft_target_update_inside_the_adam_launch(dev):
+    """pfpn_adam_groups / pfpn_clip_adam_prenorm with soft_target == the same launch followed by pfpn_soft_update on the
+    updated parameters, bit for bit; parameters outside [soft_off, soft_off + soft_len) leave the targets alone."""
+    import ctypes
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(16)
+    n, off, ln, tau = 30000, 4000, 16000, 0.005
+    p0 = torch.from_numpy(rng.normal(0, 1, n).astype(np.float32)).to(dev)
+    g0 = torch.from_numpy(rng.normal(0, 0.05, n).astype(np.float32)).to(dev)
+    t0 = torch.from_numpy(rng.normal(0, 1, ln).astype(np.float32)).to(dev)
+    G = 2
+    offs, lens, lrs = (ctypes.c_longlong * G)(0, 12000), (ctypes.c_longlong * G)(12000, 18000), (ctypes.c_float * G)(1e-4, 3e-4)
+    res = []
+    for fused in (False, True):
+        p, g, m, v, t = p0.clone(), g0.clone(), torch.zeros_like(p0), torch.zeros_like(p0), t0.clone()
+        bp = torch.tensor([[0.9, 0.999, 0.9, 0.999]] * G, device=dev)
+        kernels.adam_groups(p, g, m, v, offs, lens, lrs, bp, 0.5, soft=(t, off, ln, tau) if fused else None)
+        if not fused:
+            kernels.soft_update(t, p[off:off + ln], tau)
+        res.append((p, m, v, t))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert not torch.equal(res[0][3], t0)
+
+
+def test_column_sum_job_over_two_slab_sets(dev):
+    """PFPN_JOB_COLSUM with a second slab set: out = sum(first set) + sum(second set), each summed as a job of its own
+    sums it."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(17)
+    n, k1, s1, k2, s2 = 1260, 64, 2524, 16, 2520
+    w1 = torch.from_numpy(rng.normal(0, 1, k1 * s1).astype(np.float32)).to(dev)
+    w2 = torch.from_numpy(rng.normal(0, 1, 100 + k2 * s2).astype(np.float32)).to(dev)
+    b1, b2 = w1.view(torch.uint8), w2.view(torch.uint8)
+    o1, o2, o12 = (torch.empty(n, device=dev) for _ in range(3))
+    kernels.reduce_jobs([kernels.job_colsum(b1, 4, k1, s1, n, o1), kernels.job_colsum(b2, 100, k2, s2, n, o2),
+                         kernels.job_colsum(b1, 4, k1, s1, n, o12, second=(b2, 100, k2, s2))])
+    assert torch.equal(o12, o1 + o2)
+    ref = w1.view(k1, s1)[:, 4:4 + n].double().sum(0) + w2[100:].view(k2, s2)[:, :n].double().sum(0)
+    torch.testing.assert_close(o12.double(), ref, rtol=1e-5, atol=1e-4)
