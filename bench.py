@@ -567,7 +567,7 @@ def main():
             except Exception as e:
                 out["sac_step"] = {"error": repr(e)}
         # ---- config5_step: BASELINE.json config 5 as a learner step on ONE GPU's shard (8192 rows over 8 GPUs = 1024 rows
-        # per GPU): 128 action dims x 256 particles, head 512 -> 32768, eager launches
+        # per GPU): 128 action dims x 256 particles, head 512 -> 32768, as one hipGraph
         if extras:
             try:
                 cA, cN, cB = 128, 256, 1024
@@ -585,12 +585,21 @@ def main():
                     cp, _, chc = cnet._forward(ct["state"])
                     c_lp = cp.log_prob(ct["action"]).clone()
                     c_v = cnet._value(chc).clone()
+                cargs = (ct["state"], ct["action"], c_v, c_lp, ct["advantage"])
                 for _ in range(5):
-                    cnet.train_device(copt, ct["state"], ct["action"], c_v, c_lp, ct["advantage"])
+                    cnet.train_device(copt, *cargs)
+                torch.cuda.synchronize()
+                claunch = "hipGraph"
+                try:
+                    cstep = graphs.GraphedLearnerStep(cnet, copt, *[t.clone() for t in cargs])
+                except Exception:                       # (capture refused: time the eager launches)
+                    claunch, cstep = "eager", (lambda: cnet.train_device(copt, *cargs))
+                for _ in range(3):
+                    cstep()
                 torch.cuda.synchronize()
                 t_c = time.perf_counter()
                 for _ in range(30):
-                    cnet.train_device(copt, ct["state"], ct["action"], c_v, c_lp, ct["advantage"])
+                    cstep()
                 torch.cuda.synchronize()
                 cms = (time.perf_counter() - t_c) / 30 * 1e3
                 cl3 = cnet.train_out["loss3"].cpu().numpy()
@@ -598,7 +607,7 @@ def main():
                 flops = 2.0 * cB * (mac + S * 2048 + 2 * 2 * 1024 * 512 + 2 * 512 * cA * cN)
                 out["config5_step"] = {"workload": "128 action dims x 256 particles, %d rows (one GPU's shard of the 8192-row "
                                                    "batch over 8 GPUs), head 512 -> 32768" % cB,
-                                       "ms_per_step": cms, "steps_per_s": 1e3 / cms, "gemm_flops": flops,
+                                       "ms_per_step": cms, "steps_per_s": 1e3 / cms, "launch": claunch, "gemm_flops": flops,
                                        "gemm_tflops_if_all_time_were_gemm": flops / (cms * 1e-3) / 1e12,
                                        "finite_loss": bool(np.all(np.isfinite(cl3)))}
                 del cnet, copt
