@@ -11,7 +11,9 @@ import tempfile
 
 import torch
 
-TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "tunableop_gfx950.csv")
+# (PFPN_TUNED_FILE: another selection file, for A/B runs of a re-tuned selection against the shipped one)
+TUNED_FILE = os.environ.get("PFPN_TUNED_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned",
+                                                                 "tunableop_gfx950.csv")
 
 
 def enable_tuned_gemms(tune_missing=True, max_duration_ms=30, max_iterations=20):
