@@ -1,0 +1,498 @@
+// Small-row dense layers for gfx950 (MI355X): ONE launch per layer and direction for batches of <= ~1024 rows.
+//
+// Replaces, for the short learner steps (the 512-row shard of a data-parallel step, the reference's own 256-row global
+// step, a worker's 32-row minibatch, the SAC / TD3 replay batches) and the rollout's policy call, the sequence
+//   library GEMM -> bias/ReLU6 pass -> (critic head pass)            forward   (reference networks/ops.py:82-118)
+//   library dW GEMM, library dX GEMM -> Relu6Grad/BiasAddGrad pass   backward  (tf.gradients of the same lines)
+// by a JOB TABLE kernel: a launch carries up to PFPN_DENSE_MAX_JOBS jobs, each a tiled fp32-MFMA product
+// (v_mfma_f32_32x32x2_f32: exact fp32, the reference's arithmetic) with its epilogue fused --
+//   NN  Y  = act(X W + b) (+ per-32-column partial dot products with a scalar head's weights: critic fc3 / twin Q)
+//   NT  dX = (dY W^T) * [0 < H < 6]                      (MatMul_grad input side + Relu6Grad of the layer below)
+//   TN  dW = X^T dY, db = column sums of dY               (MatMul_grad weight side + BiasAddGrad; the batch is the
+//                                                          reduction, it never leaves the block: no partial slabs)
+// or one of three tiny helpers (head partials -> value, the rank-1 backward of a scalar head, its weight gradient).
+// A block picks its job from its index, so the dW and dX products of a layer -- different operand layouts, different
+// tile shapes -- share one launch.  At these sizes a launch costs >= ~4.5 us from dispatch to completion whatever its
+// rows, so the step time is the launch count: 16 -> 10 launches per DPPO learner step.
+//
+// Tiles.  256 threads = 4 waves per block, every wave owns ONE 32x32 accumulator (16 VGPRs; a single dependent MFMA
+// chain issues back to back: 64 cycles issue = 64 cycles latency).  Three arrangements of the four waves:
+//   cfg 0: 2x2 waves, tile 64x64, k-tile 32      cfg 1: 1x2 waves x 2 k-halves, tile 32x64, k-tile 64
+//   cfg 2: 1x1 wave x 4 k-quarters, tile 32x32, k-tile 128
+// so a 512-row layer still spreads over all 256 CUs (small tiles) while each block keeps four SIMDs busy (the K range
+// of a tile is split over the block's waves and summed through LDS in wave order: bitwise reproducible).
+// Staging: global -> registers (float4; scalar loads for operands whose rows are not 16-byte aligned, e.g. the
+// 197-wide state) -> LDS, double buffered, the loads of k-tile t+2 in flight during the MFMAs of tile t; every load is
+// branch-free (clamped address + select) so hipcc keeps counted vmcnt waits.  LDS images and fragment maps are those
+// of gemm_kernels.hip: a K-contiguous operand as [rows][k-tile + 4] read by ds_read_b128 (conflict-free: 16 rows of a
+// lane group land on 16 disjoint 16-B slots), a tile-contiguous operand as [k][tile] read by ds_read_b32; MFMA step q of
+// chunk c multiplies k = 8c + 4h + q on lane half h for BOTH operands.
+#include <cstdlib>
+#include "pfpn_common.h"
+#include "pfpn_hip.h"
+
+namespace pfpn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DenseJobDev {
+    PfpnDenseJob j;
+    int block0, tiles_m, tiles_n, avec;
+};
+struct DenseTable {
+    int n;
+    DenseJobDev job[PFPN_DENSE_MAX_JOBS];
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+// one operand of a product.  KC: memory rows = tile rows, k along the row.  TC: memory rows = k, tile dim along the row.
+template <bool KC, int T, int BKT, bool VEC>
+struct RowOperand {
+    static constexpr int LDK = BKT + 4;
+    static constexpr int FLOATS = KC ? T * LDK : BKT * T;
+    static constexpr int NL = T * BKT / 1024;                 // float4 loads per thread and k-tile
+    static constexpr int PER_ROW = KC ? BKT / 4 : T / 4;      // float4s per memory row of the tile
+    const float* base;          // operand base (always readable: the clamp target)
+    const float* p[NL];         // my float4s of the current k-tile
+    bool tok[NL];               // tile index (row / column group) in range
+    int tlim[NL];               // VEC = false, TC: valid elements of my float4 in the tile direction
+    int kk[NL];                 // KC: my k offset inside the k-tile; TC: my k row inside the k-tile
+    int sts[NL];
+    long long step;             // pointer advance per k-tile
+    int K;
+
+    __device__ __forceinline__ void init(const float* P, int ld, int t0, int n_t, int Kred, int t) {
+        base = P; K = Kred;
+        step = KC ? (long long)BKT : (long long)BKT * ld;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int idx = t + 256 * j;
+            const int r = idx / PER_ROW, c4 = (idx % PER_ROW) * 4;
+            if (KC) {
+                kk[j] = c4;
+                tok[j] = (t0 + r) < n_t;
+                tlim[j] = 4;
+                p[j] = P + (size_t)(tok[j] ? t0 + r : 0) * ld + c4;
+                sts[j] = r * LDK + c4;
+            } else {
+                kk[j] = r;
+                tok[j] = (t0 + c4) < n_t;
+                tlim[j] = n_t - (t0 + c4);
+                p[j] = P + (size_t)r * ld + (tok[j] ? t0 + c4 : 0);
+                sts[j] = r * T + c4;
+            }
+        }
+    }
+    // k0 = first k of the tile being fetched.  RAW loads only (clamped addresses, always readable): nothing here uses a
+    // loaded value, so the requests stay in flight across the MFMAs of the current tile; out-of-range elements are zeroed
+    // when the registers go to LDS (store), one k-tile later.
+    __device__ __forceinline__ void load(float4 (&r)[NL], int k0) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (VEC) {
+                const bool ok = tok[j] && (k0 + kk[j] < K);
+                r[j] = ld4(ok ? p[j] : base);
+            } else if (KC) {
+                const int kl = K - (k0 + kk[j]);                 // valid k elements from here
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = *((tok[j] && q < kl) ? p[j] + q : base);
+                r[j] = make_float4(e[0], e[1], e[2], e[3]);
+            } else {
+                const bool kok = (k0 + kk[j]) < K;
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e[q] = *((kok && q < tlim[j]) ? p[j] + q : base);
+                r[j] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+            p[j] += step;
+        }
+    }
+    // registers of the k-tile that starts at k0 -> LDS, invalid elements as zeros; returns nothing, `r` is masked in place
+    __device__ __forceinline__ void store(float* __restrict__ S, float4 (&r)[NL], int k0) const {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (VEC) {
+                r[j] = sel4(tok[j] && (k0 + kk[j] < K), r[j]);
+            } else if (KC) {
+                const int kl = K - (k0 + kk[j]);
+                r[j] = make_float4((tok[j] && 0 < kl) ? r[j].x : 0.f, (tok[j] && 1 < kl) ? r[j].y : 0.f,
+                                   (tok[j] && 2 < kl) ? r[j].z : 0.f, (tok[j] && 3 < kl) ? r[j].w : 0.f);
+            } else {
+                const bool kok = (k0 + kk[j]) < K;
+                r[j] = make_float4((kok && 0 < tlim[j]) ? r[j].x : 0.f, (kok && 1 < tlim[j]) ? r[j].y : 0.f,
+                                   (kok && 2 < tlim[j]) ? r[j].z : 0.f, (kok && 3 < tlim[j]) ? r[j].w : 0.f);
+            }
+            *reinterpret_cast<float4*>(S + sts[j]) = r[j];
+        }
+    }
+    // fragment of chunk c of the wave's 32-k slice `wk`, 32-wide block `wt`: f[q], q = MFMA step inside the chunk
+    __device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S, int wt, int wk, int c, int lane) const {
+        const int fh = lane >> 5, fc = lane & 31;
+        if (KC) {
+            const float4 v = *reinterpret_cast<const float4*>(S + (32 * wt + fc) * LDK + 32 * wk + 8 * c + 4 * fh);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = S[(32 * wk + 8 * c + 4 * fh + q) * T + 32 * wt + fc];
+        }
+    }
+};
+
+template <int KIND, int WM, int WN, int WK, bool AVEC>
+__device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, int tn, float* lds) {
+    constexpr int TM = 32 * WM, TN = 32 * WN, BKT = 32 * WK;
+    constexpr bool AKC = KIND != PFPN_DENSE_TN;
+    constexpr bool BKC = KIND == PFPN_DENSE_NT;
+    typedef RowOperand<AKC, TM, BKT, AVEC> OpA;
+    typedef RowOperand<BKC, TN, BKT, true> OpB;
+    constexpr int AF = OpA::FLOATS, BF = OpB::FLOATS;
+    const PfpnDenseJob& j = d.j;
+    float* As0 = lds;
+    float* Bs0 = lds + AF;
+    float* As1 = lds + AF + BF;
+    float* Bs1 = lds + 2 * AF + BF;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const float* A = j.A + (size_t)g * j.sA;
+    const float* B = j.B + (size_t)g * j.sB;
+    const int K = j.K;
+
+    OpA opA;
+    OpB opB;
+    opA.init(A, j.lda, m0, j.M, K, t);
+    opB.init(B, j.ldb, n0, j.N, K, t);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool do_csum = (KIND == PFPN_DENSE_TN) && (j.flags & PFPN_DENSE_COLSUM) && tm == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    float4 ra[OpA::NL], rb[OpB::NL];
+#define RD_STORE(As_, Bs_, k_)                                                                  \
+    do {                                                                                        \
+        opA.store((As_), ra, (k_));                                                             \
+        opB.store((Bs_), rb, (k_));                                                             \
+        if (KIND == PFPN_DENSE_TN && do_csum) {                                                 \
+            _Pragma("unroll") for (int q_ = 0; q_ < OpB::NL; ++q_) {                            \
+                csum.x += rb[q_].x; csum.y += rb[q_].y; csum.z += rb[q_].z; csum.w += rb[q_].w; \
+            }                                                                                   \
+        }                                                                                       \
+    } while (0)
+    opA.load(ra, 0);
+    opB.load(rb, 0);
+    RD_STORE(As0, Bs0, 0);
+    opA.load(ra, BKT);
+    opB.load(rb, BKT);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += BKT) {
+        const float* Ac = buf ? As1 : As0;
+        const float* Bc = buf ? Bs1 : Bs0;
+        if (k0 + BKT < K) {
+            if (buf) RD_STORE(As0, Bs0, k0 + BKT); else RD_STORE(As1, Bs1, k0 + BKT);
+            opA.load(ra, k0 + 2 * BKT);
+            opB.load(rb, k0 + 2 * BKT);
+        }
+        float fa[2][4], fb[2][4];
+        opA.frag(fa[0], Ac, wm, wk, 0, lane);
+        opB.frag(fb[0], Bc, wn, wk, 0, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3) {
+                opA.frag(fa[(c + 1) & 1], Ac, wm, wk, c + 1, lane);
+                opB.frag(fb[(c + 1) & 1], Bc, wn, wk, c + 1, lane);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][q], fb[c & 1][q], acc, 0, 0, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#undef RD_STORE
+
+    // ---- the K split over the block's waves: partial accumulators through LDS, summed in wave order ----------------
+    if (WK > 1) {
+        float* red = lds;
+        if (wk > 0) {
+            float* dst = red + (((wk - 1) * WM + wm) * WN + wn) * 1024 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[r * 64] = acc[r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int s = 1; s < WK; ++s) {
+                const float* src = red + (((s - 1) * WM + wm) * WN + wn) * 1024 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += src[r * 64];
+            }
+        }
+    }
+
+    // ---- epilogue (waves wk == 0).  32x32 C/D map: col = lane & 31, row = 8 (r >> 2) + 4 (lane >> 5) + (r & 3) -----
+    if (wk == 0) {
+        const int fh = lane >> 5, fc = lane & 31;
+        const int col = n0 + 32 * wn + fc;
+        const bool cok = col < j.N;
+        float* C = j.C + (size_t)g * j.sC;
+        const float bv = ((j.flags & PFPN_DENSE_BIAS) && cok) ? j.bias[(size_t)g * j.sBias + col] : 0.f;
+        const bool relu = j.flags & PFPN_DENSE_RELU6;
+        const float* H = (j.flags & PFPN_DENSE_MASK) ? j.H + (size_t)g * j.sH : nullptr;
+        const bool head = (KIND == PFPN_DENSE_NN) && (j.flags & PFPN_DENSE_HEADPART) && (j.hgroup < 0 || j.hgroup == g);
+        const float hwv = (head && cok) ? j.hw[(j.hgroup < 0 ? (size_t)g * j.sHw : 0) + col] : 0.f;
+        const int hparts = (j.N + 31) >> 5;
+        float* hp = head ? j.aux + (j.hgroup < 0 ? (size_t)g * j.sAux : 0) : nullptr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wm + 8 * (r >> 2) + 4 * fh + (r & 3);
+            const bool ok = cok && row < j.M;
+            float v = acc[r] + bv;
+            if (relu) v = fminf(fmaxf(v, 0.f), 6.f);
+            if (H) {
+                const float h = ok ? H[(size_t)row * j.ldh + col] : 0.f;
+                v = (h > 0.f && h < 6.f) ? v : 0.f;
+            }
+            if (ok) C[(size_t)row * j.ldc + col] = v;
+            if (head) {
+                float pv = ok ? v * hwv : 0.f;
+                pv += __shfl_xor(pv, 1, 64);
+                pv += __shfl_xor(pv, 2, 64);
+                pv += __shfl_xor(pv, 4, 64);
+                pv += __shfl_xor(pv, 8, 64);
+                pv += __shfl_xor(pv, 16, 64);
+                if (fc == 0 && row < j.M) hp[(size_t)row * hparts + ((n0 >> 5) + wn)] = pv;
+            }
+        }
+    }
+    // ---- BiasAddGrad: column sums of the B operand (dY), threads with the same column group in fixed order ---------
+    if (KIND == PFPN_DENSE_TN && (j.flags & PFPN_DENSE_COLSUM) && tm == 0) {
+        constexpr int CG = TN / 4;              // column groups; thread t owns group t % CG on every load
+        __syncthreads();
+        float4* red4 = reinterpret_cast<float4*>(lds);
+        red4[t] = csum;
+        __syncthreads();
+        if (t < CG) {
+            float4 s = red4[t];
+            for (int q = 1; q < 256 / CG; ++q) {
+                const float4 u = red4[t + q * CG];
+                s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+            }
+            const int col = n0 + 4 * t;
+            if (col < j.N) *reinterpret_cast<float4*>(j.aux + (size_t)g * j.sAux + col) = s;
+        }
+    }
+}
+
+// ---- helpers on [rows] vectors --------------------------------------------------------------------------------------
+// out[g][b] = hb[g*sBias] + sum_t part[g][b][t] (t ascending): finishes a scalar head whose per-32-column partial dot
+// products the previous layer's epilogue left.
+__device__ __forceinline__ void aux_head_final(const PfpnDenseJob& j, int local) {
+    const int per = (j.M + 255) / 256;
+    const int g = local / per;
+    const int b = (local - g * per) * 256 + threadIdx.x;
+    if (b >= j.M) return;
+    const float* part = j.A + (size_t)g * j.sA + (size_t)b * j.K;
+    float s = j.bias[(size_t)g * j.sBias];
+    for (int q = 0; q < j.K; ++q) s += part[q];
+    j.C[(size_t)g * j.sC + b] = s;
+}
+// C[g][b][c] = dv[g][b] * w[g][c] * [0 < H[g][b][c] < 6]: backward of a scalar head into the (ReLU6) layer below it
+__device__ __forceinline__ void aux_rank1(const PfpnDenseJob& j, int local) {
+    const int n4 = j.N >> 2;
+    const size_t per_g = (size_t)j.M * n4;
+    const int bpg = (int)((per_g + 255) / 256);
+    const int g = local / bpg;
+    const size_t i = (size_t)(local - g * bpg) * 256 + threadIdx.x;
+    if (i >= per_g) return;
+    const int b = (int)(i / n4), c = (int)(i % n4) * 4;
+    const float dv = j.A[(size_t)g * j.sA + b];
+    const float4 w = ld4(j.B + (size_t)g * j.sB + c);
+    const float4 h = ld4(j.H + (size_t)g * j.sH + (size_t)b * j.ldh + c);
+    float4 o;
+    o.x = (h.x > 0.f && h.x < 6.f) ? dv * w.x : 0.f;
+    o.y = (h.y > 0.f && h.y < 6.f) ? dv * w.y : 0.f;
+    o.z = (h.z > 0.f && h.z < 6.f) ? dv * w.z : 0.f;
+    o.w = (h.w > 0.f && h.w < 6.f) ? dv * w.w : 0.f;
+    *reinterpret_cast<float4*>(j.C + (size_t)g * j.sC + (size_t)b * j.ldc + c) = o;
+}
+// dw[g][c] = sum_b dv[g][b] * h[g][b][c] (b ascending per row phase, the 4 phases in order), db[g] = sum_b dv[g][b]
+__device__ __forceinline__ void aux_head_wgrad(const PfpnDenseJob& j, int local, float* lds) {
+    const int cblk = (j.N + 63) / 64;
+    const int g = local / (cblk + 1);
+    const int cb = local - g * (cblk + 1);
+    const float* dv = j.A + (size_t)g * j.sA;
+    const int t = threadIdx.x;
+    if (cb == cblk) {                       // the bias gradient: 256 strided partial sums, then in thread order
+        float s = 0.f;
+        for (int b = t; b < j.M; b += 256) s += dv[b];
+        lds[t] = s;
+        __syncthreads();
+        if (t == 0) {
+            float tot = 0.f;
+            for (int q = 0; q < 256; ++q) tot += lds[q];
+            j.aux[(size_t)g * j.sAux] = tot;
+        }
+        return;
+    }
+    const int c = cb * 64 + (t & 63), ph = t >> 6;
+    const float* h = j.H + (size_t)g * j.sH;
+    float s = 0.f;
+    if (c < j.N)
+        for (int b = ph; b < j.M; b += 4) s += dv[b] * h[(size_t)b * j.ldh + c];
+    lds[t] = s;
+    __syncthreads();
+    if (ph == 0 && c < j.N) j.C[(size_t)g * j.sC + c] = (lds[t] + lds[t + 64]) + (lds[t + 128] + lds[t + 192]);
+}
+
+__global__ __launch_bounds__(256, 2) void k_dense_jobs(DenseTable tab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // the block's job, copied out of the kernel-argument segment with CONSTANT indices (a dynamic index makes hipcc
+    // copy the whole table to scratch); everything of it is wave-uniform and stays in SGPRs
+    DenseJobDev d = tab.job[0];
+#pragma unroll
+    for (int q = 1; q < PFPN_DENSE_MAX_JOBS; ++q)
+        if (q < tab.n && (int)blockIdx.x >= tab.job[q].block0) d = tab.job[q];
+    const int local = blockIdx.x - d.block0;
+    const int kind = d.j.kind;
+    if (kind == PFPN_DENSE_HEAD_FINAL) { aux_head_final(d.j, local); return; }
+    if (kind == PFPN_DENSE_RANK1) { aux_rank1(d.j, local); return; }
+    if (kind == PFPN_DENSE_HEAD_WGRAD) { aux_head_wgrad(d.j, local, lds); return; }
+    const int per_g = d.tiles_m * d.tiles_n;
+    const int g = local / per_g;
+    const int rem = local - g * per_g;
+    const int tn = rem / d.tiles_m, tm = rem - tn * d.tiles_m;
+    const int variant = (kind * 3 + d.j.cfg) * 2 + d.avec;
+#define RD_CASE(KIND_, CFG_, WM_, WN_, WK_)                                                          \
+    case (KIND_ * 3 + CFG_) * 2 + 1: dense_tile<KIND_, WM_, WN_, WK_, true>(d, g, tm, tn, lds); break;
+#define RD_CASE_U(KIND_, CFG_, WM_, WN_, WK_)                                                        \
+    case (KIND_ * 3 + CFG_) * 2 + 0: dense_tile<KIND_, WM_, WN_, WK_, false>(d, g, tm, tn, lds); break;
+    switch (variant) {
+        RD_CASE(PFPN_DENSE_NN, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_NN, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_NN, 2, 1, 1, 4)
+        RD_CASE(PFPN_DENSE_NT, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_NT, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_NT, 2, 1, 1, 4)
+        RD_CASE(PFPN_DENSE_TN, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_TN, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_TN, 2, 1, 1, 4)
+        RD_CASE_U(PFPN_DENSE_NN, 0, 2, 2, 1) RD_CASE_U(PFPN_DENSE_NN, 1, 1, 2, 2) RD_CASE_U(PFPN_DENSE_NN, 2, 1, 1, 4)
+        RD_CASE_U(PFPN_DENSE_TN, 0, 2, 2, 1) RD_CASE_U(PFPN_DENSE_TN, 1, 1, 2, 2) RD_CASE_U(PFPN_DENSE_TN, 2, 1, 1, 4)
+        default: break;
+    }
+#undef RD_CASE
+#undef RD_CASE_U
+}
+
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static const int CFG_TM[3] = {64, 32, 32}, CFG_TN[3] = {64, 64, 32}, CFG_WK[3] = {1, 2, 4};
+
+static size_t cfg_lds_bytes(int kind, int cfg) {
+    const int TM = CFG_TM[cfg], TN = CFG_TN[cfg], BKT = 32 * CFG_WK[cfg];
+    const size_t af = (kind != PFPN_DENSE_TN) ? (size_t)TM * (BKT + 4) : (size_t)BKT * TM;
+    const size_t bf = (kind == PFPN_DENSE_NT) ? (size_t)TN * (BKT + 4) : (size_t)BKT * TN;
+    return 2 * (af + bf) * sizeof(float);
+}
+
+// blocks of a product under a tile arrangement
+static long long cfg_blocks(const PfpnDenseJob& j, int cfg) {
+    return (long long)((j.M + CFG_TM[cfg] - 1) / CFG_TM[cfg]) * ((j.N + CFG_TN[cfg] - 1) / CFG_TN[cfg]) * j.batch;
+}
+
+}  // namespace pfpn
+
+using namespace pfpn;
+
+extern "C" {
+
+int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
+    PFPN_BEGIN();
+    if (!jobs || n_jobs < 1 || n_jobs > PFPN_DENSE_MAX_JOBS) return PFPN_ERR_ARG;
+    static const int force_cfg = getenv("PFPN_DENSE_CFG") ? atoi(getenv("PFPN_DENSE_CFG")) : -1;
+    DenseTable tab{};
+    tab.n = n_jobs;
+    long long blocks = 0, gemm_work = 0;
+    size_t lds = 1024 * sizeof(float);
+    // pass 1: validate, total work of the launch's products (the arrangement of each depends on what shares the chip)
+    for (int i = 0; i < n_jobs; ++i) {
+        const PfpnDenseJob& j = jobs[i];
+        if (j.M < 1 || j.batch < 1) return PFPN_ERR_ARG;
+        if (j.kind <= PFPN_DENSE_TN) {
+            if (j.kind < 0 || !j.A || !j.B || !j.C || j.N < 1 || j.K < 1) return PFPN_ERR_ARG;
+            gemm_work += (long long)j.M * j.N * j.batch * (long long)j.K;
+        }
+    }
+    for (int i = 0; i < n_jobs; ++i) {
+        DenseJobDev& d = tab.job[i];
+        d.j = jobs[i];
+        PfpnDenseJob& j = d.j;
+        d.block0 = (int)blocks;
+        if (j.kind <= PFPN_DENSE_TN) {
+            const bool a_kc = j.kind != PFPN_DENSE_TN, b_kc = j.kind == PFPN_DENSE_NT;
+            // B operand: float4 loads only
+            if (!al16(j.B) || (j.ldb & 3) || (j.sB & 3) || (b_kc ? (j.K & 3) : (j.N & 3))) return PFPN_ERR_ARG;
+            if (j.lda < (a_kc ? j.K : j.M) || j.ldb < (b_kc ? j.K : j.N) || j.ldc < j.N) return PFPN_ERR_ARG;
+            d.avec = al16(j.A) && !(j.lda & 3) && !(j.sA & 3) && !((a_kc ? j.K : j.M) & 3);
+            if (!d.avec && j.kind == PFPN_DENSE_NT) return PFPN_ERR_ARG;
+            if ((j.flags & PFPN_DENSE_BIAS) && !j.bias) return PFPN_ERR_ARG;
+            if ((j.flags & PFPN_DENSE_MASK) && (!j.H || j.ldh < j.N)) return PFPN_ERR_ARG;
+            if (j.flags & PFPN_DENSE_COLSUM) {
+                if (j.kind != PFPN_DENSE_TN || !j.aux || !al16(j.aux) || (j.sAux & 3)) return PFPN_ERR_ARG;
+            }
+            if (j.flags & PFPN_DENSE_HEADPART) {
+                if (j.kind != PFPN_DENSE_NN || !j.aux || !j.hw || j.hgroup >= j.batch) return PFPN_ERR_ARG;
+            }
+            int cfg = j.cfg;
+            if (cfg < 0 || cfg > 2) {
+                // smallest tiles (most blocks) while the launch stays under ~4 blocks per CU and a wave keeps >= 64 of K
+                cfg = 0;
+                if (force_cfg >= 0 && force_cfg <= 2) cfg = force_cfg;
+                else {
+                    const double share = gemm_work > 0 ? (double)j.M * j.N * j.batch * (double)j.K / (double)gemm_work : 1.0;
+                    const double budget = 768.0 * share + 64.0;      // blocks this product may take
+                    for (int c = 1; c <= 2; ++c) {
+                        if (j.K / CFG_WK[c] < 64) break;
+                        if ((double)cfg_blocks(j, c - 1) >= budget) break;      // already enough blocks
+                        cfg = c;
+                    }
+                }
+            }
+            j.cfg = cfg;
+            d.tiles_m = (j.M + CFG_TM[cfg] - 1) / CFG_TM[cfg];
+            d.tiles_n = (j.N + CFG_TN[cfg] - 1) / CFG_TN[cfg];
+            blocks += (long long)d.tiles_m * d.tiles_n * j.batch;
+            const size_t need = cfg_lds_bytes(j.kind, cfg);
+            if (need > lds) lds = need;
+        } else if (j.kind == PFPN_DENSE_HEAD_FINAL) {
+            if (!j.A || !j.C || !j.bias || j.K < 1) return PFPN_ERR_ARG;
+            blocks += (long long)((j.M + 255) / 256) * j.batch;
+        } else if (j.kind == PFPN_DENSE_RANK1) {
+            if (!j.A || !j.B || !j.C || !j.H || j.N < 4 || (j.N & 3) || (j.ldc & 3) || (j.ldh & 3) || (j.sB & 3) ||
+                (j.sC & 3) || (j.sH & 3) || !al16(j.B) || !al16(j.C) || !al16(j.H))
+                return PFPN_ERR_ARG;
+            blocks += (((long long)j.M * (j.N >> 2) + 255) / 256) * j.batch;
+        } else if (j.kind == PFPN_DENSE_HEAD_WGRAD) {
+            if (!j.A || !j.C || !j.H || !j.aux || j.N < 1) return PFPN_ERR_ARG;
+            blocks += (long long)((j.N + 63) / 64 + 1) * j.batch;
+        } else {
+            return PFPN_ERR_ARG;
+        }
+        if (blocks > (1 << 20)) return PFPN_ERR_ARG;
+    }
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_jobs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(72 * 1024)) != hipSuccess)
+            return PFPN_ERR_LAUNCH;
+        lds_set = 72 * 1024;
+    }
+    hipLaunchKernelGGL(k_dense_jobs, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, tab);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+}  // extern "C"

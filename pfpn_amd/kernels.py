@@ -854,3 +854,166 @@ def dense_wgrad(x, dy, dw, db):
     _lib.check(lib.pfpn_dense_wgrad(x.data_ptr(), gstride, ldx, _f32(dy, G, rows, N), G, rows, K, N, _f32(dw, G, K, N),
                                     _f32(db, G, N) if db is not None else None, ws, wsn, _stream()), "pfpn_dense_wgrad")
     return dw, db
+
+
+# ---- small-row dense layers: one launch per layer and direction (csrc/rowdense_kernels.hip) ---------------------------
+class DenseJob(ctypes.Structure):
+    """mirror of PfpnDenseJob (include/pfpn_hip.h)"""
+    _fields_ = [("kind", ctypes.c_int), ("flags", ctypes.c_int), ("cfg", ctypes.c_int),
+                ("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("batch", ctypes.c_int),
+                ("lda", ctypes.c_int), ("ldb", ctypes.c_int), ("ldc", ctypes.c_int), ("ldh", ctypes.c_int),
+                ("hgroup", ctypes.c_int),
+                ("sA", ctypes.c_longlong), ("sB", ctypes.c_longlong), ("sC", ctypes.c_longlong),
+                ("sH", ctypes.c_longlong), ("sBias", ctypes.c_longlong), ("sAux", ctypes.c_longlong),
+                ("sHw", ctypes.c_longlong),
+                ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("H", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("hw", ctypes.c_void_p)]
+
+
+DENSE_NN, DENSE_NT, DENSE_TN, DENSE_HEAD_FINAL, DENSE_RANK1, DENSE_HEAD_WGRAD = 0, 1, 2, 8, 9, 10
+DENSE_BIAS, DENSE_RELU6, DENSE_MASK, DENSE_COLSUM, DENSE_HEADPART = 1, 2, 4, 8, 16
+DENSE_MAX_JOBS = 8
+
+
+def _mat(t, G, rows, cols, name):
+    """(ptr, ld, group stride) of a float32 CUDA matrix view [rows, cols] (shared by the G groups) or [G, rows, cols]
+    whose rows are contiguous; shapes are checked here so the kernel never reads outside the view."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise ValueError("%s must be a float32 CUDA tensor" % name)
+    if t.dim() == 2:
+        if tuple(t.shape) != (rows, cols) or (cols > 1 and t.stride(1) != 1):
+            raise ValueError("%s: shape %s / strides %s, expected [%d, %d] with contiguous rows"
+                             % (name, tuple(t.shape), t.stride(), rows, cols))
+        return t.data_ptr(), t.stride(0), 0
+    if t.dim() != 3 or tuple(t.shape) != (G, rows, cols) or (cols > 1 and t.stride(2) != 1):
+        raise ValueError("%s: shape %s / strides %s, expected [%d, %d, %d] with contiguous rows"
+                         % (name, tuple(t.shape), t.stride(), G, rows, cols))
+    return t.data_ptr(), t.stride(1), (t.stride(0) if G > 1 else 0)
+
+
+def _vec(t, G, n, name):
+    """(ptr, group stride) of a float32 CUDA vector [n] (shared) or [G, n] with contiguous elements."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32):
+        raise ValueError("%s must be a float32 CUDA tensor" % name)
+    if t.dim() == 1:
+        if t.shape[0] != n or (n > 1 and t.stride(0) != 1):
+            raise ValueError("%s: shape %s, expected [%d]" % (name, tuple(t.shape), n))
+        return t.data_ptr(), 0
+    if t.dim() != 2 or tuple(t.shape) != (G, n) or (n > 1 and t.stride(1) != 1):
+        raise ValueError("%s: shape %s, expected [%d, %d]" % (name, tuple(t.shape), G, n))
+    return t.data_ptr(), (t.stride(0) if G > 1 else 0)
+
+
+def _groups(*ts):
+    return max([t.shape[0] for t in ts if t is not None and t.dim() == 3] + [1])
+
+
+def dense_job_nn(x, w, out, bias=None, relu6=False, head=None, cfg=-1):
+    """out[g] = act(x[g] w[g] + bias[g]): x [M,K] (shared) or [G,M,K], w [K,N] or [G,K,N], out [G,M,N] / [M,N].
+    head = (hgroup, hw [N] or [G,N], hpart [M, ceil(N/32)] or [G, M, ceil(N/32)]): the per-32-column partial dot products
+    of the output with a scalar head's weights on group `hgroup` (-1: every group) -- finished by dense_job_head_final."""
+    G = _groups(x, w, out)
+    M, K, N = x.shape[-2], x.shape[-1], w.shape[-1]
+    j = DenseJob(kind=DENSE_NN, cfg=int(cfg), M=M, N=N, K=K, batch=G, hgroup=0)
+    j.A, j.lda, j.sA = _mat(x, G, M, K, "x")
+    j.B, j.ldb, j.sB = _mat(w, G, K, N, "w")
+    j.C, j.ldc, j.sC = _mat(out, G, M, N, "out")
+    if bias is not None:
+        j.bias, j.sBias = _vec(bias, G, N, "bias")
+        j.flags |= DENSE_BIAS
+    if relu6:
+        j.flags |= DENSE_RELU6
+    if head is not None:
+        hg, hw, hpart = head
+        parts = (N + 31) // 32
+        if not -1 <= hg < G:
+            raise ValueError("head group outside the batch")
+        j.hgroup = int(hg)
+        j.hw, j.sHw = _vec(hw, G, N, "head weight")
+        j.aux, _, j.sAux = _mat(hpart, G, M, parts, "head partials")
+        if not hpart.is_contiguous():
+            raise ValueError("head partials must be contiguous")
+        j.flags |= DENSE_HEADPART
+    return j
+
+
+def dense_job_nt(a, bt, out, mask=None, cfg=-1):
+    """out[g] = (a[g] bt[g]^T) * [0 < mask[g] < 6]: a [G,M,K], bt [G,N,K], out [G,M,N], mask like out (or None)."""
+    G = _groups(a, bt, out)
+    M, K, N = a.shape[-2], a.shape[-1], bt.shape[-2]
+    j = DenseJob(kind=DENSE_NT, cfg=int(cfg), M=M, N=N, K=K, batch=G)
+    j.A, j.lda, j.sA = _mat(a, G, M, K, "a")
+    j.B, j.ldb, j.sB = _mat(bt, G, N, K, "bt")
+    j.C, j.ldc, j.sC = _mat(out, G, M, N, "out")
+    if mask is not None:
+        j.H, j.ldh, j.sH = _mat(mask, G, M, N, "mask")
+        j.flags |= DENSE_MASK
+    return j
+
+
+def dense_job_tn(at, b, out, colsum=None, cfg=-1):
+    """out[g] = at[g]^T b[g], colsum[g] = column sums of b[g]: at [G,K,M] (or [K,M] shared), b [G,K,N], out [G,M,N],
+    colsum [G,N] / [N]."""
+    G = _groups(at, b, out)
+    K, M, N = at.shape[-2], at.shape[-1], b.shape[-1]
+    j = DenseJob(kind=DENSE_TN, cfg=int(cfg), M=M, N=N, K=K, batch=G)
+    j.A, j.lda, j.sA = _mat(at, G, K, M, "at")
+    j.B, j.ldb, j.sB = _mat(b, G, K, N, "b")
+    j.C, j.ldc, j.sC = _mat(out, G, M, N, "out")
+    if colsum is not None:
+        j.aux, j.sAux = _vec(colsum, G, N, "colsum")
+        j.flags |= DENSE_COLSUM
+    return j
+
+
+def dense_job_head_final(part, bias, out):
+    """out[g][b] = bias[g] + sum_t part[g][b][t]: part [M,P] / [G,M,P] contiguous, bias [1] / [G,1] (or [G]), out [M] / [G,M]."""
+    G = part.shape[0] if part.dim() == 3 else 1
+    M, P = part.shape[-2], part.shape[-1]
+    if not part.is_contiguous() or not out.is_contiguous():
+        raise ValueError("head partials / outputs must be contiguous")
+    j = DenseJob(kind=DENSE_HEAD_FINAL, M=M, N=1, K=P, batch=G)
+    j.A, _, j.sA = _mat(part, G, M, P, "part")
+    b2 = bias.view(G, -1) if G > 1 else bias.view(-1)
+    j.bias, j.sBias = _vec(b2[..., :1], G, 1, "head bias")
+    if G > 1:
+        j.sBias = b2.stride(0)
+    j.C, j.sC = _vec(out, G, M, "out")
+    return j
+
+
+def dense_job_rank1(dv, w, h, out):
+    """out[g][b][n] = dv[g][b] * w[g][n] * [0 < h[g][b][n] < 6]: dv [M] / [G,M], w [N] / [G,N], h and out [M,N] / [G,M,N]."""
+    G = _groups(h, out)
+    M, N = h.shape[-2], h.shape[-1]
+    j = DenseJob(kind=DENSE_RANK1, M=M, N=N, K=1, batch=G)
+    j.A, j.sA = _vec(dv, G, M, "dv")
+    j.B, j.sB = _vec(w, G, N, "w")
+    j.H, j.ldh, j.sH = _mat(h, G, M, N, "h")
+    j.C, j.ldc, j.sC = _mat(out, G, M, N, "out")
+    return j
+
+
+def dense_job_head_wgrad(dv, h, dw, db):
+    """dw[g][n] = sum_b dv[g][b] h[g][b][n], db[g] = sum_b dv[g][b]: dv [M] / [G,M], h [M,N] / [G,M,N], dw [N] / [G,N],
+    db [1] / [G,1]."""
+    G = _groups(h)
+    M, N = h.shape[-2], h.shape[-1]
+    j = DenseJob(kind=DENSE_HEAD_WGRAD, M=M, N=N, K=1, batch=G)
+    j.A, j.sA = _vec(dv, G, M, "dv")
+    j.H, j.ldh, j.sH = _mat(h, G, M, N, "h")
+    j.C, j.sC = _vec(dw, G, N, "dw")
+    d2 = db.view(G, -1) if G > 1 else db.view(-1)
+    j.aux, j.sAux = _vec(d2[..., :1], G, 1, "db")
+    if G > 1:
+        j.sAux = d2.stride(0)
+    return j
+
+
+def dense_jobs(jobs):
+    """ONE launch for up to DENSE_MAX_JOBS jobs (products with fused epilogues + scalar-head helpers)."""
+    lib = _lib.load()
+    if not 1 <= len(jobs) <= DENSE_MAX_JOBS:
+        raise ValueError("1..%d dense jobs per launch" % DENSE_MAX_JOBS)
+    arr = (DenseJob * len(jobs))(*jobs)
+    _lib.check(lib.pfpn_dense_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_dense_jobs")

@@ -184,6 +184,15 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
     # -- forward -----------------------------------------------------------------------------------
     def _policy_logits(self, ha):
         """fc_policy: logits [B, A*N] = h W + b (a2c.py:541-554)."""
+        pending = getattr(self, "_pending_jobs", None) or []
+        self._pending_jobs = []
+        stack = self.trunk if self.trunk is not None else self.actor_trunk
+        if stack is not None and stack.small(ha.shape[0]):
+            # small batches: the hand-written dense kernel, with the critic head's finishing job riding in the same launch
+            kernels.dense_jobs([kernels.dense_job_nn(ha, self.policy_weight, self.logits, bias=self.policy_bias)] + pending)
+            return self.logits
+        if pending:
+            kernels.dense_jobs(pending)
         # bias through the GEMM epilogue (hipBLASLt): no separate pass over the 20 MB of logits
         torch.addmm(self.policy_bias, ha, self.policy_weight, out=self.logits)
         return self.logits
@@ -237,6 +246,20 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         st = self.store
         w3 = st["critic/fc3/weight"].view(-1)
         dh_a, dh_c = (self.dh[0], self.dh[1]) if self.trunk is not None else (self.dh_a[0], self.dh_c[0])
+        B = dlogits.shape[0]
+        if self.trunk is not None and self.trunk.small(B):
+            # small batches, ONE launch: fc_policy's dW (+ its bias gradient when the mixture kernel did not emit it) and dX
+            # -- masked by the ReLU6 of the actor trunk's output, i.e. already the gradient w.r.t. its pre-activation --
+            # and the critic head's backward (rank-1 dX, dW, db); then one launch per trunk layer
+            gb = None if fused_db else st.g("actor/fc_policy/bias")
+            jobs = [kernels.dense_job_tn(ha, dlogits, st.g("actor/fc_policy/weight"), colsum=gb),
+                    kernels.dense_job_nt(dlogits, self.policy_weight, dh_a, mask=ha)]
+            jobs += self.trunk.head_backward_jobs((1, w3, dvalue, st.g("critic/fc3/weight"), st.g("critic/fc3/bias")),
+                                                  B, out=self.dh)
+            kernels.dense_jobs(jobs)
+            self.trunk.backward(self.dh, premasked=True)
+            self._dw_pending = False
+            return
         if deferred is not None:
             if not fused_db:
                 kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)

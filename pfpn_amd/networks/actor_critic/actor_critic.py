@@ -141,6 +141,7 @@ class ActorCriticNetwork(object):
         settings: [1024, 512] both, deepmimic_base.py:4-6)."""
         if self.actor_net_shape == self.critic_net_shape:
             self.trunk = DenseStack(store, ["actor", "critic"], self.S, self.actor_net_shape)
+            self.trunk.rowdense = True
             self.actor_trunk = self.critic_trunk = None
         else:
             self.trunk = None
@@ -256,10 +257,13 @@ class ActorCriticNetwork(object):
     def _trunks_forward(self, x, value_head=None, masks=False):
         """-> (actor hidden [B,Ha], critic hidden [B,Hc]) (views of the stacks' activation buffers).
         `value_head` = (w, b, out): also evaluate the critic head inside the merged trunk's last epilogue;
-        `masks`: hidden layers leave their ReLU6 masks as bits for the deferred backward."""
+        `masks`: hidden layers leave their ReLU6 masks as bits for the deferred backward.
+        Small batches (DenseStack.small): the head's finishing job waits in `self._pending_jobs` for the policy head's
+        launch (`_policy_logits`)."""
         if self.trunk is not None:
+            self._pending_jobs = []
             h = self.trunk.forward(x, value_head=(1,) + tuple(value_head) if value_head is not None else None,
-                                   masks=masks)
+                                   masks=masks, pending=self._pending_jobs)
             return h[0], h[1]
         if value_head is not None:
             raise ValueError("the folded critic head needs the merged actor+critic trunk")

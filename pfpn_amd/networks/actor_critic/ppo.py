@@ -52,8 +52,10 @@ def clip_ppo_network_wrapper(a2c_base_class):
             deferred = self._deferred_jobs(B, fused_mixture=True)
             x = self.prologue(state, advantage, deferred=deferred)   # normalised state, state-norm EMA, advantage moments
             w3, b3 = st["critic/fc3/weight"], st["critic/fc3/bias"]
-            if deferred is not None:
-                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf), masks=True)
+            if deferred is not None or (self.trunk is not None and self.trunk.small(B)):
+                # (small batches: the head always rides on the last trunk layer's launch -- one arithmetic for the
+                # deferred and the immediate step)
+                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf), masks=deferred is not None)
                 v = self.value_buf
             else:
                 ha, hc = self._trunks_forward(x)
@@ -114,6 +116,10 @@ def clip_ppo_network_wrapper(a2c_base_class):
             device columns the graph's gathers read, so a round of another size gets its own graph (at most two are
             kept).  PFPN_GRAPH_ROUND=0: one-step replays only."""
             if (B, id(optimizer)) not in self._train_graphs or os.environ.get("PFPN_GRAPH_ROUND", "1") == "0":
+                return None
+            if getattr(optimizer, "exchange", optimizer.world > 1):
+                # data-parallel steps are two graphs around the all-reduce: a K-step replay cannot hold the collective,
+                # so DP rounds run one-step (split-graph) replays
                 return None
             n = cols[0].shape[0]
             key = (B, n, K, id(optimizer))

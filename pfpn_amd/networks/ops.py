@@ -9,6 +9,7 @@ gradient lands directly in the flat gradient buffer (one RCCL bucket, one Adam l
 step can be captured in a hipGraph.
 """
 import math
+import os
 
 import torch
 
@@ -133,6 +134,15 @@ class DenseStack:
         self.pinned = set()       # batch sizes a captured graph points at (the network shares its set): never dropped
 
     MAX_BUFFER_SETS = 64
+    # batches of at most this many rows run on the hand-written small-row dense kernels (csrc/rowdense_kernels.hip):
+    # ONE launch per layer and direction with every epilogue fused; above it PyTorch-ROCm GEMMs + the streaming epilogue
+    # kernels (threshold by measurement; PFPN_ROWDENSE_MAX=0 switches the family off)
+    ROW_MAX = int(os.environ.get("PFPN_ROWDENSE_MAX", "1024"))
+
+    rowdense = False            # set by the owning network once all of its callers speak the small-row protocol
+
+    def small(self, B):
+        return self.rowdense and 0 < B <= self.ROW_MAX and self.store.device.type == "cuda"
 
     def group_view(self, t, layer, g, bias=False):
         """group g's slice of a layer tensor (parameter, gradient or Adam slot) in the reference's shape."""
@@ -223,7 +233,98 @@ class DenseStack:
         """`group_rows` of the epilogue kernels: layer 0 merged is one [B, G*H] matrix with a [G*H] bias."""
         return 0 if (i == 0 and self.merged0) else B
 
-    def forward(self, x, slot=0, params=None, value_head=None, masks=False):
+    def _head_partials(self, buf, B, every_group):
+        key = "hpart_all" if every_group else "hpart"
+        if buf.get(key) is None:
+            P = (self.dims[-1] + 31) // 32
+            buf[key] = torch.empty((self.G, B, P) if every_group else (B, P), dtype=torch.float32,
+                                   device=self.store.device)
+        return buf[key]
+
+    def _forward_small(self, x, buf, st, value_head, pending):
+        """<= ROW_MAX rows: one launch per layer -- GEMM + bias + ReLU6 (+ the scalar head's per-32-column partial dot
+        products on the last layer) in `kernels.dense_jobs`.  The head's finishing job (partials -> value) is appended
+        to `pending` for the caller's next launch (the policy head's GEMM), or launched here when no list is given."""
+        B = x.shape[0]
+        act, act2d = buf["act"], buf["act2d"]
+        for i in range(self.L):
+            w, b = st[self.wn[i]], st[self.bn[i]]
+            head = None
+            if value_head is not None and i == self.L - 1:
+                g, vw, vb, vout = value_head
+                part = self._head_partials(buf, B, g < 0)
+                head = (g, vw.view(self.G, -1) if g < 0 else vw.view(-1), part)
+            if i == 0 and self.merged0:
+                job = kernels.dense_job_nn(x, w, act2d[0], bias=b.view(-1), relu6=True)
+            else:
+                job = kernels.dense_job_nn(x if i == 0 else act[i - 1], w, act[i], bias=b, relu6=True, head=head)
+            kernels.dense_jobs([job])
+            buf["mask_ok"][i] = False
+        if value_head is not None:
+            g, vw, vb, vout = value_head
+            fin = kernels.dense_job_head_final(part, vb, vout)
+            if pending is not None:
+                pending.append(fin)
+            else:
+                kernels.dense_jobs([fin])
+        return act[-1]
+
+    def head_backward_jobs(self, value, B, slot=0, out=None):
+        """small-row path: the backward of a scalar head on the last layer's output as two jobs for the CALLER's launch
+        (it must precede this stack's backward): dY_last[group] = dvalue (x) w * Relu6Grad, and dW / db of the head.
+        value = (group, w, dvalue, grad_w, grad_b) as in backward(); out: the [G,B,H] gradient buffer backward() gets."""
+        g, w, dv, gw, gb = value
+        act = self._bufs[(B, slot)]["act"][-1]
+        if g < 0:
+            return [kernels.dense_job_rank1(dv, w.view(self.G, -1), act, out),
+                    kernels.dense_job_head_wgrad(dv, act, gw.view(self.G, -1), gb.view(self.G, -1))]
+        return [kernels.dense_job_rank1(dv, w.view(-1), act[g], out[g]),
+                kernels.dense_job_head_wgrad(dv, act[g], gw.view(-1), gb.view(-1))]
+
+    def _backward_small(self, dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows):
+        """<= ROW_MAX rows, `dlast` = gradient w.r.t. the last layer's PRE-activation (its producer applied Relu6Grad):
+        one launch per layer -- dW = X^T dY with the bias gradient (column sums of dY) from the same operand tiles, and
+        dX = dY W^T masked by the ReLU6 of the layer below -- every result final in the flat gradient buffer (the batch
+        is the reduction length of dW: it never leaves a block, no partial slabs, nothing deferred)."""
+        act, dact, dact2d, x = buf["act"], buf["dact"], buf["dact2d"], buf["x"]
+        st = self.store
+        r0, r1 = dw_rows if dw_rows is not None else (0, B)
+        d, d2d = dlast, None
+        dx = None
+        for i in reversed(range(self.L)):
+            w, gw, gb = st[self.wn[i]], st.g(self.wn[i]), st.g(self.bn[i])
+            jobs = []
+            if i == 0:
+                merged = self.merged0
+                if merged:
+                    d2d = dact2d[0] if self.L > 1 else dlast.view(B, -1)
+                    if need_dw:
+                        jobs.append(kernels.dense_job_tn(x[r0:r1], d2d[r0:r1], gw, colsum=gb.view(-1)))
+                    if need_dx:
+                        wx = w if need_dx is True else w[need_dx[0]:need_dx[1]]
+                        a = d2d if dx_rows is None else d2d[dx_rows[0]:dx_rows[1]]
+                        dx = torch.empty(a.shape[0], wx.shape[0], dtype=torch.float32, device=st.device)
+                        jobs.append(kernels.dense_job_nt(a, wx, dx))
+                else:
+                    if need_dw:
+                        jobs.append(kernels.dense_job_tn(x[r0:r1], d[:, r0:r1], gw, colsum=gb))
+                    if need_dx:
+                        if self.G != 1:
+                            raise NotImplementedError("input gradient of an unmerged multi-group first layer")
+                        wx = w[0] if need_dx is True else w[0][need_dx[0]:need_dx[1]]
+                        a = d[0] if dx_rows is None else d[0][dx_rows[0]:dx_rows[1]]
+                        dx = torch.empty(a.shape[0], wx.shape[0], dtype=torch.float32, device=st.device)
+                        jobs.append(kernels.dense_job_nt(a, wx, dx))
+            else:
+                if need_dw:
+                    jobs.append(kernels.dense_job_tn(act[i - 1][:, r0:r1], d[:, r0:r1], gw, colsum=gb))
+                jobs.append(kernels.dense_job_nt(d, w, dact[i - 1], mask=act[i - 1]))
+                d = dact[i - 1]
+            if jobs:
+                kernels.dense_jobs(jobs)
+        return dx
+
+    def forward(self, x, slot=0, params=None, value_head=None, masks=False, pending=None):
         """x: [B, in], shared by all groups.  Returns act[-1]  [G, B, H_last].
         `slot` selects an activation set (a stack evaluated on several inputs in one step keeps one
         set per input for the backward); `params` = another ParamStore with the same layout (SAC
@@ -237,6 +338,8 @@ class DenseStack:
         buf["x"] = x
         self._last = buf
         act, act2d = buf["act"], buf["act2d"]
+        if self.small(B):
+            return self._forward_small(x, buf, st, value_head, pending)
         for i in range(self.L):
             w, b = st[self.wn[i]], st[self.bn[i]]
             if i == 0 and self.merged0:
@@ -269,7 +372,7 @@ class DenseStack:
         return act[-1]
 
     def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None,
-                 dw_rows=None, dx_rows=None):
+                 dw_rows=None, dx_rows=None, premasked=False):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output (the stack's own dact[-1] buffer
         or any contiguous tensor); masked in place.
         `deferred` (a list): the bias-gradient column sums are left as per-chunk partials and a reduce job per
@@ -288,8 +391,12 @@ class DenseStack:
         overlap the next layer's dX GEMM; the caller joins the stream before using the gradients."""
         if B is None:
             B = dlast.shape[1]
-        main = torch.cuda.current_stream() if dw_stream is not None else None
         buf = self._bufs[(B, slot)]
+        if premasked:
+            if not self.small(B) or value is not None or dw_stream is not None:
+                raise ValueError("a pre-masked gradient is the small-row path's input (no folded head, one stream)")
+            return self._backward_small(dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows)
+        main = torch.cuda.current_stream() if dw_stream is not None else None
         act, act2d, dact, dact2d, x = buf["act"], buf["act2d"], buf["dact"], buf["dact2d"], buf["x"]
         d, d2d = dlast, dlast.view(self.G * B, -1)
         dx = None
