@@ -34,6 +34,7 @@
 namespace pfpn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int RD_THREADS = 256;      // 4 waves per block (8-wave blocks with twice the in-block K split measured slower)
 
 struct DenseJobDev {
     PfpnDenseJob j;
@@ -54,7 +55,7 @@ template <bool KC, int T, int BKT, bool VEC>
 struct RowOperand {
     static constexpr int LDK = BKT + 4;
     static constexpr int FLOATS = KC ? T * LDK : BKT * T;
-    static constexpr int NL = T * BKT / 1024;                 // float4 loads per thread and k-tile
+    static constexpr int NL = T * BKT / (4 * RD_THREADS);     // float4 loads per thread and k-tile
     static constexpr int PER_ROW = KC ? BKT / 4 : T / 4;      // float4s per memory row of the tile
     const float* base;          // operand base (always readable: the clamp target)
     const float* p[NL];         // my float4s of the current k-tile
@@ -70,7 +71,7 @@ struct RowOperand {
         step = KC ? (long long)BKT : (long long)BKT * ld;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int idx = t + 256 * j;
+            const int idx = t + RD_THREADS * j;
             const int r = idx / PER_ROW, c4 = (idx % PER_ROW) * 4;
             if (KC) {
                 kk[j] = c4;
@@ -87,48 +88,60 @@ struct RowOperand {
             }
         }
     }
-    // k0 = first k of the tile being fetched.  RAW loads only (clamped addresses, always readable): nothing here uses a
-    // loaded value, so the requests stay in flight across the MFMAs of the current tile; out-of-range elements are zeroed
-    // when the registers go to LDS (store), one k-tile later.
+    // item j of the k-tile that starts at k0.  RAW load only (clamped address, always readable): nothing here uses the
+    // loaded value, so the request stays in flight across the MFMAs of the current tile; out-of-range elements are
+    // zeroed when the register goes to LDS (store1), one k-tile later.
+    // MASKED = false (inside the full k-tiles): no predicate, no select -- one load, one pointer bump; rows / columns of
+    // the tile that lie outside the matrix were clamped to row / column 0 at init and feed only outputs that are never
+    // stored.  (An operand with unaligned rows qualifies only where its tile is interior: see dense_tile.)
+    template <bool MASKED = true>
+    __device__ __forceinline__ void load1(float4 (&r)[NL], int j, int k0) {
+        if (VEC && !MASKED) {
+            r[j] = ld4(p[j]);
+        } else if (!MASKED) {               // unaligned rows, tile interior: four plain dword loads
+            r[j] = make_float4(p[j][0], p[j][1], p[j][2], p[j][3]);
+        } else if (VEC) {
+            const bool ok = tok[j] && (k0 + kk[j] < K);
+            r[j] = ld4(ok ? p[j] : base);
+        } else if (KC) {
+            const int kl = K - (k0 + kk[j]);                 // valid k elements from here
+            float e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = *((tok[j] && q < kl) ? p[j] + q : base);
+            r[j] = make_float4(e[0], e[1], e[2], e[3]);
+        } else {
+            const bool kok = (k0 + kk[j]) < K;
+            float e[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = *((kok && q < tlim[j]) ? p[j] + q : base);
+            r[j] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        p[j] += step;
+    }
     __device__ __forceinline__ void load(float4 (&r)[NL], int k0) {
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            if (VEC) {
-                const bool ok = tok[j] && (k0 + kk[j] < K);
-                r[j] = ld4(ok ? p[j] : base);
-            } else if (KC) {
-                const int kl = K - (k0 + kk[j]);                 // valid k elements from here
-                float e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = *((tok[j] && q < kl) ? p[j] + q : base);
-                r[j] = make_float4(e[0], e[1], e[2], e[3]);
-            } else {
-                const bool kok = (k0 + kk[j]) < K;
-                float e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) e[q] = *((kok && q < tlim[j]) ? p[j] + q : base);
-                r[j] = make_float4(e[0], e[1], e[2], e[3]);
-            }
-            p[j] += step;
-        }
+        for (int j = 0; j < NL; ++j) load1(r, j, k0);
     }
-    // registers of the k-tile that starts at k0 -> LDS, invalid elements as zeros; returns nothing, `r` is masked in place
+    // register j of the k-tile that starts at k0 -> LDS, invalid elements as zeros (`r` is masked in place)
+    template <bool MASKED = true>
+    __device__ __forceinline__ void store1(float* __restrict__ S, float4 (&r)[NL], int j, int k0) const {
+        if (!MASKED) {
+        } else if (VEC) {
+            r[j] = sel4(tok[j] && (k0 + kk[j] < K), r[j]);
+        } else if (KC) {
+            const int kl = K - (k0 + kk[j]);
+            r[j] = make_float4((tok[j] && 0 < kl) ? r[j].x : 0.f, (tok[j] && 1 < kl) ? r[j].y : 0.f,
+                               (tok[j] && 2 < kl) ? r[j].z : 0.f, (tok[j] && 3 < kl) ? r[j].w : 0.f);
+        } else {
+            const bool kok = (k0 + kk[j]) < K;
+            r[j] = make_float4((kok && 0 < tlim[j]) ? r[j].x : 0.f, (kok && 1 < tlim[j]) ? r[j].y : 0.f,
+                               (kok && 2 < tlim[j]) ? r[j].z : 0.f, (kok && 3 < tlim[j]) ? r[j].w : 0.f);
+        }
+        *reinterpret_cast<float4*>(S + sts[j]) = r[j];
+    }
     __device__ __forceinline__ void store(float* __restrict__ S, float4 (&r)[NL], int k0) const {
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            if (VEC) {
-                r[j] = sel4(tok[j] && (k0 + kk[j] < K), r[j]);
-            } else if (KC) {
-                const int kl = K - (k0 + kk[j]);
-                r[j] = make_float4((tok[j] && 0 < kl) ? r[j].x : 0.f, (tok[j] && 1 < kl) ? r[j].y : 0.f,
-                                   (tok[j] && 2 < kl) ? r[j].z : 0.f, (tok[j] && 3 < kl) ? r[j].w : 0.f);
-            } else {
-                const bool kok = (k0 + kk[j]) < K;
-                r[j] = make_float4((kok && 0 < tlim[j]) ? r[j].x : 0.f, (kok && 1 < tlim[j]) ? r[j].y : 0.f,
-                                   (kok && 2 < tlim[j]) ? r[j].z : 0.f, (kok && 3 < tlim[j]) ? r[j].w : 0.f);
-            }
-            *reinterpret_cast<float4*>(S + sts[j]) = r[j];
-        }
+        for (int j = 0; j < NL; ++j) store1(S, r, j, k0);
     }
     // fragment of chunk c of the wave's 32-k slice `wk`, 32-wide block `wt`: f[q], q = MFMA step inside the chunk
     __device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S, int wt, int wk, int c, int lane) const {
@@ -152,10 +165,6 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
     typedef RowOperand<BKC, TN, BKT, true> OpB;
     constexpr int AF = OpA::FLOATS, BF = OpB::FLOATS;
     const PfpnDenseJob& j = d.j;
-    float* As0 = lds;
-    float* Bs0 = lds + AF;
-    float* As1 = lds + AF + BF;
-    float* Bs1 = lds + 2 * AF + BF;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
@@ -172,52 +181,87 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool do_csum = (KIND == PFPN_DENSE_TN) && (j.flags & PFPN_DENSE_COLSUM) && tm == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    float4 ra[OpA::NL], rb[OpB::NL];
-#define RD_STORE(As_, Bs_, k_)                                                                  \
-    do {                                                                                        \
-        opA.store((As_), ra, (k_));                                                             \
-        opB.store((Bs_), rb, (k_));                                                             \
-        if (KIND == PFPN_DENSE_TN && do_csum) {                                                 \
-            _Pragma("unroll") for (int q_ = 0; q_ < OpB::NL; ++q_) {                            \
-                csum.x += rb[q_].x; csum.y += rb[q_].y; csum.z += rb[q_].z; csum.w += rb[q_].w; \
-            }                                                                                   \
-        }                                                                                       \
-    } while (0)
+    // Pipeline: two LDS stages, one register set.  Per k-tile t: every fragment of the wave's k-slice is read up front
+    // (one LDS round trip per tile, not one per MFMA pair), then the 16 MFMAs issue (one dependent chain, 64 cycles each)
+    // with ONE staging item in the shadow of each: the registers of tile t+1 go to the other LDS stage (its readers passed
+    // the last barrier), then the loads of tile t+2 refill them (one iteration, ~0.5 us+, to land).  Items are
+    // unconditional and the body is one basic block -- a branch per item makes hipcc drain vmcnt(0) at every join.  The
+    // loop runs twice: over the k-tiles whose staged and loaded tiles lie wholly inside K with no predicate or select at
+    // all (fp32 MFMA and VALU share the SIMD's issue: ~100 address / mask instructions per tile cost more than the
+    // memory they guard), then over the last tiles with the masks (out-of-range elements become zeros on their way to LDS).
+    constexpr int NA = OpA::NL, NB = OpB::NL;
+    static_assert(2 * (NA + NB) <= 16, "one staging item per MFMA gap");
+    constexpr int STAGE = AF + BF;
+    float4 ra[NA], rb[NB];
     opA.load(ra, 0);
     opB.load(rb, 0);
-    RD_STORE(As0, Bs0, 0);
+    opA.store(lds, ra, 0);
+    opB.store(lds + AF, rb, 0);
+    if (KIND == PFPN_DENSE_TN) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) { csum.x += rb[q].x; csum.y += rb[q].y; csum.z += rb[q].z; csum.w += rb[q].w; }
+    }
     opA.load(ra, BKT);
     opB.load(rb, BKT);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += BKT) {
-        const float* Ac = buf ? As1 : As0;
-        const float* Bc = buf ? Bs1 : Bs0;
-        if (k0 + BKT < K) {
-            if (buf) RD_STORE(As0, Bs0, k0 + BKT); else RD_STORE(As1, Bs1, k0 + BKT);
-            opA.load(ra, k0 + 2 * BKT);
-            opB.load(rb, k0 + 2 * BKT);
-        }
-        float fa[2][4], fb[2][4];
-        opA.frag(fa[0], Ac, wm, wk, 0, lane);
-        opB.frag(fb[0], Bc, wn, wk, 0, lane);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < 3) {
-                opA.frag(fa[(c + 1) & 1], Ac, wm, wk, c + 1, lane);
-                opB.frag(fb[(c + 1) & 1], Bc, wn, wk, c + 1, lane);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][q], fb[c & 1][q], acc, 0, 0, 0);
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-#undef RD_STORE
+    int k0 = 0;
+#ifdef RD_DIAG_NO_LOOP
+    k0 = K;
+#endif
+#define RD_TILE(MASKED_)                                                                                     \
+    do {                                                                                                     \
+        const float* Ac = lds + buf * STAGE;                                                                 \
+        const float* Bc = Ac + AF;                                                                           \
+        float* An = lds + (buf ^ 1) * STAGE;                                                                 \
+        float* Bn = An + AF;                                                                                 \
+        float fa[16], fb[16];                                                                                \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                   \
+            opA.frag(*reinterpret_cast<float(*)[4]>(&fa[4 * c_]), Ac, wm, wk, c_, lane);                     \
+            opB.frag(*reinterpret_cast<float(*)[4]>(&fb[4 * c_]), Bc, wn, wk, c_, lane);                     \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                  \
+            RD_MFMA(i_);                                                                                     \
+            RD_STAGE_ITEM(MASKED_, i_);                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+        __syncthreads();                                                                                     \
+        buf ^= 1;                                                                                            \
+    } while (0)
+#ifndef RD_DIAG_NO_MFMA
+#define RD_MFMA(i_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i_], fb[i_], acc, 0, 0, 0)
+#else
+#define RD_MFMA(i_) acc[i_] += fa[i_] * fb[i_]
+#endif
+#ifndef RD_DIAG_NO_STAGE
+#define RD_STAGE_ITEM(MASKED_, i_)                                                                           \
+    do {                                                                                                     \
+        if ((i_) < NA) opA.template store1<MASKED_>(An, ra, (i_), k0 + BKT);                                 \
+        else if ((i_) < NA + NB) {                                                                           \
+            opB.template store1<MASKED_>(Bn, rb, (i_) - NA, k0 + BKT);                                       \
+            if (KIND == PFPN_DENSE_TN) {                                                                     \
+                const float4 u_ = rb[(i_) - NA];                                                             \
+                csum.x += u_.x; csum.y += u_.y; csum.z += u_.z; csum.w += u_.w;                              \
+            }                                                                                                \
+        } else if ((i_) < 2 * NA + NB) opA.template load1<MASKED_>(ra, (i_) - NA - NB, k0 + 2 * BKT);        \
+        else if ((i_) < 2 * (NA + NB)) opB.template load1<MASKED_>(rb, (i_) - 2 * NA - NB, k0 + 2 * BKT);    \
+    } while (0)
+#else
+#define RD_STAGE_ITEM(MASKED_, i_) do { } while (0)
+#endif
+    // full tiles: iteration t stores tile t+1 and loads tile t+2, both inside K (and the block's rows / columns exist or
+    // were clamped)
+    // (an unaligned tile-contiguous A -- the 197-wide state as X^T -- may end inside a float4: its edge tile keeps the masks)
+    const bool fast = AVEC || AKC || (m0 + TM <= j.M);
+    if (fast)
+        for (; k0 + 3 * BKT <= K; k0 += BKT) RD_TILE(false);
+    for (; k0 < K; k0 += BKT) RD_TILE(true);
+#undef RD_TILE
+#undef RD_MFMA
+#undef RD_STAGE_ITEM
 
     // ---- the K split over the block's waves: partial accumulators through LDS, summed in wave order ----------------
     if (WK > 1) {
@@ -263,13 +307,15 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
             }
             if (ok) C[(size_t)row * j.ldc + col] = v;
             if (head) {
+                // sum over the 32 columns (lanes) of this lane half: four row_shr steps inside each row of 16 lanes, then
+                // row_bcast:15 carries the sum of rows 0 / 2 into rows 1 / 3 -- lanes 31 and 63 hold the two halves' sums
                 float pv = ok ? v * hwv : 0.f;
-                pv += __shfl_xor(pv, 1, 64);
-                pv += __shfl_xor(pv, 2, 64);
-                pv += __shfl_xor(pv, 4, 64);
-                pv += __shfl_xor(pv, 8, 64);
-                pv += __shfl_xor(pv, 16, 64);
-                if (fc == 0 && row < j.M) hp[(size_t)row * hparts + ((n0 >> 5) + wn)] = pv;
+                pv += dpp_shift<0x111, 0xf>(pv, 0.f);
+                pv += dpp_shift<0x112, 0xf>(pv, 0.f);
+                pv += dpp_shift<0x114, 0xf>(pv, 0.f);
+                pv += dpp_shift<0x118, 0xf>(pv, 0.f);
+                pv += dpp_shift<0x142, 0xa>(pv, 0.f);
+                if (fc == 31 && row < j.M) hp[(size_t)row * hparts + ((n0 >> 5) + wn)] = pv;
             }
         }
     }
@@ -282,7 +328,7 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
         __syncthreads();
         if (t < CG) {
             float4 s = red4[t];
-            for (int q = 1; q < 256 / CG; ++q) {
+            for (int q = 1; q < RD_THREADS / CG; ++q) {
                 const float4 u = red4[t + q * CG];
                 s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
             }
@@ -296,9 +342,9 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
 // out[g][b] = hb[g*sBias] + sum_t part[g][b][t] (t ascending): finishes a scalar head whose per-32-column partial dot
 // products the previous layer's epilogue left.
 __device__ __forceinline__ void aux_head_final(const PfpnDenseJob& j, int local) {
-    const int per = (j.M + 255) / 256;
+    const int per = (j.M + RD_THREADS - 1) / RD_THREADS;
     const int g = local / per;
-    const int b = (local - g * per) * 256 + threadIdx.x;
+    const int b = (local - g * per) * RD_THREADS + threadIdx.x;
     if (b >= j.M) return;
     const float* part = j.A + (size_t)g * j.sA + (size_t)b * j.K;
     float s = j.bias[(size_t)g * j.sBias];
@@ -309,9 +355,9 @@ __device__ __forceinline__ void aux_head_final(const PfpnDenseJob& j, int local)
 __device__ __forceinline__ void aux_rank1(const PfpnDenseJob& j, int local) {
     const int n4 = j.N >> 2;
     const size_t per_g = (size_t)j.M * n4;
-    const int bpg = (int)((per_g + 255) / 256);
+    const int bpg = (int)((per_g + RD_THREADS - 1) / RD_THREADS);
     const int g = local / bpg;
-    const size_t i = (size_t)(local - g * bpg) * 256 + threadIdx.x;
+    const size_t i = (size_t)(local - g * bpg) * RD_THREADS + threadIdx.x;
     if (i >= per_g) return;
     const int b = (int)(i / n4), c = (int)(i % n4) * 4;
     const float dv = j.A[(size_t)g * j.sA + b];
@@ -324,36 +370,48 @@ __device__ __forceinline__ void aux_rank1(const PfpnDenseJob& j, int local) {
     o.w = (h.w > 0.f && h.w < 6.f) ? dv * w.w : 0.f;
     *reinterpret_cast<float4*>(j.C + (size_t)g * j.sC + (size_t)b * j.ldc + c) = o;
 }
-// dw[g][c] = sum_b dv[g][b] * h[g][b][c] (b ascending per row phase, the 4 phases in order), db[g] = sum_b dv[g][b]
+// dw[g][c] = sum_b dv[g][b] * h[g][b][c], db[g] = sum_b dv[g][b].  A block owns 32 columns; its 8 row phases each keep
+// four interleaved partial sums (rows ph + 8 q + 32 i: four loads in flight per thread instead of one dependent chain),
+// combined in a fixed order.
 __device__ __forceinline__ void aux_head_wgrad(const PfpnDenseJob& j, int local, float* lds) {
-    const int cblk = (j.N + 63) / 64;
+    const int cblk = (j.N + 31) / 32;
     const int g = local / (cblk + 1);
     const int cb = local - g * (cblk + 1);
     const float* dv = j.A + (size_t)g * j.sA;
     const int t = threadIdx.x;
-    if (cb == cblk) {                       // the bias gradient: 256 strided partial sums, then in thread order
+    if (cb == cblk) {                       // the bias gradient: RD_THREADS strided partial sums, then in thread order
         float s = 0.f;
-        for (int b = t; b < j.M; b += 256) s += dv[b];
+        for (int b = t; b < j.M; b += RD_THREADS) s += dv[b];
         lds[t] = s;
         __syncthreads();
         if (t == 0) {
             float tot = 0.f;
-            for (int q = 0; q < 256; ++q) tot += lds[q];
+            for (int q = 0; q < RD_THREADS; ++q) tot += lds[q];
             j.aux[(size_t)g * j.sAux] = tot;
         }
         return;
     }
-    const int c = cb * 64 + (t & 63), ph = t >> 6;
-    const float* h = j.H + (size_t)g * j.sH;
-    float s = 0.f;
-    if (c < j.N)
-        for (int b = ph; b < j.M; b += 4) s += dv[b] * h[(size_t)b * j.ldh + c];
-    lds[t] = s;
+    constexpr int PH = RD_THREADS / 32;
+    const int c = cb * 32 + (t & 31), ph = t >> 5;
+    const float* h = j.H + (size_t)g * j.sH + (c < j.N ? c : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = ph;
+    for (; b + 3 * PH < j.M; b += 4 * PH) {
+        const float h0 = h[(size_t)b * j.ldh], h1 = h[(size_t)(b + PH) * j.ldh];
+        const float h2 = h[(size_t)(b + 2 * PH) * j.ldh], h3 = h[(size_t)(b + 3 * PH) * j.ldh];
+        s0 += dv[b] * h0; s1 += dv[b + PH] * h1; s2 += dv[b + 2 * PH] * h2; s3 += dv[b + 3 * PH] * h3;
+    }
+    for (; b < j.M; b += PH) s0 += dv[b] * h[(size_t)b * j.ldh];
+    lds[t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (ph == 0 && c < j.N) j.C[(size_t)g * j.sC + c] = (lds[t] + lds[t + 64]) + (lds[t + 128] + lds[t + 192]);
+    if (ph == 0 && c < j.N) {
+        float tot = lds[t];
+        for (int q = 1; q < PH; ++q) tot += lds[t + 32 * q];
+        j.C[(size_t)g * j.sC + c] = tot;
+    }
 }
 
-__global__ __launch_bounds__(256, 2) void k_dense_jobs(DenseTable tab) {
+__global__ __launch_bounds__(RD_THREADS, 2) void k_dense_jobs(DenseTable tab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // the block's job, copied out of the kernel-argument segment with CONSTANT indices (a dynamic index makes hipcc
     // copy the whole table to scratch); everything of it is wave-uniform and stays in SGPRs
@@ -416,7 +474,7 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
     DenseTable tab{};
     tab.n = n_jobs;
     long long blocks = 0, gemm_work = 0;
-    size_t lds = 1024 * sizeof(float);
+    size_t lds = 4 * RD_THREADS * sizeof(float);
     // pass 1: validate, total work of the launch's products (the arrangement of each depends on what shares the chip)
     for (int i = 0; i < n_jobs; ++i) {
         const PfpnDenseJob& j = jobs[i];
@@ -448,16 +506,18 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
             }
             int cfg = j.cfg;
             if (cfg < 0 || cfg > 2) {
-                // smallest tiles (most blocks) while the launch stays under ~4 blocks per CU and a wave keeps >= 64 of K
+                // the largest tile arrangement that still gives the product its share of ~3/4 of the CUs (measured on the
+                // learner's layers at 32 .. 1024 rows, tools/rowdense_gemm_probe.py): bigger tiles move fewer operand bytes
+                // per MFMA, but at one block per CU an idle CU costs more than that
                 cfg = 0;
                 if (force_cfg >= 0 && force_cfg <= 2) cfg = force_cfg;
                 else {
                     const double share = gemm_work > 0 ? (double)j.M * j.N * j.batch * (double)j.K / (double)gemm_work : 1.0;
-                    const double budget = 768.0 * share + 64.0;      // blocks this product may take
-                    for (int c = 1; c <= 2; ++c) {
-                        if (j.K / CFG_WK[c] < 64) break;
-                        if ((double)cfg_blocks(j, c - 1) >= budget) break;      // already enough blocks
+                    const double target = 192.0 * share;
+                    for (int c = 0; c <= 2; ++c) {
+                        if (c > 0 && j.K / CFG_WK[c] < 32) break;
                         cfg = c;
+                        if ((double)cfg_blocks(j, c) >= target) break;
                     }
                 }
             }
@@ -469,15 +529,15 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
             if (need > lds) lds = need;
         } else if (j.kind == PFPN_DENSE_HEAD_FINAL) {
             if (!j.A || !j.C || !j.bias || j.K < 1) return PFPN_ERR_ARG;
-            blocks += (long long)((j.M + 255) / 256) * j.batch;
+            blocks += (long long)((j.M + RD_THREADS - 1) / RD_THREADS) * j.batch;
         } else if (j.kind == PFPN_DENSE_RANK1) {
             if (!j.A || !j.B || !j.C || !j.H || j.N < 4 || (j.N & 3) || (j.ldc & 3) || (j.ldh & 3) || (j.sB & 3) ||
                 (j.sC & 3) || (j.sH & 3) || !al16(j.B) || !al16(j.C) || !al16(j.H))
                 return PFPN_ERR_ARG;
-            blocks += (((long long)j.M * (j.N >> 2) + 255) / 256) * j.batch;
+            blocks += (((long long)j.M * (j.N >> 2) + RD_THREADS - 1) / RD_THREADS) * j.batch;
         } else if (j.kind == PFPN_DENSE_HEAD_WGRAD) {
             if (!j.A || !j.C || !j.H || !j.aux || j.N < 1) return PFPN_ERR_ARG;
-            blocks += (long long)((j.N + 63) / 64 + 1) * j.batch;
+            blocks += (long long)((j.N + 31) / 32 + 1) * j.batch;
         } else {
             return PFPN_ERR_ARG;
         }
@@ -490,7 +550,7 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
             return PFPN_ERR_LAUNCH;
         lds_set = 72 * 1024;
     }
-    hipLaunchKernelGGL(k_dense_jobs, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, tab);
+    hipLaunchKernelGGL(k_dense_jobs, dim3((unsigned)blocks), dim3(RD_THREADS), lds, (hipStream_t)stream, tab);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -135,10 +135,11 @@ class DenseStack:
 
     MAX_BUFFER_SETS = 64
     # batches of at most this many rows run on the hand-written small-row dense kernels (csrc/rowdense_kernels.hip):
-    # ONE launch per layer and direction with every epilogue fused; above it PyTorch-ROCm GEMMs + the streaming epilogue
-    # kernels (threshold by measurement; PFPN_ROWDENSE_MAX=0 switches the family off)
-    ROW_MAX = int(os.environ.get("PFPN_ROWDENSE_MAX", "1024"))
-
+    # ONE launch per layer and direction with every epilogue fused (10 launches per DPPO step instead of 16).  Threshold
+    # by measurement (tools/rowdense_probe.py): on MI355X the family ties PyTorch-ROCm GEMMs + the
+    # streaming epilogue kernels at 32 rows (93 vs 91 us per step) and loses above (156 vs 130 us at 512 rows), so the
+    # default keeps the library path; PFPN_ROWDENSE_MAX=<rows> routes batches up to that size through the family.
+    ROW_MAX = int(os.environ.get("PFPN_ROWDENSE_MAX", "0"))
     rowdense = False            # set by the owning network once all of its callers speak the small-row protocol
 
     def small(self, B):

@@ -191,3 +191,35 @@ def test_argument_validation(dev):
         kernels.dense_job_nn(x, torch.zeros(5, 8, device=dev), out)
     with pytest.raises(ValueError):
         kernels.dense_jobs([])
+
+
+@pytest.mark.parametrize("B", [32, 256, 600])
+def test_learner_step_through_the_family_matches_the_library_path(dev, monkeypatch, B):
+    """the whole DPPO step with every dense layer on the job kernel (10 launches) against the same step on PyTorch-ROCm
+    GEMMs + epilogue kernels: same losses, gradients and updated parameters up to fp32 summation order."""
+    from test_gpu_dppo_step import make_net, make_batch
+    from pfpn_amd.models import SyncReplicasApplier
+    from pfpn_amd.networks.ops import DenseStack
+    monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
+    res = []
+    for rmax in (0, 1 << 20):
+        monkeypatch.setattr(DenseStack, "ROW_MAX", rmax)
+        net = make_net(dev, seed=3, resample_interval=10 ** 9)
+        opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+        rng = np.random.default_rng(B)
+        for it in range(2):
+            b = make_batch(rng, B)
+            b["log_prob"] = np.full(B, -40.0, np.float32)
+            loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+        assert net.trunk.small(B) == (rmax > 0)
+        res.append((loss, net.store.grad.clone(), net.store.flat.clone(), net.value_buf.clone(),
+                    net.train_out["logp"].clone()))
+    (l0, g0, p0, v0, lp0), (l1, g1, p1, v1, lp1) = res
+    np.testing.assert_allclose([l1[0], l1[2], l1[3]], [l0[0], l0[2], l0[3]], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(lp1, lp0, rtol=1e-5, atol=0)
+    assert float((v1 - v0).abs().max()) <= 1e-6
+    # gradients: 1e-4 of the largest entry of the buffer (Relu6Grad masks flip nowhere: both paths mask by the same
+    # activations up to rounding, and the batches keep the pre-activations off the kinks with probability ~1)
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 1e-4 * scale
+    assert float((p1 - p0).abs().max()) <= 2e-6
