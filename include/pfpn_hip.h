@@ -387,6 +387,23 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
  * soft_target[i] <- (1 - soft_tau) soft_target[i] + soft_tau params[soft_off + i] (pfpn_soft_update's arithmetic). */
 int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm_scale, float* beta_pow, int n_groups,
                             float beta1, float beta2, void* workspace, size_t workspace_bytes, void* stream);
+/* Sharded exchange of the same step (W replicas; sync_model.py:64-95 semantics unchanged): the mean of the per-replica
+ * clipped gradients is sum_w s_w g_w / W with ONE scalar s_w per replica, so the gradient bytes need not wait for the norm.
+ * pfpn_clip_scale_only leaves {norm, s_w} in norm_scale WITHOUT touching the gradients (from the partial sums of
+ * pfpn_reduce_jobs_norm when sq_partial != NULL -- the powers were rotated there -- else from grads, rotating beta_pow
+ * like pfpn_clip_scale_inplace).  After an all-to-all (replica w's slice j of the bucket [grads | statistics] to replica j)
+ * and an all-gather of the W scalars, pfpn_shard_adam on replica j: for its bucket-space slice [shard_lo, shard_lo +
+ * shard_len): gradient = (sum_w scales[w] * recv[w][i]) / W in replica order, TF-Adam ("used" powers, group learning
+ * rates) on params_x / m / v at those indices; indices in [n_params, n_bucket) (the replicated statistics) become the
+ * plain replica mean, written to params_x at the same index; bumps step_counter.  recv [world][shard_len].  An all-gather
+ * of params_x then hands every replica the owners' bits (replicas stay bit-identical). */
+int pfpn_clip_scale_only(const float* grads, size_t n, float clip_norm, float* norm_scale, const float* sq_partial,
+                         int n_partials, float* beta_pow, int n_groups, float beta1, float beta2, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int pfpn_shard_adam(float* params_x, float* m, float* v, const float* recv, const float* scales, int world,
+                    long long shard_lo, long long shard_len, long long n_params, long long n_bucket, int n_groups,
+                    const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                    float beta2, float eps, const float* beta_pow, float* step_counter, void* stream);
 int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                      const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                      float beta2, float eps, const float* beta_pow, float grad_mul, float* step_counter,

@@ -777,6 +777,63 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
     }
 }
 
+
+// ---- sharded exchange (data parallel): the owner of a 1/W slice of the bucket forms the MEAN of the per-replica CLIPPED
+// gradients itself -- sum_w s_w g_w / W with ONE scalar s_w per replica (its clip factor) -- from the W unscaled slices an
+// all-to-all delivered, applies TF-Adam to its slice of the parameters only, and turns the statistics behind the
+// gradients into replica means (sync_model.py:64-95: per-worker clip_by_global_norm, accumulator mean, 14 x ApplyAdam,
+// push_weights).  The bytes of a gradient can leave a replica before its norm is known; Adam's traffic is 1/W per replica.
+__global__ __launch_bounds__(256) void k_shard_adam(float* __restrict__ px, float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ recv, const float* __restrict__ scales,
+                                                    int W, size_t lo4, size_t L4, size_t size4, size_t nb4, AdamGroups gr,
+                                                    float b1, float b2, float eps, const float* __restrict__ beta_pow,
+                                                    float* __restrict__ step) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && step) step[0] += 1.0f;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2, invw = 1.0f / (float)W;
+    float alpha[4];
+    for (int k = 0; k < 4; ++k)
+        alpha[k] = k < gr.n ? gr.lr[k] * sqrtf(1.f - beta_pow[4 * k + 3]) / (1.f - beta_pow[4 * k + 2]) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < L4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t idx = lo4 + i;                          // float4 index in bucket space
+        if (idx >= nb4) continue;                            // padding behind the bucket
+        const float4* r = reinterpret_cast<const float4*>(recv) + i;
+        if (idx < size4) {
+            float4 g = r[0];
+            const float s0 = scales[0];
+            g.x *= s0; g.y *= s0; g.z *= s0; g.w *= s0;
+            for (int w = 1; w < W; ++w) {                    // replica order: every owner sums the same way
+                const float4 u = r[(size_t)w * L4];
+                const float sw = scales[w];
+                g.x += u.x * sw; g.y += u.y * sw; g.z += u.z * sw; g.w += u.w * sw;
+            }
+            g.x *= invw; g.y *= invw; g.z *= invw; g.w *= invw;
+            int k = -1;
+            for (int q = 0; q < gr.n; ++q)
+                if (idx >= ((size_t)gr.off[q] >> 2) && idx < ((size_t)(gr.off[q] + gr.len[q]) >> 2)) k = q;
+            if (k < 0) continue;
+            float4 pp = reinterpret_cast<float4*>(px)[idx];
+            float4 mm = reinterpret_cast<float4*>(m)[idx];
+            float4 vv = reinterpret_cast<float4*>(v)[idx];
+            const float a = alpha[k];
+            adam1(pp.x, g.x, mm.x, vv.x, a, omb1, omb2, eps);
+            adam1(pp.y, g.y, mm.y, vv.y, a, omb1, omb2, eps);
+            adam1(pp.z, g.z, mm.z, vv.z, a, omb1, omb2, eps);
+            adam1(pp.w, g.w, mm.w, vv.w, a, omb1, omb2, eps);
+            reinterpret_cast<float4*>(px)[idx] = pp;
+            reinterpret_cast<float4*>(m)[idx] = mm;
+            reinterpret_cast<float4*>(v)[idx] = vv;
+        } else {                                             // replicated statistics: plain mean over the replicas
+            float4 t = r[0];
+            for (int w = 1; w < W; ++w) {
+                const float4 u = r[(size_t)w * L4];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            t.x *= invw; t.y *= invw; t.z *= invw; t.w *= invw;
+            reinterpret_cast<float4*>(px)[idx] = t;
+        }
+    }
+}
+
 // beta powers advance after the applies (Adam/mul, Adam/mul_1 in the saved graph)
 __global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2, float* __restrict__ step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1704,6 +1761,59 @@ int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, flo
     if (!grads || !norm_scale || !sq_partial || n < 1 || n_partials < 1 || ((uintptr_t)grads & 15)) return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_clip_scale_inplace, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, grads, n,
                        sq_partial, n_partials, clip_norm, norm_scale);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_clip_scale_only(const float* grads, size_t n, float clip_norm, float* norm_scale, const float* sq_partial,
+                         int n_partials, float* beta_pow, int n_groups, float beta1, float beta2, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
+    if (!norm_scale || (beta_pow && (n_groups < 1 || n_groups > 4))) return PFPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (sq_partial) {                    // partial sums (and rotated powers) left by pfpn_reduce_jobs_norm
+        if (n_partials < 1) return PFPN_ERR_ARG;
+        hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, st, sq_partial, n_partials, clip_norm, norm_scale);
+        PFPN_CHECK_LAUNCH();
+        return PFPN_OK;
+    }
+    if (!grads || n < 1 || ((uintptr_t)grads & 15)) return PFPN_ERR_ARG;
+    if (!workspace || workspace_bytes < 256 * sizeof(float)) return PFPN_ERR_WORKSPACE;
+    int nblk = stream_grid(n >> 2);
+    if (nblk > 256) nblk = 256;
+    float* partial = (float*)workspace;
+    if (beta_pow)
+        hipLaunchKernelGGL(k_sqsum_partial_rot, dim3(nblk), dim3(256), 0, st, grads, n, partial, beta_pow, n_groups, beta1,
+                           beta2);
+    else
+        hipLaunchKernelGGL(k_sqsum_partial, dim3(nblk), dim3(256), 0, st, grads, n, partial);
+    PFPN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_clip_scale, dim3(1), dim3(256), 0, st, (const float*)partial, nblk, clip_norm, norm_scale);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_shard_adam(float* params_x, float* m, float* v, const float* recv, const float* scales, int world,
+                    long long shard_lo, long long shard_len, long long n_params, long long n_bucket, int n_groups,
+                    const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
+                    float beta2, float eps, const float* beta_pow, float* step_counter, void* stream) {
+    PFPN_BEGIN();
+    if (!params_x || !m || !v || !recv || !scales || !beta_pow || !group_off || !group_len || !group_lr || world < 1 ||
+        n_groups < 1 || n_groups > 4 || shard_lo < 0 || shard_len < 4 || n_params < 4 || n_bucket < n_params)
+        return PFPN_ERR_ARG;
+    if ((shard_lo | shard_len | n_params | n_bucket) & 3) return PFPN_ERR_ARG;
+    if (((uintptr_t)params_x | (uintptr_t)m | (uintptr_t)v | (uintptr_t)recv) & 15) return PFPN_ERR_ARG;
+    AdamGroups gr{};
+    gr.n = n_groups;
+    for (int k = 0; k < n_groups; ++k) {
+        if (group_off[k] < 0 || group_len[k] < 0 || (group_off[k] & 3) || (group_len[k] & 3) ||
+            group_off[k] + group_len[k] > n_params)
+            return PFPN_ERR_ARG;
+        gr.off[k] = group_off[k]; gr.len[k] = group_len[k]; gr.lr[k] = group_lr[k];
+    }
+    hipLaunchKernelGGL(k_shard_adam, dim3(stream_grid((size_t)shard_len >> 2)), dim3(256), 0, (hipStream_t)stream,
+                       params_x, m, v, recv, scales, world, (size_t)shard_lo >> 2, (size_t)shard_len >> 2,
+                       (size_t)n_params >> 2, (size_t)n_bucket >> 2, gr, beta1, beta2, eps, beta_pow, step_counter);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -137,6 +137,7 @@ class GraphedLearnerStep(object):
         if self.split:
             self.opt.reduce(self.net)
             self.graph_post.replay()
+            self.opt.finish_reduce(self.net)         # (sharded exchange: the all-gather of the owners' slices)
         for _ in range(self.K):
             self.opt.apply_host(self.net)
         return self.loss3

@@ -727,6 +727,40 @@ def clip_scale_inplace(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0
                                            float(beta2), ws, wsn, _stream()), "pfpn_clip_scale_inplace")
 
 
+def clip_scale_only(grads_flat, clip_norm, norm_scale, beta_pow=None, beta1=0.9, beta2=0.999, prenorm=None):
+    """norm_scale <- {global norm, clip factor} WITHOUT touching the gradients (sharded exchange: the owner of a bucket
+    slice applies every replica's factor itself).  prenorm = (partial, count) from reduce_jobs(norm=...): one launch, the
+    powers were rotated there; else two launches over the gradients, rotating the [G,4] Adam powers when given."""
+    lib = _lib.load()
+    if prenorm is not None:
+        _lib.check(lib.pfpn_clip_scale_only(None, 0, float(clip_norm), _f32(norm_scale, 2), _f32(prenorm[0]),
+                                            int(prenorm[1]), None, 0, 0.0, 0.0, None, 0, _stream()), "pfpn_clip_scale_only")
+        return
+    ws, wsn = _learn_ws(1, 1, grads_flat.device)
+    G = beta_pow.shape[0] if beta_pow is not None else 0
+    _lib.check(lib.pfpn_clip_scale_only(_f32(grads_flat), grads_flat.numel(), float(clip_norm), _f32(norm_scale, 2), None, 0,
+                                        _f32(beta_pow, G, 4) if beta_pow is not None else None, G, float(beta1),
+                                        float(beta2), ws, wsn, _stream()), "pfpn_clip_scale_only")
+
+
+def shard_adam(params_x, m, v, recv, scales, world, shard_lo, shard_len, n_params, n_bucket, group_off, group_len, group_lr,
+               beta_pow, beta1=0.9, beta2=0.999, eps=1e-8, step_counter=None):
+    """the owner's part of the sharded exchange (pfpn_shard_adam): mean of the replicas' clipped gradients on the bucket
+    slice [shard_lo, shard_lo + shard_len), TF-Adam there, statistics slice -> replica mean."""
+    lib = _lib.load()
+    if recv.numel() != world * shard_len or scales.numel() != world or params_x.numel() < shard_lo + shard_len or \
+            shard_lo + shard_len > world * shard_len or min(m.numel(), v.numel()) < n_params or \
+            params_x.numel() < n_bucket:
+        raise ValueError("sharded exchange buffers do not match the shard geometry")
+    G = len(group_off)
+    _lib.check(lib.pfpn_shard_adam(_f32(params_x), _f32(m), _f32(v), _f32(recv), _f32(scales, world), int(world),
+                                   int(shard_lo), int(shard_len), int(n_params), int(n_bucket), G,
+                                   ctypes.addressof(group_off), ctypes.addressof(group_len), ctypes.addressof(group_lr),
+                                   float(beta1), float(beta2), float(eps), _f32(beta_pow, G, 4),
+                                   _f32(step_counter, 1) if step_counter is not None else None, _stream()),
+               "pfpn_shard_adam")
+
+
 def adam_groups(params, grads, m, v, group_off, group_len, group_lr, beta_pow, grad_mul=1.0, beta1=0.9, beta2=0.999,
                 eps=1e-8, step_counter=None, scale=None, scale_mul=1.0, soft=None):
     """TF-Adam of every parameter group in one launch, on the powers pfpn_clip_scale_inplace / pfpn_clip_adam rotated.

@@ -23,6 +23,32 @@ from .distributed_model import AbstractDistributedWorker, DistributedModel
 __all__ = ["SyncModel", "SyncReplicasApplier"]
 
 
+def _host_staged(t, group):
+    """gloo moves all-to-all / all-gather through host memory only: GPU tensors are staged (the multi-rank tests that share
+    one GPU run over gloo; RCCL takes device tensors as they are)."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(out, inp, group):
+    if _host_staged(inp, group):
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_to_all_single(o, i, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
+def _all_gather(out, inp, group):
+    if _host_staged(inp, group):
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_gather_into_tensor(o, i, group=group)
+        out.copy_(o)
+    elif dist.get_backend(group) == "gloo":
+        dist.all_gather_into_tensor(out, inp.clone(), group=group)      # (`inp` may be a slice of `out`: RCCL gathers in place)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class SyncReplicasApplier(object):
     """clip (per replica) -> mean over replicas -> TF-Adam -> statistics -> train_ops.
 
@@ -31,7 +57,7 @@ class SyncReplicasApplier(object):
     reference base_worker.py:33-45)."""
 
     def __init__(self, net, groups, norm_clip=None, beta1=0.9, beta2=0.999, epsilon=1e-8,
-                 process_group=None, world_size=None, force_exchange=False):
+                 process_group=None, world_size=None, force_exchange=False, exchange_mode=None):
         self.net = net
         st = net.store
         self.norm_clip = norm_clip
@@ -79,7 +105,28 @@ class SyncReplicasApplier(object):
         if self._soft_net and not getattr(net, "_soft_by_optimizer", False):
             net.train_ops.remove(net.sync_target_net_soft)
             net._soft_by_optimizer = True
-        if self.exchange and hasattr(net, "adopt_tail_statistics"):
+        # Exchange form (PFPN_EXCHANGE): "allreduce" (default) = ONE all-reduce of the bucket of per-replica clipped
+        # gradients + statistics, every replica applies Adam to the whole buffer; "sharded" = all-to-all of UNSCALED bucket
+        # slices to their owners (the bytes do not wait for the norm: they can leave while the rest of the backward runs),
+        # all-gather of the W clip factors, each owner forms sum_w s_w g_w / W in replica order and runs Adam on 1/W of
+        # the buffer, in-place all-gather of the parameter + statistics slices.  Same semantics
+        # (sync_model.py:64-95), same results up to the order of W additions; replicas stay bit-identical.
+        mode = os.environ.get("PFPN_EXCHANGE", "allreduce") if exchange_mode is None else exchange_mode
+        if mode not in ("allreduce", "sharded"):
+            raise ValueError("PFPN_EXCHANGE is 'allreduce' or 'sharded'")
+        self.sharded = bool(self.exchange and mode == "sharded")
+        if self.sharded:
+            W = self.world
+            if st.npad % (4 * W) or not self._fused_ok() or self._soft_net or st.device.type != "cuda":
+                raise ValueError("the sharded exchange needs a replica count that divides the padded buffer into 16-byte "
+                                 "slices, a global-norm clip, <= 4 Adam groups and no soft target network")
+            self.shard_len = st.npad // W
+            self.recv = torch.zeros(st.npad, dtype=torch.float32, device=st.device)
+            self.scales = torch.ones(W, dtype=torch.float32, device=st.device)
+            self.rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
+            if hasattr(net, "adopt_tail_statistics"):
+                net.adopt_tail_statistics(home=st.flat_tail)
+        elif self.exchange and hasattr(net, "adopt_tail_statistics"):
             net.adopt_tail_statistics()        # replicated statistics live in the all-reduce bucket from now on
 
     # -- device part (no host sync) ------------------------------------------------------------------------
@@ -101,6 +148,7 @@ class SyncReplicasApplier(object):
             self.pre_reduce(net)
             self.reduce(net)
             self.post_reduce(net)
+            self.finish_reduce(net)
             return
         net.join_side_stream()
         soft = net.soft_update_args() if self._soft_net else None
@@ -126,9 +174,15 @@ class SyncReplicasApplier(object):
 
     def pre_reduce(self, net):
         """per-replica global-norm clip of the local gradients, in place (the bucket then holds what
-        `AccumulatorApplyGradient_i` receives in the reference's graph)."""
+        `AccumulatorApplyGradient_i` receives in the reference's graph).  Sharded exchange: only the clip FACTOR is
+        formed (norm_scale[1]); the gradients stay as they are and the activation statistics join them in the tail."""
         st = net.store
         net.join_side_stream()
+        if self.sharded:
+            kernels.clip_scale_only(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2,
+                                    prenorm=self._prenorm(net))
+            net.pack_local_stats(st.tail)
+            return
         if self._fused_ok():
             kernels.clip_scale_inplace(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2,
                                        prenorm=self._prenorm(net))
@@ -138,6 +192,12 @@ class SyncReplicasApplier(object):
     def post_reduce(self, net):
         """Adam on the all-reduced sum with 1/W folded in; the statistics tail becomes the replica mean."""
         st, W = net.store, self.world
+        if self.sharded:
+            L = self.shard_len
+            kernels.shard_adam(st.flatx, st.m, st.v, self.recv, self.scales, W, self.rank * L, L, st.size,
+                               st.size + st.extra, self._g_off, self._g_len, self._g_lr, self.beta_pow, self.beta1,
+                               self.beta2, self.epsilon, step_counter=net.step_dev)
+            return
         soft = net.soft_update_args() if self._soft_net else None
         if self._fused_ok():
             in_tail = getattr(net, "_stats_in_tail", False) and st.tail.numel() > 0
@@ -166,8 +226,20 @@ class SyncReplicasApplier(object):
         (reference sync_model.py:92-95 accumulators 0-13 for the gradients, 14-17 for push_weights).
         Plain torch ops only, so the same code runs over gloo on CPU tensors in the tests."""
         st = net.store
+        if getattr(self, "sharded", False):
+            # slice j of every replica's bucket [unscaled grads | local statistics] to replica j; the W clip factors to all
+            _all_to_all(self.recv, st.bucketx, self.pg)
+            _all_gather(self.scales, self.norm_scale[1:2], self.pg)
+            return
         net.pack_local_stats(st.tail)
         dist.all_reduce(st.bucket, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def finish_reduce(self, net):
+        """sharded exchange: every replica receives the owners' parameter + statistics slices (in place: its own slice is
+        already where it belongs).  No-op for the all-reduce form."""
+        if getattr(self, "sharded", False):
+            st, L = net.store, self.shard_len
+            _all_gather(st.flatx, st.flatx[self.rank * L:(self.rank + 1) * L], self.pg)
 
     # -- host part -----------------------------------------------------------------------------------
     def apply_host(self, net):

@@ -329,16 +329,20 @@ class ActorCriticNetwork(object):
         return [(self.state_normalizer, "mean"), (self.state_normalizer, "std")] \
             if (self.normalize_state and self.trainable) else []
 
-    def adopt_tail_statistics(self):
+    def adopt_tail_statistics(self, home=None):
         """Data-parallel runs: the replicated statistics LIVE in the all-reduce bucket's tail (the attributes become
         views of it), so nothing is packed before the all-reduce and one scale by 1/W afterwards turns the sums
-        into the replica mean for all of them."""
-        tail = self.store.tail
+        into the replica mean for all of them.
+        `home` (sharded exchange): they live behind the PARAMETERS instead (store.flat_tail) -- the all-gather of the
+        parameter slices hands every replica the owners' means -- while a replica's local contribution still travels in
+        the bucket tail (the EMA writes it there, pack_local_stats copies the activation statistics)."""
+        tail = self.store.tail if home is None else home
         for (t, off, n, _), (owner, attr) in zip(self.stat_slots(), self._stat_attrs()):
             view = tail[off:off + n].view(t.shape)
             view.copy_(t)
             setattr(owner, attr, view)
-        self._stats_in_tail = True
+        self._stats_in_tail = home is None
+        self._stats_in_flat = home is not None
 
     def pack_local_stats(self, tail):
         if getattr(self, "_stats_in_tail", False):
@@ -410,7 +414,9 @@ class ActorCriticNetwork(object):
             return x
         nz, tail, S = self.state_normalizer, self.store.tail, self.S
         B = state.shape[0]
-        in_place = self.dp_world == 1 or getattr(self, "_stats_in_tail", False)
+        # (sharded exchange: the statistics live behind the parameters, a replica's contribution goes to the bucket tail)
+        in_place = (self.dp_world == 1 and not getattr(self, "_stats_in_flat", False)) or \
+            getattr(self, "_stats_in_tail", False)
         if deferred is not None:
             # the moments stay in a private workspace; the EMA itself is one job of the step's single reduce launch
             # (its result is first read by the NEXT step's prologue)
@@ -442,7 +448,8 @@ class ActorCriticNetwork(object):
         side = self.side_stream if self.overlap_ema else main
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            if self.dp_world == 1 or getattr(self, "_stats_in_tail", False):
+            if (self.dp_world == 1 and not getattr(self, "_stats_in_flat", False)) or \
+                    getattr(self, "_stats_in_tail", False):
                 nz.updated(state, self.step_dev, nz.mean, nz.std)
             else:
                 nz.updated(state, self.step_dev, tail[:S], tail[S:2 * S])

@@ -50,8 +50,16 @@ class ParamStore:
 
     def allocate(self, extra=0, with_optimizer=True):
         self.extra = (int(extra) + 3) // 4 * 4
-        self.flat = torch.zeros(self.size, dtype=torch.float32, device=self.device)
-        self.bucket = torch.zeros(self.size + self.extra, dtype=torch.float32, device=self.device)
+        # both buffers are padded to a multiple of 256 floats (zeros): any power-of-two replica count up to 64 then cuts
+        # them into equal 16-byte-aligned slices (the sharded exchange: an all-to-all of bucket slices to their owners,
+        # an in-place all-gather of the parameter slices), and the parameter buffer has room behind the parameters for
+        # the replicated statistics -- the bucket's index space [parameters | statistics | padding] on both sides
+        self.npad = (self.size + self.extra + 255) // 256 * 256
+        self.flatx = torch.zeros(self.npad, dtype=torch.float32, device=self.device)
+        self.flat = self.flatx[:self.size]
+        self.flat_tail = self.flatx[self.size:self.size + self.extra]
+        self.bucketx = torch.zeros(self.npad, dtype=torch.float32, device=self.device)
+        self.bucket = self.bucketx[:self.size + self.extra]
         self.grad = self.bucket[:self.size]
         self.tail = self.bucket[self.size:]
         if with_optimizer:

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, q):
+def _rank(rank, world, port, q, mode="allreduce"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,8 +35,8 @@ def _rank(rank, world, port, q):
         from test_gpu_dppo_step import make_batch, make_net, sync_oracle_state
         dev = torch.device("cuda:0")
         net = make_net(dev, resample_interval=2)
-        opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world)
-        assert net.dp_world == 2
+        opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world, exchange_mode=mode)
+        assert net.dp_world == world and opt.sharded == (mode == "sharded")
         st = orc.DPPOState(np.random.default_rng(0), resample_interval=2)
         sync_oracle_state(orc, net, st)
         rng = np.random.default_rng(77)                 # same stream on both ranks: all shards known everywhere
@@ -92,21 +92,24 @@ def _rank(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_learner_step_matches_oracle(dev):
+@pytest.mark.parametrize("world,mode", [(2, "allreduce"), (2, "sharded"), (4, "sharded")])
+def test_two_rank_learner_step_matches_oracle(dev, world, mode):
+    """`sharded`: all-to-all of unscaled bucket slices, the owner's sum_w s_w g_w / W + Adam on its slice, all-gather
+    (pfpn_amd/models/sync_model.py) -- the same reference semantics as the all-reduce form."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(60)
     assert all(r[1] for r in res), res
-    assert res[0][2] == res[1][2] and res[0][3] == res[1][3], "replicas diverged"
+    assert all(r[2] == res[0][2] and r[3] == res[0][3] for r in res), "replicas diverged"
 
 
-def _golden_rank(rank, world, port, q, tag):
+def _golden_rank(rank, world, port, q, tag, mode="allreduce"):
     """Two replicas against the reference graph's own two-worker step (tests/golden/graph_*_w2.npz: per-worker clipped
     gradients and statistics through the accumulator means, Assign..Assign_3, 14 x ApplyAdam, resample cond)."""
     import torch.distributed as dist
@@ -121,7 +124,9 @@ def _golden_rank(rank, world, port, q, tag):
         fi = gg.fi
         dev = torch.device("cuda:0")
         fx = gg.load(tag)
+        os.environ["PFPN_EXCHANGE"] = mode
         net, opt = gg.build(dev, fx, world=world)
+        assert opt.sharded == (mode == "sharded")
         net.max_active.copy_(torch.from_numpy(fx["in%d:max_active" % rank]))
         net.sum_active.copy_(torch.from_numpy(fx["in%d:sum_active" % rank]))
         if bool(fx["fired"]):
@@ -164,11 +169,12 @@ def _golden_rank(rank, world, port, q, tag):
 
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("tag", ["step_b64_w2", "resample_b32_w2"])
-def test_two_rank_step_matches_reference_graph(dev, tag):
+@pytest.mark.parametrize("mode", ["allreduce", "sharded"])
+def test_two_rank_step_matches_reference_graph(dev, tag, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_golden_rank, args=(r, 2, port, q, tag)) for r in range(2)]
+    procs = [ctx.Process(target=_golden_rank, args=(r, 2, port, q, tag, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -283,6 +289,73 @@ def test_exchange_path_over_rccl_single_rank_matches_fused_path(dev):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_rank, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert res[1], res
+
+
+def _rccl_sharded_rank(port, q):
+    """world-size-1 RCCL group, sharded exchange (all-to-all, factor all-gather, owner Adam, in-place all-gather through
+    RCCL): eager for every step on one replica, captured as two hipGraphs on another -- same bits; against the single-replica
+    fused path to summation-order precision; a training round driven through worker-style flat_train plans."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        from pfpn_amd.models import SyncReplicasApplier
+        from test_gpu_dppo_step import make_batch, make_net
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        nets = [make_net(dev, seed=9, resample_interval=3) for _ in range(3)]
+        opts = [SyncReplicasApplier(nets[0], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True,
+                                    exchange_mode="sharded"),
+                SyncReplicasApplier(nets[1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True,
+                                    exchange_mode="sharded"),
+                SyncReplicasApplier(nets[2], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)]
+        ok = opts[0].sharded and opts[1].sharded and not opts[2].exchange and nets[0]._stats_in_flat
+        rng = np.random.default_rng(4)
+        for it in range(9):
+            b = make_batch(rng, 256)
+            b["log_prob"] = np.full(256, -40.0, F)
+            mx = torch.rand(36, 35, device=dev); sm = torch.rand(36, 35, device=dev) * 5
+            out = []
+            for i, (net, opt) in enumerate(zip(nets, opts)):
+                os.environ["PFPN_GRAPH_TRAIN"] = "0" if i == 1 else "1"
+                net.max_active.copy_(mx); net.sum_active.copy_(sm)
+                out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
+                                     b["advantage"]))
+            ok &= out[0] == out[1]
+            ok &= torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
+            ok &= torch.equal(nets[0].state_normalizer.mean, nets[1].state_normalizer.mean)
+            ok &= torch.equal(nets[0].max_active, nets[1].max_active) and torch.equal(nets[0].sum_active, nets[1].sum_active)
+            # one replica: the owner's sum has ONE term, so only the norm's partial-sum grouping differs from the fused path
+            ok &= bool(torch.allclose(nets[0].store.flat, nets[2].store.flat, rtol=1e-5, atol=2e-8))
+            ok &= bool(torch.allclose(nets[0].state_normalizer.std, nets[2].state_normalizer.std, rtol=1e-6))
+            ok &= bool(torch.allclose(nets[0].sum_active, nets[2].sum_active, rtol=1e-6))
+        os.environ["PFPN_GRAPH_TRAIN"] = "1"
+        ok &= nets[0].global_step == 9 and nets[0].train_flag == 0
+        g = list(nets[0]._train_graphs.values())
+        ok &= len(g) == 1 and g[0].split and len(nets[1]._train_graphs) == 0
+        q.put((0, bool(ok), "", ""))
+    except Exception as e:
+        import traceback
+        traceback.print_exc()
+        q.put((0, False, repr(e), ""))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_exchange_over_rccl_single_rank(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_sharded_rank, args=(_free_port(), q))
     p.start()
     res = q.get(timeout=240)
     p.join(60)
