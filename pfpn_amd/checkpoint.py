@@ -343,6 +343,8 @@ def network_tensors(net, optimizer=None, n_workers=0, total_samples=0, episodes=
     for name, t in var.items():
         out[SCOPE + name] = cpu(t).astype(np.float32)
     if optimizer is not None and net.store.m is not None:
+        if hasattr(optimizer, "gather_optimizer_state"):
+            optimizer.gather_optimizer_state(net)        # (sharded exchange: every replica takes part in the all-gather)
         st = net.store
         for slot, buf in (("Adam", st.m), ("Adam_1", st.v)):
             for name, t in net.variables(st.views_of(buf)).items():

@@ -241,6 +241,14 @@ class SyncReplicasApplier(object):
             st, L = net.store, self.shard_len
             _all_gather(st.flatx, st.flatx[self.rank * L:(self.rank + 1) * L], self.pg)
 
+    def gather_optimizer_state(self, net):
+        """sharded exchange: a replica's Adam slots are current on ITS slice only; all-gather both (in place) so that every
+        replica holds the complete slots (checkpoint writer, tests).  No-op otherwise."""
+        if getattr(self, "sharded", False):
+            st, L = net.store, self.shard_len
+            for buf in (st.mx, st.vx):
+                _all_gather(buf, buf[self.rank * L:(self.rank + 1) * L], self.pg)
+
     # -- host part -----------------------------------------------------------------------------------
     def apply_host(self, net):
         net.global_step += 1

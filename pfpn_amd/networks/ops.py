@@ -63,8 +63,11 @@ class ParamStore:
         self.grad = self.bucket[:self.size]
         self.tail = self.bucket[self.size:]
         if with_optimizer:
-            self.m = torch.zeros(self.size, dtype=torch.float32, device=self.device)
-            self.v = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+            # (padded like the parameters: under the sharded exchange a replica keeps only its slice of the Adam slots up
+            # to date; `SyncReplicasApplier.gather_optimizer_state` all-gathers them in place before a checkpoint)
+            self.mx = torch.zeros(self.npad, dtype=torch.float32, device=self.device)
+            self.vx = torch.zeros(self.npad, dtype=torch.float32, device=self.device)
+            self.m, self.v = self.mx[:self.size], self.vx[:self.size]
         for name, shape, off in self.specs:
             n = int(math.prod(shape)) if len(shape) else 1
             self._views[name] = self.flat[off:off + n].view(shape)

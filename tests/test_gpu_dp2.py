@@ -136,6 +136,7 @@ def _golden_rank(rank, world, port, q, tag, mode="allreduce"):
             net.resample_now = lambda: orig(u_res, u_noise)
         b = {k: fx["in%d:%s" % (rank, k)] for k in ("state", "action", "value", "log_prob", "advantage")}
         loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
+        opt.gather_optimizer_state(net)         # (sharded: the owners' Adam slots to every replica)
         pre = "out%d:" % rank
         gg.close(net.train_out["logp"], fx[pre + "logp"], "logp", 1e-5)
         gg.close(loss[0], fx[pre + "loss"], "loss", 1e-5, floor=1.0)
@@ -341,6 +342,27 @@ def _rccl_sharded_rank(port, q):
         ok &= nets[0].global_step == 9 and nets[0].train_flag == 0
         g = list(nets[0]._train_graphs.values())
         ok &= len(g) == 1 and g[0].split and len(nets[1]._train_graphs) == 0
+        # whole training rounds (flat_train's plan of >= 8 uniform minibatches) on an EXCHANGING optimiser, both exchange
+        # forms: a data-parallel round must stay on one-step split graphs (a K-step replay cannot hold the collective) and
+        # give the bits of per-minibatch train() calls
+        from pfpn_amd.models.distributed_model import minibatch_plan
+        names = ["state", "action", "value", "log_prob", "advantage"]
+        for mode in ("allreduce", "sharded"):
+            rn = [make_net(dev, seed=11, resample_interval=13) for _ in range(2)]
+            ro = [SyncReplicasApplier(n_, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True,
+                                      exchange_mode=mode) for n_ in rn]
+            for rnd in range(3):
+                b = make_batch(rng, 256)
+                b["log_prob"] = rng.normal(-38, 0.3, 256).astype(F)
+                plan = minibatch_plan(256, 32, 2, np.random.RandomState(rnd))
+                cols = {k: b[k] for k in names}
+                out_round = rn[0].train_round(ro[0], ["global_step"], names, cols, plan)
+                out_steps = [rn[1].train(None, ro[1], ["global_step"], *[cols[k][rows] for k in names]) for rows in plan]
+                ok &= len(out_round) == len(plan) == 16 and all(a == b_ for a, b_ in zip(out_round, out_steps))
+                ok &= torch.equal(rn[0].store.flat, rn[1].store.flat)
+                ok &= torch.equal(rn[0].state_normalizer.mean, rn[1].state_normalizer.mean)
+            ok &= rn[0].global_step == 48 and not getattr(rn[0], "_round_graphs", {})
+            ok &= all(g_.split and g_.K == 1 for g_ in rn[0]._train_graphs.values()) and len(rn[0]._train_graphs) >= 1
         q.put((0, bool(ok), "", ""))
     except Exception as e:
         import traceback
