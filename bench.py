@@ -131,14 +131,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    def make_learner(rows, seed, exchange_group=False):
+    def make_learner(rows, seed, exchange_group=False, exchange_mode=None):
         """a network + optimiser + `rows` synthetic transitions resident in HBM + the step callable"""
         net_ = ParticleFilteringClipPPONetwork(trainable=True, state_shape=[S], action_shape=[A],
                                                action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
                                                device=dev, seed=SEED, **NET_OPTS)
         net_.init()
         opt_ = SyncReplicasApplier(net_, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=world,
-                                   force_exchange=args.force_exchange or exchange_group)
+                                   force_exchange=args.force_exchange or exchange_group, exchange_mode=exchange_mode)
         hb = synth_batch(np.random.default_rng(seed), rows)
         t = {k: torch.from_numpy(hb[k]).to(dev) for k in ("state", "action", "advantage")}
         with torch.no_grad():      # value_old / log_prob_old = outputs of the (frozen) initial net: ratio ~ 1
@@ -148,32 +148,56 @@ def main():
         return net_, opt_, (t["state"], t["action"], t["value"], t["log_prob"], t["advantage"])
 
     def make_stepper(net_, opt_, inputs, allow_multi=True):
-        """-> (run_steps(n), launch description).  One replica: hipGraph replays of `--steps-per-graph` learner steps;
-        data parallel: two hipGraphs around the RCCL all-reduce per step (pfpn_amd/graphs.py); --no-graph: eager."""
+        """-> (run_steps(n), launch description).  One replica: hipGraph replays of `--steps-per-graph` learner steps, the
+        remainder n % K as ONE replay of a K'-step graph (captured by run_steps.prepare(n), outside every timed region);
+        data parallel: two hipGraphs around the exchange per step (pfpn_amd/graphs.py); --no-graph: eager."""
         if args.no_graph:
-            return (lambda n: [net_.train_device(opt_, *inputs) for _ in range(n)]), "eager"
+            f = lambda n: [net_.train_device(opt_, *inputs) for _ in range(n)]
+            f.prepare = lambda n: None
+            return f, "eager"
         one = graphs.GraphedLearnerStep(net_, opt_, *inputs)
         spg_ = max(1, args.steps_per_graph) if (allow_multi and not one.split) else 1
-        many = graphs.GraphedLearnerStep(net_, opt_, *inputs, steps_per_replay=spg_) if spg_ > 1 else None
+        sized = {1: one}
         one()                    # the FIRST replay of a hipGraph uploads it: keep that out of every timed region
-        if many is not None and many.can_replay():
-            many()
+
+        def graph_of(k):
+            g = sized.get(k)
+            if g is None:
+                g = sized[k] = graphs.GraphedLearnerStep(net_, opt_, *inputs, steps_per_replay=k)
+                if g.can_replay():
+                    g()
+            return g
+
+        def prepare(n):
+            """capture (and upload) every graph a run of n steps will replay"""
+            if spg_ > 1:
+                if n >= spg_:
+                    graph_of(spg_)
+                if n % spg_ > 1:
+                    graph_of(n % spg_)
 
         def run_steps(n):
-            """exactly n learner steps: K-step replays while they fit (and no resample tick falls inside)"""
+            """exactly n learner steps: K-step replays while they fit, the rest as one K'-step replay (one-step replays
+            only up to a resample tick that falls inside a multi-step replay)"""
             while n > 0:
-                if many is not None and n >= spg_ and many.can_replay():
-                    many()
-                    n -= spg_
+                k = min(n, spg_)
+                g = sized.get(k) if k > 1 else None
+                if g is not None and g.can_replay():
+                    g()
+                    n -= k
                 else:
                     one()
                     n -= 1
-        what = "two hipGraphs around the RCCL all-reduce" if one.split else \
-            ("hipGraph, %d learner steps per replay" % spg_ if spg_ > 1 else "hipGraph")
+        run_steps.prepare = prepare
+        what = ("two hipGraphs around the %s" % ("sharded exchange (all-to-all | owner Adam | all-gather)"
+                                                 if getattr(opt_, "sharded", False) else "RCCL all-reduce")) if one.split else \
+            ("hipGraph, %d learner steps per replay (remainder as one shorter replay)" % spg_ if spg_ > 1 else "hipGraph")
         return run_steps, what
 
     def timed_steps(run_steps, n_steps, n_warm):
         """the contract's timed region: barrier + synchronize on both sides, MAX over ranks."""
+        run_steps.prepare(n_warm)
+        run_steps.prepare(n_steps)
         run_steps(n_warm)
         torch.cuda.synchronize()
         if world > 1:
@@ -192,13 +216,27 @@ def main():
             el_ = float(t.item())
         return el_
 
+    def prelude(run_steps, seconds=0.25):
+        """untimed, disclosed clock-ramp: a fresh box starts its first kernels at a low clock and a 20-step window
+        (~10 ms) would otherwise be measured on the ramp.  Returns its length in ms."""
+        run_steps.prepare(8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            run_steps(8)
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
     assert B % world == 0, "--gpus must divide 4096"
     strong = not args.weak
     rows = B // world if strong else B            # rank r owns rows [r * B/W, (r+1) * B/W) of the global batch
     net, opt, inputs = make_learner(rows, SEED + rank)
     state, action, value_old, logp_old, adv = inputs
     run_steps, launch = make_stepper(net, opt, inputs)
-    el = timed_steps(run_steps, args.steps, args.warmup)
+    prelude_ms = prelude(run_steps)
+    el = timed_steps(run_steps, args.steps, args.warmup)          # the contract's window: `value`
+    windows = [el] + [timed_steps(run_steps, args.steps, 0) for _ in range(4)]       # its spread over 5 windows
+    el_200 = timed_steps(run_steps, 200, 0) if args.steps != 200 else el               # the same figure over 200 steps
     loss3 = net.train_out["loss3"].cpu().numpy()
     assert np.all(np.isfinite(loss3)), "non-finite loss in the benchmark loop"
     use_graph = not args.no_graph
@@ -214,6 +252,39 @@ def main():
         except Exception as e:
             weak_extra = {"error": repr(e)}
 
+    sharded_extra = None
+    if world > 1 and strong and not getattr(opt, "sharded", False):
+        # the other exchange form on the same shard (PFPN_EXCHANGE=sharded makes it the headline): all-to-all of unscaled
+        # bucket slices, owner-side clip factors + Adam on 1/W of the buffer, in-place all-gather
+        try:
+            xnet, xopt, xin = make_learner(rows, SEED + rank, exchange_mode="sharded")
+            xrun, xlaunch = make_stepper(xnet, xopt, xin)
+            xel = timed_steps(xrun, args.steps, args.warmup)
+            sharded_extra = {"value": args.steps / xel, "unit": "steps/s", "ms_per_step": xel / args.steps * 1e3,
+                             "launch": xlaunch}
+            del xnet, xopt, xin, xrun
+        except Exception as e:
+            sharded_extra = {"error": repr(e)}
+    rccl_info = None
+    if world > 1 or args.force_exchange:
+        # evidence from the LIVE process group that N ranks took part: a sum of ones and every rank's device index
+        tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        ones = torch.ones(1, device=tdev)
+        dist.all_reduce(ones)
+        devs = [torch.zeros(1, dtype=torch.int64, device=tdev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=tdev))
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        rccl_info = {"world": dist.get_world_size(), "ranks_seen": int(ones.item()), "backend": dist.get_backend(),
+                     "rccl_version": ver, "devices": [int(d.item()) for d in devs],
+                     "bucket_MB": net.store.bucket.numel() * 4 / 1e6,
+                     "exchange": ("sharded: all_to_all_single of %.2f MB bucket slices + all_gather of %d clip factors + "
+                                  "in-place all_gather_into_tensor of the parameter slices"
+                                  % (net.store.npad * 4 / 1e6, world)) if getattr(opt, "sharded", False)
+                     else "one all_reduce(SUM) of the bucket [clipped grads | statistics]"}
+
     out = None
     if rank == 0:
         ms = el / args.steps * 1e3
@@ -221,6 +292,11 @@ def main():
             "metric": "DPPO learner steps/sec (4096 trans, 36 act-dim x 35 particles)",
             "value": (1 if strong else world) * args.steps / el, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "prelude_ms": prelude_ms, "windows": len(windows),
+            "ms_per_step_min": min(windows) / args.steps * 1e3,
+            "ms_per_step_median": sorted(windows)[len(windows) // 2] / args.steps * 1e3,
+            "ms_per_step_max": max(windows) / args.steps * 1e3,
+            "value_200": (1 if strong else world) * 200 / el_200,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DeepMimicWalk-v0 DPPO-PFPN 35 particles, 4096-transition batch%s "
@@ -238,6 +314,10 @@ def main():
         }
         if weak_extra is not None:
             out["weak_scaling"] = weak_extra
+        if sharded_extra is not None:
+            out["exchange_sharded"] = sharded_extra
+        if rccl_info is not None:
+            out["rccl"] = rccl_info
 
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
     if rank == 0 and world == 1:
@@ -488,6 +568,7 @@ def main():
                 r_lp = rp.log_prob(rt[1]).clone()
                 r_v = net._value(rhc).clone()
             rrun, rlaunch = make_stepper(net, opt, (rt[0], rt[1], r_v, r_lp, rt[2]))      # K steps per replay, like the headline
+            rrun.prepare(16); rrun.prepare(208)
             rrun(16)
             torch.cuda.synchronize()
             tr = time.perf_counter()
@@ -512,17 +593,25 @@ def main():
                     dist.init_process_group(backend=args.backend, rank=0, world_size=1)
                 shard = {}
                 for n_gpu in (1, 2, 4, 8):
-                    snet, sopt, sin = make_learner(B // n_gpu, SEED, exchange_group=True)
-                    srun, slaunch = make_stepper(snet, sopt, sin)
-                    srun(20)
-                    torch.cuda.synchronize()
-                    t_s = time.perf_counter()
-                    srun(200)
-                    torch.cuda.synchronize()
-                    us_s = (time.perf_counter() - t_s) / 200 * 1e6
-                    shard[str(B // n_gpu)] = {"gpus_of_the_run_it_stands_for": n_gpu, "us_per_step": us_s,
-                                              "steps_per_s_without_links": 1e6 / us_s}
-                    del snet, sopt, sin, srun
+                    entry = {"gpus_of_the_run_it_stands_for": n_gpu}
+                    for mode in ("allreduce", "sharded"):
+                        snet, sopt, sin = make_learner(B // n_gpu, SEED, exchange_group=True, exchange_mode=mode)
+                        srun, sl_ = make_stepper(snet, sopt, sin)
+                        srun(20)
+                        torch.cuda.synchronize()
+                        t_s = time.perf_counter()
+                        srun(200)
+                        torch.cuda.synchronize()
+                        us_s = (time.perf_counter() - t_s) / 200 * 1e6
+                        if mode == "allreduce":
+                            slaunch = sl_
+                            entry.update({"us_per_step": us_s, "steps_per_s_without_links": 1e6 / us_s})
+                        else:
+                            # (world size 1: the owner's slice is the whole buffer -- the launch structure and the three
+                            # collectives' host cost, not the 1/W Adam of a real run)
+                            entry["us_per_step_sharded_exchange"] = us_s
+                        del snet, sopt, sin, srun
+                    shard[str(B // n_gpu)] = entry
                 bucket_mb = (net.store.bucket.numel() * 4) / 1e6
                 out["strong_shard"] = {"rows_per_gpu": shard, "launch": slaunch, "bucket_MB": bucket_mb,
                                        "note": "one rank's step with the RCCL call in it but nothing on the links (world size "
