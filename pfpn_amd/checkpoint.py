@@ -358,6 +358,11 @@ def network_tensors(net, optimizer=None, n_workers=0, total_samples=0, episodes=
         # SAC checkpoint, so unlike the DPPO names above this scope name is not pinned by reference data.
         for name, t in net.target_variables().items():
             out[SCOPE + "target_net/" + name] = cpu(t).astype(np.float32)
+    if getattr(net, "target_norm", None) is not None:
+        # TD3 keeps a FULL target network, its normaliser statistics included (ddpg.py:56-60: the target net is built by
+        # the same init() under variable_scope('target_net') and soft-updated variable by variable)
+        out[SCOPE + "target_net/state_normalizer/mean"] = cpu(net.target_norm[0])
+        out[SCOPE + "target_net/state_normalizer/std"] = cpu(net.target_norm[1])
     if getattr(net, "state_normalizer", None) is not None:
         out[SCOPE + "state_normalizer/mean"] = cpu(net.state_normalizer.mean)
         out[SCOPE + "state_normalizer/std"] = cpu(net.state_normalizer.std)
@@ -404,6 +409,16 @@ def restore(prefix, net, optimizer=None, strict=True):
     if getattr(net, "state_normalizer", None) is not None and SCOPE + "state_normalizer/mean" in rd.entries:
         net.state_normalizer.mean.copy_(torch.from_numpy(rd.get(SCOPE + "state_normalizer/mean")))
         net.state_normalizer.std.copy_(torch.from_numpy(rd.get(SCOPE + "state_normalizer/std")))
+    if getattr(net, "target_norm", None) is not None:
+        # the target network's own statistics; a checkpoint without them (written before they were stored) starts the
+        # target normaliser from the live statistics instead of from mean 0 / std 1
+        key = SCOPE + "target_net/state_normalizer/"
+        if key + "mean" in rd.entries:
+            net.target_norm[0].copy_(torch.from_numpy(rd.get(key + "mean")))
+            net.target_norm[1].copy_(torch.from_numpy(rd.get(key + "std")))
+        elif getattr(net, "state_normalizer", None) is not None:
+            net.target_norm[0].copy_(net.state_normalizer.mean)
+            net.target_norm[1].copy_(net.state_normalizer.std)
     if getattr(net, "max_active", None) is not None and SCOPE + "max_active_degree" in rd.entries:
         net.max_active.copy_(torch.from_numpy(rd.get(SCOPE + "max_active_degree")))
         net.sum_active.copy_(torch.from_numpy(rd.get(SCOPE + "sum_active_degree")))

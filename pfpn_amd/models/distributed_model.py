@@ -146,8 +146,10 @@ class AbstractDistributedWorker(object):
         # independently: the sampling generator restarts from the worker's own seed (reference: every worker calls
         # tf.set_random_seed(seed + task_id + 1), :568, :73-78)
         rng = getattr(self.global_net, "rng", None)
-        if self.seed is not None and hasattr(rng, "manual_seed"):
-            rng.manual_seed(int(self.seed))
+        if hasattr(rng, "manual_seed"):
+            # (no seed given: every worker still explores with its own stream -- entropy from the OS, as the reference
+            # draws its seed from os.urandom in that case, :565-568)
+            rng.manual_seed(int(self.seed) if self.seed is not None else int.from_bytes(os.urandom(4), "little"))
         self.init_ops = list(self.global_net.init_ops)
         self.build_local_net(self.name)
 

@@ -37,6 +37,13 @@ class Buffer(object):
     def __getitem__(self, i):
         return self.filled()[i]
 
+    def shift(self, start, delta):
+        """add `delta` to the slots [start, len()) -- the rows since the environment's last `episode_reward` report
+        (distributed_model.py:277-282 loops `range(stamp, len(buffer))` over them).  Slot order, like the reference's
+        indices; once the ring is full len() stops growing and the range is empty, as it is there."""
+        if self.data is not None and start < self.size:
+            self.data[max(0, int(start)):self.size] += delta
+
     def clear(self):
         self.pointer = self.size = 0
 

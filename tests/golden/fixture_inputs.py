@@ -18,6 +18,7 @@ SHAPES = {"actor/fc1/weight": (S, H1), "actor/fc1/bias": (H1,), "actor/fc2/weigh
           "critic/fc2/weight": (H1, H2), "critic/fc2/bias": (H2,), "critic/fc3/weight": (H2, 1), "critic/fc3/bias": (1,)}
 BIG = [k for k, s in SHAPES.items() if int(np.prod(s)) > 4096]
 ROW_STRIDE = 64          # rows of a big matrix kept in the fixture: [::ROW_STRIDE]
+P_ROW_STRIDE = 16        # compact fixtures: rows of the [B, A] mixture probabilities kept
 
 
 def hash_uniform(shape, seed):
@@ -93,3 +94,46 @@ def summarize(x):
 
 def subsample(name, x):
     return np.ascontiguousarray(x[::ROW_STRIDE]) if name in BIG else x
+
+
+def make_batch_off_kinks(B, bseed, vseed, step, margin=1e-4):
+    """make_batch(B, bseed) with every row redrawn whose trunk pre-activations (either trunk, either layer, evaluated in
+    float64 with the fixture's parameters make_variables(vseed)) come within `margin` of a ReLU6 kink (0 or 6).  At 4096 rows
+    ~12.6 M pre-activations are in play and fp32 evaluations that differ only in summation order (the reference's BLAS,
+    the MFMA GEMMs) WILL put one of them on different sides of a kink: one unit's gradient then moves by a whole row's
+    contribution, and everything below it by ~1e-3 of its scale -- a property of the batch, not of either implementation.
+    The big fixtures therefore use batches with a clear margin (the small ones carry the MASK_FLIPS allowance instead).
+    Deterministic: generator and tests call this same function."""
+    init = initial_state(vseed, step)
+    P, mean, std = init["P"], init["mean"].astype(np.float64), init["std"].astype(np.float64)
+    b = make_batch(B, bseed)
+
+    def bad_rows(state):
+        x = np.clip((state.astype(np.float64) - mean) / std, -5.0, 5.0)
+        bad = np.zeros(len(state), bool)
+        for t in ("actor", "critic"):
+            h1 = x @ P[t + "/fc1/weight"].astype(np.float64) + P[t + "/fc1/bias"]
+            bad |= ((np.abs(h1) < margin) | (np.abs(h1 - 6.0) < margin)).any(1)
+            h2 = np.clip(h1, 0.0, 6.0) @ P[t + "/fc2/weight"].astype(np.float64) + P[t + "/fc2/bias"]
+            bad |= ((np.abs(h2) < margin) | (np.abs(h2 - 6.0) < margin)).any(1)
+        return bad
+
+    for attempt in range(1, 64):
+        bad = bad_rows(b["state"])
+        if not bad.any():
+            return b
+        fresh = (hash_normal((B, S), bseed * 10 + 1 + 7919 * attempt) * 2 + 0.3).astype(F)
+        b["state"][bad] = fresh[bad]
+    raise RuntimeError("could not move every row off the ReLU6 kinks")
+
+
+def batch_of(fx, w):
+    """worker w's learner inputs of a fixture: stored ones, or -- compact fixtures -- recreated from the hash streams
+    (the generator drew them as make_batch_off_kinks(B, seed * 10 + w, seed, step)); the old log-prob is always stored (a
+    graph output)."""
+    if "in%d:state" % w in fx:
+        return {k: fx["in%d:%s" % (w, k)] for k in ("state", "action", "value", "advantage", "log_prob")}
+    B, W, step, train_flag, seed = [int(v) for v in fx["meta"]]
+    b = make_batch_off_kinks(B, seed * 10 + w, seed, step)
+    b["log_prob"] = fx["in%d:log_prob" % w]
+    return b

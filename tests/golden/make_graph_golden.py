@@ -150,7 +150,10 @@ def save_vars(v, prefix=G):
     return out
 
 
-def scenario(nodes, tag, B, W, step, train_flag, seed, dead_pattern=False, guard=False):
+def scenario(nodes, tag, B, W, step, train_flag, seed, dead_pattern=False, guard=False, compact=False):
+    """compact: the big scenarios (the bench's 4096-row batch, eight 512-row shards) keep only what cannot be recreated:
+    the batches come back from fixture_inputs.make_batch(B, seed * 10 + w) (fixture_inputs.batch_of), only the old
+    log-prob (a graph output) is stored, and the [B, A] mixture probabilities are kept for every 16th row."""
     workers = tuple("worker_%d" % i for i in range(W))
     v = fresh_vars(seed, step, train_flag, workers)
     ev = ge.Evaluator(nodes, v)
@@ -180,7 +183,7 @@ def scenario(nodes, tag, B, W, step, train_flag, seed, dead_pattern=False, guard
         v[workers[w] + "/max_active_degree"][...] = mx
         v[workers[w] + "/sum_active_degree"][...] = sm
     for w in range(W):
-        b = fi.make_batch(B, seed * 10 + w)
+        b = fi.make_batch_off_kinks(B, seed * 10 + w, seed, step) if compact else fi.make_batch(B, seed * 10 + w)
         # old log-prob = the graph's own log-prob of the action, perturbed so ratios straddle the clip range
         b["log_prob"] = np.zeros(B, F)
         if guard:       # rows whose mixture probability underflows to 0: log p = -inf forward, `foo` zeroes 0/0 backward
@@ -193,10 +196,10 @@ def scenario(nodes, tag, B, W, step, train_flag, seed, dead_pattern=False, guard
             b["log_prob"][[3, 17]] = F(-200.0)
         r = phase1(ev, nodes, b)
         shards.append(b)
-        for k in ("state", "action", "value", "advantage", "log_prob"):
+        for k in (("log_prob",) if compact else ("state", "action", "value", "advantage", "log_prob")):
             fx["in%d:%s" % (w, k)] = b[k]
         for k in ("logp", "p", "value", "loss", "policy_loss", "value_loss", "global_norm"):
-            fx["out%d:%s" % (w, k)] = r[k]
+            fx["out%d:%s" % (w, k)] = r[k][::fi.P_ROW_STRIDE] if (compact and k == "p") else r[k]
         for k in fi.TRAINABLES:
             fx["out%d:grad:%s" % (w, k)] = fi.subsample(k, r["grads"][k])
             fx["out%d:grad_sum:%s" % (w, k)] = fi.summarize(r["grads"][k])
@@ -355,13 +358,20 @@ def rollout(nodes, tag, E, seed):
 
 def main():
     nodes, order = ge.load_graph(os.path.join(wire.REF, wire.META["walk"]))
-    scenario(nodes, "step_b32", B=32, W=1, step=1234, train_flag=5, seed=1)
-    scenario(nodes, "step_b256", B=256, W=1, step=77, train_flag=100, seed=2)
-    scenario(nodes, "step_b64_w2", B=64, W=2, step=500, train_flag=9, seed=3)
-    scenario(nodes, "resample_b32", B=32, W=1, step=367, train_flag=367, seed=4, dead_pattern=True)
-    scenario(nodes, "resample_b32_w2", B=32, W=2, step=735, train_flag=367, seed=5, dead_pattern=True)
-    scenario(nodes, "guard_b32", B=32, W=1, step=3, train_flag=0, seed=7, guard=True)
-    rollout(nodes, "rollout_e32", E=32, seed=6)
+    only = set(sys.argv[1:])                        # `make_graph_golden.py tag ...`: just these scenarios
+    want = lambda tag: not only or tag in only
+    if want("step_b32"): scenario(nodes, "step_b32", B=32, W=1, step=1234, train_flag=5, seed=1)
+    if want("step_b256"): scenario(nodes, "step_b256", B=256, W=1, step=77, train_flag=100, seed=2)
+    if want("step_b64_w2"): scenario(nodes, "step_b64_w2", B=64, W=2, step=500, train_flag=9, seed=3)
+    if want("resample_b32"): scenario(nodes, "resample_b32", B=32, W=1, step=367, train_flag=367, seed=4, dead_pattern=True)
+    if want("resample_b32_w2"):
+        scenario(nodes, "resample_b32_w2", B=32, W=2, step=735, train_flag=367, seed=5, dead_pattern=True)
+    if want("guard_b32"): scenario(nodes, "guard_b32", B=32, W=1, step=3, train_flag=0, seed=7, guard=True)
+    # round 3: the bench's headline batch (BASELINE.json config 2) and the 8-GPU strong-scaling exchange (config 4's
+    # shard size: eight workers x 512 rows, accumulator mean over 8) -- straight from the reference's graph
+    if want("step_b4096"): scenario(nodes, "step_b4096", B=4096, W=1, step=4321, train_flag=50, seed=8, compact=True)
+    if want("step_b512_w8"): scenario(nodes, "step_b512_w8", B=512, W=8, step=910, train_flag=120, seed=9, compact=True)
+    if want("rollout_e32"): rollout(nodes, "rollout_e32", E=32, seed=6)
     worst = {}
     for tag, name, e in REPORT:
         key = (tag, name.split(" ")[1] if name.startswith("w") or name.startswith("post") else name)

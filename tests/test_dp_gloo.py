@@ -206,7 +206,7 @@ def _sharded_rank_main(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_exchange_transport_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -134,7 +134,7 @@ def _golden_rank(rank, world, port, q, tag, mode="allreduce"):
             u_noise = torch.from_numpy(fx["resample:u_noise_slot"]).to(dev)
             orig = net.resample_now
             net.resample_now = lambda: orig(u_res, u_noise)
-        b = {k: fx["in%d:%s" % (rank, k)] for k in ("state", "action", "value", "log_prob", "advantage")}
+        b = fi.batch_of(fx, rank)
         loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
         opt.gather_optimizer_state(net)         # (sharded: the owners' Adam slots to every replica)
         pre = "out%d:" % rank

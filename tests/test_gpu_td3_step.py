@@ -25,7 +25,7 @@ def make_net(dev, trainable=True, S=197, A=36, seed=7, **kw):
     return net
 
 
-@pytest.mark.parametrize("B", [16, 256])
+@pytest.mark.parametrize("B", [16, 256, 1024])         # 1024 = the replay batch of BASELINE.json config 3
 def test_td3_step_matches_oracle(oracle, dev, B):
     from pfpn_amd.models import SyncReplicasApplier
     S, A, N = 197, 36, 35
@@ -51,6 +51,34 @@ def test_td3_step_matches_oracle(oracle, dev, B):
                  "state_": (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F)}
         noise_t = rng.normal(0, 1, (B, A)).astype(F)
         sync = st.global_step % 2 == 0
+        # keep every pre-activation that has a backward off the ReLU6 kinks (Relu6Grad is a step function: a value the
+        # GPU's GEMM rounds to the other side moves a whole row's contribution, and at 1024 rows x ~6000 units one does)
+        for _ in range(20):
+            _, _, aux0 = oracle.td3_grads(st.P, st.PT, (st.norm_mean, st.norm_std), (st.norm_mean_t, st.norm_std_t), batch,
+                                          noise_t, A, N, sync)
+            x = oracle.state_normalize(batch["state"], st.norm_mean, st.norm_std, 5.0)
+            xa = np.concatenate([x, aux0["a_opt"]], -1).astype(F)
+            xh = np.concatenate([x, batch["action"]], -1).astype(F)
+            bad = np.zeros(B, bool)
+            for prefix, h in (("actor", x), ("critic/q", xa), ("critic/q", xh), ("critic/twin_q", xh)):
+                for layer in ("fc1", "fc2"):
+                    pre = h @ st.P["%s/%s/weight" % (prefix, layer)] + st.P["%s/%s/bias" % (prefix, layer)]
+                    bad |= (np.minimum(np.abs(pre), np.abs(pre - 6.0)) < 2e-6).any(axis=1)
+                    h = np.minimum(np.maximum(pre, 0), 6).astype(F)
+            # ... and every argmax over a dimension's particle logits off a tie (fp32 logits from another GEMM order differ
+            # by ~1e-7: a second-best within that of the best picks another particle, an O(0.1) jump of the action)
+            def tied(Pn, xin):
+                lg, _ = oracle.actor_forward(Pn, xin, A, N)
+                top = np.sort(lg.reshape(B, A, N), axis=-1)
+                return ((top[..., -1] - top[..., -2]) < 2e-6).any(axis=1)
+            bad |= tied(st.P, x)
+            x2 = oracle.state_normalize(batch["state_"], st.norm_mean_t, st.norm_std_t, 5.0)
+            bad2 = tied(st.PT, x2)
+            if not bad.any() and not bad2.any():
+                break
+            batch["state"][bad] = (rng.normal(0, 1, (int(bad.sum()), S)) * 2 + 0.3).astype(F)
+            batch["state_"][bad2] = (rng.normal(0, 1, (int(bad2.sum()), S)) * 2 + 0.3).astype(F)
+        assert not bad.any() and not bad2.any()
         (l_ref, pl_ref, vl_ref), G_ref, aux = oracle.td3_grads(
             st.P, st.PT, (st.norm_mean, st.norm_std), (st.norm_mean_t, st.norm_std_t), batch, noise_t, A, N, sync)
         oracle.td3_learner_step(st, batch, noise_t)
@@ -159,3 +187,49 @@ def test_td3_train_captures_one_graph_per_kind_of_step(dev):
         tgt.append(not torch.equal(before, net.target_store.flat))
     assert len(net._train_graphs) == 2 and {k[2] for k in net._train_graphs} == {True, False}
     assert tgt == [it % 2 == 0 for it in range(16)]         # the target moves on policy steps (even global_step) only
+
+
+def test_td3_checkpoint_keeps_the_target_normaliser(dev, tmp_path):
+    """the target network's OWN normaliser statistics (soft-updated with tau) survive save -> restore: the Q-target of the
+    first step after a resume is the one the uninterrupted run computes."""
+    from pfpn_amd import checkpoint as ck
+    from pfpn_amd.models import SyncReplicasApplier
+    S, A = 197, 36
+    rng = np.random.default_rng(3)
+
+    def build(seed):
+        net = make_net(dev, seed=seed)
+        for op in net.init_ops:
+            op()
+        opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                        {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+        return net, opt
+
+    def batch(B=64):
+        return [(rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F), np.tanh(rng.normal(0, 1, (B, A))).astype(F),
+                rng.random(B).astype(F), (rng.random(B) < 0.9).astype(F), (rng.normal(0, 1, (B, S)) * 2 + 0.3).astype(F)]
+
+    net, opt = build(7)
+    for _ in range(4):                      # the live statistics move every step, the target's every other step (tau)
+        net.train(None, opt, [], *batch())
+    assert not torch.equal(net.target_norm[0], net.state_normalizer.mean)
+    assert float(net.target_norm[0].abs().max()) > 0
+    prefix = str(tmp_path / "td3.ckpt-4")
+    entries = ck.save(prefix, net, opt)
+    assert "global_net/target_net/state_normalizer/mean" in entries
+    net2, opt2 = build(99)
+    ck.restore(prefix, net2, opt2)
+    assert torch.equal(net2.target_norm[0], net.target_norm[0]) and torch.equal(net2.target_norm[1], net.target_norm[1])
+    assert torch.equal(net2.target_store.flat, net.target_store.flat)
+    b = batch()
+    noise = {"target": torch.randn(64, A, device=dev)}
+    l1 = net.compute_gradients(*[net._to_dev(x) for x in b], noise={k: v.clone() for k, v in noise.items()})
+    l2 = net2.compute_gradients(*[net2._to_dev(x) for x in b], noise={k: v.clone() for k, v in noise.items()})
+    assert torch.equal(l1, l2) and torch.equal(net.store.grad, net2.store.grad)
+    # a checkpoint written without the target statistics starts the target normaliser from the live ones
+    rd_entries = {k: v for k, v in ck.network_tensors(net, opt).items() if "target_net/state_normalizer" not in k}
+    ck.write_checkpoint(str(tmp_path / "old.ckpt-4"), rd_entries)
+    net3, opt3 = build(5)
+    ck.restore(str(tmp_path / "old.ckpt-4"), net3, opt3)
+    assert torch.equal(net3.target_norm[0], net3.state_normalizer.mean)
+    assert torch.equal(net3.target_norm[1], net3.state_normalizer.std)

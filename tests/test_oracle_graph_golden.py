@@ -23,7 +23,8 @@ import fixture_inputs as fi   # noqa: E402
 
 F = np.float32
 RTOL = 2e-5
-STEP_CASES = ["step_b32", "step_b256", "step_b64_w2", "resample_b32", "resample_b32_w2", "guard_b32"]
+STEP_CASES = ["step_b32", "step_b256", "step_b64_w2", "resample_b32", "resample_b32_w2", "guard_b32",
+              "step_b4096", "step_b512_w8"]      # round 3: the bench's batch (config 2) and eight 512-row shards (config 4)
 
 
 def load(tag):
@@ -67,7 +68,7 @@ def oracle_state(oracle, fx):
 
 
 def shard(fx, w):
-    return {k: fx["in%d:%s" % (w, k)] for k in ("state", "action", "value", "advantage", "log_prob")}
+    return fi.batch_of(fx, w)         # (compact fixtures recreate the batch from the hash streams)
 
 
 @pytest.mark.parametrize("tag", STEP_CASES)
@@ -81,7 +82,8 @@ def test_worker_phase(oracle, tag):
         pre = "out%d:" % w
         close(aux["logp"], fx[pre + "logp"], "global_net/policy_loss/pi_target/Sum_1")
         _, p = oracle.mixture_log_prob(aux["logits"], b["action"], st.P["actor/samples"], st.P["actor/samples_std"])
-        close(p, fx[pre + "p"], "global_net/policy_loss/pi_target/Sum")
+        close(p[::fi.P_ROW_STRIDE] if len(fx[pre + "p"]) != len(p) else p, fx[pre + "p"],
+              "global_net/policy_loss/pi_target/Sum")
         close(aux["value"], fx[pre + "value"], "global_net/critic/Squeeze")
         close(loss, fx[pre + "loss"], "global_net/loss/add", floor=1.0)
         close(pl, fx[pre + "policy_loss"], "global_net/policy_loss/Neg", floor=1.0)

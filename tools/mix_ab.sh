@@ -12,3 +12,6 @@ if [ -n "$2" ]; then
 fi
 cat $O/probe*.log
 rm -rf pfpn_amd/build && PFPN_BUILD_STAMPS=1 python -m pfpn_amd.build > $O/build.log 2>&1 && python tools/stamp_probe.py 2>&1 | grep -v amdgpu.ids > $O/stamps.log
+
+# leave the DEFAULT library behind: later bench / test runs must not silently measure a diagnostic or flagged build
+rm -rf pfpn_amd/build && python3 -m pfpn_amd.build > /dev/null 2>&1

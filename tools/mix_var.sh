@@ -6,6 +6,8 @@ shift
 mkdir -p $O
 : > $O/probe.log
 cp pfpn_amd/csrc/mixture_kernels.hip /tmp/cur.hip
+# the tracked source is overwritten below: put it back however the script ends
+trap 'cp /tmp/cur.hip pfpn_amd/csrc/mixture_kernels.hip' EXIT
 if [ -f tools/ab_prev_mixture_kernels.hip.txt ]; then   # (untracked: git show HEAD:pfpn_amd/csrc/mixture_kernels.hip > that file)
   cp tools/ab_prev_mixture_kernels.hip.txt pfpn_amd/csrc/mixture_kernels.hip
   rm -rf pfpn_amd/build && python -m pfpn_amd.build > $O/build.log 2>&1
@@ -17,3 +19,6 @@ for f in "$@"; do
   for i in 1 2 3; do echo "cur [$f]:" >> $O/probe.log; python tools/mix_probe.py 2>&1 | grep -v amdgpu.ids >> $O/probe.log; done
 done
 cat $O/probe.log
+
+# leave the DEFAULT library behind: later bench / test runs must not silently measure a diagnostic or flagged build
+rm -rf pfpn_amd/build && python3 -m pfpn_amd.build > /dev/null 2>&1

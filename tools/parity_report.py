@@ -29,7 +29,8 @@ def stat(name, got, ref):
 
 def main():
     dev = torch.device("cuda:0")
-    for tag in ("step_b32", "step_b256", "guard_b32", "resample_b32"):
+    tags = sys.argv[1:] or ("step_b32", "step_b256", "guard_b32", "resample_b32", "step_b4096")
+    for tag in tags:
         fx = gg.load(tag)
         net, opt = gg.build(dev, fx)
         if bool(fx["fired"]):
@@ -37,7 +38,7 @@ def main():
             u_noise = torch.from_numpy(fx["resample:u_noise_slot"]).to(dev)
             orig = net.resample_now
             net.resample_now = lambda: orig(u_res, u_noise)
-        b = {k: fx["in0:" + k] for k in ("state", "action", "value", "log_prob", "advantage")}
+        b = fi.batch_of(fx, 0)
         loss, _ = net.train(None, opt, [], b["state"], b["action"], b["value"], b["log_prob"], b["advantage"])
         print(tag)
         stat("logp", net.train_out["logp"], fx["out0:logp"])

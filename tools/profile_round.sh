@@ -25,3 +25,6 @@ echo "bench done" >> $O/progress.log
 rm -rf pfpn_amd/build && PFPN_BUILD_STAMPS=1 python3 -m pfpn_amd.build > $O/stamp_build.log 2>&1 && python3 tools/stamp_probe.py 2>&1 | grep -v amdgpu.ids > $O/stamps.txt
 python3 tools/profile_collect.py $O gpurun_out/prof_summary $TAG > $O/collect.log 2>&1
 tail -3 $O/collect.log
+
+# leave the DEFAULT library behind: later bench / test runs must not silently measure a diagnostic or flagged build
+rm -rf pfpn_amd/build && python3 -m pfpn_amd.build > /dev/null 2>&1

@@ -15,3 +15,6 @@ PY
   done
 done
 cat $O/out.log
+
+# leave the DEFAULT library behind: later bench / test runs must not silently measure a diagnostic or flagged build
+rm -rf pfpn_amd/build && python3 -m pfpn_amd.build > /dev/null 2>&1
