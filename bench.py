@@ -513,24 +513,42 @@ def main():
                           "peak": HBM_PEAK_GBS, "frac": nb / u / 1e3 / HBM_PEAK_GBS,
                           "note": "3L composition; a fused 2L pass needs a row (128 KiB) AND the [A,N] bank (393 KB) on one CU"}
             del s_out
-            # this box's read+write roof in the same run: a device copy of the 1 GiB logits (the backward kernel streams
-            # the same 2L; the forward is bounded by its two v_exp_f32 per particle, tools/bw_probe8.hip)
+            # this box's roof for the two access patterns, in the same run, from the build's OWN streaming kernels
+            # (pfpn_stream_copy: float4 grid-stride; the few launch shapes that won tools/copy_probe.py's sweep, best taken):
+            # read + write of the 1 GiB logits (what the backward streams) and the read-only stream (the forward)
+            def best_of(fn_of_cfg, cfgs, nbytes, reps=8):
+                best_ = None
+                for cfg in cfgs:
+                    f_ = fn_of_cfg(*cfg)
+                    f_(); f_()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(reps):
+                        f_()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    u_ = e0.elapsed_time(e1) * 1e3 / reps
+                    if best_ is None or u_ < best_[0]:
+                        best_ = (u_, cfg)
+                return {"us_per_launch": best_[0], "algorithmic_bytes": nbytes, "achieved": nbytes / best_[0] / 1e3,
+                        "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": nbytes / best_[0] / 1e3 / HBM_PEAK_GBS,
+                        "config": {"unroll": best_[1][0], "nontemporal": best_[1][1], "blocks": best_[1][2]}}
             s_cp = torch.empty_like(sl)
-            s_cp.copy_(sl); s_cp.copy_(sl)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(10):
-                s_cp.copy_(sl)
-            e1.record()
-            torch.cuda.synchronize()
-            u = e0.elapsed_time(e1) * 1e3 / 10
-            res["device_copy"] = {"kernel": "torch copy_ of the same logits (read L + write L)", "us_per_launch": u,
-                                  "algorithmic_bytes": 2 * L_, "achieved": 2 * L_ / u / 1e3, "unit": "GB/s",
-                                  "peak": HBM_PEAK_GBS, "frac": 2 * L_ / u / 1e3 / HBM_PEAK_GBS}
+            res["device_copy"] = dict(best_of(lambda u_, nt_, bl_: (lambda: kernels.stream_copy(s_cp, sl, u_, nt_, bl_)),
+                                              [(1, 1, 32768), (1, 1, 1024), (2, 1, 16384), (1, 0, 1024), (4, 0, 2048)], 2 * L_),
+                                      kernel="pfpn_stream_copy (own float4 grid-stride copy of the same logits: read L + write L)")
             del s_cp
-            res["note"] = ("bwd streams 2L at the box's copy rate (device_copy); fwd is bound by its arithmetic -- two "
-                           "v_exp_f32 per particle: with the rows already in LDS (LDS-DMA ring, tools/bw_probe8.hip) the same "
-                           "math takes ~203 us, while the bare stream runs at 0.74-0.79 of the roof")
+            sinks = {bl_: torch.empty(bl_ * 256, device=dev) for bl_ in (2048, 8192, 32768)}
+            res["device_read"] = dict(best_of(lambda u_, nt_, bl_: (lambda: kernels.stream_copy(sinks[bl_], sl, 0, nt_, bl_)),
+                                              [(0, 1, 2048), (0, 1, 8192), (0, 1, 32768), (0, 0, 8192)], L_),
+                                      kernel="pfpn_stream_copy, read-only (own float4 grid-stride sum of the same logits: read L)")
+            for k_, ref_ in (("fwd", "device_read"), ("bwd", "device_copy"), ("ppo", "device_copy")):
+                res[k_]["frac_of_box_copy"] = res[k_]["achieved"] / res[ref_]["achieved"]
+                res[k_]["box_copy"] = ref_
+            res["note"] = ("frac: of the 8 TB/s spec; frac_of_box_copy: of what this box's memory system moves for the same "
+                           "access pattern with NO arithmetic (device_read for the forward, device_copy for the backward and "
+                           "the 3L composition).  fwd is bound by its arithmetic -- two v_exp_f32 per particle: with the rows "
+                           "already in LDS (LDS-DMA ring, tools/bw_probe8.hip) the same math takes ~203 us")
             out["roofline_stress"] = {"shape": [sB, sA, sN], "bound": "hbm", **res}
             del sl, sx, sg
         except Exception as ex:      # never fail the headline line on the auxiliary measurement

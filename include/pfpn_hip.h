@@ -387,6 +387,11 @@ int pfpn_clip_adam(float* params, const float* grads, float* m, float* v, size_t
  * soft_target[i] <- (1 - soft_tau) soft_target[i] + soft_tau params[soft_off + i] (pfpn_soft_update's arithmetic). */
 int pfpn_clip_scale_inplace(float* grads, size_t n, float clip_norm, float* norm_scale, float* beta_pow, int n_groups,
                             float beta1, float beta2, void* workspace, size_t workspace_bytes, void* stream);
+/* Calibration kernel (no reference counterpart): dst[i] = src[i] as a float4 grid-stride stream, `unroll` (1, 2, 4, 8) loads
+ * in flight per thread before their stores, `blocks` blocks of 256 threads, nontemporal != 0: nt loads and stores.  The
+ * box's read+write rate for the mixture kernels' access pattern (bench.py: roofline_stress.device_copy).  unroll = 0: the
+ * read-only stream -- src is summed into dst [blocks * 256] (one float per thread), the forward kernels' pattern. */
+int pfpn_stream_copy(float* dst, const float* src, size_t n, int unroll, int nontemporal, int blocks, void* stream);
 /* Sharded exchange of the same step (W replicas; sync_model.py:64-95 semantics unchanged): the mean of the per-replica
  * clipped gradients is sum_w s_w g_w / W with ONE scalar s_w per replica, so the gradient bytes need not wait for the norm.
  * pfpn_clip_scale_only leaves {norm, s_w} in norm_scale WITHOUT touching the gradients (from the partial sums of

@@ -834,6 +834,42 @@ __global__ __launch_bounds__(256) void k_shard_adam(float* __restrict__ px, floa
     }
 }
 
+
+// ---- calibration: the build's own streaming copy (float4 grid-stride, U loads in flight per thread before the stores).
+// The HBM roofline fractions of the mixture kernels are quoted against the 8 TB/s spec AND against what this access
+// pattern moves on the box at hand (bench.py roofline_stress.device_copy / frac_of_box_copy).
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_stream_copy(float* __restrict__ dst, const float* __restrict__ src, size_t n4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const f4* s = reinterpret_cast<const f4*>(src);
+    f4* d = reinterpret_cast<f4*>(dst);
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(s + i + u * stride) : s[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NT) __builtin_nontemporal_store(v[u], d + i + u * stride);
+            else d[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n4; i += stride) d[i] = s[i];
+}
+// read-only variant (the forward kernels' pattern): the stream is folded into one float per thread so the loads cannot be
+// dropped; sink [gridDim.x * 256]
+template <bool NT>
+__global__ __launch_bounds__(256) void k_stream_read(float* __restrict__ sink, const float* __restrict__ src, size_t n4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const f4* s = reinterpret_cast<const f4*>(src);
+    f4 a = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        a += NT ? __builtin_nontemporal_load(s + i) : s[i];
+    sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (a.x + a.y) + (a.z + a.w);
+}
+
 // beta powers advance after the applies (Adam/mul, Adam/mul_1 in the saved graph)
 __global__ void k_beta_pow_step(float* __restrict__ beta_pow, float b1, float b2, float* __restrict__ step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1761,6 +1797,30 @@ int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, flo
     if (!grads || !norm_scale || !sq_partial || n < 1 || n_partials < 1 || ((uintptr_t)grads & 15)) return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_clip_scale_inplace, dim3(stream_grid(n >> 2)), dim3(256), 0, (hipStream_t)stream, grads, n,
                        sq_partial, n_partials, clip_norm, norm_scale);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_stream_copy(float* dst, const float* src, size_t n, int unroll, int nontemporal, int blocks, void* stream) {
+    PFPN_BEGIN();
+    if (!dst || !src || n < 4 || (n & 3) || (((uintptr_t)dst | (uintptr_t)src) & 15) || blocks < 1 || blocks > 65536)
+        return PFPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n4 = n >> 2;
+    if (unroll == 0) {                 // read-only stream: dst is the [blocks * 256] sink
+        if (nontemporal) hipLaunchKernelGGL((k_stream_read<true>), dim3(blocks), dim3(256), 0, st, dst, src, n4);
+        else hipLaunchKernelGGL((k_stream_read<false>), dim3(blocks), dim3(256), 0, st, dst, src, n4);
+        PFPN_CHECK_LAUNCH();
+        return PFPN_OK;
+    }
+#define PFPN_COPY_CASE(U_, NT_)                                                                              \
+    hipLaunchKernelGGL((k_stream_copy<U_, NT_>), dim3(blocks), dim3(256), 0, st, dst, src, n4)
+    if (unroll == 1) { if (nontemporal) PFPN_COPY_CASE(1, true); else PFPN_COPY_CASE(1, false); }
+    else if (unroll == 2) { if (nontemporal) PFPN_COPY_CASE(2, true); else PFPN_COPY_CASE(2, false); }
+    else if (unroll == 4) { if (nontemporal) PFPN_COPY_CASE(4, true); else PFPN_COPY_CASE(4, false); }
+    else if (unroll == 8) { if (nontemporal) PFPN_COPY_CASE(8, true); else PFPN_COPY_CASE(8, false); }
+    else return PFPN_ERR_ARG;
+#undef PFPN_COPY_CASE
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

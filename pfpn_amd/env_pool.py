@@ -80,6 +80,7 @@ class EnvPool(object):
         P = min(self.E, processes or min(self.E, max(1, (mp.cpu_count() or 2) - 1)))
         ctx = mp.get_context(start_method)
         bounds = np.linspace(0, self.E, P + 1).astype(int)
+        self.bounds = [int(b) for b in bounds]
         self.conns, self.procs = [], []
         for p in range(P):
             lo, hi = int(bounds[p]), int(bounds[p + 1])
@@ -96,6 +97,33 @@ class EnvPool(object):
         for c in self.conns:
             if c.recv_bytes() != b"k":
                 raise RuntimeError("environment worker failed")
+
+    # -- two halves that step independently (the overlapped rollout: one half's environments step on the host while the
+    # GPU runs the other half's policy call) ----------------------------------------------------------------------------
+    def halves(self):
+        """[(env slice, worker connections)] x 2: the first / second half of the worker processes with their
+        environments (needs >= 2 processes)."""
+        P = len(self.conns)
+        if P < 2:
+            raise ValueError("the overlapped rollout needs at least two worker processes")
+        h = P // 2
+        mid = self.bounds[h]
+        return [(slice(0, mid), self.conns[:h]), (slice(mid, self.E), self.conns[h:])]
+
+    def step_send(self, half, actions):
+        sl, conns = half
+        self.np["action"][sl] = np.asarray(actions, np.float32).reshape(self.np["action"][sl].shape)
+        for c in conns:
+            c.send_bytes(b"s")
+
+    def step_wait(self, half):
+        sl, conns = half
+        for c in conns:
+            if c.recv_bytes() != b"k":
+                raise RuntimeError("environment worker failed")
+        n = self.np
+        return (n["state"][sl].copy(), n["reward"][sl].copy(), n["done"][sl].astype(bool), n["trunc"][sl].astype(bool),
+                n["last"][sl].copy())
 
     def reset(self):
         self._round(b"r")
@@ -132,15 +160,32 @@ class BatchedPPORollout(object):
     UNCLIPPED action is stored, a true terminal bootstraps with 0 and a time limit / unroll boundary with
     V(last state), GAE runs per environment segment (device scan over ragged sequences)."""
 
-    def __init__(self, net, pool, unroll_length, graph=None):
+    def __init__(self, net, pool, unroll_length, graph=None, overlap=False):
+        """overlap: the pool's two halves alternate -- while half A's environments step on the host, the GPU runs half
+        B's policy call (and vice versa), so neither side waits for the other's whole turn.  Same draws as the
+        sequential rollout: the noise of a time step is drawn ONCE for all E environments (one generator call per
+        tensor, as `run_batch` over E rows makes) and each half's call reads its rows of it."""
         self.net, self.pool, self.T = net, pool, int(unroll_length)
         self.state = pool.reset()
         self.total_samples = 0
+        self.overlap = bool(overlap)
         # on a GPU the per-step policy call is one hipGraph replay (pfpn_amd/graphs.py: GraphedRollout)
         if graph is None:
             graph = getattr(net, "device", None) is not None and getattr(net.device, "type", "cpu") == "cuda"
         self._infer = net.run_batch
-        if graph:
+        if self.overlap:
+            self.halves = pool.halves()
+            sizes = [h[0].stop - h[0].start for h in self.halves]
+            if graph:
+                from .graphs import GraphedRollout
+                full = GraphedRollout(net, pool.E, capture=False)          # owns the step's noise buffers [E, ...]
+                self._noise_owner = full
+                self._infer_half = [GraphedRollout(net, n, noise={k: v[h[0]] for k, v in full.noise.items()})
+                                    for n, h in zip(sizes, self.halves)]
+            else:
+                self._noise_owner = None
+                self._infer_half = [net.run_batch, net.run_batch]
+        elif graph:
             from .graphs import GraphedRollout
             self._infer = GraphedRollout(net, pool.E)
 
@@ -157,17 +202,43 @@ class BatchedPPORollout(object):
         cut = np.zeros((T, E), bool)                      # a segment ends after this step
         boot_state = np.zeros((T, E, S), np.float32)      # ... and bootstraps with V(this state) unless terminal
         boot_zero = np.zeros((T, E), bool)
-        for t in range(T):
-            a, lp, v = self._infer(self.state)
-            states[t] = self.state
-            actions[t], logps[t], values[t] = a, lp, v
-            nxt, r, done, trunc, last = self.pool.step(a.cpu().numpy())
-            rewards[t] = r
+        def book(t, sl, nxt, r, done, trunc, last):
+            rewards[t, sl] = r
             end = done | (t == T - 1)
-            cut[t] = end
-            boot_zero[t] = done & ~trunc                   # a real terminal: bootstrap value 0
-            boot_state[t][end] = np.where(done[:, None], last, nxt)[end]
-            self.state = nxt
+            cut[t, sl] = end
+            boot_zero[t, sl] = done & ~trunc               # a real terminal: bootstrap value 0
+            bs = boot_state[t, sl]
+            bs[end] = np.where(done[:, None], last, nxt)[end]
+            boot_state[t, sl] = bs
+            self.state[sl] = nxt
+
+        if self.overlap:
+            # half h's environments step while the other half's policy call runs: send(A) | infer(B) | send(B) | wait(A) ...
+            pool, halves = self.pool, self.halves
+            pending = [False, False]
+            for t in range(T):
+                if self._noise_owner is not None:
+                    self._noise_owner.refill()             # ONE draw per time step for all E environments
+                for h, (sl, _) in enumerate(halves):
+                    if pending[h]:
+                        book(t - 1, sl, *pool.step_wait(halves[h]))
+                        pending[h] = False
+                    st_h = self.state[sl]
+                    a, lp, v = self._infer_half[h](st_h) if self._noise_owner is None else \
+                        self._infer_half[h](st_h, refill=False)
+                    states[t, sl] = st_h
+                    actions[t, sl], logps[t, sl], values[t, sl] = a, lp, v
+                    pool.step_send(halves[h], a.cpu().numpy())
+                    pending[h] = True
+            for h, (sl, _) in enumerate(halves):
+                book(T - 1, sl, *pool.step_wait(halves[h]))
+        else:
+            full = slice(0, E)
+            for t in range(T):
+                a, lp, v = self._infer(self.state)
+                states[t] = self.state
+                actions[t], logps[t], values[t] = a, lp, v
+                book(t, full, *self.pool.step(a.cpu().numpy()))
         self.total_samples += T * E
         # bootstrap values of all segment ends in one batched critic call
         idx = np.argwhere(cut)                             # (t, e) pairs, time-major

@@ -24,7 +24,10 @@ class SyntheticDeepMimicEnv(object):
     """Same observation/action spaces as DeepMimic{Walk,Kick,Punch}-v0; 600-step episodes with the
     gym TimeLimit convention (info['TimeLimit.truncated'])."""
 
-    def __init__(self, state_dim=197, action_dim=36, episode_length=600, seed=0):
+    def __init__(self, state_dim=197, action_dim=36, episode_length=600, seed=0, step_cost=0.0):
+        # step_cost: seconds of host CPU a step burns (busy, like physics -- a PyBullet DeepMimic step is ~1 ms), so the
+        # overlap of environment stepping with the policy call can be measured without pybullet
+        self.step_cost = float(step_cost)
         self.observation_space = Box(-np.inf * np.ones(state_dim), np.inf * np.ones(state_dim))
         self.action_space = Box(-np.ones(action_dim), np.ones(action_dim))
         self.episode_length = episode_length
@@ -42,6 +45,11 @@ class SyntheticDeepMimicEnv(object):
 
     def step(self, a):
         self.t += 1
+        if self.step_cost > 0:
+            import time
+            t_end = time.perf_counter() + self.step_cost
+            while time.perf_counter() < t_end:
+                pass
         self.s = (0.95 * self.s + np.asarray(a, np.float32) @ self.W
                   + 0.05 * self.rng.randn(self.s.shape[0]).astype(np.float32))
         reward = float(np.exp(-0.05 * np.square(self.s[:8]).sum()))

@@ -151,13 +151,18 @@ class GraphedRollout(object):
     the states, two RNG fills (the draws stay OUTSIDE the graph, from the network's generator) and one replay.
     Returns the same (action, log_prob, value) device tensors on every call (overwritten by the next one)."""
 
-    def __init__(self, net, E, warmup=2):
+    def __init__(self, net, E, warmup=2, noise=None, capture=True):
+        """`noise`: static noise buffers to read (row views of another instance's: the overlapped rollout draws a time
+        step's noise once for all environments and runs the policy on half of them at a time); `capture=False`: only
+        own the noise buffers of an E-row call (`refill()`), no graph."""
         self.net, self.E = net, int(E)
         dev = net.device
         self.states = torch.zeros(self.E, net.S, dtype=torch.float32, device=dev)
-        net._ensure_buffers(self.E, pin=True)
+        net._ensure_buffers(self.E, pin=capture)
         policy, _, _ = net._forward(self.states)
-        self.noise = policy.make_noise(net.rng)              # static buffers of the right shapes / dtypes
+        self.noise = policy.make_noise(net.rng) if noise is None else noise      # static buffers of the right shapes / dtypes
+        if not capture:
+            return
         stats = [t for t in (getattr(net, "max_active", None), getattr(net, "sum_active", None)) if t is not None]
         saved = [t.clone() for t in stats]
         s = torch.cuda.Stream()
@@ -174,10 +179,14 @@ class GraphedRollout(object):
             self.out = net.run_batch(self.states, noise=self.noise)
         self.policy = net.policy
 
-    def __call__(self, states):
+    def refill(self):
+        refill_noise(self.noise, self.net.rng)               # fresh draws, same distributions as make_noise
+
+    def __call__(self, states, refill=True):
         net = self.net
         self.states.copy_(torch.as_tensor(states, dtype=torch.float32).view(self.E, net.S), non_blocking=True)
-        refill_noise(self.noise, net.rng)                    # fresh draws, same distributions as make_noise
+        if refill:
+            self.refill()
         self.graph.replay()
         net.policy = self.policy
         return self.out

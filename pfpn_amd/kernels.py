@@ -1051,3 +1051,14 @@ def dense_jobs(jobs):
         raise ValueError("1..%d dense jobs per launch" % DENSE_MAX_JOBS)
     arr = (DenseJob * len(jobs))(*jobs)
     _lib.check(lib.pfpn_dense_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_dense_jobs")
+
+
+def stream_copy(dst, src, unroll=4, nontemporal=False, blocks=2048):
+    """the build's own streaming copy (calibration of the HBM roofline fractions on the box at hand)."""
+    lib = _lib.load()
+    n = src.numel()
+    if dst.numel() != (n if unroll else blocks * 256):
+        raise ValueError("stream_copy: dst is src-sized (copy) or [blocks * 256] (unroll = 0: read-only stream)")
+    _lib.check(lib.pfpn_stream_copy(_f32(dst), _f32(src), n, int(unroll), int(nontemporal), int(blocks), _stream()),
+               "pfpn_stream_copy")
+    return dst

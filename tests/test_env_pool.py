@@ -89,3 +89,57 @@ def test_batched_rollout_buffers(oracle):
         np.testing.assert_allclose(buf["advantage"].numpy()[:T], np.concatenate([adv_a, adv_b]), rtol=1e-5, atol=1e-6)
     finally:
         pool.close()
+
+
+class FnNet(StubNet):
+    """a deterministic policy (the action is a function of the state) so that two rollouts can be compared row by row."""
+    def run_batch(self, states):
+        st = torch.as_tensor(np.asarray(states, np.float32))
+        self.calls += 1
+        return 1.5 * torch.tanh(st[:, :36] * 2.0), torch.full((st.shape[0],), -40.0), st[:, :3].sum(1)
+
+
+def test_pool_halves_step_independently():
+    """step_send / step_wait on the two halves, in the overlapped order, give what the sequential environments give."""
+    E, steps = 6, 50
+    pool = EnvPool(make_fns(E), processes=4)
+    try:
+        ref = [fn() for fn in make_fns(E)]
+        s = pool.reset()
+        assert np.array_equal(s, np.stack([e.reset() for e in ref]))
+        halves = pool.halves()
+        assert halves[0][0].start == 0 and halves[0][0].stop == halves[1][0].start and halves[1][0].stop == E
+        rng = np.random.default_rng(0)
+        for _ in range(steps):
+            a = rng.uniform(-1.5, 1.5, (E, 36)).astype(np.float32)
+            pool.step_send(halves[0], a[halves[0][0]])
+            pool.step_send(halves[1], a[halves[1][0]])          # both halves in flight
+            outs = [pool.step_wait(halves[1]), pool.step_wait(halves[0])][::-1]
+            for (sl, _), (sh, r, d, tr, last) in zip(halves, outs):
+                for j, i in enumerate(range(sl.start, sl.stop)):
+                    si, ri, di, info = ref[i].step(np.clip(a[i], -1, 1))
+                    assert np.array_equal(last[j], si) and r[j] == np.float32(ri) and d[j] == di
+                    assert np.array_equal(sh[j], ref[i].reset() if di else si)
+    finally:
+        pool.close()
+
+
+def test_overlapped_rollout_matches_sequential_rollout(oracle):
+    """the two-half rollout (one half's environments step while the other half's policy call runs) fills the same buffers
+    as the sequential one: same states, actions, values, advantages, row for row."""
+    E, T = 6, 40
+    bufs, calls = [], []
+    for overlap in (False, True):
+        pool = EnvPool(make_fns(E), processes=4)
+        try:
+            net = FnNet(oracle)
+            ro = BatchedPPORollout(net, pool, T, overlap=overlap)
+            bufs.append(ro.collect())
+            bufs.append(ro.collect())                           # a second unroll continues from the first one's states
+            calls.append(net.calls)
+        finally:
+            pool.close()
+    assert calls == [2 * T, 4 * T]                              # one call per step | one per step and half
+    for a, b in ((bufs[0], bufs[2]), (bufs[1], bufs[3])):
+        for k in ("state", "action", "value", "log_prob", "advantage"):
+            assert torch.equal(a[k], b[k]), k

@@ -170,3 +170,34 @@ def test_gather_columns_kernel(dev):
     kernels.gather_columns(srcs, dsts, rows)
     for s, d in zip(srcs, dsts):
         assert torch.equal(d, s[rows])
+
+
+def test_overlapped_rollout_on_the_gpu_matches_the_sequential_one(dev):
+    """EnvPool halves + two hipGraph policy replays per time step (each half's environments step on the host while the
+    GPU runs the other half) against the sequential pool with the same seeds: the step's noise is drawn once for all E
+    environments in both, so the drawn particles agree and the buffers agree to the rounding of a GEMM over E/2 instead
+    of E rows."""
+    import numpy as np
+    import torch
+    from pfpn_amd.env_pool import BatchedPPORollout, EnvPool
+    from pfpn_amd.envs import SyntheticDeepMimicEnv
+    from test_gpu_dppo_step import make_net
+    E, T = 8, 24
+    fns = [(lambda i=i: SyntheticDeepMimicEnv(episode_length=17, seed=50 + i)) for i in range(E)]
+    bufs, ks = [], []
+    for overlap in (False, True):
+        pool = EnvPool(fns, processes=4)
+        try:
+            net = make_net(dev, seed=21)
+            ro = BatchedPPORollout(net, pool, T, overlap=overlap)
+            bufs.append(ro.collect())
+            ks.append((net.max_active.clone(), net.sum_active.clone()))
+        finally:
+            pool.close()
+    a, b = bufs
+    for k in ("state", "action", "value", "log_prob", "advantage"):
+        assert a[k].shape == b[k].shape
+        torch.testing.assert_close(a[k], b[k], rtol=2e-4, atol=2e-4, msg=k)
+    # the activation statistics saw the same rows (in two halves per step): same maxima, sums to summation order
+    torch.testing.assert_close(ks[0][0], ks[1][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ks[0][1], ks[1][1], rtol=1e-4, atol=1e-6)

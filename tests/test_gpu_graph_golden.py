@@ -26,7 +26,7 @@ import fixture_inputs as fi   # noqa: E402
 
 pytestmark = pytest.mark.gpu
 F = np.float32
-MASK_FLIPS = 8
+MASK_FLIPS = 0          # round 3: tools/parity_report.py observes NO entry beyond 5e-5 of scale on any fixture (profiles/r03_parity_report.txt)
 
 
 def load(tag):

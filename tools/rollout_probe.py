@@ -41,3 +41,19 @@ for E, P in ((8, 4), (32, 8)):
     t = time.perf_counter() - t0
     print("EnvPool E=%2d (%d procs) + batched policy, 64-step unroll incl. GAE: %.1f ms -> %.0f env steps/s" % (E, P, t * 1e3, E * 64 / t))
     pool.close()
+
+# overlapped rollout: one half's environments step on the host while the GPU runs the other half's policy call
+# (BatchedPPORollout(overlap=True)), against the sequential pool, at several synthetic step costs (PyBullet DeepMimic ~1 ms)
+for cost in (0.0, 100e-6, 300e-6, 1e-3):
+    for E, P in ((16, 8),):
+        res = {}
+        for overlap in (False, True):
+            pool = EnvPool([(lambda i=i: SyntheticDeepMimicEnv(seed=i, step_cost=cost)) for i in range(E)], processes=P)
+            ro = BatchedPPORollout(net, pool, 64, overlap=overlap)
+            ro.collect()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            ro.collect(); ro.collect()
+            res[overlap] = E * 128 / (time.perf_counter() - t0)
+            pool.close()
+        print("step cost %4.0f us, E=%d, %d procs (%d envs each): sequential %.0f env steps/s, overlapped %.0f (%.2fx)"
+              % (cost * 1e6, E, P, E // P, res[False], res[True], res[True] / res[False]), flush=True)
