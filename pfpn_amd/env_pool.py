@@ -82,14 +82,27 @@ class EnvPool(object):
         bounds = np.linspace(0, self.E, P + 1).astype(int)
         self.bounds = [int(b) for b in bounds]
         self.conns, self.procs = [], []
-        for p in range(P):
-            lo, hi = int(bounds[p]), int(bounds[p + 1])
-            parent, child = ctx.Pipe()
-            pr = ctx.Process(target=_worker, args=(child, env_fns[lo:hi], lo, self.raws, self.shapes), daemon=True)
-            pr.start()
-            child.close()
-            self.conns.append(parent)
-            self.procs.append(pr)
+        # Forked workers inherit the parent's Python heap -- in a learner process that holds HIP objects (streams, graphs,
+        # tensors).  A garbage collection inside a child would finalise its COPIES of them (observed: a segmentation fault
+        # in the child's first collection, right behind fork).  gc.freeze() moves everything alive now into the permanent
+        # generation, which the children inherit: their collector never looks at the parent's objects.
+        import gc
+        frozen = start_method == "fork"
+        if frozen:
+            gc.collect()
+            gc.freeze()
+        try:
+            for p in range(P):
+                lo, hi = int(bounds[p]), int(bounds[p + 1])
+                parent, child = ctx.Pipe()
+                pr = ctx.Process(target=_worker, args=(child, env_fns[lo:hi], lo, self.raws, self.shapes), daemon=True)
+                pr.start()
+                child.close()
+                self.conns.append(parent)
+                self.procs.append(pr)
+        finally:
+            if frozen:
+                gc.unfreeze()
 
     def _round(self, cmd):
         for c in self.conns:
