@@ -38,7 +38,7 @@ constexpr int RD_THREADS = 256;      // 4 waves per block (8-wave blocks with tw
 
 struct DenseJobDev {
     PfpnDenseJob j;
-    int block0, tiles_m, tiles_n, avec;
+    int block0, tiles_m, tiles_n, avec, xcd_remap;
 };
 struct DenseTable {
     int n;
@@ -424,9 +424,20 @@ __global__ __launch_bounds__(RD_THREADS, 2) void k_dense_jobs(DenseTable tab) {
     if (kind == PFPN_DENSE_HEAD_FINAL) { aux_head_final(d.j, local); return; }
     if (kind == PFPN_DENSE_RANK1) { aux_rank1(d.j, local); return; }
     if (kind == PFPN_DENSE_HEAD_WGRAD) { aux_head_wgrad(d.j, local, lds); return; }
+    // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by index (observed, for speed only): blocks whose
+    // index within the job is equal mod 8 share an L2.  Deal each of these 8 classes a CONTIGUOUS range of the job's tiles
+    // (tm fastest, then tn, then the group): an XCD then works a few column panels of one group against that group's rows
+    // -- a working set of ~2.5 MB in its 4 MiB L2 -- instead of every 8th tile of everything (all of W and A: 8 MB, served
+    // from the Infinity Cache at ~33 GB/s per CU, which is what bounded the k-loop whatever its instruction schedule).
     const int per_g = d.tiles_m * d.tiles_n;
-    const int g = local / per_g;
-    const int rem = local - g * per_g;
+    int lin = local;
+    if (d.xcd_remap) {
+        const int T = per_g * d.j.batch, full = T >> 3, extra = T & 7;
+        const int x = local & 7, r = local >> 3;
+        lin = x * full + (x < extra ? x : extra) + r;
+    }
+    const int g = lin / per_g;
+    const int rem = lin - g * per_g;
     const int tn = rem / d.tiles_m, tm = rem - tn * d.tiles_m;
     const int variant = (kind * 3 + d.j.cfg) * 2 + d.avec;
 #define RD_CASE(KIND_, CFG_, WM_, WN_, WK_)                                                          \
@@ -471,6 +482,7 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
     PFPN_BEGIN();
     if (!jobs || n_jobs < 1 || n_jobs > PFPN_DENSE_MAX_JOBS) return PFPN_ERR_ARG;
     static const int force_cfg = getenv("PFPN_DENSE_CFG") ? atoi(getenv("PFPN_DENSE_CFG")) : -1;
+    static const int xcd_remap = getenv("PFPN_DENSE_XCD") ? atoi(getenv("PFPN_DENSE_XCD")) : 1;
     DenseTable tab{};
     tab.n = n_jobs;
     long long blocks = 0, gemm_work = 0;
@@ -489,6 +501,7 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
         d.j = jobs[i];
         PfpnDenseJob& j = d.j;
         d.block0 = (int)blocks;
+        d.xcd_remap = xcd_remap;
         if (j.kind <= PFPN_DENSE_TN) {
             const bool a_kc = j.kind != PFPN_DENSE_TN, b_kc = j.kind == PFPN_DENSE_NT;
             // B operand: float4 loads only
