@@ -328,18 +328,30 @@ int pfpn_dense_wgrad(const float* X, long long x_gstride, int ldx, const float* 
  *   PFPN_DENSE_HEAD_FINAL  C[g][b] = bias[g*sBias] + sum_{t<K} A[g][b][t]           (the HEADPART partials, K = ceil(N/32))
  *   PFPN_DENSE_RANK1       C[g][b][n] = A[g][b] * B[g][n] * [0 < H[g][b][n] < 6]    (head backward into the layer below)
  *   PFPN_DENSE_HEAD_WGRAD  C[g][n] = sum_b A[g][b] * H[g][b][n], aux[g*sAux] = sum_b A[g][b]   (dW, db of the head) */
-#define PFPN_DENSE_MAX_JOBS 8
+#define PFPN_DENSE_MAX_JOBS 16
 #define PFPN_DENSE_NN 0
 #define PFPN_DENSE_NT 1
 #define PFPN_DENSE_TN 2
 #define PFPN_DENSE_HEAD_FINAL 8
 #define PFPN_DENSE_RANK1 9
 #define PFPN_DENSE_HEAD_WGRAD 10
+/* fixed-order reductions riding in the step's LAST dense launch (what pfpn_reduce_jobs does in a launch of its own):
+ *   PFPN_DENSE_SLABSUM   C[i] = sum_{k<K} A[k*lda + i] (+ sum_{k<M} B[k*ldb + i] when B != NULL), i < N
+ *   PFPN_DENSE_SQSUM     squares of the finished gradient segment A[0..N) (N % 4 == 0, 16-byte aligned) over K blocks
+ *   PFPN_DENSE_PPO_LOSS  the two loss columns of pfpn_ppo_mixture_fwd_bwd's slabs (A, stride lda, K slabs) -> C = loss3;
+ *                        p0 = 1/B, p1 = value coefficient
+ *   PFPN_DENSE_NORM_EMA  A = float64 moments of pfpn_state_prologue [K chunks][2][N], M = batch rows, bias = step,
+ *                        B = mean_in, H = std_in, C = mean_out, aux = std_out (utils.py:60-68) */
+#define PFPN_DENSE_SLABSUM 11
+#define PFPN_DENSE_SQSUM 12
+#define PFPN_DENSE_PPO_LOSS 13
+#define PFPN_DENSE_NORM_EMA 14
 #define PFPN_DENSE_BIAS 1
 #define PFPN_DENSE_RELU6 2
 #define PFPN_DENSE_MASK 4
 #define PFPN_DENSE_COLSUM 8
 #define PFPN_DENSE_HEADPART 16
+#define PFPN_DENSE_NORM 32        /* the job's outputs are gradients: their squares count (pfpn_dense_jobs_norm) */
 typedef struct PfpnDenseJob {
     int kind, flags, cfg;
     int M, N, K, batch;
@@ -353,8 +365,16 @@ typedef struct PfpnDenseJob {
     const float* H;
     float* aux;
     const float* hw;
+    float p0, p1;
 } PfpnDenseJob;
 int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream);
+/* The same launch also leaving the partial sums of the global gradient norm (tf.clip_by_global_norm, base_worker.py:97-102)
+ * for pfpn_clip_adam_prenorm / pfpn_clip_scale_only: block b writes sq_partial[b] = the squares of what it stored for jobs
+ * flagged PFPN_DENSE_NORM (dW tiles and their column sums, SLABSUM / HEAD_WGRAD outputs, SQSUM segments), 0 otherwise;
+ * *n_partials = the launch's block count (<= sq_capacity).  beta_pow != NULL: block 0 rotates the Adam powers like
+ * pfpn_reduce_jobs_norm. */
+int pfpn_dense_jobs_norm(const PfpnDenseJob* jobs, int n_jobs, float* sq_partial, size_t sq_capacity, int* n_partials,
+                         float* beta_pow, int n_groups, float beta1, float beta2, void* stream);
 
 /* tf.clip_by_global_norm -- base_worker.py:97-102: norm_scale = {norm, clip*min(1/norm, 1/clip)};
  * apply != 0 scales grads in place (needed before a data-parallel all-reduce). */

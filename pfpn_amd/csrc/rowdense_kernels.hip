@@ -42,6 +42,13 @@ struct DenseJobDev {
 };
 struct DenseTable {
     int n;
+    // the launch also leaves the partial sums of the global gradient norm (one per block, fixed order: block index) and
+    // rotates the Adam powers, like pfpn_reduce_jobs_norm -- the step's last dense launch then stands in for the separate
+    // reduction launch
+    float* sq_partial;
+    float* beta_pow;
+    int n_groups;
+    float b1, b2;
     DenseJobDev job[PFPN_DENSE_MAX_JOBS];
 };
 
@@ -157,7 +164,8 @@ struct RowOperand {
 };
 
 template <int KIND, int WM, int WN, int WK, bool AVEC>
-__device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, int tn, float* lds) {
+__device__ __forceinline__ float dense_tile(const DenseJobDev& d, int g, int tm, int tn, float* lds) {
+    float sq = 0.f;                                  // squares of the values this thread stores (PFPN_DENSE_NORM)
     constexpr int TM = 32 * WM, TN = 32 * WN, BKT = 32 * WK;
     constexpr bool AKC = KIND != PFPN_DENSE_TN;
     constexpr bool BKC = KIND == PFPN_DENSE_NT;
@@ -305,7 +313,7 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
                 const float h = ok ? H[(size_t)row * j.ldh + col] : 0.f;
                 v = (h > 0.f && h < 6.f) ? v : 0.f;
             }
-            if (ok) C[(size_t)row * j.ldc + col] = v;
+            if (ok) { C[(size_t)row * j.ldc + col] = v; sq += v * v; }
             if (head) {
                 // sum over the 32 columns (lanes) of this lane half: four row_shr steps inside each row of 16 lanes, then
                 // row_bcast:15 carries the sum of rows 0 / 2 into rows 1 / 3 -- lanes 31 and 63 hold the two halves' sums
@@ -333,23 +341,29 @@ __device__ __forceinline__ void dense_tile(const DenseJobDev& d, int g, int tm, 
                 s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
             }
             const int col = n0 + 4 * t;
-            if (col < j.N) *reinterpret_cast<float4*>(j.aux + (size_t)g * j.sAux + col) = s;
+            if (col < j.N) {
+                *reinterpret_cast<float4*>(j.aux + (size_t)g * j.sAux + col) = s;
+                sq += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+            }
         }
+        __syncthreads();                             // (the caller may reuse the LDS words the column sums went through)
     }
+    return sq;
 }
 
-// ---- helpers on [rows] vectors --------------------------------------------------------------------------------------
+// ---- helpers on [rows] vectors (no early exits: every thread reaches the block's square-sum hand-off) -----------------
 // out[g][b] = hb[g*sBias] + sum_t part[g][b][t] (t ascending): finishes a scalar head whose per-32-column partial dot
 // products the previous layer's epilogue left.
 __device__ __forceinline__ void aux_head_final(const PfpnDenseJob& j, int local) {
     const int per = (j.M + RD_THREADS - 1) / RD_THREADS;
     const int g = local / per;
     const int b = (local - g * per) * RD_THREADS + threadIdx.x;
-    if (b >= j.M) return;
-    const float* part = j.A + (size_t)g * j.sA + (size_t)b * j.K;
-    float s = j.bias[(size_t)g * j.sBias];
-    for (int q = 0; q < j.K; ++q) s += part[q];
-    j.C[(size_t)g * j.sC + b] = s;
+    if (b < j.M) {
+        const float* part = j.A + (size_t)g * j.sA + (size_t)b * j.K;
+        float s = j.bias[(size_t)g * j.sBias];
+        for (int q = 0; q < j.K; ++q) s += part[q];
+        j.C[(size_t)g * j.sC + b] = s;
+    }
 }
 // C[g][b][c] = dv[g][b] * w[g][c] * [0 < H[g][b][c] < 6]: backward of a scalar head into the (ReLU6) layer below it
 __device__ __forceinline__ void aux_rank1(const PfpnDenseJob& j, int local) {
@@ -358,27 +372,29 @@ __device__ __forceinline__ void aux_rank1(const PfpnDenseJob& j, int local) {
     const int bpg = (int)((per_g + RD_THREADS - 1) / RD_THREADS);
     const int g = local / bpg;
     const size_t i = (size_t)(local - g * bpg) * RD_THREADS + threadIdx.x;
-    if (i >= per_g) return;
-    const int b = (int)(i / n4), c = (int)(i % n4) * 4;
-    const float dv = j.A[(size_t)g * j.sA + b];
-    const float4 w = ld4(j.B + (size_t)g * j.sB + c);
-    const float4 h = ld4(j.H + (size_t)g * j.sH + (size_t)b * j.ldh + c);
-    float4 o;
-    o.x = (h.x > 0.f && h.x < 6.f) ? dv * w.x : 0.f;
-    o.y = (h.y > 0.f && h.y < 6.f) ? dv * w.y : 0.f;
-    o.z = (h.z > 0.f && h.z < 6.f) ? dv * w.z : 0.f;
-    o.w = (h.w > 0.f && h.w < 6.f) ? dv * w.w : 0.f;
-    *reinterpret_cast<float4*>(j.C + (size_t)g * j.sC + (size_t)b * j.ldc + c) = o;
+    if (i < per_g) {
+        const int b = (int)(i / n4), c = (int)(i % n4) * 4;
+        const float dv = j.A[(size_t)g * j.sA + b];
+        const float4 w = ld4(j.B + (size_t)g * j.sB + c);
+        const float4 h = ld4(j.H + (size_t)g * j.sH + (size_t)b * j.ldh + c);
+        float4 o;
+        o.x = (h.x > 0.f && h.x < 6.f) ? dv * w.x : 0.f;
+        o.y = (h.y > 0.f && h.y < 6.f) ? dv * w.y : 0.f;
+        o.z = (h.z > 0.f && h.z < 6.f) ? dv * w.z : 0.f;
+        o.w = (h.w > 0.f && h.w < 6.f) ? dv * w.w : 0.f;
+        *reinterpret_cast<float4*>(j.C + (size_t)g * j.sC + (size_t)b * j.ldc + c) = o;
+    }
 }
 // dw[g][c] = sum_b dv[g][b] * h[g][b][c], db[g] = sum_b dv[g][b].  A block owns 32 columns; its 8 row phases each keep
 // four interleaved partial sums (rows ph + 8 q + 32 i: four loads in flight per thread instead of one dependent chain),
-// combined in a fixed order.
-__device__ __forceinline__ void aux_head_wgrad(const PfpnDenseJob& j, int local, float* lds) {
+// combined in a fixed order.  Returns the thread's share of the outputs' squares.
+__device__ __forceinline__ float aux_head_wgrad(const PfpnDenseJob& j, int local, float* lds) {
     const int cblk = (j.N + 31) / 32;
     const int g = local / (cblk + 1);
     const int cb = local - g * (cblk + 1);
     const float* dv = j.A + (size_t)g * j.sA;
     const int t = threadIdx.x;
+    float sq = 0.f;
     if (cb == cblk) {                       // the bias gradient: RD_THREADS strided partial sums, then in thread order
         float s = 0.f;
         for (int b = t; b < j.M; b += RD_THREADS) s += dv[b];
@@ -388,8 +404,10 @@ __device__ __forceinline__ void aux_head_wgrad(const PfpnDenseJob& j, int local,
             float tot = 0.f;
             for (int q = 0; q < RD_THREADS; ++q) tot += lds[q];
             j.aux[(size_t)g * j.sAux] = tot;
+            sq = tot * tot;
         }
-        return;
+        __syncthreads();
+        return sq;
     }
     constexpr int PH = RD_THREADS / 32;
     const int c = cb * 32 + (t & 31), ph = t >> 5;
@@ -408,7 +426,108 @@ __device__ __forceinline__ void aux_head_wgrad(const PfpnDenseJob& j, int local,
         float tot = lds[t];
         for (int q = 1; q < PH; ++q) tot += lds[t + 32 * q];
         j.C[(size_t)g * j.sC + c] = tot;
+        sq = tot * tot;
     }
+    __syncthreads();
+    return sq;
+}
+// Column sums of K partial slabs in the order of pfpn_reduce_jobs (slab_reduce_1024: k-lane l sums slabs l, l+16, ..
+// in k order, then lanes 0..15 in order), so a gradient has the same bits whichever launch finishes it.  16 columns x 16
+// k-lanes per block; valid on k-lane 0.
+__device__ __forceinline__ float slab_sum16(const float* __restrict__ slab, int K, size_t stride, int col, bool ok,
+                                            float* lds) {
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    float acc = 0.f;
+    if (ok)
+        for (int k = kl; k < K; k += 16) acc += slab[(size_t)k * stride + col];
+    lds[kl * 16 + cl] = acc;
+    __syncthreads();
+    float s = lds[cl];
+    if (kl == 0)
+        for (int q = 1; q < 16; ++q) s += lds[q * 16 + cl];
+    __syncthreads();
+    return s;
+}
+// out[i] = sum_{k<K} A[k*lda + i] (+ sum_{k<M} B[k*ldb + i] for a second slab set), i < N: the fixed-order finish of
+// per-block partial slabs (the mixture kernel's particle-grid / head-bias gradients).
+__device__ __forceinline__ float aux_slabsum(const PfpnDenseJob& j, int local, float* lds) {
+    const int i = local * 16 + (threadIdx.x & 15);
+    const bool ok = i < j.N;
+    float s = slab_sum16(j.A, j.K, (size_t)j.lda, i, ok, lds);
+    if (j.B) s = s + slab_sum16(j.B, j.M, (size_t)j.ldb, i, ok, lds);
+    float sq = 0.f;
+    if (ok && (threadIdx.x >> 4) == 0) {
+        j.C[i] = s;
+        sq = s * s;
+    }
+    return sq;
+}
+// squares of a FINISHED gradient segment A[0 .. N) (N % 4 == 0), block `local` of K takes its share
+__device__ __forceinline__ float aux_sqsum(const PfpnDenseJob& j, int local) {
+    const float4* g4 = reinterpret_cast<const float4*>(j.A);
+    const size_t n4 = (size_t)j.N >> 2;
+    const size_t share = (n4 + j.K - 1) / j.K;
+    const size_t lo = (size_t)local * share, hi = lo + share < n4 ? lo + share : n4;
+    float s = 0.f;
+    size_t i = lo + threadIdx.x;
+    for (; i + 3 * RD_THREADS < hi; i += 4 * RD_THREADS) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = g4[i + u * RD_THREADS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+    }
+    for (; i < hi; i += RD_THREADS) { const float4 v = g4[i]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    return s;
+}
+// the two loss columns of the fused PPO kernel's slabs -> loss3 = {loss, policy_loss, value_loss * coef} (ppo.py:39-54):
+// A -> the columns, lda = slab stride, K = slabs, p0 = 1/B, p1 = value coefficient
+__device__ __forceinline__ void aux_ppo_loss(const PfpnDenseJob& j, float* lds) {
+    const int cl = threadIdx.x & 15;
+    const float s = slab_sum16(j.A, j.K, (size_t)j.lda, cl & 1, cl < 2, lds);
+    if ((threadIdx.x >> 4) == 0 && cl < 2) lds[256 + cl] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float pl = -lds[256] * j.p0, vl = lds[257] * j.p0 * j.p1;
+        j.C[0] = pl + vl;
+        j.C[1] = pl;
+        j.C[2] = vl;
+    }
+    __syncthreads();
+}
+// float64 chunk moments of the state (pfpn_state_prologue) -> EMA of the normaliser (utils.py:60-68): A = moments
+// [K chunks][2][N], M = batch rows, bias = step, B = mean_in, H = std_in, C = mean_out, aux = std_out.  16 columns per
+// block, 16 chunk lanes per column (lane l sums chunks l, l+16, ..; then lanes 0..15 in order).
+__device__ __forceinline__ void aux_norm_ema(const PfpnDenseJob& j, int local, float* lds) {
+    double* dred = reinterpret_cast<double*>(lds);          // [2][16][16]
+    const double* partial = reinterpret_cast<const double*>(j.A);
+    const int S = j.N, C = j.K;
+    const int ecl = threadIdx.x & 15, ekl = threadIdx.x >> 4;      // 256 threads: 16 columns x 16 chunk lanes
+    const int c = local * 16 + ecl;
+    const bool active = c < S;
+    double a1 = 0.0, a2 = 0.0;
+    if (active)
+        for (int k = ekl; k < C; k += 16) {
+            a1 += partial[((size_t)k * 2 + 0) * S + c];
+            a2 += partial[((size_t)k * 2 + 1) * S + c];
+        }
+    dred[ekl * 16 + ecl] = a1;
+    dred[256 + ekl * 16 + ecl] = a2;
+    __syncthreads();
+    if (active && ekl == 0) {
+        for (int m = 1; m < 16; ++m) { a1 += dred[m * 16 + ecl]; a2 += dred[256 + m * 16 + ecl]; }
+        const double Bd = (double)j.M;
+        const double mu = a1 / Bd;
+        double var = a2 / Bd - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float bmean = (float)mu, bvar = (float)var;
+        const float step = j.bias[0];
+        const float dk = fminf(0.9999f, (1.f + step) / (10.f + step));
+        const float omd = 1.f - dk;
+        j.C[c] = dk * j.B[c] + omd * bmean;
+        j.aux[c] = fmaxf(1e-6f, dk * j.H[c] + omd * sqrtf(bvar));
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(RD_THREADS, 2) void k_dense_jobs(DenseTable tab) {
@@ -421,39 +540,65 @@ __global__ __launch_bounds__(RD_THREADS, 2) void k_dense_jobs(DenseTable tab) {
         if (q < tab.n && (int)blockIdx.x >= tab.job[q].block0) d = tab.job[q];
     const int local = blockIdx.x - d.block0;
     const int kind = d.j.kind;
-    if (kind == PFPN_DENSE_HEAD_FINAL) { aux_head_final(d.j, local); return; }
-    if (kind == PFPN_DENSE_RANK1) { aux_rank1(d.j, local); return; }
-    if (kind == PFPN_DENSE_HEAD_WGRAD) { aux_head_wgrad(d.j, local, lds); return; }
-    // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by index (observed, for speed only): blocks whose
-    // index within the job is equal mod 8 share an L2.  Deal each of these 8 classes a CONTIGUOUS range of the job's tiles
-    // (tm fastest, then tn, then the group): an XCD then works a few column panels of one group against that group's rows
-    // -- a working set of ~2.5 MB in its 4 MiB L2 -- instead of every 8th tile of everything (all of W and A: 8 MB, served
-    // from the Infinity Cache at ~33 GB/s per CU, which is what bounded the k-loop whatever its instruction schedule).
-    const int per_g = d.tiles_m * d.tiles_n;
-    int lin = local;
-    if (d.xcd_remap) {
-        const int T = per_g * d.j.batch, full = T >> 3, extra = T & 7;
-        const int x = local & 7, r = local >> 3;
-        lin = x * full + (x < extra ? x : extra) + r;
-    }
-    const int g = lin / per_g;
-    const int rem = lin - g * per_g;
-    const int tn = rem / d.tiles_m, tm = rem - tn * d.tiles_m;
-    const int variant = (kind * 3 + d.j.cfg) * 2 + d.avec;
+    float sq = 0.f;
+    if (kind == PFPN_DENSE_HEAD_FINAL) aux_head_final(d.j, local);
+    else if (kind == PFPN_DENSE_RANK1) aux_rank1(d.j, local);
+    else if (kind == PFPN_DENSE_HEAD_WGRAD) sq = aux_head_wgrad(d.j, local, lds);
+    else if (kind == PFPN_DENSE_SLABSUM) sq = aux_slabsum(d.j, local, lds);
+    else if (kind == PFPN_DENSE_SQSUM) sq = aux_sqsum(d.j, local);
+    else if (kind == PFPN_DENSE_PPO_LOSS) aux_ppo_loss(d.j, lds);
+    else if (kind == PFPN_DENSE_NORM_EMA) aux_norm_ema(d.j, local, lds);
+    else {
+        // XCD-aware tile order.  Blocks are dealt to the 8 XCDs round-robin by index (observed, for speed only): blocks whose
+        // index within the job is equal mod 8 share an L2.  Deal each of these 8 classes a CONTIGUOUS range of the job's
+        // tiles (tm fastest, then tn, then the group): an XCD then works a few column panels of one group against that
+        // group's rows -- a working set of ~2.5 MB in its 4 MiB L2 -- instead of every 8th tile of everything.
+        const int per_g = d.tiles_m * d.tiles_n;
+        int lin = local;
+        if (d.xcd_remap) {
+            const int T = per_g * d.j.batch, full = T >> 3, extra = T & 7;
+            const int x = local & 7, r = local >> 3;
+            lin = x * full + (x < extra ? x : extra) + r;
+        }
+        const int g = lin / per_g;
+        const int rem = lin - g * per_g;
+        const int tn = rem / d.tiles_m, tm = rem - tn * d.tiles_m;
+        const int variant = (kind * 3 + d.j.cfg) * 2 + d.avec;
 #define RD_CASE(KIND_, CFG_, WM_, WN_, WK_)                                                          \
-    case (KIND_ * 3 + CFG_) * 2 + 1: dense_tile<KIND_, WM_, WN_, WK_, true>(d, g, tm, tn, lds); break;
+    case (KIND_ * 3 + CFG_) * 2 + 1: sq = dense_tile<KIND_, WM_, WN_, WK_, true>(d, g, tm, tn, lds); break;
 #define RD_CASE_U(KIND_, CFG_, WM_, WN_, WK_)                                                        \
-    case (KIND_ * 3 + CFG_) * 2 + 0: dense_tile<KIND_, WM_, WN_, WK_, false>(d, g, tm, tn, lds); break;
-    switch (variant) {
-        RD_CASE(PFPN_DENSE_NN, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_NN, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_NN, 2, 1, 1, 4)
-        RD_CASE(PFPN_DENSE_NT, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_NT, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_NT, 2, 1, 1, 4)
-        RD_CASE(PFPN_DENSE_TN, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_TN, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_TN, 2, 1, 1, 4)
-        RD_CASE_U(PFPN_DENSE_NN, 0, 2, 2, 1) RD_CASE_U(PFPN_DENSE_NN, 1, 1, 2, 2) RD_CASE_U(PFPN_DENSE_NN, 2, 1, 1, 4)
-        RD_CASE_U(PFPN_DENSE_TN, 0, 2, 2, 1) RD_CASE_U(PFPN_DENSE_TN, 1, 1, 2, 2) RD_CASE_U(PFPN_DENSE_TN, 2, 1, 1, 4)
-        default: break;
-    }
+    case (KIND_ * 3 + CFG_) * 2 + 0: sq = dense_tile<KIND_, WM_, WN_, WK_, false>(d, g, tm, tn, lds); break;
+        switch (variant) {
+            RD_CASE(PFPN_DENSE_NN, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_NN, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_NN, 2, 1, 1, 4)
+            RD_CASE(PFPN_DENSE_NT, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_NT, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_NT, 2, 1, 1, 4)
+            RD_CASE(PFPN_DENSE_TN, 0, 2, 2, 1) RD_CASE(PFPN_DENSE_TN, 1, 1, 2, 2) RD_CASE(PFPN_DENSE_TN, 2, 1, 1, 4)
+            RD_CASE_U(PFPN_DENSE_NN, 0, 2, 2, 1) RD_CASE_U(PFPN_DENSE_NN, 1, 1, 2, 2) RD_CASE_U(PFPN_DENSE_NN, 2, 1, 1, 4)
+            RD_CASE_U(PFPN_DENSE_TN, 0, 2, 2, 1) RD_CASE_U(PFPN_DENSE_TN, 1, 1, 2, 2) RD_CASE_U(PFPN_DENSE_TN, 2, 1, 1, 4)
+            default: break;
+        }
 #undef RD_CASE
 #undef RD_CASE_U
+    }
+    if (tab.sq_partial) {
+        // this block's share of the global gradient norm: the squares of what it stored where the job says they are
+        // gradients (PFPN_DENSE_NORM), threads in order -- fixed order, no atomics; EVERY block writes its slot
+        __syncthreads();
+        lds[threadIdx.x] = (d.j.flags & PFPN_DENSE_NORM) ? sq : 0.f;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float s4 = (lds[threadIdx.x] + lds[threadIdx.x + 64]) + (lds[threadIdx.x + 128] + lds[threadIdx.x + 192]);
+            s4 = wave_sum(s4);
+            if (threadIdx.x == 0) {
+                tab.sq_partial[blockIdx.x] = s4;
+                if (blockIdx.x == 0 && tab.beta_pow)
+                    for (int k = 0; k < tab.n_groups; ++k) {          // powers: used <- next, next <- next * beta
+                        float* bp = tab.beta_pow + 4 * k;
+                        bp[2] = bp[0]; bp[3] = bp[1];
+                        bp[0] *= tab.b1; bp[1] *= tab.b2;
+                    }
+            }
+        }
+    }
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -478,15 +623,17 @@ using namespace pfpn;
 
 extern "C" {
 
-int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
+static int dense_jobs_launch(const PfpnDenseJob* jobs, int n_jobs, float* sq_partial, size_t sq_capacity, int* n_partials,
+                             float* beta_pow, int n_groups, float beta1, float beta2, void* stream) {
     PFPN_BEGIN();
     if (!jobs || n_jobs < 1 || n_jobs > PFPN_DENSE_MAX_JOBS) return PFPN_ERR_ARG;
     static const int force_cfg = getenv("PFPN_DENSE_CFG") ? atoi(getenv("PFPN_DENSE_CFG")) : -1;
     static const int xcd_remap = getenv("PFPN_DENSE_XCD") ? atoi(getenv("PFPN_DENSE_XCD")) : 1;
     DenseTable tab{};
     tab.n = n_jobs;
+    tab.sq_partial = sq_partial; tab.beta_pow = beta_pow; tab.n_groups = n_groups; tab.b1 = beta1; tab.b2 = beta2;
     long long blocks = 0, gemm_work = 0;
-    size_t lds = 4 * RD_THREADS * sizeof(float);
+    size_t lds = 8 * RD_THREADS * sizeof(float);
     // pass 1: validate, total work of the launch's products (the arrangement of each depends on what shares the chip)
     for (int i = 0; i < n_jobs; ++i) {
         const PfpnDenseJob& j = jobs[i];
@@ -551,10 +698,27 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
         } else if (j.kind == PFPN_DENSE_HEAD_WGRAD) {
             if (!j.A || !j.C || !j.H || !j.aux || j.N < 1) return PFPN_ERR_ARG;
             blocks += (long long)((j.N + 31) / 32 + 1) * j.batch;
+        } else if (j.kind == PFPN_DENSE_SLABSUM) {
+            if (!j.A || !j.C || j.N < 1 || j.K < 1 || j.lda < j.N || (j.B && (j.M < 1 || j.ldb < j.N))) return PFPN_ERR_ARG;
+            blocks += (j.N + 15) / 16;
+        } else if (j.kind == PFPN_DENSE_SQSUM) {
+            if (!j.A || j.N < 4 || (j.N & 3) || !al16(j.A) || j.K < 1 || j.K > 4096) return PFPN_ERR_ARG;
+            blocks += j.K;
+        } else if (j.kind == PFPN_DENSE_PPO_LOSS) {
+            if (!j.A || !j.C || j.K < 1 || j.lda < 2) return PFPN_ERR_ARG;
+            blocks += 1;
+        } else if (j.kind == PFPN_DENSE_NORM_EMA) {
+            if (!j.A || !j.B || !j.H || !j.C || !j.aux || !j.bias || j.N < 1 || j.K < 1 || j.M < 1 || ((uintptr_t)j.A & 7))
+                return PFPN_ERR_ARG;
+            blocks += (j.N + 15) / 16;
         } else {
             return PFPN_ERR_ARG;
         }
         if (blocks > (1 << 20)) return PFPN_ERR_ARG;
+    }
+    if (sq_partial) {
+        if (!n_partials || (size_t)blocks > sq_capacity) return PFPN_ERR_ARG;
+        *n_partials = (int)blocks;
     }
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -566,6 +730,16 @@ int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
     hipLaunchKernelGGL(k_dense_jobs, dim3((unsigned)blocks), dim3(RD_THREADS), lds, (hipStream_t)stream, tab);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
+}
+
+int pfpn_dense_jobs(const PfpnDenseJob* jobs, int n_jobs, void* stream) {
+    return dense_jobs_launch(jobs, n_jobs, nullptr, 0, nullptr, nullptr, 0, 0.f, 0.f, stream);
+}
+
+int pfpn_dense_jobs_norm(const PfpnDenseJob* jobs, int n_jobs, float* sq_partial, size_t sq_capacity, int* n_partials,
+                         float* beta_pow, int n_groups, float beta1, float beta2, void* stream) {
+    if (!sq_partial || !n_partials || (beta_pow && (n_groups < 1 || n_groups > 4))) return PFPN_ERR_ARG;
+    return dense_jobs_launch(jobs, n_jobs, sq_partial, sq_capacity, n_partials, beta_pow, n_groups, beta1, beta2, stream);
 }
 
 }  // extern "C"

@@ -901,12 +901,14 @@ class DenseJob(ctypes.Structure):
                 ("sH", ctypes.c_longlong), ("sBias", ctypes.c_longlong), ("sAux", ctypes.c_longlong),
                 ("sHw", ctypes.c_longlong),
                 ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
-                ("H", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("hw", ctypes.c_void_p)]
+                ("H", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("hw", ctypes.c_void_p),
+                ("p0", ctypes.c_float), ("p1", ctypes.c_float)]
 
 
 DENSE_NN, DENSE_NT, DENSE_TN, DENSE_HEAD_FINAL, DENSE_RANK1, DENSE_HEAD_WGRAD = 0, 1, 2, 8, 9, 10
-DENSE_BIAS, DENSE_RELU6, DENSE_MASK, DENSE_COLSUM, DENSE_HEADPART = 1, 2, 4, 8, 16
-DENSE_MAX_JOBS = 8
+DENSE_SLABSUM, DENSE_SQSUM, DENSE_PPO_LOSS, DENSE_NORM_EMA = 11, 12, 13, 14
+DENSE_BIAS, DENSE_RELU6, DENSE_MASK, DENSE_COLSUM, DENSE_HEADPART, DENSE_NORM = 1, 2, 4, 8, 16, 32
+DENSE_MAX_JOBS = 16
 
 
 def _mat(t, G, rows, cols, name):
@@ -1044,21 +1046,50 @@ def dense_job_head_wgrad(dv, h, dw, db):
     return j
 
 
-def dense_jobs(jobs):
-    """ONE launch for up to DENSE_MAX_JOBS jobs (products with fused epilogues + scalar-head helpers)."""
+def dense_job_of_reduce(job):
+    """a deferred reduction (ReduceJob of reduce_jobs()) as a job of the small-row family's LAST dense launch, which then
+    stands in for the separate reduction launch: column sums of partial slabs, the PPO loss columns, the state-normaliser
+    EMA, square sums of finished gradient segments.  Pointers were validated when the ReduceJob was made."""
+    if job.kind == JOB_COLSUM:
+        j = DenseJob(kind=DENSE_SLABSUM, M=1, N=job.n, K=job.nslab, batch=1, lda=job.stride, ldb=0)
+        j.A, j.C = job.src, job.out
+        if job.in0:
+            j.B, j.M, j.ldb = job.in0, int(job.p0), int(job.p1)
+        if job.norm:
+            j.flags |= DENSE_NORM
+        return j
+    if job.kind == JOB_SQSUM:
+        j = DenseJob(kind=DENSE_SQSUM, M=1, N=job.n, K=job.nslab, batch=1, flags=DENSE_NORM)
+        j.A = job.src
+        return j
+    if job.kind == JOB_PPO_LOSS:
+        j = DenseJob(kind=DENSE_PPO_LOSS, M=1, N=2, K=job.nslab, batch=1, lda=job.stride, p0=job.p0, p1=job.p1)
+        j.A, j.C = job.src, job.out
+        return j
+    if job.kind == JOB_NORM_EMA:
+        j = DenseJob(kind=DENSE_NORM_EMA, M=job.stride, N=job.n, K=job.nslab, batch=1)
+        j.A, j.C, j.aux, j.bias, j.B, j.H = job.src, job.out, job.out2, job.in0, job.in1, job.in2
+        return j
+    raise ValueError("reduce job kind %d has no dense-launch form" % job.kind)
+
+
+def dense_jobs(jobs, norm=None):
+    """ONE launch for up to DENSE_MAX_JOBS jobs (products with fused epilogues + scalar-head helpers + reductions).
+    norm = dict(partial [>= #blocks] f32, beta_pow [G,4] or None, beta1, beta2): the launch also leaves the global-norm
+    partial sums (one per block: squares of the outputs of jobs flagged DENSE_NORM) and rotates the Adam powers; returns
+    the number of partials (for clip_adam(prenorm=...))."""
     lib = _lib.load()
     if not 1 <= len(jobs) <= DENSE_MAX_JOBS:
         raise ValueError("1..%d dense jobs per launch" % DENSE_MAX_JOBS)
     arr = (DenseJob * len(jobs))(*jobs)
-    _lib.check(lib.pfpn_dense_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_dense_jobs")
-
-
-def stream_copy(dst, src, unroll=4, nontemporal=False, blocks=2048):
-    """the build's own streaming copy (calibration of the HBM roofline fractions on the box at hand)."""
-    lib = _lib.load()
-    n = src.numel()
-    if dst.numel() != (n if unroll else blocks * 256):
-        raise ValueError("stream_copy: dst is src-sized (copy) or [blocks * 256] (unroll = 0: read-only stream)")
-    _lib.check(lib.pfpn_stream_copy(_f32(dst), _f32(src), n, int(unroll), int(nontemporal), int(blocks), _stream()),
-               "pfpn_stream_copy")
-    return dst
+    if norm is None:
+        _lib.check(lib.pfpn_dense_jobs(ctypes.addressof(arr), len(jobs), _stream()), "pfpn_dense_jobs")
+        return 0
+    nb = ctypes.c_int(0)
+    bp = norm.get("beta_pow")
+    G = bp.shape[0] if bp is not None else 0
+    _lib.check(lib.pfpn_dense_jobs_norm(ctypes.addressof(arr), len(jobs), _f32(norm["partial"]), norm["partial"].numel(),
+                                        ctypes.addressof(nb), _f32(bp, G, 4) if bp is not None else None, G,
+                                        float(norm.get("beta1", 0.9)), float(norm.get("beta2", 0.999)), _stream()),
+               "pfpn_dense_jobs_norm")
+    return nb.value

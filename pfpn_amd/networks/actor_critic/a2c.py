@@ -257,7 +257,13 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             jobs += self.trunk.head_backward_jobs((1, w3, dvalue, st.g("critic/fc3/weight"), st.g("critic/fc3/bias")),
                                                   B, out=self.dh)
             kernels.dense_jobs(jobs)
-            self.trunk.backward(self.dh, premasked=True)
+            final = self._final_dense_jobs(deferred, allow_norm=not self.fixed_sigma) if deferred else None
+            self.trunk.backward(self.dh, premasked=True, final=final)
+            if final is not None:
+                # the reductions rode in the trunk's last launch: nothing is left for `_finish_deferred`
+                self._norm_ready = self.trunk.norm_partials
+                del deferred[:]
+                self._deferred_done = True
             self._dw_pending = False
             return
         if deferred is not None:

@@ -277,6 +277,9 @@ class ActorCriticNetwork(object):
         optimiser needs ONE launch (pfpn_clip_adam_prenorm) instead of two.  A step that takes this path MUST be followed
         by the optimiser's apply (the powers have moved)."""
         hook = getattr(self, "_norm_hook", None)
+        if getattr(self, "_deferred_done", False):      # (small-row path: the last dense launch carried the reductions)
+            self._deferred_done = False
+            return
         self._norm_ready = 0
         if hook is None or not allow_norm:
             kernels.reduce_jobs(deferred)
@@ -305,6 +308,41 @@ class ActorCriticNetwork(object):
             kernels.reduce_jobs(deferred)
             return
         self._norm_ready = kernels.reduce_jobs(jobs, norm=hook)
+
+    def _final_dense_jobs(self, deferred, allow_norm=True):
+        """small-row path: the step's deferred reductions as jobs of its LAST dense launch (the first trunk layer's
+        backward) -- `_finish_deferred` without a launch of its own.  -> (make_jobs(written) -> [DenseJob], norm hook) for
+        DenseStack.backward(final=...), or None when the launch cannot carry them (then `_finish_deferred` runs as usual).
+        `written`: the gradient tensors that launch itself produces; their squares are counted by the producing blocks,
+        everything else of the flat gradient buffer is final by then and is covered by square-sum jobs."""
+        hook = getattr(self, "_norm_hook", None)
+        if hook is None or not allow_norm or os.environ.get("PFPN_ROWDENSE_TAIL", "1") == "0":
+            return None
+        if any(j.kind not in (kernels.JOB_COLSUM, kernels.JOB_PPO_LOSS, kernels.JOB_NORM_EMA) for j in deferred):
+            return None
+        st = self.store
+        base, end = st.grad.data_ptr(), st.grad.data_ptr() + 4 * st.size
+        red = list(deferred)
+
+        def make_jobs(written):
+            cover = []
+            for j in red:
+                if j.kind == kernels.JOB_COLSUM and j.out is not None and base <= j.out < end:
+                    j.norm = 1
+                    cover.append((j.out, min(end, (j.out + 4 * j.n + 15) // 16 * 16)))
+            for t in written:
+                cover.append((t.data_ptr(), min(end, (t.data_ptr() + 4 * t.numel() + 15) // 16 * 16)))
+            if any(lo % 16 for lo, _ in cover):
+                raise ValueError("gradient tensors must start on 16-byte boundaries")
+            cover.sort()
+            jobs, pos = [kernels.dense_job_of_reduce(j) for j in red], base
+            for lo, hi in cover + [(end, end)]:
+                if lo > pos:
+                    nfl = (lo - pos) // 4
+                    jobs.append(kernels.dense_job_of_reduce(kernels.job_sqsum(pos, nfl, max(1, min(64, nfl // 16384)))))
+                pos = max(pos, hi)
+            return jobs
+        return make_jobs, hook
 
     def _to_dev(self, a, dtype=torch.float32):
         if isinstance(a, torch.Tensor):

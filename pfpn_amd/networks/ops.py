@@ -293,7 +293,7 @@ class DenseStack:
         return [kernels.dense_job_rank1(dv, w.view(-1), act[g], out[g]),
                 kernels.dense_job_head_wgrad(dv, act[g], gw.view(-1), gb.view(-1))]
 
-    def _backward_small(self, dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows):
+    def _backward_small(self, dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows, final=None):
         """<= ROW_MAX rows, `dlast` = gradient w.r.t. the last layer's PRE-activation (its producer applied Relu6Grad):
         one launch per layer -- dW = X^T dY with the bias gradient (column sums of dY) from the same operand tiles, and
         dX = dY W^T masked by the ReLU6 of the layer below -- every result final in the flat gradient buffer (the batch
@@ -332,7 +332,17 @@ class DenseStack:
                     jobs.append(kernels.dense_job_tn(act[i - 1][:, r0:r1], d[:, r0:r1], gw, colsum=gb))
                 jobs.append(kernels.dense_job_nt(d, w, dact[i - 1], mask=act[i - 1]))
                 d = dact[i - 1]
-            if jobs:
+            if i == 0 and final is not None:
+                # the step's LAST dense launch also carries its deferred reductions and the gradient norm's partial sums:
+                # final = (make_jobs(written) -> extra jobs, norm hook); `written` = gradient tensors this launch writes
+                # (their squares are counted where they are produced)
+                make_jobs, hook = final
+                for jb in jobs:
+                    if jb.kind == kernels.DENSE_TN:
+                        jb.flags |= kernels.DENSE_NORM
+                extra = make_jobs([gw, gb] if need_dw else [])
+                self.norm_partials = kernels.dense_jobs(jobs + extra, norm=hook)
+            elif jobs:
                 kernels.dense_jobs(jobs)
         return dx
 
@@ -384,7 +394,7 @@ class DenseStack:
         return act[-1]
 
     def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None,
-                 dw_rows=None, dx_rows=None, premasked=False):
+                 dw_rows=None, dx_rows=None, premasked=False, final=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output (the stack's own dact[-1] buffer
         or any contiguous tensor); masked in place.
         `deferred` (a list): the bias-gradient column sums are left as per-chunk partials and a reduce job per
@@ -407,7 +417,7 @@ class DenseStack:
         if premasked:
             if not self.small(B) or value is not None or dw_stream is not None:
                 raise ValueError("a pre-masked gradient is the small-row path's input (no folded head, one stream)")
-            return self._backward_small(dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows)
+            return self._backward_small(dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows, final)
         main = torch.cuda.current_stream() if dw_stream is not None else None
         act, act2d, dact, dact2d, x = buf["act"], buf["act2d"], buf["dact"], buf["dact2d"], buf["x"]
         d, d2d = dlast, dlast.view(self.G * B, -1)

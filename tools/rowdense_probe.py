@@ -26,10 +26,11 @@ for rows in rows_list:
         opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=exchange)
         b = make_batch(np.random.default_rng(0), rows); b["log_prob"] = np.full(rows, -40.0, np.float32)
         args = [torch.from_numpy(b[k]).to(dev) for k in ("state", "action", "value", "log_prob", "advantage")]
-        step = graphs.GraphedLearnerStep(net, opt, *args)
+        K = 1 if exchange else int(os.environ.get("PROBE_STEPS_PER_REPLAY", "8"))      # (a worker's training round replays
+        step = graphs.GraphedLearnerStep(net, opt, *args, steps_per_replay=K)           #  eight minibatch steps per graph)
         for _ in range(20): step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(300): step()
-        torch.cuda.synchronize(); res[mode] = (time.perf_counter() - t0) / 300 * 1e6
+        for _ in range(300 // K): step()
+        torch.cuda.synchronize(); res[mode] = (time.perf_counter() - t0) / (300 // K * K) * 1e6
         del net, opt, step
     print("rows %5d: library %.1f us/step, rowdense %.1f us/step" % (rows, res["library"], res["rowdense"]), flush=True)
