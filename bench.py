@@ -310,7 +310,9 @@ def main():
                        else "library default",
                        "step": "state-norm, MLP fwd (+critic head), fused mixture logp+PPO+bwd, MLP bwd, one deferred "
                                "reduction launch (bias grads, particle grads, loss, state-norm EMA), clip, "
-                               + ("RCCL all-reduce, " if (world > 1 or args.force_exchange) else "") + "TF-Adam, resample tick"},
+                               + (("sharded exchange (all-to-all, owner Adam, all-gather), " if getattr(opt, "sharded", False)
+                                   else "RCCL all-reduce, ") if (world > 1 or args.force_exchange) else "")
+                               + "TF-Adam, resample tick"},
         }
         if weak_extra is not None:
             out["weak_scaling"] = weak_extra
@@ -393,7 +395,7 @@ def main():
         ab = algorithmic_bytes_fused(B)
         ach = ab / (us * 1e-6) / 1e9
         traffic, traffic_source = None, None
-        for rnd in ("r02", "r01"):     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE)
+        for rnd in ("r03", "r02", "r01"):     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE)
             try:
                 with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
                     traffic = json.load(f)["kernels"]["k_mix_tile<35,PPO>"]["traffic_bytes"]
