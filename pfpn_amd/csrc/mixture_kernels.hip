@@ -888,14 +888,15 @@ __global__ __launch_bounds__(256) void k_mix_wave(
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-// The wide kernel's read-once logits stream (1 GiB at 8192 x 128 x 256) with the non-temporal cache policy in the
-// FORWARD kernel: measured 207 -> 195 us there (0.65 -> 0.69 of 8 TB/s, two boxes, A/B in one session).  In the backward
-// kernel, which also streams 1 GiB of stores, nt loads measured 2-4 % SLOWER and nt stores changed nothing (431-436 us
-// either way, = a device copy of the same bytes), so it keeps the default policy.  PFPN_WIDE_NT overrides for A/B runs:
-// bit 0 = nt loads in every mode, bit 1 = nt stores, bit 2 = no nt anywhere.
-#ifndef PFPN_WIDE_NT
-#define PFPN_WIDE_NT 0
-#endif
+// The wide kernel's read-once logits stream (1 GiB at 8192 x 128 x 256) takes the non-temporal cache policy in the
+// FORWARD kernel: measured 207 -> 195 us there (0.65 -> 0.69 of 8 TB/s, two boxes, A/B in one session).  The backward
+// kernel also streams 1 GiB of stores; STREAM = nt loads + nt stores there.  With the launch sized for ~12 waves per CU
+// it changes nothing (428-437 us either way), but with nt stores the best launch moves to 8 waves per CU = exactly two
+// blocks per CU (C = 16 at A = 128): 385-404 us against 430-437 for the default policy at its own best C, alternating
+// builds over four rounds on one box (tools/wide_sweep.sh, profiles/r03_wide_stream.txt).  C = 18 (2.25 blocks per CU,
+// an uneven last round) measures 460-470 us: the chunk count is kept to a whole number of blocks per CU.  STREAM is
+// only taken when the dlogits tensor is larger than the 256 MiB infinity cache: below that the dW GEMM that follows
+// re-reads dlogits from cache, which a streaming store would give up.
 template <bool NT>
 __device__ __forceinline__ float4 ld4_stream(const float* p) {
     if (NT) {
@@ -904,17 +905,15 @@ __device__ __forceinline__ float4 ld4_stream(const float* p) {
     }
     return ld4(p);
 }
+template <bool NT>
 __device__ __forceinline__ void st4_stream(float* p, float a, float b, float c, float d) {
-#if PFPN_WIDE_NT & 2
-    __builtin_nontemporal_store((f4v){a, b, c, d}, reinterpret_cast<f4v*>(p));
-#else
-    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
-#endif
+    if (NT) __builtin_nontemporal_store((f4v){a, b, c, d}, reinterpret_cast<f4v*>(p));
+    else *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 
-template <int M, int MODE, bool TANH, bool FULLN>
+template <int M, int MODE, bool TANH, bool FULLN, bool STREAM = false>
 __global__ __launch_bounds__(256) void k_mix_wide(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
@@ -927,7 +926,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     float* __restrict__ partial)             // [C][2*A*N]  (BWD)
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
-    constexpr bool NT_LOADS = !(PFPN_WIDE_NT & 4) && ((PFPN_WIDE_NT & 1) || MODE == MODE_FWD);
+    constexpr bool NT_LOADS = STREAM || MODE == MODE_FWD;
     const int lane = threadIdx.x & 63;
     // wave-uniform indices through readfirstlane: row/segment address arithmetic goes to the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
@@ -1076,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                                 acc_ls2[j][h]);
                             if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, b_isc2[j][h] * PFPN_2LN2, dx2);
                         }
-                        if (live) st4_stream(drow + 4 * (lane + 64 * j), d[0].x, d[0].y, d[1].x, d[1].y);
+                        if (live) st4_stream<STREAM>(drow + 4 * (lane + 64 * j), d[0].x, d[0].y, d[1].x, d[1].y);
                     }
                 }
                 dxa[u] = dx2.x + dx2.y;
@@ -1288,13 +1287,22 @@ static bool wide_ok(int A, int N, const void* logits, const void* dlogits) {
            (dlogits == nullptr || (uintptr_t)dlogits % 16 == 0);
 }
 static int wide_c_env() { static const int v = getenv("PFPN_WIDE_C") ? atoi(getenv("PFPN_WIDE_C")) : 0; return v; }
-// waves per action dim: ~16 waves per CU over the chip, at least 2 rows per wave, <= 64 slabs
-static int wide_chunks(int B, int A, bool bwd = false) {
+// streaming policy of the backward wide kernel (see ld4_stream): on when dlogits cannot stay in the 256 MiB infinity
+// cache for the GEMM that follows.  PFPN_WIDE_STREAM=0/1 forces it for A/B runs.
+static bool wide_stream(int B, int A, int N) {
+    static const int env = getenv("PFPN_WIDE_STREAM") ? atoi(getenv("PFPN_WIDE_STREAM")) : -1;
+    if (env >= 0) return env != 0;
+    return (size_t)B * A * N * sizeof(float) > ((size_t)256 << 20);
+}
+// waves per action dim: a whole number of 4-wave blocks per CU over the chip, at least 4 rows per wave, <= 64 slabs
+static int wide_chunks(int B, int A, int N, bool bwd = false) {
     // measured on the 8192 x 128 x 256 stress shape (sweeps of PFPN_WIDE_C, +-3 % run to run): ~20 waves/CU
-    // forward (C = 38..48: 199-207 us; 32: 209-213; 24: 245; 64: 232) and ~12 waves/CU backward, which also
-    // streams 1 KiB stores per segment (C = 22..24: 419-433 us; 32: 484; 48: 467).  More in flight only lengthens
+    // forward (C = 38..48: 199-207 us; 32: 209-213; 24: 245; 64: 232); backward, which also streams 1 KiB stores per
+    // segment, ~12 waves/CU with the default cache policy (C = 22..24: 419-433 us; 32: 484; 48: 467) and 8 waves/CU
+    // with streaming stores (C = 16: 385-404 us; 14: 417; 18: 460-470; 20: 425-437).  More in flight only lengthens
     // the HBM queues (tools/bw_probe.hip), and power-of-two row strides between a wave's rows alias HBM channels.
-    int C = ((bwd ? cu_count() * 12 : cu_count() * 20) + A - 1) / A;
+    const int per_cu = !bwd ? 20 : wide_stream(B, A, N) ? 8 : 12;
+    int C = (cu_count() * per_cu + A - 1) / A;
     if (C > 64) C = 64;
     if (wide_c_env() > 0) C = wide_c_env();
     if (C > (B + 3) / 4) C = (B + 3) / 4;      // at least U = 4 rows per wave
@@ -1342,7 +1350,7 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
     if (!workspace || workspace_bytes < (size_t)B * A * sizeof(float)) return PFPN_ERR_WORKSPACE;
     float* lpseg = (float*)workspace;
     if (wide_ok(A, N, logits, nullptr)) {
-        const int C = wide_chunks(B, A);
+        const int C = wide_chunks(B, A, N);
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
 #define PFPN_WIDE_FWD(MM, TT)                                                                                  \
@@ -1407,21 +1415,22 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         return PFPN_OK;
     }
     if (wide_ok(A, N, logits, dlogits)) {
-        const int C = wide_chunks(B, A, true);
+        const int C = wide_chunks(B, A, N, true);
+        const bool stream = wide_stream(B, A, N);
         if (workspace_bytes < (size_t)C * 2 * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
+#define PFPN_WIDE_BWD_LAUNCH(MM, TT, FF, SS)                                                                    \
+    hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
+                       dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial)
 #define PFPN_WIDE_BWD(MM, TT)                                                                                  \
     do {                                                                                                       \
-        if (N == 256 * MM)                                                                                     \
-            hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, true>), dim3(blocks), dim3(256), 0, st, logits, x, loc,   \
-                               logstd, dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial); \
-        else                                                                                                   \
-            hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, false>), dim3(blocks), dim3(256), 0, st, logits, x, loc,  \
-                               logstd, dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial); \
+        if (N == 256 * MM) { if (stream) PFPN_WIDE_BWD_LAUNCH(MM, TT, true, true); else PFPN_WIDE_BWD_LAUNCH(MM, TT, true, false); } \
+        else { if (stream) PFPN_WIDE_BWD_LAUNCH(MM, TT, false, true); else PFPN_WIDE_BWD_LAUNCH(MM, TT, false, false); } \
     } while (0)
         if (tanh_mode) { if (M == 1) PFPN_WIDE_BWD(1, true); else if (M == 2) PFPN_WIDE_BWD(2, true); else PFPN_WIDE_BWD(4, true); }
         else { if (M == 1) PFPN_WIDE_BWD(1, false); else if (M == 2) PFPN_WIDE_BWD(2, false); else PFPN_WIDE_BWD(4, false); }
+#undef PFPN_WIDE_BWD_LAUNCH
 #undef PFPN_WIDE_BWD
         PFPN_CHECK_LAUNCH();
         if (finalize) hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
@@ -1449,7 +1458,7 @@ int pfpn_logprob_bwd_slabs(const float* logits, const float* dlogits, int B, int
     const int AN = A * N;
     TilePlan pl = plan_tile(B, A, N, logits, dlogits);
     if (pl.ok && tile_has(N)) { *nslab = pl.grid; *stride = 2 * AN + 4; return PFPN_OK; }
-    if (wide_ok(A, N, logits, dlogits)) { *nslab = wide_chunks(B, A, true); *stride = 2 * AN; return PFPN_OK; }
+    if (wide_ok(A, N, logits, dlogits)) { *nslab = wide_chunks(B, A, N, true); *stride = 2 * AN; return PFPN_OK; }
     *nslab = (B < 64) ? B : 64;
     *stride = 2 * AN;
     return PFPN_OK;
