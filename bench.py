@@ -87,6 +87,44 @@ def _flush_c_stdio():
     sys.stdout.flush()
 
 
+class ExtrasDeadline(object):
+    """Multi-rank runs only.  The informational extras behind the headline hold collectives of their own (a second
+    learner on the other scaling mode / exchange form); if ONE rank fails inside them, the others would wait in a
+    collective for ever and the headline -- already measured -- would be lost with the job.  So: once the headline is
+    known a timer starts on every rank; a rank whose extra raised parks here instead of walking into the next
+    collective; when the timer fires rank 0 prints the headline line it has (marked `extras_timed_out`) and every rank
+    leaves with exit code 0."""
+
+    def __init__(self, seconds, emit):
+        import threading
+        self.lock, self.done, self.emit = threading.Lock(), False, emit
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def fire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        self.emit()
+        os._exit(0)
+
+    def park(self):
+        """a rank that cannot take part in the remaining collectives waits for the timer"""
+        while True:
+            time.sleep(1.0)
+
+    def finish(self):
+        """-> True when the caller owns the final print (the timer has not fired and will not)"""
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+        self.timer.cancel()
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +148,10 @@ def main():
                     help="N=1 only: run the data-parallel step (clip in place, RCCL all-reduce in a world-size-1 group, "
                          "Adam with 1/W) instead of the fused single-replica step -- its cost without the links")
     args = ap.parse_args()
+    if os.environ.get("PFPN_BENCH_WATCHDOG"):
+        # diagnostic: every rank dumps its Python stacks to stderr and exits if the run takes longer than this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PFPN_BENCH_WATCHDOG"]), exit=True)
 
     import torch
     import torch.distributed as dist
@@ -222,6 +264,17 @@ def main():
         run_steps.prepare(8)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if world > 1:
+            # the steps hold collectives: every rank must run the SAME number of them, so the count is agreed (from the
+            # slowest rank's time for one replay) instead of each rank watching its own clock
+            run_steps(8)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            for _ in range(int(min(max(seconds / max(float(t.item()), 1e-6) - 1, 0), 4096))):
+                run_steps(8)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3
         while time.perf_counter() - t0 < seconds:
             run_steps(8)
             torch.cuda.synchronize()
@@ -240,51 +293,6 @@ def main():
     loss3 = net.train_out["loss3"].cpu().numpy()
     assert np.all(np.isfinite(loss3)), "non-finite loss in the benchmark loop"
     use_graph = not args.no_graph
-    weak_extra = None
-    if world > 1 and strong:         # the other scaling mode as an extra key: 4096 rows on every rank
-        try:
-            wnet, wopt, winputs = make_learner(B, SEED + rank)
-            wrun, _ = make_stepper(wnet, wopt, winputs)
-            wel = timed_steps(wrun, args.steps, args.warmup)
-            weak_extra = {"value": world * args.steps / wel, "unit": "steps/s of 4096 transitions (4096 rows per GPU)",
-                          "ms_per_step": wel / args.steps * 1e3, "global_batch": B * world}
-            del wnet, wopt, winputs, wrun
-        except Exception as e:
-            weak_extra = {"error": repr(e)}
-
-    sharded_extra = None
-    if world > 1 and strong and not getattr(opt, "sharded", False):
-        # the other exchange form on the same shard (PFPN_EXCHANGE=sharded makes it the headline): all-to-all of unscaled
-        # bucket slices, owner-side clip factors + Adam on 1/W of the buffer, in-place all-gather
-        try:
-            xnet, xopt, xin = make_learner(rows, SEED + rank, exchange_mode="sharded")
-            xrun, xlaunch = make_stepper(xnet, xopt, xin)
-            xel = timed_steps(xrun, args.steps, args.warmup)
-            sharded_extra = {"value": args.steps / xel, "unit": "steps/s", "ms_per_step": xel / args.steps * 1e3,
-                             "launch": xlaunch}
-            del xnet, xopt, xin, xrun
-        except Exception as e:
-            sharded_extra = {"error": repr(e)}
-    rccl_info = None
-    if world > 1 or args.force_exchange:
-        # evidence from the LIVE process group that N ranks took part: a sum of ones and every rank's device index
-        tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        ones = torch.ones(1, device=tdev)
-        dist.all_reduce(ones)
-        devs = [torch.zeros(1, dtype=torch.int64, device=tdev) for _ in range(world)]
-        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=tdev))
-        try:
-            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            ver = None
-        rccl_info = {"world": dist.get_world_size(), "ranks_seen": int(ones.item()), "backend": dist.get_backend(),
-                     "rccl_version": ver, "devices": [int(d.item()) for d in devs],
-                     "bucket_MB": net.store.bucket.numel() * 4 / 1e6,
-                     "exchange": ("sharded: all_to_all_single of %.2f MB bucket slices + all_gather of %d clip factors + "
-                                  "in-place all_gather_into_tensor of the parameter slices"
-                                  % (net.store.npad * 4 / 1e6, world)) if getattr(opt, "sharded", False)
-                     else "one all_reduce(SUM) of the bucket [clipped grads | statistics]"}
-
     out = None
     if rank == 0:
         ms = el / args.steps * 1e3
@@ -314,12 +322,75 @@ def main():
                                    else "RCCL all-reduce, ") if (world > 1 or args.force_exchange) else "")
                                + "TF-Adam, resample tick"},
         }
-        if weak_extra is not None:
-            out["weak_scaling"] = weak_extra
-        if sharded_extra is not None:
-            out["exchange_sharded"] = sharded_extra
-        if rccl_info is not None:
-            out["rccl"] = rccl_info
+
+    # ---- multi-rank extras, behind a deadline: the headline above is already safe (see ExtrasDeadline) ----------
+    deadline = None
+    if world > 1:
+        def emit_headline():
+            if rank == 0:
+                out["extras_timed_out"] = True
+                _flush_c_stdio()
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+        deadline = ExtrasDeadline(float(os.environ.get("PFPN_BENCH_EXTRAS_DEADLINE", "150")), emit_headline)
+
+    def guarded(fn):
+        """an extra on every rank: its result, or -- when THIS rank failed in it -- no way on into the next collective"""
+        try:
+            if os.environ.get("PFPN_BENCH_FAIL_EXTRA") == "%s:%d" % (fn.__name__, rank):       # rehearsal of the deadline
+                raise RuntimeError("injected failure")
+            return fn()
+        except Exception as e:
+            sys.stderr.write("bench.py rank %d: extra %s failed: %r\n" % (rank, fn.__name__, e))
+            if deadline is None:
+                return {"error": repr(e)}
+            deadline.park()
+
+    def rccl_block():
+        # evidence from the LIVE process group that N ranks took part: a sum of ones and every rank's device index
+        tdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        ones = torch.ones(1, device=tdev)
+        dist.all_reduce(ones)
+        devs = [torch.zeros(1, dtype=torch.int64, device=tdev) for _ in range(world)]
+        dist.all_gather(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=tdev))
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        return {"world": dist.get_world_size(), "ranks_seen": int(ones.item()), "backend": dist.get_backend(),
+                "rccl_version": ver, "devices": [int(d.item()) for d in devs],
+                "bucket_MB": net.store.bucket.numel() * 4 / 1e6,
+                "exchange": ("sharded: all_to_all_single of %.2f MB bucket slices + all_gather of %d clip factors + "
+                             "in-place all_gather_into_tensor of the parameter slices"
+                             % (net.store.npad * 4 / 1e6, world)) if getattr(opt, "sharded", False)
+                else "one all_reduce(SUM) of the bucket [clipped grads | statistics]"}
+
+    def weak_block():                # the other scaling mode as an extra key: 4096 rows on every rank
+        wnet, wopt, winputs = make_learner(B, SEED + rank)
+        wrun, _ = make_stepper(wnet, wopt, winputs)
+        wel = timed_steps(wrun, args.steps, args.warmup)
+        return {"value": world * args.steps / wel, "unit": "steps/s of 4096 transitions (4096 rows per GPU)",
+                "ms_per_step": wel / args.steps * 1e3, "global_batch": B * world}
+
+    def sharded_block():
+        # the other exchange form on the same shard (PFPN_EXCHANGE=sharded makes it the headline): all-to-all of unscaled
+        # bucket slices, owner-side clip factors + Adam on 1/W of the buffer, in-place all-gather
+        xnet, xopt, xin = make_learner(rows, SEED + rank, exchange_mode="sharded")
+        xrun, xlaunch = make_stepper(xnet, xopt, xin)
+        xel = timed_steps(xrun, args.steps, args.warmup)
+        return {"value": args.steps / xel, "unit": "steps/s", "ms_per_step": xel / args.steps * 1e3, "launch": xlaunch}
+
+    def extra(key, fn):
+        res = guarded(fn)
+        if rank == 0:
+            out[key] = res                                          # at once: a later deadline still prints it
+
+    if world > 1 or args.force_exchange:
+        extra("rccl", rccl_block)                                   # two tiny collectives: first, so it is never lost
+    if world > 1 and strong:
+        extra("weak_scaling", weak_block)
+        if not getattr(opt, "sharded", False):
+            extra("exchange_sharded", sharded_block)
 
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
     if rank == 0 and world == 1:
@@ -737,6 +808,8 @@ def main():
         dist.barrier()                      # every rank has flushed its banner
         dist.destroy_process_group()
     _flush_c_stdio()
+    if deadline is not None and not deadline.finish():
+        return                              # the deadline fired meanwhile: it prints (rank 0) and ends the process
     if rank == 0:
         sys.stdout.write(json.dumps(out) + "\n")
         sys.stdout.flush()

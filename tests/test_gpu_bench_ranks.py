@@ -1,0 +1,45 @@
+"""GPU: the multi-rank control flow of bench.py, rehearsed with two ranks on ONE device over gloo (`--one-device`; RCCL
+refuses two ranks on one GPU).  What it guards: every rank runs the same number of collectives (the clock-ramp prelude once
+looped on each rank's own clock and could deadlock), the line rank 0 prints, and the deadline that saves the headline when a
+rank fails inside an informational extra."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(port, extra_env=None, ranks=2):
+    env = dict(os.environ)
+    env.update({"PFPN_BENCH_WATCHDOG": "200", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(ranks), "--steps", "8", "--warmup", "2", "--backend", "gloo", "--one-device"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]             # ONE JSON line
+    assert r.stdout.decode().rstrip().endswith(lines[0])          # and it is the last thing on stdout
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_line():
+    d = run_bench(29531)
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["per_gpu_batch"] == 2048 and d["config"]["global_batch"] == 4096
+    assert d["rccl"]["ranks_seen"] == 2 and d["rccl"]["world"] == 2
+    assert d["weak_scaling"]["value"] > 0 and d["weak_scaling"]["global_batch"] == 8192
+    assert d["exchange_sharded"]["value"] > 0
+    assert "extras_timed_out" not in d
+
+
+def test_headline_survives_a_rank_failing_in_an_extra():
+    d = run_bench(29532, {"PFPN_BENCH_EXTRAS_DEADLINE": "30", "PFPN_BENCH_FAIL_EXTRA": "weak_block:1"})
+    assert d["extras_timed_out"] is True and d["value"] > 0 and d["n_gpus"] == 2
+    assert d["rccl"]["ranks_seen"] == 2                           # the extra before the failing one is kept
+    assert "weak_scaling" not in d
