@@ -1046,6 +1046,17 @@ def dense_job_head_wgrad(dv, h, dw, db):
     return j
 
 
+def stream_copy(dst, src, unroll=4, nontemporal=False, blocks=2048):
+    """the build's own streaming copy (calibration of the HBM roofline fractions on the box at hand)."""
+    lib = _lib.load()
+    n = src.numel()
+    if dst.numel() != (n if unroll else blocks * 256):
+        raise ValueError("stream_copy: dst is src-sized (copy) or [blocks * 256] (unroll = 0: read-only stream)")
+    _lib.check(lib.pfpn_stream_copy(_f32(dst), _f32(src), n, int(unroll), int(nontemporal), int(blocks), _stream()),
+               "pfpn_stream_copy")
+    return dst
+
+
 def dense_job_of_reduce(job):
     """a deferred reduction (ReduceJob of reduce_jobs()) as a job of the small-row family's LAST dense launch, which then
     stands in for the separate reduction launch: column sums of partial slabs, the PPO loss columns, the state-normaliser

@@ -29,6 +29,20 @@ def test_library_builds_and_exports_header(lib_path):
     assert exported == set(protos), exported ^ set(protos)
 
 
+def test_every_export_has_a_host_wrapper():
+    """every entry point of the header is called from pfpn_amd/ (a wrapper deleted by accident shows up here, not as a
+    missing key in a bench line)."""
+    from pfpn_amd import _lib
+    src = ""
+    for d, _, files in os.walk(os.path.join(ROOT, "pfpn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src += open(os.path.join(d, f)).read()
+    diagnostics = {"pfpn_abi_version", "pfpn_debug_stamps"}        # called from tests / tools/stamp_probe.py only
+    missing = [name for name in _lib.parse_header() if name not in diagnostics and not re.search(r"\b%s\b" % name, src)]
+    assert not missing, missing
+
+
 def test_loader_attaches_prototypes(lib_path):
     from pfpn_amd import _lib
     lib = _lib.load()
