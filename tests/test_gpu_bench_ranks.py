@@ -43,3 +43,31 @@ def test_headline_survives_a_rank_failing_in_an_extra():
     assert d["extras_timed_out"] is True and d["value"] > 0 and d["n_gpus"] == 2
     assert d["rccl"]["ranks_seen"] == 2                           # the extra before the failing one is kept
     assert "weak_scaling" not in d
+
+
+def _errors(o, path=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            if k == "error":
+                yield path, v
+            yield from _errors(v, path + "/" + k)
+
+
+def test_single_gpu_line_carries_every_block_without_a_swallowed_error():
+    """the informational blocks of the line are built under try/except (they must not cost the headline): a block that
+    failed says {"error": ...} -- which nobody reads.  Here it is read."""
+    env = dict(os.environ, PFPN_BENCH_WATCHDOG="250")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    failed = [(k, v) for k, v in _errors(d) if "skipped with --no-cpu-baseline" not in v]
+    assert not failed, failed
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["windows"] == 5 and d["value_200"] > 0
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "hbm"
+    st = d["roofline_stress"]
+    for leg in ("fwd", "bwd", "ppo"):
+        assert 0 < st[leg]["frac"] < 1 and 0 < st[leg]["frac_of_box_copy"] < 1.2, (leg, st[leg])
+    assert 0 < d["roofline_gemm"]["frac"] < 1
+    for k in ("sac_step", "config5_step"):
+        assert k not in d or d[k]["finite_loss"]
