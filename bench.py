@@ -189,7 +189,7 @@ def main():
             t["value"] = net_._value(hc).clone()
         return net_, opt_, (t["state"], t["action"], t["value"], t["log_prob"], t["advantage"])
 
-    def make_stepper(net_, opt_, inputs, allow_multi=True):
+    def make_stepper(net_, opt_, inputs, allow_multi=True, capture_exchange=None):
         """-> (run_steps(n), launch description).  One replica: hipGraph replays of `--steps-per-graph` learner steps, the
         remainder n % K as ONE replay of a K'-step graph (captured by run_steps.prepare(n), outside every timed region);
         data parallel: two hipGraphs around the exchange per step (pfpn_amd/graphs.py); --no-graph: eager."""
@@ -197,7 +197,7 @@ def main():
             f = lambda n: [net_.train_device(opt_, *inputs) for _ in range(n)]
             f.prepare = lambda n: None
             return f, "eager"
-        one = graphs.GraphedLearnerStep(net_, opt_, *inputs)
+        one = graphs.GraphedLearnerStep(net_, opt_, *inputs, capture_exchange=capture_exchange)
         spg_ = max(1, args.steps_per_graph) if (allow_multi and not one.split) else 1
         sized = {1: one}
         one()                    # the FIRST replay of a hipGraph uploads it: keep that out of every timed region
@@ -205,7 +205,8 @@ def main():
         def graph_of(k):
             g = sized.get(k)
             if g is None:
-                g = sized[k] = graphs.GraphedLearnerStep(net_, opt_, *inputs, steps_per_replay=k)
+                g = sized[k] = graphs.GraphedLearnerStep(net_, opt_, *inputs, steps_per_replay=k,
+                                                         capture_exchange=capture_exchange)
                 if g.can_replay():
                     g()
             return g
@@ -234,6 +235,8 @@ def main():
         what = ("two hipGraphs around the %s" % ("sharded exchange (all-to-all | owner Adam | all-gather)"
                                                  if getattr(opt_, "sharded", False) else "RCCL all-reduce")) if one.split else \
             ("hipGraph, %d learner steps per replay (remainder as one shorter replay)" % spg_ if spg_ > 1 else "hipGraph")
+        if one.in_graph_exchange:
+            what += ", the RCCL collectives captured inside"
         return run_steps, what
 
     def timed_steps(run_steps, n_steps, n_warm):
@@ -380,6 +383,13 @@ def main():
         xel = timed_steps(xrun, args.steps, args.warmup)
         return {"value": args.steps / xel, "unit": "steps/s", "ms_per_step": xel / args.steps * 1e3, "launch": xlaunch}
 
+    def in_graph_block():
+        # the all-reduce captured INSIDE the step's graph, K steps per replay (PFPN_GRAPH_EXCHANGE=1 makes it the headline)
+        gnet, gopt, gin = make_learner(rows, SEED + rank)
+        grun, glaunch = make_stepper(gnet, gopt, gin, capture_exchange=True)
+        gel = timed_steps(grun, args.steps, args.warmup)
+        return {"value": args.steps / gel, "unit": "steps/s", "ms_per_step": gel / args.steps * 1e3, "launch": glaunch}
+
     def extra(key, fn):
         res = guarded(fn)
         if rank == 0:
@@ -391,6 +401,8 @@ def main():
         extra("weak_scaling", weak_block)
         if not getattr(opt, "sharded", False):
             extra("exchange_sharded", sharded_block)
+        if dist.get_backend() == "nccl" and os.environ.get("PFPN_GRAPH_EXCHANGE", "0") == "0":
+            extra("exchange_in_graph", in_graph_block)              # last: the one form no multi-GPU node has run yet
 
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
     if rank == 0 and world == 1:
@@ -540,7 +552,11 @@ def main():
         try:
             sB, sA, sN = 8192, 128, 256
             g = torch.Generator(device=dev); g.manual_seed(1)
-            sl = torch.randn(sB, sA * sN, device=dev, generator=g)
+            # logits / dlogits placed as the network places them at this size (kernels.stream_pair: one allocation, the
+            # second stream a fixed distance behind the first -- independent allocations time 380-485 us by luck of placement)
+            sl, s_dl = kernels.stream_pair(sB, sA * sN, dev)
+            sl.normal_(generator=g)
+            s_bw = {"dlogits": s_dl, "dloc": torch.empty(sA, sN, device=dev), "dlogstd": torch.empty(sA, sN, device=dev)}
             sx = torch.rand(sB, sA, device=dev, generator=g) * 2.2 - 1.1
             sloc = torch.linspace(-1, 1, sN, device=dev).repeat(sA, 1).contiguous()
             sls = torch.full((sA, sN), float(np.log(2.0 / (sN - 1))), device=dev)
@@ -548,7 +564,7 @@ def main():
             L_, X_, V_, P_ = 4 * sB * sA * sN, 4 * sB * sA, 4 * sB, 8 * sA * sN
             res = {}
             for name, fn, nbytes in (("fwd", lambda: kernels.logprob_fwd(sl, sx, sloc, sls), L_ + X_ + V_ + P_),
-                                     ("bwd", lambda: kernels.logprob_bwd(sl, sx, sloc, sls, sg), 2 * L_ + X_ + 2 * V_ + 2 * P_)):
+                                     ("bwd", lambda: kernels.logprob_bwd(sl, sx, sloc, sls, sg, out=s_bw), 2 * L_ + X_ + 2 * V_ + 2 * P_)):
                 fn(); fn()
                 torch.cuda.synchronize()
                 e0.record()
@@ -565,7 +581,7 @@ def main():
             # between the two passes)
             s_lp_old = kernels.logprob_fwd(sl, sx, sloc, sls).clone()
             s_stats = kernels.adv_stats(sg)
-            s_out = {"logp": torch.empty(sB, device=dev), "dlogits": torch.empty(sB, sA * sN, device=dev),
+            s_out = {"logp": torch.empty(sB, device=dev), "dlogits": s_dl,
                      "dloc": torch.empty(sA, sN, device=dev), "dlogstd": torch.empty(sA, sN, device=dev),
                      "dvalue": torch.empty(sB, device=dev), "loss3": torch.empty(3, device=dev)}
             s_v = torch.zeros(sB, device=dev)
@@ -605,12 +621,18 @@ def main():
                         best_ = (u_, cfg)
                 return {"us_per_launch": best_[0], "algorithmic_bytes": nbytes, "achieved": nbytes / best_[0] / 1e3,
                         "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": nbytes / best_[0] / 1e3 / HBM_PEAK_GBS,
-                        "config": {"unroll": best_[1][0], "nontemporal": best_[1][1], "blocks": best_[1][2]}}
+                        "config": {"unroll": best_[1][0], "nontemporal": best_[1][1], "blocks": best_[1][2],
+                                   **({"destination": ("independent allocation", "paired buffer")[best_[1][3]]}
+                                      if len(best_[1]) > 3 else {})}}
+            # (destination: an independent allocation AND the paired buffer the backward writes -- placement moves a copy
+            # by ~10 % too, and not the way it moves the backward; the calibration takes its own best)
             s_cp = torch.empty_like(sl)
-            res["device_copy"] = dict(best_of(lambda u_, nt_, bl_: (lambda: kernels.stream_copy(s_cp, sl, u_, nt_, bl_)),
-                                              [(1, 1, 32768), (1, 1, 1024), (2, 1, 16384), (1, 0, 1024), (4, 0, 2048)], 2 * L_),
+            dsts = (s_cp.view(-1), s_dl.view(-1))
+            res["device_copy"] = dict(best_of(lambda u_, nt_, bl_, d_: (lambda: kernels.stream_copy(dsts[d_], sl, u_, nt_, bl_)),
+                                              [(u_, nt_, bl_, d_) for d_ in (0, 1) for (u_, nt_, bl_) in
+                                               ((1, 1, 32768), (1, 1, 1024), (2, 1, 16384), (1, 0, 1024), (4, 0, 2048))], 2 * L_),
                                       kernel="pfpn_stream_copy (own float4 grid-stride copy of the same logits: read L + write L)")
-            del s_cp
+            del s_cp, dsts
             sinks = {bl_: torch.empty(bl_ * 256, device=dev) for bl_ in (2048, 8192, 32768)}
             res["device_read"] = dict(best_of(lambda u_, nt_, bl_: (lambda: kernels.stream_copy(sinks[bl_], sl, 0, nt_, bl_)),
                                               [(0, 1, 2048), (0, 1, 8192), (0, 1, 32768), (0, 0, 8192)], L_),
@@ -685,9 +707,11 @@ def main():
                 shard = {}
                 for n_gpu in (1, 2, 4, 8):
                     entry = {"gpus_of_the_run_it_stands_for": n_gpu}
-                    for mode in ("allreduce", "sharded"):
-                        snet, sopt, sin = make_learner(B // n_gpu, SEED, exchange_group=True, exchange_mode=mode)
-                        srun, sl_ = make_stepper(snet, sopt, sin)
+                    for mode in ("allreduce", "sharded", "allreduce_in_graph"):
+                        if mode == "allreduce_in_graph" and dist.get_backend() != "nccl":
+                            continue
+                        snet, sopt, sin = make_learner(B // n_gpu, SEED, exchange_group=True, exchange_mode=mode.split("_")[0])
+                        srun, sl_ = make_stepper(snet, sopt, sin, capture_exchange=(mode == "allreduce_in_graph"))
                         srun(20)
                         torch.cuda.synchronize()
                         t_s = time.perf_counter()
@@ -697,6 +721,9 @@ def main():
                         if mode == "allreduce":
                             slaunch = sl_
                             entry.update({"us_per_step": us_s, "steps_per_s_without_links": 1e6 / us_s})
+                        elif mode == "allreduce_in_graph":
+                            # (PFPN_GRAPH_EXCHANGE=1: the all-reduce captured inside ONE graph, 8 steps per replay)
+                            entry["us_per_step_exchange_in_graph"] = us_s
                         else:
                             # (world size 1: the owner's slice is the whole buffer -- the launch structure and the three
                             # collectives' host cost, not the 1/W Adam of a real run)

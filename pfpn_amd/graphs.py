@@ -6,6 +6,8 @@ dispatch cost is comparable to the device time, so the whole device part of the 
 Host-side bookkeeping (global_step, the resample tick every `resample_interval` steps) stays outside
 the graph: the resample kernels run eagerly between replays.
 """
+import os
+
 import torch
 
 from . import kernels
@@ -41,16 +43,32 @@ class GraphedLearnerStep(object):
     runs after the replay, so a K-step replay is only legal while no resample falls inside it: `can_replay()`."""
 
     def __init__(self, net, optimizer, *inputs, warmup=3, noise=None, steps_per_replay=1, input_sets=None,
-                 gather_from=None):
+                 gather_from=None, capture_exchange=None):
         """`gather_from` = (columns, rows [K, B] int64, losses [K, 3]), all static device tensors: step k of a replay
         first gathers rows[k] of the staged rollout `columns` into its input set (the minibatch slicing of a training
-        round, inside the graph) and leaves its loss3 in losses[k]."""
+        round, inside the graph) and leaves its loss3 in losses[k].
+        `capture_exchange` (default: env PFPN_GRAPH_EXCHANGE, off): data-parallel step with the RCCL collectives INSIDE
+        the capture (one graph, K steps per replay allowed) instead of two graphs around an eagerly enqueued collective."""
         self.net, self.opt = net, optimizer
         self.gather_from = gather_from
         # data parallel: the step is captured as TWO graphs around the bucket all-reduce (everything up to the
         # per-replica clip | Adam + statistics); the collective itself is enqueued between the two replays, so the
-        # capture never contains an RCCL call and the host enqueues 3 things per step instead of ~25
-        self.split = bool(getattr(optimizer, "exchange", optimizer.world > 1))
+        # capture never contains an RCCL call and the host enqueues 3 things per step instead of ~25.
+        # Opt-in alternative (`capture_exchange`): RCCL's kernels are captured like any other (the communicator must exist
+        # before the capture starts: one tiny eager all-reduce here, which every replica runs because every replica
+        # builds its stepper), so a data-parallel step is ONE graph and K steps share a replay as on one replica.
+        # Checked on a world-size-1 RCCL group only (tests/test_gpu_dp2.py); no multi-GPU node has run it.
+        exchanging = bool(getattr(optimizer, "exchange", optimizer.world > 1))
+        if capture_exchange is None:
+            capture_exchange = os.environ.get("PFPN_GRAPH_EXCHANGE", "0") != "0"
+        self.in_graph_exchange = bool(exchanging and capture_exchange)
+        if self.in_graph_exchange:
+            import torch.distributed as dist
+            if dist.get_backend(optimizer.pg) != "nccl":
+                raise ValueError("capture_exchange needs the RCCL backend (gloo collectives run on the host)")
+            dist.all_reduce(torch.zeros(1, device=net.device), group=optimizer.pg)
+            torch.cuda.synchronize()
+        self.split = exchanging and not self.in_graph_exchange
         self.K = int(steps_per_replay)
         assert not (self.split and self.K > 1), "multi-step replays cover the single-replica step"
         assert self.K >= 1 and (self.K == 1 or noise is None), "one noise set per captured step is not built"
@@ -68,7 +86,7 @@ class GraphedLearnerStep(object):
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 net.compute_gradients(*self._args(0))
-                if self.split:         # the warm-up must not talk to the other replicas: skip the collective
+                if self.split or self.in_graph_exchange:   # the warm-up must not talk to the other replicas: no collective
                     optimizer.pre_reduce(net)
                     optimizer.post_reduce(net)
                 else:
@@ -79,13 +97,20 @@ class GraphedLearnerStep(object):
         for t, sv in zip(self._state_tensors(), saved):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):      # same stream as the warm-up: per-stream workspaces exist
+        # (thread-local capture mode with collectives inside: the process group's watchdog thread may query events meanwhile)
+        mode = {"capture_error_mode": "thread_local"} if self.in_graph_exchange else {}
+        with torch.cuda.graph(self.graph, stream=s, **mode):      # same stream as the warm-up: per-stream workspaces exist
             for k in range(self.K):
                 if gather_from is not None:
                     kernels.gather_columns(list(gather_from[0]), list(self.input_sets[k]), gather_from[1][k])
                 self.loss3 = net.compute_gradients(*self._args(k))
                 if self.split:
                     optimizer.pre_reduce(net)
+                elif self.in_graph_exchange:
+                    optimizer.pre_reduce(net)
+                    optimizer.reduce(net)
+                    optimizer.post_reduce(net)
+                    optimizer.finish_reduce(net)
                 else:
                     optimizer.apply_device(net)
                 if gather_from is not None:

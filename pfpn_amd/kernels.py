@@ -1046,6 +1046,27 @@ def dense_job_head_wgrad(dv, h, dw, db):
     return j
 
 
+STREAM_PAIR_MIN_BYTES = 256 << 20          # = the wide backward's streaming regime (dlogits beyond the infinity cache)
+
+
+def stream_pair(rows, cols, device):
+    """Two [rows, cols] float32 buffers for a kernel that streams the first in while it streams the second out (logits ->
+    dlogits of the wide mixture backward).  Where the second sits RELATIVE to the first decides how the two streams meet
+    in the memory system: measured on the 8192 x 128 x 256 shape, one allocation with the second buffer at
+    (a multiple of 256 MiB) + 4 KiB behind the first runs the backward in 379-381 us in every process and on every box
+    tried; + 16 KiB, + 16 MiB or + 64 MiB: 445-485 us; two independent allocations land anywhere in between, a different
+    place in every process (tools/skew_probe.py, profiles/r03_stream_skew.txt).  Below STREAM_PAIR_MIN_BYTES: two plain
+    allocations."""
+    n = int(rows) * int(cols)
+    if n * 4 < STREAM_PAIR_MIN_BYTES:
+        return (torch.empty(rows, cols, dtype=torch.float32, device=device),
+                torch.empty(rows, cols, dtype=torch.float32, device=device))
+    step = 256 << 20
+    off = ((n * 4 + step - 1) // step * step + 4096) // 4
+    pool = torch.empty(off + n, dtype=torch.float32, device=device)
+    return pool[:n].view(rows, cols), pool[off:off + n].view(rows, cols)
+
+
 def stream_copy(dst, src, unroll=4, nontemporal=False, blocks=2048):
     """the build's own streaming copy (calibration of the HBM roofline fractions on the box at hand)."""
     lib = _lib.load()

@@ -143,13 +143,15 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
 
     def _alloc_policy_buffers(self, B):
         dev, AN = self.device, self.n_actions * self.particles
-        self.logits = torch.empty(B, AN, dtype=torch.float32, device=dev)
         if not self.trainable:
+            self.logits = torch.empty(B, AN, dtype=torch.float32, device=dev)
             return
+        # (large shapes: logits and dlogits at the relative placement the streaming backward runs best at)
+        self.logits, dlogits = kernels.stream_pair(B, AN, dev)
         hc = self.critic_net_shape[-1]
         self.train_out = {
             "logp": torch.empty(B, dtype=torch.float32, device=dev),
-            "dlogits": torch.empty(B, AN, dtype=torch.float32, device=dev),
+            "dlogits": dlogits,
             "dloc": self.store.g("actor/samples"),
             "dlogstd": self.store.g("actor/samples_std"),
             "dvalue": torch.empty(B, dtype=torch.float32, device=dev),

@@ -212,6 +212,10 @@ def _rccl_rank(port, q):
         nets.append(make_net(dev, seed=9, resample_interval=3))
         opts.append(SyncReplicasApplier(nets[2], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1,
                                         force_exchange=True))
+        # and a fourth whose captured form holds the RCCL all-reduce INSIDE the graph (PFPN_GRAPH_EXCHANGE=1)
+        nets.append(make_net(dev, seed=9, resample_interval=3))
+        opts.append(SyncReplicasApplier(nets[3], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1,
+                                        force_exchange=True))
         for it in range(9):
             b = make_batch(rng, 256)
             b["log_prob"] = np.full(256, -40.0, F)
@@ -219,19 +223,40 @@ def _rccl_rank(port, q):
             out = []
             for i, (net, opt) in enumerate(zip(nets, opts)):
                 os.environ["PFPN_GRAPH_TRAIN"] = "0" if i == 2 else "1"
+                os.environ["PFPN_GRAPH_EXCHANGE"] = "1" if i == 3 else "0"
                 net.max_active.copy_(mx); net.sum_active.copy_(sm)
                 out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
                                      b["advantage"]))
-            ok &= out[0] == out[1] == out[2]
+            ok &= out[0] == out[1] == out[2] == out[3]
             for other in nets[1:]:
                 ok &= torch.equal(nets[0].store.flat, other.store.flat) and torch.equal(nets[0].store.v, other.store.v)
                 ok &= torch.equal(nets[0].state_normalizer.mean, other.state_normalizer.mean)
                 ok &= torch.equal(nets[0].state_normalizer.std, other.state_normalizer.std)
                 ok &= torch.equal(nets[0].max_active, other.max_active) and torch.equal(nets[0].sum_active, other.sum_active)
         os.environ["PFPN_GRAPH_TRAIN"] = "1"
+        os.environ["PFPN_GRAPH_EXCHANGE"] = "0"
         ok &= nets[0].global_step == 9 and nets[0].train_flag == 0
         g = list(nets[0]._train_graphs.values())
         ok &= len(g) == 1 and g[0].split and len(nets[2]._train_graphs) == 0      # captured as two graphs | eager
+        g3 = list(nets[3]._train_graphs.values())
+        ok &= len(g3) == 1 and g3[0].in_graph_exchange and not g3[0].split        # ONE graph with the collective inside
+        # four data-parallel steps in ONE replay (the collective captured four times) == four eager exchange steps
+        from pfpn_amd.graphs import GraphedLearnerStep
+        pair = [make_net(dev, seed=11, resample_interval=50) for _ in range(2)]
+        popt = [SyncReplicasApplier(n, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True)
+                for n in pair]
+        b = make_batch(rng, 256)
+        b["log_prob"] = np.full(256, -40.0, F)
+        tin = [torch.from_numpy(np.asarray(b[k], F)).to(dev) for k in ("state", "action", "value", "log_prob", "advantage")]
+        multi = GraphedLearnerStep(pair[0], popt[0], *tin, steps_per_replay=4, capture_exchange=True)
+        ok &= multi.in_graph_exchange and multi.K == 4
+        multi()
+        for _ in range(4):
+            pair[1].train_device(popt[1], *tin)
+        torch.cuda.synchronize()
+        ok &= torch.equal(pair[0].store.flat, pair[1].store.flat) and torch.equal(pair[0].store.m, pair[1].store.m)
+        ok &= torch.equal(pair[0].state_normalizer.mean, pair[1].state_normalizer.mean)
+        ok &= pair[0].global_step == pair[1].global_step == 4
         nets, opts = nets[:2], opts[:2]
         # with the global norm produced by the reduction launch on both paths: equal to summation-order precision
         os.environ["PFPN_FUSED_NORM"] = "1"
