@@ -90,55 +90,44 @@ __device__ __forceinline__ float quad_max(float v) {
     return v;
 }
 
-// Four independent wave reductions for the price of ~one: a transposing butterfly.  Lanes first trade
-// rows (xor 1, xor 2: afterwards lane class (lane & 3) = {0,1,2,3} carries a 4-lane partial of row
-// {0,2,1,3}), then ONE value per lane is combined over the remaining 16 lane groups (row_ror 4/8 inside
-// a row of 16, then xor 16 / xor 32 across rows).  ~13 cross-lane ops for 4 rows instead of 24; results
-// come back wave-uniform through v_readlane.  Fixed combination order -> deterministic.
+// Four independent wave reductions for the price of ~one: a transposing butterfly on gfx950's lane-swap instructions.
+// v_permlane16_swap(a, b) -> {[a.row0 b.row0 a.row2 b.row2], [a.row1 b.row1 a.row3 b.row3]} (rows of 16 lanes) and
+// v_permlane32_swap(a, b) -> {[a.lo32 | b.lo32], [a.hi32 | b.hi32]} (tools/permlane_probe.hip prints both): combining the
+// two results of a swap halves the number of live values while every lane keeps working.  r0..r3 -> 2 values -> ONE value
+// whose row j (lanes 16j..16j+15) carries r_j summed over the four rows' lanes of the same column; four DPP steps
+// (row_ror 8, 4, quad_perm xor 2, xor 1) finish inside the row.  10 VALU instructions, no LDS round trip (the previous
+// form: 6 selects, 5 DPP steps and two ds_bpermute for the xor-16 / xor-32 steps).  Fixed order -> deterministic.
 template <bool IS_MAX>
 __device__ __forceinline__ float red_comb(float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; }
 
+// -> every lane holds the total of r[wave_reduce4_row(lane)]: results left DISTRIBUTED, for per-row follow-up math that
+// can then run once across the four rows instead of four times on wave-uniform values.
+__device__ __forceinline__ int wave_reduce4_row(int lane) { return lane >> 4; }
+
 template <bool IS_MAX>
-__device__ __forceinline__ void wave_reduce4(float& r0, float& r1, float& r2, float& r3, int lane) {
+__device__ __forceinline__ float wave_reduce4_dist(float r0, float r1, float r2, float r3, int /*lane*/) {
     const float id = IS_MAX ? -INFINITY : 0.f;
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float k0 = b0 ? r2 : r0, k1 = b0 ? r3 : r1;
-    const float s0 = b0 ? r0 : r2, s1 = b0 ? r1 : r3;
-    k0 = red_comb<IS_MAX>(k0, dpp_shift<0xB1, 0xf>(s0, id));      // quad_perm [1,0,3,2]  (xor 1)
-    k1 = red_comb<IS_MAX>(k1, dpp_shift<0xB1, 0xf>(s1, id));
-    float k = b1 ? k1 : k0;
-    const float sn = b1 ? k0 : k1;
-    k = red_comb<IS_MAX>(k, dpp_shift<0x4E, 0xf>(sn, id));        // quad_perm [2,3,0,1]  (xor 2)
-    k = red_comb<IS_MAX>(k, dpp_shift<0x124, 0xf>(k, id));        // row_ror:4
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(r0), __float_as_uint(r1), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2), __float_as_uint(r3), false, false);
+    const float s01 = red_comb<IS_MAX>(__uint_as_float(a[0]), __uint_as_float(a[1]));   // rows [r0 r1 r0 r1]
+    const float s23 = red_comb<IS_MAX>(__uint_as_float(b[0]), __uint_as_float(b[1]));   // rows [r2 r3 r2 r3]
+    const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
+    float k = red_comb<IS_MAX>(__uint_as_float(c[0]), __uint_as_float(c[1]));           // rows [r0 r1 r2 r3]
     k = red_comb<IS_MAX>(k, dpp_shift<0x128, 0xf>(k, id));        // row_ror:8
-    k = red_comb<IS_MAX>(k, __shfl_xor(k, 16, 64));
-    k = red_comb<IS_MAX>(k, __shfl_xor(k, 32, 64));
-    r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 0));
-    r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 1));
-    r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 2));
-    r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 3));
+    k = red_comb<IS_MAX>(k, dpp_shift<0x124, 0xf>(k, id));        // row_ror:4
+    k = red_comb<IS_MAX>(k, dpp_shift<0x4E, 0xf>(k, id));         // quad_perm [2,3,0,1]  (xor 2)
+    k = red_comb<IS_MAX>(k, dpp_shift<0xB1, 0xf>(k, id));         // quad_perm [1,0,3,2]  (xor 1)
+    return k;
 }
 
-// The same butterfly, results left DISTRIBUTED: every lane returns the total of row wave_reduce4_row(lane) -- for
-// per-row follow-up math that can then run once across the four rows instead of four times on wave-uniform values.
-__device__ __forceinline__ int wave_reduce4_row(int lane) { return ((lane & 1) << 1) | ((lane >> 1) & 1); }   // 0,2,1,3
-
+// the same, results wave-uniform (v_readlane of one lane per row)
 template <bool IS_MAX>
-__device__ __forceinline__ float wave_reduce4_dist(float r0, float r1, float r2, float r3, int lane) {
-    const float id = IS_MAX ? -INFINITY : 0.f;
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float k0 = b0 ? r2 : r0, k1 = b0 ? r3 : r1;
-    const float s0 = b0 ? r0 : r2, s1 = b0 ? r1 : r3;
-    k0 = red_comb<IS_MAX>(k0, dpp_shift<0xB1, 0xf>(s0, id));
-    k1 = red_comb<IS_MAX>(k1, dpp_shift<0xB1, 0xf>(s1, id));
-    float k = b1 ? k1 : k0;
-    const float sn = b1 ? k0 : k1;
-    k = red_comb<IS_MAX>(k, dpp_shift<0x4E, 0xf>(sn, id));
-    k = red_comb<IS_MAX>(k, dpp_shift<0x124, 0xf>(k, id));
-    k = red_comb<IS_MAX>(k, dpp_shift<0x128, 0xf>(k, id));
-    k = red_comb<IS_MAX>(k, __shfl_xor(k, 16, 64));
-    k = red_comb<IS_MAX>(k, __shfl_xor(k, 32, 64));
-    return k;
+__device__ __forceinline__ void wave_reduce4(float& r0, float& r1, float& r2, float& r3, int lane) {
+    const float k = wave_reduce4_dist<IS_MAX>(r0, r1, r2, r3, lane);
+    r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 0));
+    r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 16));
+    r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 32));
+    r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k), 48));
 }
 
 // Block-wide sum in a fixed order (deterministic): wave shuffle, then wave 0 adds the
