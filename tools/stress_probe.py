@@ -6,7 +6,9 @@ from pfpn_amd import kernels
 dev = torch.device("cuda:0")
 B, A, N = int(os.environ.get("SB", 8192)), int(os.environ.get("SA", 128)), int(os.environ.get("SN", 256))
 g = torch.Generator(device=dev); g.manual_seed(0)
-logits = torch.randn(B, A * N, device=dev, generator=g)
+logits, dlogits = kernels.stream_pair(B, A * N, dev)          # placed as the network places them
+logits.normal_(generator=g)
+bw_out = {"dlogits": dlogits, "dloc": torch.empty(A, N, device=dev), "dlogstd": torch.empty(A, N, device=dev)}
 x = torch.rand(B, A, device=dev, generator=g) * 2.2 - 1.1
 loc = torch.linspace(-1, 1, N, device=dev).repeat(A, 1).contiguous()
 logstd = torch.full((A, N), float(np.log(2 / (N - 1))), device=dev)
@@ -21,7 +23,7 @@ def timeit(f, n=10):
     return e0.elapsed_time(e1) * 1e3 / n
 L, X, V, P = 4 * B * A * N, 4 * B * A, 4 * B, 8 * A * N
 t_f = timeit(lambda: kernels.logprob_fwd(logits, x, loc, logstd))
-t_b = timeit(lambda: kernels.logprob_bwd(logits, x, loc, logstd, dl))
+t_b = timeit(lambda: kernels.logprob_bwd(logits, x, loc, logstd, dl, out=bw_out))
 cp = torch.empty_like(logits)
 t_c = timeit(lambda: cp.copy_(logits))
 out = {"shape": [B, A, N],
