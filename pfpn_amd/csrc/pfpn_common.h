@@ -97,8 +97,29 @@ __device__ __forceinline__ float quad_max(float v) {
 // whose row j (lanes 16j..16j+15) carries r_j summed over the four rows' lanes of the same column; four DPP steps
 // (row_ror 8, 4, quad_perm xor 2, xor 1) finish inside the row.  10 VALU instructions, no LDS round trip (the previous
 // form: 6 selects, 5 DPP steps and two ds_bpermute for the xor-16 / xor-32 steps).  Fixed order -> deterministic.
+// (max as v_med3_f32(a, b, +inf): fmaxf() makes hipcc canonicalise both operands first -- a v_max_f32 x, x each -- whenever
+// they come out of a lane swap or a DPP move; the values here are finite products, never signalling NaNs)
 template <bool IS_MAX>
-__device__ __forceinline__ float red_comb(float a, float b) { return IS_MAX ? fmaxf(a, b) : a + b; }
+__device__ __forceinline__ float red_comb(float a, float b) { return IS_MAX ? __builtin_amdgcn_fmed3f(a, b, INFINITY) : a + b; }
+
+// one in-row butterfly step k = op(k, k rotated / permuted inside its row of 16): the sum folds into v_add_f32_dpp by
+// itself; for the maximum the DPP form is written out (hipcc emits fill + v_mov_dpp + 2 canonicalisations + v_max).
+// s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write, which hipcc cannot see inside the asm.
+#define PFPN_ROW_STEP(name, ctrl_text, CTRL)                                                                        \
+    template <bool IS_MAX>                                                                                          \
+    __device__ __forceinline__ float name(float k) {                                                                \
+        if (IS_MAX) {                                                                                               \
+            float r;                                                                                                \
+            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl_text " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(k)); \
+            return r;                                                                                               \
+        }                                                                                                           \
+        return k + dpp_shift<CTRL, 0xf>(k, 0.f);                                                                    \
+    }
+PFPN_ROW_STEP(row_step_ror8, "row_ror:8", 0x128)
+PFPN_ROW_STEP(row_step_ror4, "row_ror:4", 0x124)
+PFPN_ROW_STEP(row_step_xor2, "quad_perm:[2,3,0,1]", 0x4E)
+PFPN_ROW_STEP(row_step_xor1, "quad_perm:[1,0,3,2]", 0xB1)
+#undef PFPN_ROW_STEP
 
 // -> every lane holds the total of r[wave_reduce4_row(lane)]: results left DISTRIBUTED, for per-row follow-up math that
 // can then run once across the four rows instead of four times on wave-uniform values.
@@ -106,17 +127,16 @@ __device__ __forceinline__ int wave_reduce4_row(int lane) { return lane >> 4; }
 
 template <bool IS_MAX>
 __device__ __forceinline__ float wave_reduce4_dist(float r0, float r1, float r2, float r3, int /*lane*/) {
-    const float id = IS_MAX ? -INFINITY : 0.f;
     const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(r0), __float_as_uint(r1), false, false);
     const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(r2), __float_as_uint(r3), false, false);
     const float s01 = red_comb<IS_MAX>(__uint_as_float(a[0]), __uint_as_float(a[1]));   // rows [r0 r1 r0 r1]
     const float s23 = red_comb<IS_MAX>(__uint_as_float(b[0]), __uint_as_float(b[1]));   // rows [r2 r3 r2 r3]
     const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(s01), __float_as_uint(s23), false, false);
     float k = red_comb<IS_MAX>(__uint_as_float(c[0]), __uint_as_float(c[1]));           // rows [r0 r1 r2 r3]
-    k = red_comb<IS_MAX>(k, dpp_shift<0x128, 0xf>(k, id));        // row_ror:8
-    k = red_comb<IS_MAX>(k, dpp_shift<0x124, 0xf>(k, id));        // row_ror:4
-    k = red_comb<IS_MAX>(k, dpp_shift<0x4E, 0xf>(k, id));         // quad_perm [2,3,0,1]  (xor 2)
-    k = red_comb<IS_MAX>(k, dpp_shift<0xB1, 0xf>(k, id));         // quad_perm [1,0,3,2]  (xor 1)
+    k = row_step_ror8<IS_MAX>(k);
+    k = row_step_ror4<IS_MAX>(k);
+    k = row_step_xor2<IS_MAX>(k);
+    k = row_step_xor1<IS_MAX>(k);
     return k;
 }
 
