@@ -385,7 +385,7 @@ def main():
 
     def in_graph_block():
         # the all-reduce captured INSIDE the step's graph, K steps per replay (PFPN_GRAPH_EXCHANGE=1 makes it the headline)
-        gnet, gopt, gin = make_learner(rows, SEED + rank)
+        gnet, gopt, gin = make_learner(rows, SEED + rank, exchange_mode="allreduce")
         grun, glaunch = make_stepper(gnet, gopt, gin, capture_exchange=True)
         gel = timed_steps(grun, args.steps, args.warmup)
         return {"value": args.steps / gel, "unit": "steps/s", "ms_per_step": gel / args.steps * 1e3, "launch": glaunch}

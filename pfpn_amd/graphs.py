@@ -59,9 +59,17 @@ class GraphedLearnerStep(object):
         # builds its stepper), so a data-parallel step is ONE graph and K steps share a replay as on one replica.
         # Checked on a world-size-1 RCCL group only (tests/test_gpu_dp2.py); no multi-GPU node has run it.
         exchanging = bool(getattr(optimizer, "exchange", optimizer.world > 1))
+        explicit_arg = capture_exchange is not None
         if capture_exchange is None:
             capture_exchange = os.environ.get("PFPN_GRAPH_EXCHANGE", "0") != "0"
         self.in_graph_exchange = bool(exchanging and capture_exchange)
+        if self.in_graph_exchange and getattr(optimizer, "sharded", False):
+            # all-reduce form only: with all_to_all_single / all_gather_into_tensor captured, the process group's shutdown
+            # waits for ever on work it recorded during the capture (destroy_process_group hangs; seen on a world-size-1
+            # group).  Asked for by the environment default: the sharded step stays on two graphs; asked for by argument: refuse.
+            if explicit_arg:
+                raise ValueError("capture_exchange covers the all-reduce exchange only")
+            self.in_graph_exchange = False
         if self.in_graph_exchange:
             import torch.distributed as dist
             if dist.get_backend(optimizer.pg) != "nccl":

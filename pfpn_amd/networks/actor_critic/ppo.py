@@ -117,10 +117,14 @@ def clip_ppo_network_wrapper(a2c_base_class):
             kept).  PFPN_GRAPH_ROUND=0: one-step replays only."""
             if (B, id(optimizer)) not in self._train_graphs or os.environ.get("PFPN_GRAPH_ROUND", "1") == "0":
                 return None
+            in_graph = False
             if getattr(optimizer, "exchange", optimizer.world > 1):
                 # data-parallel steps are two graphs around the all-reduce: a K-step replay cannot hold the collective,
-                # so DP rounds run one-step (split-graph) replays
-                return None
+                # so DP rounds run one-step (split-graph) replays -- unless the step captures its collectives
+                # (PFPN_GRAPH_EXCHANGE=1: the one-step graph of this size was built that way)
+                in_graph = getattr(self._train_graphs[(B, id(optimizer))], "in_graph_exchange", False)
+                if not in_graph:
+                    return None
             n = cols[0].shape[0]
             key = (B, n, K, id(optimizer))
             rg = self._round_graphs.get(key) if hasattr(self, "_round_graphs") else None
@@ -135,7 +139,8 @@ def clip_ppo_network_wrapper(a2c_base_class):
                 losses = torch.zeros(K, 3, dtype=torch.float32, device=self.device)
                 sets = [tuple(c[:B].clone() for c in cols) for _ in range(K)]      # sane inputs for the warm-up steps
                 rg = self._round_graphs[key] = GraphedLearnerStep(self, optimizer, steps_per_replay=K, input_sets=sets,
-                                                                  gather_from=(stage, rows, losses))
+                                                                  gather_from=(stage, rows, losses),
+                                                                  capture_exchange=in_graph)
             for dst, src in zip(rg.gather_from[0], cols):
                 dst.copy_(src, non_blocking=True)
             return rg

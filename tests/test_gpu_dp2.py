@@ -188,6 +188,8 @@ def test_two_rank_step_matches_reference_graph(dev, tag, mode):
 def _rccl_rank(port, q):
     """world-size-1 RCCL group: the exchange path of the step (clip in place, bucket all-reduce through RCCL, Adam with
     1/W and the statistics tail in one launch) must give the bits of the single-replica fused path."""
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)      # a hang (teardown included) becomes a failure with stacks
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -310,21 +312,24 @@ def _rccl_rank(port, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 def test_exchange_path_over_rccl_single_rank_matches_fused_path(dev):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_rank, args=(_free_port(), q))
     p.start()
     res = q.get(timeout=240)
-    p.join(60)
+    p.join(230)
     assert res[1], res
+    assert p.exitcode == 0, "the rank did not exit cleanly (exit code %r)" % (p.exitcode,)
 
 
 def _rccl_sharded_rank(port, q):
     """world-size-1 RCCL group, sharded exchange (all-to-all, factor all-gather, owner Adam, in-place all-gather through
     RCCL): eager for every step on one replica, captured as two hipGraphs on another -- same bits; against the single-replica
     fused path to summation-order precision; a training round driven through worker-style flat_train plans."""
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)      # a hang (teardown included) becomes a failure with stacks
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -372,7 +377,11 @@ def _rccl_sharded_rank(port, q):
         # give the bits of per-minibatch train() calls
         from pfpn_amd.models.distributed_model import minibatch_plan
         names = ["state", "action", "value", "log_prob", "advantage"]
-        for mode in ("allreduce", "sharded"):
+        for mode in ("allreduce", "sharded", "allreduce+in_graph", "sharded+in_graph"):
+            # (+in_graph: PFPN_GRAPH_EXCHANGE=1 for the first replica -- its rounds then DO replay 8 minibatch steps per
+            # graph, the collectives captured inside, and must still give the bits of per-minibatch train() calls)
+            captured = mode.endswith("+in_graph")
+            mode = mode.split("+")[0]
             rn = [make_net(dev, seed=11, resample_interval=13) for _ in range(2)]
             ro = [SyncReplicasApplier(n_, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True,
                                       exchange_mode=mode) for n_ in rn]
@@ -381,13 +390,26 @@ def _rccl_sharded_rank(port, q):
                 b["log_prob"] = rng.normal(-38, 0.3, 256).astype(F)
                 plan = minibatch_plan(256, 32, 2, np.random.RandomState(rnd))
                 cols = {k: b[k] for k in names}
+                os.environ["PFPN_GRAPH_EXCHANGE"] = "1" if captured else "0"
                 out_round = rn[0].train_round(ro[0], ["global_step"], names, cols, plan)
+                os.environ["PFPN_GRAPH_EXCHANGE"] = "0"
                 out_steps = [rn[1].train(None, ro[1], ["global_step"], *[cols[k][rows] for k in names]) for rows in plan]
                 ok &= len(out_round) == len(plan) == 16 and all(a == b_ for a, b_ in zip(out_round, out_steps))
                 ok &= torch.equal(rn[0].store.flat, rn[1].store.flat)
                 ok &= torch.equal(rn[0].state_normalizer.mean, rn[1].state_normalizer.mean)
-            ok &= rn[0].global_step == 48 and not getattr(rn[0], "_round_graphs", {})
-            ok &= all(g_.split and g_.K == 1 for g_ in rn[0]._train_graphs.values()) and len(rn[0]._train_graphs) >= 1
+            ok &= rn[0].global_step == 48 and len(rn[0]._train_graphs) >= 1
+            if captured and mode == "sharded":
+                # the sharded exchange is never captured (its collectives inside a graph leave the process group's
+                # shutdown waiting for ever): the environment switch is ignored, the round stays on split graphs
+                ok &= not getattr(rn[0], "_round_graphs", {})
+                ok &= all(g_.split and not g_.in_graph_exchange for g_ in rn[0]._train_graphs.values())
+            elif captured:
+                rgs = list(getattr(rn[0], "_round_graphs", {}).values())
+                ok &= len(rgs) == 1 and rgs[0].K == 8 and rgs[0].in_graph_exchange and rgs[0].replays >= 2
+                ok &= all(g_.in_graph_exchange and g_.K == 1 for g_ in rn[0]._train_graphs.values())
+            else:
+                ok &= not getattr(rn[0], "_round_graphs", {})
+                ok &= all(g_.split and g_.K == 1 for g_ in rn[0]._train_graphs.values())
         q.put((0, bool(ok), "", ""))
     except Exception as e:
         import traceback
@@ -398,12 +420,13 @@ def _rccl_sharded_rank(port, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(600)
 def test_sharded_exchange_over_rccl_single_rank(dev):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_sharded_rank, args=(_free_port(), q))
     p.start()
     res = q.get(timeout=240)
-    p.join(60)
+    p.join(230)
     assert res[1], res
+    assert p.exitcode == 0, "the rank did not exit cleanly (exit code %r)" % (p.exitcode,)
