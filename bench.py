@@ -360,7 +360,33 @@ def main():
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             ver = None
+        coll = None
+        if dist.get_backend() == "nccl":
+            # what the links give the step's collectives on their own (20 back-to-back calls each, max over ranks): the
+            # bucket all-reduce of the default exchange; the all-to-all + in-place all-gather of the sharded one
+            nb_ = net.store.bucket.numel()
+            npad_ = (nb_ + 256 * world - 1) // (256 * world) * (256 * world)
+            bufs = (torch.zeros(nb_, device=dev), torch.zeros(npad_, device=dev), torch.zeros(npad_, device=dev))
+            calls = {"all_reduce_bucket": lambda: dist.all_reduce(bufs[0]),
+                     "all_to_all_bucket": lambda: dist.all_to_all_single(bufs[2], bufs[1]),
+                     "all_gather_in_place": lambda: dist.all_gather_into_tensor(
+                         bufs[1], bufs[1][rank * (npad_ // world):(rank + 1) * (npad_ // world)])}
+            coll = {}
+            for name_, fn_ in calls.items():
+                for _ in range(3):
+                    fn_()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0_ = time.perf_counter()
+                for _ in range(20):
+                    fn_()
+                torch.cuda.synchronize()
+                t_ = torch.tensor([(time.perf_counter() - t0_) / 20 * 1e6], dtype=torch.float64, device=dev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                coll[name_] = float(t_.item())
+            coll["MB"] = nb_ * 4 / 1e6
         return {"world": dist.get_world_size(), "ranks_seen": int(ones.item()), "backend": dist.get_backend(),
+                "collective_us": coll,
                 "rccl_version": ver, "devices": [int(d.item()) for d in devs],
                 "bucket_MB": net.store.bucket.numel() * 4 / 1e6,
                 "exchange": ("sharded: all_to_all_single of %.2f MB bucket slices + all_gather of %d clip factors + "
