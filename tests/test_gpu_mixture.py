@@ -137,6 +137,30 @@ def test_wide_kernel_config5_full_size_properties(oracle, dev):
     np.testing.assert_allclose(dl[rows].cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * np.abs(r_dl).max())
 
 
+def test_stream_pair_placement_changes_no_bits(dev):
+    """logits / dlogits of large shapes come out of ONE allocation at a fixed distance (kernels.stream_pair: where the two
+    streams of the backward sit relative to each other decides its speed); smaller shapes get two plain
+    allocations.  Placement must not change a single bit of the results."""
+    from pfpn_amd import kernels
+    B, A, N = 2048, 128, 256                                        # 256 MiB of logits: the first paired size
+    lg, dl = kernels.stream_pair(B, A * N, dev)
+    assert lg.untyped_storage().data_ptr() == dl.untyped_storage().data_ptr()
+    assert (dl.data_ptr() - lg.data_ptr()) % (256 << 20) == 4096 and dl.data_ptr() - lg.data_ptr() >= lg.numel() * 4
+    assert lg.is_contiguous() and dl.is_contiguous() and lg.shape == dl.shape == (B, A * N)
+    s1, s2 = kernels.stream_pair(B // 2, A * N, dev)
+    assert s1.untyped_storage().data_ptr() != s2.untyped_storage().data_ptr()
+    src, x, loc, logstd, g = _config5_inputs(dev, B, seed=8)
+    lg.copy_(src.view(B, A * N))
+    outs = []
+    for dlogits in (dl, torch.empty(B, A * N, device=dev)):
+        o = {"dlogits": dlogits, "dloc": torch.empty(A, N, device=dev), "dlogstd": torch.empty(A, N, device=dev)}
+        kernels.logprob_bwd(lg.view(B, A, N), x, loc, logstd, g, out=o)
+        outs.append(o)
+    for k in ("dlogits", "dloc", "dlogstd"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert bool(torch.isfinite(outs[0]["dlogits"]).all())
+
+
 def test_logprob_underflow_guard(oracle, dev):
     """x far from every particle: p underflows to 0, logp = -inf in the forward (reference computes in
     probability space), and the backward guard zeroes the gradients (utils.py:109-117)."""
