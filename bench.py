@@ -172,6 +172,10 @@ def main():
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    if os.environ.get("PFPN_BENCH_ALLOC_SHIFT"):
+        # diagnostic (tools/placement_probe.sh): a dummy allocation of this many bytes first, which moves every buffer of
+        # the step relative to the 2 MiB segments the allocator carves -- does the headline depend on where things land?
+        _shift = torch.empty(int(os.environ["PFPN_BENCH_ALLOC_SHIFT"]), dtype=torch.uint8, device=dev)
 
     def make_learner(rows, seed, exchange_group=False, exchange_mode=None):
         """a network + optimiser + `rows` synthetic transitions resident in HBM + the step callable"""
