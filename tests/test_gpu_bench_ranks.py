@@ -4,6 +4,7 @@ looped on each rank's own clock and could deadlock), the line rank 0 prints, and
 rank fails inside an informational extra."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -13,7 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(port, extra_env=None, ranks=2):
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_bench(extra_env=None, ranks=2):
+    port = _free_port()
     env = dict(os.environ)
     env.update({"PFPN_BENCH_WATCHDOG": "200", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     env.update(extra_env or {})
@@ -29,7 +37,7 @@ def run_bench(port, extra_env=None, ranks=2):
 
 
 def test_two_rank_bench_line():
-    d = run_bench(29531)
+    d = run_bench()
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["per_gpu_batch"] == 2048 and d["config"]["global_batch"] == 4096
     assert d["rccl"]["ranks_seen"] == 2 and d["rccl"]["world"] == 2
@@ -39,7 +47,7 @@ def test_two_rank_bench_line():
 
 
 def test_headline_survives_a_rank_failing_in_an_extra():
-    d = run_bench(29532, {"PFPN_BENCH_EXTRAS_DEADLINE": "30", "PFPN_BENCH_FAIL_EXTRA": "weak_block:1"})
+    d = run_bench({"PFPN_BENCH_EXTRAS_DEADLINE": "30", "PFPN_BENCH_FAIL_EXTRA": "weak_block:1"})
     assert d["extras_timed_out"] is True and d["value"] > 0 and d["n_gpus"] == 2
     assert d["rccl"]["ranks_seen"] == 2                           # the extra before the failing one is kept
     assert "weak_scaling" not in d
