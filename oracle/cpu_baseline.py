@@ -179,12 +179,18 @@ def mixture_c(orc, budget):
     def call():
         cpu_twin.logprob_fwd(logits, x, loc, logstd)
         cpu_twin.logprob_bwd(logits, x, loc, logstd, g)
-    n, el = timed(call, budget, 2000)
-    us = el / n * 1e6
     nbytes = 2 * logits.nbytes + x.nbytes + 6 * g.nbytes + 2 * loc.nbytes * 2
-    return {"value": 1e6 / us, "unit": "forward+backward passes/s of 4096 x 36 x 35", "us_per_pass": us,
-            "algorithmic_GBps": nbytes / us / 1e3, "cores": cpu_twin.threads(),
-            "sample": "%d passes, compiled C + OpenMP, %d threads" % (n, cpu_twin.threads())}
+    best = None
+    for threads in sorted({min(os.cpu_count(), t) for t in (8, 16, 32, os.cpu_count())}):   # (a box may grant fewer cores than it shows)
+        cpu_twin.set_threads(threads)
+        n, el = timed(call, budget / 4, 500)
+        us = el / n * 1e6
+        run = {"value": 1e6 / us, "unit": "forward+backward passes/s of 4096 x 36 x 35", "us_per_pass": us,
+               "algorithmic_GBps": nbytes / us / 1e3, "cores": threads,
+               "sample": "%d passes, compiled C + OpenMP, %d threads" % (n, threads)}
+        if best is None or run["value"] > best["value"]:
+            best = run
+    return best
 
 
 def main():

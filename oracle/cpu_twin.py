@@ -23,6 +23,8 @@ def load():
         _lib.pfpn_logprob_fwd_cpu.argtypes = [fp, fp, fp, fp, ip, ip, ip, ip, fp, fp]
         _lib.pfpn_logprob_bwd_cpu.argtypes = [fp, fp, fp, fp, fp, ip, ip, ip, ip, fp, fp, fp, fp]
         _lib.pfpn_gae_cpu.argtypes = [fp, fp, ctypes.POINTER(ctypes.c_longlong), ip, ctypes.c_double, ctypes.c_double, fp]
+        _lib.pfpn_cpu_set_threads.argtypes = [ip]
+        _lib.pfpn_cpu_set_threads.restype = None
         for f in (_lib.pfpn_logprob_fwd_cpu, _lib.pfpn_logprob_bwd_cpu, _lib.pfpn_gae_cpu, _lib.pfpn_cpu_threads):
             f.restype = ip
     return _lib
@@ -38,6 +40,11 @@ def _c(a):
 
 def threads():
     return int(load().pfpn_cpu_threads())
+
+
+def set_threads(n):
+    """OpenMP threads of the following calls (a box may show 256 CPUs and grant 16: more threads than cores is slower)"""
+    load().pfpn_cpu_set_threads(int(n))
 
 
 def logprob_fwd(logits, x, loc, logstd, tanh_mode=False):

@@ -30,6 +30,14 @@ static float tanh_correction(float x) { /* 2 (log 2 - x - softplus(-2x)) = log(1
     return 2.f * (LOG2F_ - x - softplusf(-2.f * x));
 }
 
+void pfpn_cpu_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int pfpn_cpu_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
