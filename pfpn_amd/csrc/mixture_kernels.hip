@@ -591,9 +591,9 @@ __global__ __launch_bounds__(1024) void k_mix_tile(
                 const v2f arg = le + __builtin_elementwise_fma(-z, z, (v2f){b_ct[2 * k], b_ct[2 * k + 1]});
                 const v2f en = {__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
                 if (MODE != MODE_FWD) { seg[TK_G * 2 * k] = en.x; seg[TK_G * (2 * k + 1)] = en.y; }
-                s2 += en;
                 ef2_o[k] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-                n2 += ef2_o[k];
+                if (k == 0) { s2 = en; n2 = ef2_o[k]; }     // start from the first term, not from 0 + it
+                else { s2 += en; n2 += ef2_o[k]; }
             }
             float sum = s2.x + s2.y, num = n2.x + n2.y;
 #pragma unroll

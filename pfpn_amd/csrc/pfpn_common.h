@@ -84,10 +84,14 @@ __device__ __forceinline__ float quad_sum(float v) {
     v += dpp_shift<0x4E, 0xf>(v, 0.f);       // quad_perm [2,3,0,1]  (xor 2)
     return v;
 }
+// (the maximum as two hand-written v_max_f32_dpp: through fmaxf() hipcc emits a move, a DPP move and two canonicalising
+// v_max_f32 x, x around each step -- nine instructions for these two.  s_nop 1: a DPP read needs two wait states after the
+// VALU write of its source, which hipcc cannot see inside the asm.)
 __device__ __forceinline__ float quad_max(float v) {
-    v = fmaxf(v, dpp_shift<0xB1, 0xf>(v, v));
-    v = fmaxf(v, dpp_shift<0x4E, 0xf>(v, v));
-    return v;
+    float a, b;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(a));
+    return b;
 }
 
 // Four independent wave reductions for the price of ~one: a transposing butterfly on gfx950's lane-swap instructions.
