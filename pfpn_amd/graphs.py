@@ -94,7 +94,15 @@ class GraphedLearnerStep(object):
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 net.compute_gradients(*self._args(0))
-                if self.split or self.in_graph_exchange:   # the warm-up must not talk to the other replicas: no collective
+                if self.in_graph_exchange:
+                    # the warm-up DOES run the collective here, on the real bucket: RCCL sets up what a message of this
+                    # size needs (channels, buffers) on its first use, which must not fall inside the capture.  Every
+                    # replica builds its stepper at the same point, so the calls pair up; the state is restored below.
+                    optimizer.pre_reduce(net)
+                    optimizer.reduce(net)
+                    optimizer.post_reduce(net)
+                    optimizer.finish_reduce(net)
+                elif self.split:       # the warm-up must not talk to the other replicas: no collective
                     optimizer.pre_reduce(net)
                     optimizer.post_reduce(net)
                 else:
