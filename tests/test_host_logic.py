@@ -360,3 +360,26 @@ def test_dense_stack_keeps_a_bounded_number_of_activation_sets():
     sizes = {k[0] for k in stack._bufs}
     assert len(stack._bufs) <= DenseStack.MAX_BUFFER_SETS + 2
     assert 3 in sizes and 6 in sizes and 199 in sizes and 1 not in sizes
+
+
+def test_bench_extras_deadline_prints_what_it_has_and_exits_cleanly(tmp_path):
+    """bench.py's ExtrasDeadline (multi-rank runs): a rank that parks after a failed extra leaves with exit code 0 once the
+    timer fires, after the emit callback ran exactly once; finish() before the timer makes it a no-op."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time; sys.path.insert(0, %r); import bench\n"
+        "d = bench.ExtrasDeadline(0.5, lambda: (sys.stdout.write('HEADLINE\\n'), sys.stdout.flush()))\n"
+        "if sys.argv[1] == 'park':\n"
+        "    d.park()\n"
+        "else:\n"
+        "    assert d.finish() is True\n"
+        "    time.sleep(1.0)\n"
+        "    assert d.finish() is False          # already finished: the caller no longer owns a second print\n"
+        "    print('NORMAL')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code, "park"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout == "HEADLINE\n", (r.returncode, r.stdout, r.stderr[-500:])
+    r = subprocess.run([sys.executable, "-c", code, "finish"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout == "NORMAL\n", (r.returncode, r.stdout, r.stderr[-500:])
