@@ -383,3 +383,17 @@ def test_bench_extras_deadline_prints_what_it_has_and_exits_cleanly(tmp_path):
     assert r.returncode == 0 and r.stdout == "HEADLINE\n", (r.returncode, r.stdout, r.stderr[-500:])
     r = subprocess.run([sys.executable, "-c", code, "finish"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout == "NORMAL\n", (r.returncode, r.stdout, r.stderr[-500:])
+
+
+def test_stream_pair_layout_on_host_tensors(monkeypatch):
+    """kernels.stream_pair is plain tensor arithmetic: below the threshold two allocations, above it ONE pool with the second
+    buffer at (a multiple of 256 MiB) + 4 KiB behind the first (the distance the streaming backward was measured best at)."""
+    import torch
+    from pfpn_amd import kernels
+    a, b = kernels.stream_pair(8, 16, torch.device("cpu"))
+    assert a.shape == b.shape == (8, 16) and a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+    monkeypatch.setattr(kernels, "STREAM_PAIR_MIN_BYTES", 1024)
+    a, b = kernels.stream_pair(64, 100, torch.device("cpu"))         # 25,600 bytes: "large" under the patched threshold
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.is_contiguous() and b.is_contiguous()
+    gap = b.data_ptr() - a.data_ptr()
+    assert gap == (256 << 20) + 4096 and gap >= a.numel() * 4 and a.shape == b.shape == (64, 100)
