@@ -85,12 +85,11 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 // (the maximum as two hand-written v_max_f32_dpp: through fmaxf() hipcc emits a move, a DPP move and two canonicalising
-// v_max_f32 x, x around each step -- nine instructions for these two.  s_nop 1: a DPP read needs two wait states after the
-// VALU write of its source, which hipcc cannot see inside the asm.)
+// v_max_f32 x, x around each step -- nine instructions for these two.  s_nop 4: see row_step_* below.)
 __device__ __forceinline__ float quad_max(float v) {
     float a, b;
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(v));
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(a));
+    asm("s_nop 4\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(v));
+    asm("s_nop 4\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(a));
     return b;
 }
 
@@ -108,13 +107,14 @@ __device__ __forceinline__ float red_comb(float a, float b) { return IS_MAX ? __
 
 // one in-row butterfly step k = op(k, k rotated / permuted inside its row of 16): the sum folds into v_add_f32_dpp by
 // itself; for the maximum the DPP form is written out (hipcc emits fill + v_mov_dpp + 2 canonicalisations + v_max).
-// s_nop 1: a DPP read of a VGPR needs two wait states after the VALU write, which hipcc cannot see inside the asm.
+// s_nop 4: a DPP read needs two wait states after the VALU write of its source and five after a VALU write of EXEC; hipcc's
+// hazard recogniser cannot see the DPP inside the asm, so the longer of the two is always paid (five idle cycles).
 #define PFPN_ROW_STEP(name, ctrl_text, CTRL)                                                                        \
     template <bool IS_MAX>                                                                                          \
     __device__ __forceinline__ float name(float k) {                                                                \
         if (IS_MAX) {                                                                                               \
             float r;                                                                                                \
-            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl_text " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(k)); \
+            asm("s_nop 4\n\tv_max_f32_dpp %0, %1, %1 " ctrl_text " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(k)); \
             return r;                                                                                               \
         }                                                                                                           \
         return k + dpp_shift<CTRL, 0xf>(k, 0.f);                                                                    \

@@ -161,6 +161,33 @@ def test_stream_pair_placement_changes_no_bits(dev):
     assert bool(torch.isfinite(outs[0]["dlogits"]).all())
 
 
+@pytest.mark.parametrize("A,N", [(36, 35), (8, 256), (4, 100)])
+def test_row_maximum_found_wherever_it_sits(oracle, dev, A, N):
+    """The softmax shift is a cross-lane maximum (DPP / lane-swap reductions written partly in inline asm).  ANY finite shift
+    gives the same result in exact arithmetic, so a wrong maximum would pass every ordinary comparison -- except where the
+    spread is large: one logit at +60 among -60s overflows exp() unless the maximum really is that logit.  The hot particle
+    visits every position (every lane and register of the reduction) and sits under the action so that p stays normal."""
+    from pfpn_amd import kernels
+    B = N                                                            # row b: hot particle b % N
+    loc = np.tile(np.linspace(-1, 1, N, dtype=np.float32), (A, 1))
+    logstd = np.full((A, N), np.log(2.0 / (N - 1)), np.float32)
+    logits = np.full((B, A, N), -60.0, np.float32)
+    hot = (np.arange(B)[:, None] + np.arange(A)[None, :]) % N        # a different position per segment of a row too
+    np.put_along_axis(logits, hot[..., None], 60.0, axis=-1)
+    x = np.take_along_axis(np.broadcast_to(loc, (B, A, N)), hot[..., None], axis=-1)[..., 0].astype(np.float32)
+    g = np.ones(B, np.float32)
+    t = [torch.from_numpy(a).to(dev) for a in (logits, x, loc, logstd, g)]
+    ref_lp, ref_p = oracle.mixture_log_prob(logits, x, loc, logstd)
+    lp, p = kernels.logprob_fwd(t[0], t[1], t[2], t[3], False, want_pmix=True)
+    assert np.isfinite(ref_lp).all() and bool(torch.isfinite(lp).all())
+    np.testing.assert_allclose(p.cpu().numpy(), ref_p, rtol=2e-5, atol=0)
+    np.testing.assert_allclose(lp.cpu().numpy(), ref_lp, rtol=RTOL, atol=1e-5)
+    r_dl = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, g)[0]
+    dl = kernels.logprob_bwd(t[0], t[1], t[2], t[3], t[4])[0].view(B, A, N)
+    assert bool(torch.isfinite(dl).all())
+    np.testing.assert_allclose(dl.cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * max(np.abs(r_dl).max(), 1e-30))
+
+
 def test_logprob_underflow_guard(oracle, dev):
     """x far from every particle: p underflows to 0, logp = -inf in the forward (reference computes in
     probability space), and the backward guard zeroes the gradients (utils.py:109-117)."""
