@@ -277,6 +277,29 @@ int pfpn_reduce_jobs_norm(const PfpnReduceJob* jobs, int n_jobs, float* sq_parti
 /* pfpn_clip_scale_inplace's second launch on the partial sums of pfpn_reduce_jobs_norm (powers rotated there). */
 int pfpn_clip_scale_inplace_prenorm(float* grads, size_t n, float clip_norm, float* norm_scale, const float* sq_partial,
                                     int n_partials, void* stream);
+/* pfpn_clip_adam_prenorm of learner step k with pfpn_state_prologue of step k+1 (want_moments = 1, no second batch) as extra
+ * blocks of the SAME launch -- for multi-step hipGraph captures, where the next step's batch is known: the two kernels touch
+ * disjoint data (the prologue reads the normaliser statistics that the reduction launch before this one updated), so a step
+ * loses a launch without a second stream.  Same arithmetic, bit for bit, as the two separate launches.
+ * (reference: base_worker.py:97-120 for the optimiser part, actor_critic.py:223-244 / utils.py:46-68 for the prologue.) */
+typedef struct {
+    const float* s;          /* [B,S] the next step's states */
+    const float* mean;       /* [S] state-normaliser statistics (as the next step's prologue would read them) */
+    const float* std;
+    int B, S;
+    float clip;
+    float* x;                /* [B,S] normalised states out */
+    const float* adv;        /* [B] advantages (with adv_stats) */
+    int normalize_adv;
+    float* adv_stats;        /* [4] or NULL */
+    void* workspace;         /* pfpn_learner_workspace_bytes(B, S): the float64 column moments */
+    size_t workspace_bytes;
+} PfpnStatePrologue;
+int pfpn_clip_adam_prenorm_prologue(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                                    const long long* group_off, const long long* group_len, const float* group_lr,
+                                    float beta1, float beta2, float eps, const float* beta_pow, float clip_norm,
+                                    float* norm_scale, float* step_counter, const float* sq_partial, int n_partials,
+                                    const PfpnStatePrologue* next, void* stream);
 int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                            const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                            float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,

@@ -260,15 +260,15 @@ __global__ __launch_bounds__(256) void k_col_moments(const float* __restrict__ s
 //   blocks (x, ch < C): x = clip((s - mean)/std) for a 16-row chunk of 64 columns (k_state_norm's arithmetic) AND
 //                       that chunk's float64 column moments (k_col_moments' arithmetic and layout);
 //   block  (0, C)     : advantage moments {mean, 1/(std + 1e-8)} (k_adv_stats' arithmetic, 256 threads), optional.
-__global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict__ s, const float* __restrict__ mean,
-                                                        const float* __restrict__ std, int B, int S, int chunk_len,
-                                                        int C, float clip, float* __restrict__ x,
-                                                        double* __restrict__ partial, const float* __restrict__ adv,
-                                                        int normalize_adv, float* __restrict__ adv_stats,
-                                                        const float* __restrict__ s2, float* __restrict__ x2) {
+__device__ __forceinline__ void state_prologue_block(const float* __restrict__ s, const float* __restrict__ mean,
+                                                     const float* __restrict__ std, int B, int S, int chunk_len,
+                                                     int C, float clip, float* __restrict__ x,
+                                                     double* __restrict__ partial, const float* __restrict__ adv,
+                                                     int normalize_adv, float* __restrict__ adv_stats,
+                                                     const float* __restrict__ s2, float* __restrict__ x2, int bx, int by) {
     __shared__ double red[2][4][64];
-    if ((int)blockIdx.y == C) {                            // the advantage block
-        if (blockIdx.x != 0 || !adv_stats) return;
+    if (by == C) {                                         // the advantage block
+        if (bx != 0 || !adv_stats) return;
         float* fred = reinterpret_cast<float*>(&red[0][0][0]);
         if (!normalize_adv) {
             if (threadIdx.x == 0) { adv_stats[0] = 0.f; adv_stats[1] = 1.f; }
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict_
         return;
     }
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int ch = blockIdx.y;
+    const int c = bx * 64 + cl;
+    const int ch = by;
     const int b0 = ch * chunk_len, b1 = min(B, b0 + chunk_len);
     double a1 = 0.0, a2 = 0.0;
     if (c < S) {
@@ -333,6 +333,16 @@ __global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict_
         partial[((size_t)ch * 2 + 0) * S + c] = s1;
         partial[((size_t)ch * 2 + 1) * S + c] = s2;
     }
+}
+
+__global__ __launch_bounds__(256) void k_state_prologue(const float* __restrict__ s, const float* __restrict__ mean,
+                                                        const float* __restrict__ std, int B, int S, int chunk_len,
+                                                        int C, float clip, float* __restrict__ x,
+                                                        double* __restrict__ partial, const float* __restrict__ adv,
+                                                        int normalize_adv, float* __restrict__ adv_stats,
+                                                        const float* __restrict__ s2, float* __restrict__ x2) {
+    state_prologue_block(s, mean, std, B, S, chunk_len, C, clip, x, partial, adv, normalize_adv, adv_stats, s2, x2,
+                         (int)blockIdx.x, (int)blockIdx.y);
 }
 
 // Chunk moments -> batch mean / variance -> EMA update, utils.py:60-68: d = min(0.9999, (1+step)/(10+step)).
@@ -716,19 +726,18 @@ __global__ __launch_bounds__(256) void k_sqsum_partial_rot(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, AdamGroups gr,
-                                                   float b1, float b2, float eps, const float* __restrict__ beta_pow,
-                                                   const float* __restrict__ partial, int nblk, float clip_norm,
-                                                   float grad_mul, float* __restrict__ norm_scale,
-                                                   float* __restrict__ step, float* __restrict__ scale_buf = nullptr,
-                                                   size_t scale_n = 0, float scale_mul = 1.f,
-                                                   float* __restrict__ soft_t = nullptr, size_t soft_o4 = 0,
-                                                   size_t soft_n4 = 0, float tau = 0.f) {
+__device__ __forceinline__ void clip_adam_block(float* __restrict__ p, const float* __restrict__ g,
+                                                float* __restrict__ m, float* __restrict__ v, const AdamGroups& gr,
+                                                float b1, float b2, float eps, const float* __restrict__ beta_pow,
+                                                const float* __restrict__ partial, int nblk, float clip_norm,
+                                                float grad_mul, float* __restrict__ norm_scale,
+                                                float* __restrict__ step, float* __restrict__ scale_buf,
+                                                size_t scale_n, float scale_mul, float* __restrict__ soft_t,
+                                                size_t soft_o4, size_t soft_n4, float tau, unsigned bid, unsigned nblocks) {
     __shared__ float red[4];
     // data parallel: the replicated statistics behind the gradients in the all-reduce bucket turn from sums into
     // replica means here (sync_model.py:37-46 push_weights) instead of in a launch of their own
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < scale_n; i += (size_t)gridDim.x * blockDim.x)
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < scale_n; i += (size_t)nblocks * blockDim.x)
         scale_buf[i] *= scale_mul;
     float gs = 1.0f;
     if (nblk > 0) {
@@ -741,16 +750,16 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
             gs = clip_norm * fminf(1.0f / norm, 1.0f / clip_norm);
             if (!isfinite(norm)) gs = NAN;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && norm_scale) { norm_scale[0] = norm; norm_scale[1] = gs; }
+        if (bid == 0 && threadIdx.x == 0 && norm_scale) { norm_scale[0] = norm; norm_scale[1] = gs; }
     }
     if (grad_mul != 1.f) gs *= grad_mul;        // 1/W after an all-reduce sum
-    if (blockIdx.x == 0 && threadIdx.x == 0 && step)
+    if (bid == 0 && threadIdx.x == 0 && step)
         step[0] += 1.0f;                        // float(global_step) of the state-normaliser decay; no reader in this launch
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     for (int k = 0; k < gr.n; ++k) {
         const float alpha = gr.lr[k] * sqrtf(1.f - beta_pow[4 * k + 3]) / (1.f - beta_pow[4 * k + 2]);
         const size_t o4 = (size_t)gr.off[k] >> 2, n4 = (size_t)gr.len[k] >> 2;
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n4; i += (size_t)nblocks * blockDim.x) {
             float4 pp = reinterpret_cast<float4*>(p)[o4 + i];
             float4 gg = reinterpret_cast<const float4*>(g)[o4 + i];
             float4 mm = reinterpret_cast<float4*>(m)[o4 + i];
@@ -777,6 +786,47 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
     }
 }
 
+
+__global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, AdamGroups gr,
+                                                   float b1, float b2, float eps, const float* __restrict__ beta_pow,
+                                                   const float* __restrict__ partial, int nblk, float clip_norm,
+                                                   float grad_mul, float* __restrict__ norm_scale,
+                                                   float* __restrict__ step, float* __restrict__ scale_buf = nullptr,
+                                                   size_t scale_n = 0, float scale_mul = 1.f,
+                                                   float* __restrict__ soft_t = nullptr, size_t soft_o4 = 0,
+                                                   size_t soft_n4 = 0, float tau = 0.f) {
+    clip_adam_block(p, g, m, v, gr, b1, b2, eps, beta_pow, partial, nblk, clip_norm, grad_mul, norm_scale, step, scale_buf,
+                    scale_n, scale_mul, soft_t, soft_o4, soft_n4, tau, blockIdx.x, gridDim.x);
+}
+
+// The optimiser launch of learner step k with the FIRST launch of step k+1 riding in it (inside a multi-step capture,
+// pfpn_amd/graphs.py): blocks [0, adam_blocks) are k_clip_adam, the rest are k_state_prologue's blocks on the next step's
+// batch.  The two touch disjoint data (the prologue reads the normaliser statistics the reduction launch BEFORE this one
+// updated, and writes buffers -- normalised state, moment workspace, advantage moments -- whose last readers of step k ran
+// before that launch too), so one launch less per step in a single chain of kernels.
+struct PrologueRider {
+    const float* s; const float* mean; const float* std;
+    int B, S, chunk_len, C, gx;
+    float clip;
+    float* x; double* partial; const float* adv; int normalize_adv; float* adv_stats;
+};
+__global__ __launch_bounds__(256) void k_clip_adam_prologue(float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, AdamGroups gr,
+                                                            float b1, float b2, float eps,
+                                                            const float* __restrict__ beta_pow,
+                                                            const float* __restrict__ partial, int nblk, float clip_norm,
+                                                            float* __restrict__ norm_scale, float* __restrict__ step,
+                                                            unsigned adam_blocks, PrologueRider r) {
+    if (blockIdx.x < adam_blocks) {
+        clip_adam_block(p, g, m, v, gr, b1, b2, eps, beta_pow, partial, nblk, clip_norm, 1.0f, norm_scale, step, nullptr, 0,
+                        1.f, nullptr, 0, 0, 0.f, blockIdx.x, adam_blocks);
+    } else {
+        const int lin = (int)(blockIdx.x - adam_blocks);
+        state_prologue_block(r.s, r.mean, r.std, r.B, r.S, r.chunk_len, r.C, r.clip, r.x, r.partial, r.adv, r.normalize_adv,
+                             r.adv_stats, nullptr, nullptr, lin % r.gx, lin / r.gx);
+    }
+}
 
 // ---- sharded exchange (data parallel): the owner of a 1/W slice of the bucket forms the MEAN of the per-replica CLIPPED
 // gradients itself -- sum_w s_w g_w / W with ONE scalar s_w per replica (its clip factor) -- from the W unscaled slices an
@@ -1765,6 +1815,45 @@ int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v
                        v, gr, beta1, beta2, eps, beta_pow, sq_partial, n_partials, clip_norm, 1.0f, norm_scale,
                        step_counter, (float*)nullptr, (size_t)0, 1.f, soft_target, (size_t)soft_off >> 2,
                        (size_t)soft_len >> 2, soft_tau);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_clip_adam_prenorm_prologue(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
+                                    const long long* group_off, const long long* group_len, const float* group_lr,
+                                    float beta1, float beta2, float eps, const float* beta_pow, float clip_norm,
+                                    float* norm_scale, float* step_counter, const float* sq_partial, int n_partials,
+                                    const PfpnStatePrologue* next, void* stream) {
+    PFPN_BEGIN();
+    if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || !sq_partial || n < 1 ||
+        n_groups < 1 || n_groups > 4 || n_partials < 1 || !next)
+        return PFPN_ERR_ARG;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
+    if (!next->s || !next->mean || !next->std || !next->x || next->B < 1 || next->S < 1 || (next->adv_stats && !next->adv))
+        return PFPN_ERR_ARG;
+    if (!next->workspace || next->workspace_bytes < pfpn_learner_workspace_bytes(next->B, next->S)) return PFPN_ERR_WORKSPACE;
+    AdamGroups gr{};
+    gr.n = n_groups;
+    size_t longest = 0;
+    for (int k = 0; k < n_groups; ++k) {
+        if (group_off[k] < 0 || group_len[k] < 0 || (group_off[k] & 3) || (group_len[k] & 3) ||
+            (size_t)(group_off[k] + group_len[k]) > n)
+            return PFPN_ERR_ARG;
+        gr.off[k] = group_off[k]; gr.len[k] = group_len[k]; gr.lr[k] = group_lr[k];
+        if ((size_t)group_len[k] > longest) longest = (size_t)group_len[k];
+    }
+    PrologueRider r{};
+    r.s = next->s; r.mean = next->mean; r.std = next->std; r.B = next->B; r.S = next->S; r.clip = next->clip;
+    r.x = next->x; r.partial = (double*)next->workspace; r.adv = next->adv; r.normalize_adv = next->normalize_adv;
+    r.adv_stats = next->adv_stats;
+    int C = row_chunks(next->B);
+    if (C > 256) C = 256;
+    r.C = C; r.chunk_len = (next->B + C - 1) / C; r.gx = (next->S + 63) / 64;
+    const unsigned adam_blocks = (unsigned)stream_grid(longest >> 2);
+    const unsigned pro_blocks = (unsigned)(r.gx * (C + 1));
+    hipLaunchKernelGGL(k_clip_adam_prologue, dim3(adam_blocks + pro_blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
+                       m, v, gr, beta1, beta2, eps, beta_pow, sq_partial, n_partials, clip_norm, norm_scale, step_counter,
+                       adam_blocks, r);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -116,10 +116,17 @@ class GraphedLearnerStep(object):
         # (thread-local capture mode with collectives inside: the process group's watchdog thread may query events meanwhile)
         mode = {"capture_error_mode": "thread_local"} if self.in_graph_exchange else {}
         with torch.cuda.graph(self.graph, stream=s, **mode):      # same stream as the warm-up: per-stream workspaces exist
+            if gather_from is not None:
+                kernels.gather_columns(list(gather_from[0]), list(self.input_sets[0]), gather_from[1][0])
             for k in range(self.K):
-                if gather_from is not None:
-                    kernels.gather_columns(list(gather_from[0]), list(self.input_sets[k]), gather_from[1][k])
                 self.loss3 = net.compute_gradients(*self._args(k))
+                if k + 1 < self.K:
+                    # the NEXT step's batch exists before this step's optimiser launch, which can then carry the next
+                    # step's prologue as extra blocks (one launch less per step: SyncReplicasApplier.apply_device)
+                    if gather_from is not None:
+                        kernels.gather_columns(list(gather_from[0]), list(self.input_sets[k + 1]), gather_from[1][k + 1])
+                    if self.noise is None and hasattr(net, "stage_next_prologue"):
+                        net.stage_next_prologue(*self.input_sets[k + 1])
                 if self.split:
                     optimizer.pre_reduce(net)
                 elif self.in_graph_exchange:
@@ -129,6 +136,7 @@ class GraphedLearnerStep(object):
                     optimizer.finish_reduce(net)
                 else:
                     optimizer.apply_device(net)
+                net._next_prologue = None              # (a rider the optimiser path did not take must not outlive its step)
                 if gather_from is not None:
                     gather_from[2][k].copy_(self.loss3)
         if self.split:

@@ -683,15 +683,46 @@ def _soft_args(soft):
     return _f32(t), int(off), int(ln), float(tau)
 
 
+class StatePrologue(ctypes.Structure):
+    """PfpnStatePrologue (include/pfpn_hip.h): the next step's first launch as a rider of the optimiser launch"""
+    _fields_ = [("s", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("std", ctypes.c_void_p), ("B", ctypes.c_int),
+                ("S", ctypes.c_int), ("clip", ctypes.c_float), ("x", ctypes.c_void_p), ("adv", ctypes.c_void_p),
+                ("normalize_adv", ctypes.c_int), ("adv_stats", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
+                ("workspace_bytes", ctypes.c_size_t)]
+
+
+def state_prologue_rider(s, mean, std, clip, out_x, adv, normalize_adv, adv_stats, ws):
+    """the arguments of state_prologue(..., want_moments=True, ws=ws) as a rider for clip_adam(rider=...)"""
+    B, S = s.shape
+    r = StatePrologue(s=_f32(s, B, S), mean=_f32(mean, S), std=_f32(std, S), B=B, S=S, clip=float(clip or 0.0),
+                      x=_f32(out_x, B, S), adv=_f32(adv, B) if adv_stats is not None else None,
+                      normalize_adv=int(normalize_adv), adv_stats=_f32(adv_stats, 4) if adv_stats is not None else None,
+                      workspace=ws.data_ptr(), workspace_bytes=ws.numel())
+    r._keep = (s, mean, std, out_x, adv, adv_stats, ws)
+    return r
+
+
 def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, clip_norm, norm_scale, beta1=0.9,
-              beta2=0.999, eps=1e-8, step_counter=None, prenorm=None, soft=None):
+              beta2=0.999, eps=1e-8, step_counter=None, prenorm=None, soft=None, rider=None):
     """One-replica optimiser step in two launches (global-norm clip folded into TF-Adam).  group_* are ctypes
     arrays (host); beta_pow is [G,4] (see include/pfpn_hip.h).
     prenorm = (partial, count) from reduce_jobs(norm=...): the norm's partial sums exist and the powers are rotated
-    already -- ONE launch."""
+    already -- ONE launch.  rider (with prenorm, without soft): a StatePrologue -- the NEXT learner step's prologue runs as
+    extra blocks of this launch (multi-step captures)."""
     lib = _lib.load()
     n = params.numel()
     G = len(group_lr)
+    if rider is not None:
+        if prenorm is None or soft is not None:
+            raise ValueError("the prologue rider needs the one-launch optimiser (prenorm) without a soft target update")
+        _lib.check(lib.pfpn_clip_adam_prenorm_prologue(_f32(params), _f32(grads), _f32(m), _f32(v), n, G,
+                                                       ctypes.addressof(group_off), ctypes.addressof(group_len),
+                                                       ctypes.addressof(group_lr), float(beta1), float(beta2), float(eps),
+                                                       _f32(beta_pow, G, 4), float(clip_norm), _f32(norm_scale, 2),
+                                                       _f32(step_counter, 1) if step_counter is not None else None,
+                                                       _f32(prenorm[0]), int(prenorm[1]), ctypes.addressof(rider), _stream()),
+                   "pfpn_clip_adam_prenorm_prologue")
+        return
     if prenorm is not None:
         _lib.check(lib.pfpn_clip_adam_prenorm(_f32(params), _f32(grads), _f32(m), _f32(v), n, G,
                                               ctypes.addressof(group_off), ctypes.addressof(group_len),

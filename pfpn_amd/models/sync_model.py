@@ -155,9 +155,16 @@ class SyncReplicasApplier(object):
         if self._fused_ok():
             # clip + every group's Adam + power / step-counter advance in one launch (two without the norm hook)
             pre = self._prenorm(net)
+            # (multi-step captures: the next step's prologue as extra blocks of this launch -- graphs.py stages it)
+            rider = getattr(net, "_next_prologue", None)
+            net._next_prologue = None
+            if rider is not None and (pre is None or soft is not None):
+                rider = None
             kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,
-                              step_counter=net.step_dev, prenorm=pre, soft=soft if pre is not None else None)
+                              step_counter=net.step_dev, prenorm=pre, soft=soft if pre is not None else None, rider=rider)
+            if rider is not None:
+                net.prologue_staged(rider)
             if soft is not None and pre is None:
                 net.sync_target_net_soft()
             net.unpack_synced_stats(st.tail, 1.0)

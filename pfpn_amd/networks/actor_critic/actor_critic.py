@@ -458,9 +458,14 @@ class ActorCriticNetwork(object):
         if deferred is not None:
             # the moments stay in a private workspace; the EMA itself is one job of the step's single reduce launch
             # (its result is first read by the NEXT step's prologue)
-            kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
-                                   self.normalize_advantage, self.adv_stats if advantage is not None else None,
-                                   ws=self.ws_moments, s2=state2, out_x2=out2)
+            staged = getattr(self, "_prologue_staged", None)
+            self._prologue_staged = None
+            if staged is not None and state2 is None and staged == self._prologue_key(state, advantage):
+                pass        # this launch already ran, as a rider of the previous captured step's optimiser launch
+            else:
+                kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
+                                       self.normalize_advantage, self.adv_stats if advantage is not None else None,
+                                       ws=self.ws_moments, s2=state2, out_x2=out2)
             mo, so = (nz.mean, nz.std) if in_place else (tail[:S], tail[S:2 * S])
             deferred.append(kernels.job_norm_ema(self.ws_moments, B, S, self.step_dev, nz.mean, nz.std, mo, so))
             return self.xn
@@ -473,6 +478,30 @@ class ActorCriticNetwork(object):
         else:                           # into the bucket tail that the all-reduce averages
             kernels.state_norm_ema(B, S, self.step_dev, nz.mean, nz.std, tail[:S], tail[S:2 * S])
         return self.xn
+
+    @staticmethod
+    def _prologue_key(state, advantage):
+        return (state.data_ptr(), tuple(state.shape), advantage.data_ptr() if advantage is not None else 0)
+
+    def prologue_rider(self, state, advantage=None):
+        """Multi-step captures (pfpn_amd/graphs.py): the arguments of the NEXT step's deferred fused prologue, for the
+        optimiser launch of THIS step to carry (kernels.clip_adam(rider=...)), or None where that prologue would not be the
+        single fused launch.  The optimiser calls prologue_staged() once it has taken the rider; the next prologue()
+        call on the same tensors then launches nothing (it still queues its EMA job)."""
+        fusable = self.state_normalizer is not None and self.normalize_state and self.trainable and \
+            not self.overlap_ema and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0" and \
+            os.environ.get("PFPN_PROLOGUE_RIDER", "1") != "0"
+        if not fusable or getattr(self, "ws_moments", None) is None or self.xn.shape[0] != state.shape[0]:
+            return None
+        nz = self.state_normalizer
+        r = kernels.state_prologue_rider(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, advantage,
+                                         self.normalize_advantage, self.adv_stats if advantage is not None else None,
+                                         self.ws_moments)
+        r._key = self._prologue_key(state, advantage)
+        return r
+
+    def prologue_staged(self, rider):
+        self._prologue_staged = rider._key
 
     def update_state_normalizer(self, state):
         """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), on a side

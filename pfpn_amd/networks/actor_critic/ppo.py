@@ -92,6 +92,10 @@ def clip_ppo_network_wrapper(a2c_base_class):
                 out["dlogstd"].zero_()
             return out["loss3"]
 
+        def stage_next_prologue(self, state, action, value, log_prob, advantage):
+            """multi-step captures: hand the NEXT step's prologue to this step's optimiser launch (graphs.py)"""
+            self._next_prologue = self.prologue_rider(state, advantage)
+
         def train_device(self, optimizer, state, action, value, log_prob, advantage):
             """One learner step on device tensors; returns loss3 (device tensor, no sync)."""
             loss3 = self.compute_gradients(state, action, value, log_prob, advantage)

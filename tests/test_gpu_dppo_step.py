@@ -226,6 +226,42 @@ def test_multi_step_graph_replay_matches_single_steps(dev):
     assert gk.can_replay()
 
 
+def test_next_prologue_rides_in_the_optimiser_launch(dev, monkeypatch):
+    """Inside a K-step capture the optimiser launch of step k carries step k+1's prologue as extra blocks (K - 1 riders, one
+    launch less per step); PFPN_PROLOGUE_RIDER=0 keeps the separate launch.  Same bits either way."""
+    from pfpn_amd import kernels
+    from pfpn_amd.graphs import GraphedLearnerStep
+    from pfpn_amd.models import SyncReplicasApplier
+    B, K = 128, 4
+    rng = np.random.default_rng(21)
+    sets = []
+    for _ in range(K):
+        b = make_batch(rng, B); b["log_prob"] = np.full(B, -40.0, F)
+        sets.append(tuple(torch.from_numpy(b[k]).to(dev) for k in ("state", "action", "value", "log_prob", "advantage")))
+    riders, plain = [], []
+    real_adam, real_pro = kernels.clip_adam, kernels.state_prologue
+    monkeypatch.setattr(kernels, "clip_adam", lambda *a, **kw: (riders.append(kw.get("rider") is not None), real_adam(*a, **kw))[1])
+    monkeypatch.setattr(kernels, "state_prologue", lambda *a, **kw: (plain.append(1), real_pro(*a, **kw))[1])
+    finals = []
+    for flag, want_riders in (("1", K - 1), ("0", 0)):
+        monkeypatch.setenv("PFPN_PROLOGUE_RIDER", flag)
+        net = make_net(dev, seed=17, resample_interval=50)
+        opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+        g = GraphedLearnerStep(net, opt, steps_per_replay=K, input_sets=[tuple(t.clone() for t in s_) for s_ in sets],
+                               warmup=1)
+        # the capture is the last K optimiser calls / the prologue launches after the warm-up's one
+        assert sum(riders[-K:]) == want_riders, (flag, riders)
+        assert sum(plain[-(K - want_riders):]) == K - want_riders and len(plain) >= K - want_riders
+        riders.clear(); plain.clear()
+        g(); g()
+        torch.cuda.synchronize()
+        finals.append((net.store.flat.clone(), net.store.m.clone(), net.state_normalizer.mean.clone(),
+                       net.state_normalizer.std.clone(), g.loss3.clone()))
+        assert net.global_step == 2 * K
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B", [64, 4096])
 def test_global_norm_from_the_reduction_launch(dev, monkeypatch, B):
     """The reduction launch that also yields the global-norm partial sums (+ the one-launch optimiser) against the separate
