@@ -18,7 +18,9 @@ Rank 0 prints ONE JSON line; besides the contract keys it carries
   roofline_gemm -- the FC GEMMs (PyTorch-ROCm) vs the fp32 MFMA roof,
   strong_shard  -- (N = 1) the data-parallel step of ONE rank at 2048 / 1024 / 512 rows over a world-size-1 RCCL group:
                    what a rank of a 2 / 4 / 8-GPU run spends per step before any byte crosses a link,
-  sac_step      -- (N = 1) the SAC-PFPN learner step of BASELINE.json config 3 (replay batch 1024),
+  weak_scaling  -- rows per GPU constant (config 4's natural mode): 4096 rows on every rank,
+  sac_step      -- (N = 1) the SAC-PFPN learner step of BASELINE.json config 3 (replay batches 1024 and 256) with its roofline,
+  config5_step  -- (N = 1) BASELINE.json config 5 as a learner step on one GPU's 1024-row shard, with its roofline,
   cpu_baseline  -- restatements of the reference's TF1 CPU path (NOT TF1) timed on this box's host cores on a bounded
                    sample, in a child process: all-core and single-thread 4096-row steps, and the reference's own
                    8-worker x 32-row schedule (oracle/cpu_baseline.py).
@@ -61,6 +63,36 @@ def gemm_flops(rows):
     mac_fwd = S * 2048 + 2 * 1024 * 512 + 512 * A * NP      # per row (value head GEMV excluded)
     mac_bwd = S * 2048 + 2 * 2 * 1024 * 512 + 2 * 512 * A * NP
     return 2.0 * rows * (mac_fwd + mac_bwd)
+
+
+def latest_profile(suffix):
+    """the newest committed profiles/rNN_<suffix> (path, round tag) or (None, None)"""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return (fs[-1], os.path.basename(fs[-1])[:3]) if fs else (None, None)
+
+
+def rocprof_kernel_us(kernel_substring):
+    """average duration (us) of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this command
+    (profiles/rNN_bench_kernel_stats.csv) -> (us, calls, file) or None"""
+    import csv
+    path, _ = latest_profile("bench_kernel_stats.csv")
+    if not path:
+        return None
+    try:
+        for r in csv.DictReader(open(path)):
+            if kernel_substring in r.get("Name", ""):
+                return float(r["AverageNs"]) / 1e3, int(r["Calls"]), "profiles/" + os.path.basename(path)
+    except Exception:
+        return None
+    return None
+
+
+def dense_macs(S_in, hidden, head):
+    """multiply-accumulates per row of an MLP S_in -> hidden... -> head: (forward, dW, dX below the first layer)"""
+    dims = [S_in] + list(hidden) + [head]
+    fwd = sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+    return fwd, fwd, fwd - dims[0] * dims[1]
 
 
 def cpu_baseline(budget_s=24.0):
@@ -147,11 +179,20 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N=1 only: run the data-parallel step (clip in place, RCCL all-reduce in a world-size-1 group, "
                          "Adam with 1/W) instead of the fused single-replica step -- its cost without the links")
+    ap.add_argument("--two-graph-exchange", action="store_true",
+                    help="data-parallel step as two hipGraphs around an eagerly enqueued all-reduce (the automatic fall-back "
+                         "form) instead of the default: the all-reduce captured inside the step's graph")
+    ap.add_argument("--extras-deadline", type=float, default=150.0,
+                    help="N > 1: seconds the informational extras may take before rank 0 prints the headline it has")
+    ap.add_argument("--watchdog", type=float, default=0.0,
+                    help="diagnostic: every rank dumps its Python stacks and exits after this many seconds")
+    ap.add_argument("--fail-extra", default="", help="rehearsal of the extras' deadline: `<extra name>:<rank>` raises there")
+    ap.add_argument("--alloc-shift", type=int, default=0,
+                    help="diagnostic (tools/placement_probe.sh): a dummy allocation of this many bytes in front of everything")
     args = ap.parse_args()
-    if os.environ.get("PFPN_BENCH_WATCHDOG"):
-        # diagnostic: every rank dumps its Python stacks to stderr and exits if the run takes longer than this many seconds
+    if args.watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["PFPN_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import torch
     import torch.distributed as dist
@@ -172,10 +213,10 @@ def main():
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if os.environ.get("PFPN_BENCH_ALLOC_SHIFT"):
-        # diagnostic (tools/placement_probe.sh): a dummy allocation of this many bytes first, which moves every buffer of
-        # the step relative to the 2 MiB segments the allocator carves -- does the headline depend on where things land?
-        _shift = torch.empty(int(os.environ["PFPN_BENCH_ALLOC_SHIFT"]), dtype=torch.uint8, device=dev)
+    if args.alloc_shift:
+        # a dummy allocation first moves every buffer of the step relative to the 2 MiB segments the allocator carves --
+        # does the headline depend on where things land?
+        _shift = torch.empty(args.alloc_shift, dtype=torch.uint8, device=dev)
 
     def make_learner(rows, seed, exchange_group=False, exchange_mode=None):
         """a network + optimiser + `rows` synthetic transitions resident in HBM + the step callable"""
@@ -194,9 +235,12 @@ def main():
         return net_, opt_, (t["state"], t["action"], t["value"], t["log_prob"], t["advantage"])
 
     def make_stepper(net_, opt_, inputs, allow_multi=True, capture_exchange=None):
-        """-> (run_steps(n), launch description).  One replica: hipGraph replays of `--steps-per-graph` learner steps, the
-        remainder n % K as ONE replay of a K'-step graph (captured by run_steps.prepare(n), outside every timed region);
-        data parallel: two hipGraphs around the exchange per step (pfpn_amd/graphs.py); --no-graph: eager."""
+        """-> (run_steps(n), launch description).  hipGraph replays of `--steps-per-graph` learner steps, the remainder
+        n % K as ONE replay of a K'-step graph (captured by run_steps.prepare(n), outside every timed region); data parallel
+        over RCCL: the same, the all-reduce captured inside (pfpn_amd/graphs.py; it falls back to two hipGraphs around an
+        eager collective by itself, every rank together, if the capture fails anywhere); --no-graph: eager."""
+        if capture_exchange is None and args.two_graph_exchange:
+            capture_exchange = False
         if args.no_graph:
             f = lambda n: [net_.train_device(opt_, *inputs) for _ in range(n)]
             f.prepare = lambda n: None
@@ -240,7 +284,9 @@ def main():
                                                  if getattr(opt_, "sharded", False) else "RCCL all-reduce")) if one.split else \
             ("hipGraph, %d learner steps per replay (remainder as one shorter replay)" % spg_ if spg_ > 1 else "hipGraph")
         if one.in_graph_exchange:
-            what += ", the RCCL collectives captured inside"
+            what += ", the RCCL all-reduce captured inside"
+        if one.exchange_fallback:
+            what += " (FALL-BACK: capturing the exchange failed: %s)" % one.exchange_fallback[:120]
         return run_steps, what
 
     def timed_steps(run_steps, n_steps, n_warm):
@@ -339,12 +385,12 @@ def main():
                 _flush_c_stdio()
                 sys.stdout.write(json.dumps(out) + "\n")
                 sys.stdout.flush()
-        deadline = ExtrasDeadline(float(os.environ.get("PFPN_BENCH_EXTRAS_DEADLINE", "150")), emit_headline)
+        deadline = ExtrasDeadline(args.extras_deadline, emit_headline)
 
     def guarded(fn):
         """an extra on every rank: its result, or -- when THIS rank failed in it -- no way on into the next collective"""
         try:
-            if os.environ.get("PFPN_BENCH_FAIL_EXTRA") == "%s:%d" % (fn.__name__, rank):       # rehearsal of the deadline
+            if args.fail_extra == "%s:%d" % (fn.__name__, rank):       # rehearsal of the deadline
                 raise RuntimeError("injected failure")
             return fn()
         except Exception as e:
@@ -413,10 +459,10 @@ def main():
         xel = timed_steps(xrun, args.steps, args.warmup)
         return {"value": args.steps / xel, "unit": "steps/s", "ms_per_step": xel / args.steps * 1e3, "launch": xlaunch}
 
-    def in_graph_block():
-        # the all-reduce captured INSIDE the step's graph, K steps per replay (PFPN_GRAPH_EXCHANGE=1 makes it the headline)
+    def two_graph_block():
+        # the fall-back form of the exchange (--two-graph-exchange makes it the headline): two hipGraphs around an eager all-reduce
         gnet, gopt, gin = make_learner(rows, SEED + rank, exchange_mode="allreduce")
-        grun, glaunch = make_stepper(gnet, gopt, gin, capture_exchange=True)
+        grun, glaunch = make_stepper(gnet, gopt, gin, capture_exchange=False)
         gel = timed_steps(grun, args.steps, args.warmup)
         return {"value": args.steps / gel, "unit": "steps/s", "ms_per_step": gel / args.steps * 1e3, "launch": glaunch}
 
@@ -427,12 +473,16 @@ def main():
 
     if world > 1 or args.force_exchange:
         extra("rccl", rccl_block)                                   # two tiny collectives: first, so it is never lost
+    if world == 1 and rank == 0 and strong:
+        out["weak_scaling"] = {"value": out["value"], "unit": "steps/s of 4096 transitions (4096 rows per GPU)",
+                               "ms_per_step": out["ms_per_step"], "global_batch": B,
+                               "note": "one GPU: the headline IS the weak-scaling point (4096 rows per GPU)"}
     if world > 1 and strong:
         extra("weak_scaling", weak_block)
         if not getattr(opt, "sharded", False):
             extra("exchange_sharded", sharded_block)
-        if dist.get_backend() == "nccl" and os.environ.get("PFPN_GRAPH_EXCHANGE", "0") == "0":
-            extra("exchange_in_graph", in_graph_block)              # last: the one form no multi-GPU node has run yet
+        if dist.get_backend() == "nccl" and "captured inside" in launch:
+            extra("exchange_two_graphs", two_graph_block)
 
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
     if rank == 0 and world == 1:
@@ -508,17 +558,27 @@ def main():
         ab = algorithmic_bytes_fused(B)
         ach = ab / (us * 1e-6) / 1e9
         traffic, traffic_source = None, None
-        for rnd in ("r03", "r02", "r01"):     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE)
-            try:
-                with open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")) as f:
-                    traffic = json.load(f)["kernels"]["k_mix_tile<35,PPO>"]["traffic_bytes"]
-                traffic_source = "profiles/%s_pmc_traffic.json: separate rocprofv3 --pmc passes of round %s over this " \
-                                 "command (tools/pmc_traffic.py), NOT measured in this run" % (rnd, rnd[1:])
-                break
-            except Exception:
-                pass
-        out["roofline"] = {"kernel": "k_mix_tile<35,PPO>", "bound": "hbm", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        try:                                  # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE + WRITE_SIZE)
+            tpath, rnd = latest_profile("pmc_traffic.json")
+            with open(tpath) as f:
+                traffic = json.load(f)["kernels"]["k_mix_tile<35,PPO>"]["traffic_bytes"]
+            traffic_source = "profiles/%s_pmc_traffic.json: separate rocprofv3 --pmc passes of round %s over this " \
+                             "command (tools/pmc_traffic.py), NOT measured in this run" % (rnd, rnd[1:])
+        except Exception:
+            pass
+        # `frac` must not read higher than the rocprofv3 summary of this command says: the events time launches replayed
+        # back to back from a hipGraph (a launch's start-up overlaps its predecessor's drain, no tracer attached), the
+        # summary a traced kernel from begin to end (+~0.5 us of tracer).  Both are printed; `frac` is the LOWER one.
+        rp = rocprof_kernel_us("k_mix_tile<35, 2>")
+        frac_events = ach / HBM_PEAK_GBS
+        frac_rocprof = (ab / (rp[0] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp else None
+        frac = min(frac_events, frac_rocprof) if frac_rocprof else frac_events
+        out["roofline"] = {"kernel": "k_mix_tile<35,PPO>", "bound": "hbm", "achieved": frac * HBM_PEAK_GBS,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "frac_events": frac_events,
+                           "frac_rocprof": frac_rocprof,
+                           "rocprof": ({"us_per_launch": rp[0], "calls": rp[1], "source": rp[2] + " (committed rocprofv3 "
+                                        "--kernel-trace --stats summary of this command; NOT measured in this run)"} if rp else None),
+                           "traffic": traffic,
                            "traffic_source": traffic_source, "algorithmic_bytes": ab, "us_per_launch": us, "launches_timed": reps,
                            "us_in_step_event_pairs": us_in_step, "us_with_slab_finalize_launch": us_op,
                            "note": "us_per_launch: HIP events around 200 launches of the kernel alone, replayed from a hipGraph "
@@ -699,6 +759,20 @@ def main():
         out["roofline_gemm"] = {"kernel": "11 fp32 GEMMs via PyTorch-ROCm (+bias/ReLU6 epilogue kernels)",
                                 "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": tf / MFMA_F32_PEAK_TF, "us_per_step": gus, "flops": gemm_flops(B)}
+        try:      # counter evidence: share of the GEMM kernels' cycles in which the matrix pipe was busy (one --pmc pass, committed)
+            mpath, mrnd = latest_profile("gemm_mfma.json")
+            with open(mpath) as f:
+                mj = json.load(f)
+            per = {k[:72]: round(v["mfma_busy"], 3) for k, v in mj["kernels"].items() if "mfma_busy" in v}
+            out["roofline_gemm"]["mfma_busy"] = mj["mfma_busy_all_gemm_kernels"]
+            out["roofline_gemm"]["mfma_busy_per_kernel"] = per
+            out["roofline_gemm"]["mfma_busy_source"] = (
+                "profiles/%s_gemm_mfma.json: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA over this "
+                "command (tools/gemm_mfma_pmc.py): MFMA-busy cycles per SIMD / kernel cycles, launch-weighted over the step's "
+                "GEMM kernels; NOT measured in this run.  frac is flops / time / 157.3 TFLOP/s (the peak at the 2.4 GHz the "
+                "chip does not hold under MFMA load); mfma_busy is cycle-based, so the clock drops out" % mrnd)
+        except Exception:
+            pass
         # the reference's own schedule is 16 optimiser steps of global batch 256 (8 workers x 32 rows) per 4096
         # transitions (deepmimic_dppo_base.py) -- one 256-row step on this GPU, captured like the headline step
         try:
@@ -737,11 +811,11 @@ def main():
                 shard = {}
                 for n_gpu in (1, 2, 4, 8):
                     entry = {"gpus_of_the_run_it_stands_for": n_gpu}
-                    for mode in ("allreduce", "sharded", "allreduce_in_graph"):
-                        if mode == "allreduce_in_graph" and dist.get_backend() != "nccl":
+                    for mode in ("allreduce", "sharded", "allreduce_two_graphs"):
+                        if mode == "allreduce_two_graphs" and dist.get_backend() != "nccl":
                             continue
                         snet, sopt, sin = make_learner(B // n_gpu, SEED, exchange_group=True, exchange_mode=mode.split("_")[0])
-                        srun, sl_ = make_stepper(snet, sopt, sin, capture_exchange=(mode == "allreduce_in_graph"))
+                        srun, sl_ = make_stepper(snet, sopt, sin, capture_exchange=False if mode == "allreduce_two_graphs" else None)
                         srun(20)
                         torch.cuda.synchronize()
                         t_s = time.perf_counter()
@@ -751,9 +825,9 @@ def main():
                         if mode == "allreduce":
                             slaunch = sl_
                             entry.update({"us_per_step": us_s, "steps_per_s_without_links": 1e6 / us_s})
-                        elif mode == "allreduce_in_graph":
-                            # (PFPN_GRAPH_EXCHANGE=1: the all-reduce captured inside ONE graph, 8 steps per replay)
-                            entry["us_per_step_exchange_in_graph"] = us_s
+                        elif mode == "allreduce_two_graphs":
+                            # (the fall-back form: two hipGraphs around an eagerly enqueued all-reduce)
+                            entry["us_per_step_two_graph_exchange"] = us_s
                         else:
                             # (world size 1: the owner's slice is the whole buffer -- the launch structure and the three
                             # collectives' host cost, not the 1/W Adam of a real run)
@@ -761,10 +835,15 @@ def main():
                         del snet, sopt, sin, srun
                     shard[str(B // n_gpu)] = entry
                 bucket_mb = (net.store.bucket.numel() * 4) / 1e6
+                base_ = shard[str(B)]["us_per_step"]
                 out["strong_shard"] = {"rows_per_gpu": shard, "launch": slaunch, "bucket_MB": bucket_mb,
+                                       "compute_side_speedup_at_8_gpus": base_ / shard[str(B // 8)]["us_per_step"],
                                        "note": "one rank's step with the RCCL call in it but nothing on the links (world size "
                                                "1); an N-GPU strong-scaling step = the N-row entry + the all-reduce of the "
-                                               "%.2f MB bucket over xGMI" % bucket_mb}
+                                               "%.2f MB bucket over xGMI.  compute_side_speedup_at_8_gpus is the ceiling of "
+                                               "1 -> 8 GPU strong scaling BEFORE any link time: >= 3.5x is arithmetically out "
+                                               "of reach for a 0.46-ms step (DESIGN.md section 6); weak_scaling is the mode "
+                                               "that scales" % bucket_mb}
             except Exception as e:
                 out["strong_shard"] = {"error": repr(e)}
         # ---- sac_step: BASELINE.json config 3 (SAC-PFPN, replay batch 1024) as one hipGraph; a parity config, timed here
@@ -863,7 +942,8 @@ def main():
         dist.barrier()
         _flush_c_stdio()
         dist.barrier()                      # every rank has flushed its banner
-        dist.destroy_process_group()
+        from pfpn_amd.models.distributed_model import shutdown_process_group
+        shutdown_process_group()            # hipGraphs that captured collectives first, then the group (pfpn_amd/graphs.py)
     _flush_c_stdio()
     if deadline is not None and not deadline.finish():
         return                              # the deadline fired meanwhile: it prints (rank 0) and ends the process

@@ -446,9 +446,16 @@ def critic_forward(P, x):
     return v, (c1, c2)
 
 
-def _fc_bwd(x_in, w, y_out, dy, act):
+def relu6_mask(y_out):
+    """Relu6Grad's branch: the units whose gradient passes (ops.py:105-117)."""
+    return (y_out > 0) & (y_out < 6)
+
+
+def _fc_bwd(x_in, w, y_out, dy, act, mask=None):
+    """`mask` (flip-census tests only): Relu6Grad's branch decisions taken from another implementation instead of from
+    y_out -- the arithmetic given the SAME decisions is what those tests compare."""
     if act:
-        dy = np.where((y_out > 0) & (y_out < 6), dy, F(0)).astype(F)   # Relu6Grad
+        dy = np.where(relu6_mask(y_out) if mask is None else mask, dy, F(0)).astype(F)   # Relu6Grad
     dw = (x_in.T @ dy).astype(F)
     db = dy.sum(axis=0, dtype=F)
     dx = (dy @ w.T).astype(F)
@@ -468,8 +475,9 @@ def clip_advantage_bounds(clip_advantage):
 
 
 def ppo_loss(logp, logp_old, adv, v, v_old, eps_clip=0.2, value_loss_coef=0.5, normalize_adv=True,
-             clip_advantage=None):
-    """Returns (loss, policy_loss, value_loss*coef, dlogp[B], dv[B])."""
+             clip_advantage=None, grad_on=None):
+    """Returns (loss, policy_loss, value_loss*coef, dlogp[B], dv[B]).  `grad_on` [B] bool (flip-census tests only): which
+    rows' surrogate passes a gradient, taken from another implementation instead of from this one's ratio."""
     logp = np.asarray(logp, F); adv = np.asarray(adv, F); v = np.asarray(v, F)
     B = F(len(adv))
     if normalize_adv:                                             # actor_critic.py:151-156
@@ -495,7 +503,8 @@ def ppo_loss(logp, logp_old, adv, v, v_old, eps_clip=0.2, value_loss_coef=0.5, n
         to_sur = sur <= csur
         inside = (ratio >= lo) & (ratio <= hi)
         dmin = F(-1) / B
-        dratio = np.where(to_sur, dmin * nadv, np.where(inside, dmin * nadv, F(0))).astype(F)
+        on = (to_sur | inside) if grad_on is None else np.asarray(grad_on, bool)
+        dratio = np.where(on, dmin * nadv, F(0)).astype(F)
         dlogp = (dratio * ratio).astype(F)
     dv = (F(2) * (v - target) * F(value_loss_coef) / B).astype(F)
     return F(policy_loss + value_loss), F(policy_loss), F(value_loss), dlogp, dv
@@ -532,27 +541,32 @@ def tf_adam(p, g, m, v, b1p, b2p, lr=1e-4, b1=0.9, b2=0.999, eps=1e-8):
 # --------------------------------------------------------------------------- #
 # one DPPO learner step                                          #
 # --------------------------------------------------------------------------- #
-def dppo_grads(P, norm_mean, norm_std, batch, A, N, eps_clip=0.2, value_loss_coef=0.5):
+def dppo_grads(P, norm_mean, norm_std, batch, A, N, eps_clip=0.2, value_loss_coef=0.5, force=None):
     """Forward + backward of loss = policy_loss + 0.5*value_loss on one (rank-local) batch.
     batch = dict(state[B,S], action[B,A], value[B], log_prob[B], advantage[B]).
-    Returns (losses, grads dict, aux)."""
+    Returns (losses, grads dict, aux).  `force` (flip-census tests only): branch decisions of the loss's discontinuities
+    taken from another implementation -- {"actor/fc1": bool [B,H], "actor/fc2", "critic/fc1", "critic/fc2": Relu6Grad masks,
+    "ppo_on": bool [B]}; aux carries this evaluation's own decisions under "branches"."""
+    force = force or {}
     x = state_normalize(batch["state"], norm_mean, norm_std, 5.0)
     logits, (h1, h2) = actor_forward(P, x, A, N)
     v, (c1, c2) = critic_forward(P, x)
     logp, _ = mixture_log_prob(logits, batch["action"], P["actor/samples"], P["actor/samples_std"])
     loss, pl, vl, dlogp, dv = ppo_loss(logp, batch["log_prob"], batch["advantage"], v, batch["value"],
-                                       eps_clip, value_loss_coef)
+                                       eps_clip, value_loss_coef, grad_on=force.get("ppo_on"))
     dlogits, dloc, dlogstd, _ = mixture_log_prob_bwd(logits, batch["action"], P["actor/samples"],
                                                      P["actor/samples_std"], dlogp)
     G = {"actor/samples": dloc, "actor/samples_std": dlogstd}
     dl = dlogits.reshape(len(x), A * N)
     dh2, G["actor/fc_policy/weight"], G["actor/fc_policy/bias"] = _fc_bwd(h2, P["actor/fc_policy/weight"], None, dl, False)
-    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True)
-    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True)
+    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True, force.get("actor/fc2"))
+    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True, force.get("actor/fc1"))
     dc2, G["critic/fc3/weight"], G["critic/fc3/bias"] = _fc_bwd(c2, P["critic/fc3/weight"], None, dv[:, None], False)
-    dc1, G["critic/fc2/weight"], G["critic/fc2/bias"] = _fc_bwd(c1, P["critic/fc2/weight"], c2, dc2, True)
-    _, G["critic/fc1/weight"], G["critic/fc1/bias"] = _fc_bwd(x, P["critic/fc1/weight"], c1, dc1, True)
-    return (loss, pl, vl), G, {"logp": logp, "value": v, "logits": logits, "x": x}
+    dc1, G["critic/fc2/weight"], G["critic/fc2/bias"] = _fc_bwd(c1, P["critic/fc2/weight"], c2, dc2, True, force.get("critic/fc2"))
+    _, G["critic/fc1/weight"], G["critic/fc1/bias"] = _fc_bwd(x, P["critic/fc1/weight"], c1, dc1, True, force.get("critic/fc1"))
+    branches = {"actor/fc1": relu6_mask(h1), "actor/fc2": relu6_mask(h2), "critic/fc1": relu6_mask(c1),
+                "critic/fc2": relu6_mask(c2), "ppo_on": dlogp != 0}
+    return (loss, pl, vl), G, {"logp": logp, "value": v, "logits": logits, "x": x, "branches": branches, "dlogp": dlogp}
 
 
 class DPPOState:
@@ -672,12 +686,12 @@ def q_forward(P, q, xa):
     return v, (c1, c2)
 
 
-def _q_backward(P, q, xa, acts, dq, G=None):
-    """returns d xa; fills G with parameter grads when G is a dict."""
+def _q_backward(P, q, xa, acts, dq, G=None, masks=(None, None)):
+    """returns d xa; fills G with parameter grads when G is a dict.  `masks`: forced Relu6Grad decisions of fc1 / fc2."""
     c1, c2 = acts
     dc2, dw3, db3 = _fc_bwd(c2, P["critic/%s/fc3/weight" % q], None, dq[:, None], False)
-    dc1, dw2, db2 = _fc_bwd(c1, P["critic/%s/fc2/weight" % q], c2, dc2, True)
-    dxa, dw1, db1 = _fc_bwd(xa, P["critic/%s/fc1/weight" % q], c1, dc1, True)
+    dc1, dw2, db2 = _fc_bwd(c1, P["critic/%s/fc2/weight" % q], c2, dc2, True, masks[1])
+    dxa, dw1, db1 = _fc_bwd(xa, P["critic/%s/fc1/weight" % q], c1, dc1, True, masks[0])
     if G is not None:
         for i, (dw, db) in zip((1, 2, 3), ((dw1, db1), (dw2, db2), (dw3, db3))):
             G["critic/%s/fc%d/weight" % (q, i)] = dw
@@ -685,11 +699,15 @@ def _q_backward(P, q, xa, acts, dq, G=None):
     return dxa
 
 
-def sac_grads(P, PT, norm_mean, norm_std, batch, noise, A, N, gamma=0.95, value_loss_coef=0.5):
+def sac_grads(P, PT, norm_mean, norm_std, batch, noise, A, N, gamma=0.95, value_loss_coef=0.5, force=None):
     """One SAC-PFPN forward/backward.  P: eval params (actor + q1/q2 + log_alpha), PT: target q1/q2.
     batch: state, action, reward, not_terminal, state_.  noise: gumbel/eps for the eval draw and
     gumbel_/eps_ for the target draw, each [B,A,N].
-    Returns (loss tuple (loss, policy_loss, value_loss*coef), grads dict, aux)."""
+    Returns (loss tuple (loss, policy_loss, value_loss*coef), grads dict, aux).  `force` (flip-census tests only): branch
+    decisions taken from another implementation -- Relu6Grad masks "actor/fc1", "actor/fc2", "q1/pi/fc1" .. "q2/run/fc2"
+    (the live critics on (s, a_pi) and on (s, action_hist)) and "sel1" [B] (which twin the minimum routes its gradient
+    to); aux["branches"] = this evaluation's own."""
+    force = force or {}
     B = len(batch["state"])
     loc, logstd = P["actor/samples"], P["actor/samples_std"]
     alpha = np.exp(P["alpha/log_alpha"], dtype=F)                          # sac.py:38 (stop-grad)
@@ -719,13 +737,15 @@ def sac_grads(P, PT, norm_mean, norm_std, batch, noise, A, N, gamma=0.95, value_
     G = {}
     invB = F(1) / F(B)
     # critic grads: d value_loss / d q_running
-    _q_backward(P, "q1", xh, acts1r, (F(-2) * (q_target - q1r) * F(value_loss_coef) * invB).astype(F), G)
-    _q_backward(P, "q2", xh, acts2r, (F(-2) * (q_target - q2r) * F(value_loss_coef) * invB).astype(F), G)
+    fm = lambda q, path: (force.get("%s/%s/fc1" % (q, path)), force.get("%s/%s/fc2" % (q, path)))
+    _q_backward(P, "q1", xh, acts1r, (F(-2) * (q_target - q1r) * F(value_loss_coef) * invB).astype(F), G, fm("q1", "run"))
+    _q_backward(P, "q2", xh, acts2r, (F(-2) * (q_target - q2r) * F(value_loss_coef) * invB).astype(F), G, fm("q2", "run"))
     # actor grads: policy_loss w.r.t. actor variables and log_alpha only (sac.py:166-173)
     G["alpha/log_alpha"] = F(-(logp + target_entropy).mean(dtype=F))
-    sel1 = q1p <= q2p                                                     # tf.minimum grad routing
-    dxa = _q_backward(P, "q1", xa, acts1p, np.where(sel1, -invB, F(0)).astype(F)) \
-        + _q_backward(P, "q2", xa, acts2p, np.where(sel1, F(0), -invB).astype(F))
+    own_sel1 = q1p <= q2p                                                 # tf.minimum grad routing
+    sel1 = own_sel1 if force.get("sel1") is None else np.asarray(force["sel1"], bool)
+    dxa = _q_backward(P, "q1", xa, acts1p, np.where(sel1, -invB, F(0)).astype(F), None, fm("q1", "pi")) \
+        + _q_backward(P, "q2", xa, acts2p, np.where(sel1, F(0), -invB).astype(F), None, fm("q2", "pi"))
     da = dxa[:, -A:].astype(F)
     dlogp = np.full(B, alpha * invB, F)
     dl1, dloc1, dls1, dxs = mixture_log_prob_bwd(logits, s_, loc, logstd, dlogp, tanh_mode=True)
@@ -734,9 +754,15 @@ def sac_grads(P, PT, norm_mean, norm_std, batch, noise, A, N, gamma=0.95, value_
     G["actor/samples"] = (dloc1 + dloc2).astype(F)
     G["actor/samples_std"] = (dls1 + dls2).astype(F)
     dh2, G["actor/fc_policy/weight"], G["actor/fc_policy/bias"] = _fc_bwd(h2, P["actor/fc_policy/weight"], None, dlogits, False)
-    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True)
-    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True)
-    aux = {"logp": logp, "a": a, "s_": s_, "k": k, "q_target": q_target, "q1r": q1r, "q1p": q1p, "alpha": alpha}
+    dh1, G["actor/fc2/weight"], G["actor/fc2/bias"] = _fc_bwd(h1, P["actor/fc2/weight"], h2, dh2, True, force.get("actor/fc2"))
+    _, G["actor/fc1/weight"], G["actor/fc1/bias"] = _fc_bwd(x, P["actor/fc1/weight"], h1, dh1, True, force.get("actor/fc1"))
+    branches = {"actor/fc1": relu6_mask(h1), "actor/fc2": relu6_mask(h2), "sel1": own_sel1}
+    for q, ap, ar in (("q1", acts1p, acts1r), ("q2", acts2p, acts2r)):
+        for path, acts in (("pi", ap), ("run", ar)):
+            branches["%s/%s/fc1" % (q, path)] = relu6_mask(acts[0])
+            branches["%s/%s/fc2" % (q, path)] = relu6_mask(acts[1])
+    aux = {"logp": logp, "a": a, "s_": s_, "k": k, "q_target": q_target, "q1r": q1r, "q1p": q1p, "q2p": q2p, "alpha": alpha,
+           "branches": branches}
     return (F(policy_loss + value_loss), F(policy_loss), F(value_loss)), G, aux
 
 

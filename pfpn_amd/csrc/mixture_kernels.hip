@@ -913,24 +913,74 @@ __device__ __forceinline__ void st4_stream(float* p, float a, float b, float c, 
 
 template <bool V> struct BoolTag { static constexpr bool value = V; };
 
-template <int M, int MODE, bool TANH, bool FULLN, bool STREAM = false>
+// ---- in-launch hand-off of the wide kernels' partial results (round 4: no separate row-sum / finalize launch) ----------
+// Producers publish their partials with WRITE-THROUGH stores (`sc1`: the bytes leave the XCD's L2 for memory), drain them
+// (`s_waitcnt vmcnt(0)`), then take a ticket from an agent-scope counter; whoever draws the LAST ticket of its group reads
+// every partial with `sc1` loads (served past its CU's L1 and its XCD's L2: another XCD's L2 is not coherent with it) and
+// adds them in a FIXED order -- bitwise the result the separate launch gave.  No fence: an agent-scope release would write
+// back this XCD's whole L2, which holds the kernel's 1 GiB dlogits stream (MI355X_MICROARCH.md, inter-workgroup
+// visibility: `sc1` payload -> vmcnt(0) -> atomic ticket -> `sc1` loads by the wave whose add returned last).
+// The counters live in the code object, are zero at load and are handed back zeroed by the last arriver; launches of a
+// wide kernel on two streams AT THE SAME TIME would share them (the package launches on one stream).
+__device__ unsigned g_wide_tick_fwd[64];             // one per row chunk c (C <= 64)
+__device__ unsigned g_wide_tick_bwd[4096];           // one per action dim
+constexpr int WIDE_FOLD_MAX_A = 4096;
+constexpr int WIDE_FOLD_MAX_LDS = 32 * 1024;
+
+__device__ __forceinline__ void st4_sc1(float* p, float a, float b, float c, float d) {
+    const f4v v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// eight `sc1` loads and their wait as ONE asm statement: the compiler does not see these loads complete, so nothing of its
+// own (a copy at a control-flow join, a spill) may sit between a load and the wait -- the first version, one asm per load
+// with a conditional around it, summed stale registers.  Loads past `n` re-read entry n - 1 (always a valid address) and
+// are ignored by the caller.  Early-clobber outputs: a result must not land in a register a later load's address lives in.
+__device__ __forceinline__ void ld4x8_sc1(const float* p, size_t stride, int n, f4v (&v)[8]) {
+    const float* q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = p + (size_t)min(i, n - 1) * stride;
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc1\n\t"
+        "global_load_dwordx4 %1, %9, off sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc1\n\t"
+        "global_load_dwordx4 %5, %13, off sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc1\n\t"
+        "global_load_dwordx4 %7, %15, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+        : "memory");
+}
+
+// FOLD (forward): the row sum over the A segments happens inside the launch -- a wave keeps its rows' log p in LDS, the
+// block (4 consecutive action dims of ONE row chunk: A % 4 == 0) adds its four waves' values per row and publishes ONE
+// partial per row ([C][A/4][R4] in `lpseg_out`, whole float4s), the last block of a chunk adds the A/4 partials in block
+// order into fin0 = logp[B].  The loop then holds no global store at all.  Backward: `fin0` / `fin1` != nullptr = the last
+// of the C waves of an action dim adds the C slabs (k_finalize's order) into dloc / dlogstd.
+template <int M, int MODE, bool TANH, bool FULLN, bool STREAM = false, bool FOLD = false>
 __global__ __launch_bounds__(256) void k_mix_wide(
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
     const float* __restrict__ dlogp_in,
     int B, int A, int N, int C,
-    float* __restrict__ lpseg_out,           // [B,A] per-segment log p (FWD)
+    float* __restrict__ lpseg_out,           // [B,A] per-segment log p (FWD); FOLD: the per-block partials
     float* __restrict__ pmix_out,            // [B,A] optional
     float* __restrict__ dlogits,             // BWD
     float* __restrict__ dx_out,              // BWD optional
-    float* __restrict__ partial)             // [C][2*A*N]  (BWD)
+    float* __restrict__ partial,             // [C][2*A*N]  (BWD)
+    float* __restrict__ fin0 = nullptr,      // FWD FOLD: logp [B];  BWD: dloc [A,N] (null: slabs left for the caller)
+    float* __restrict__ fin1 = nullptr)      // BWD: dlogstd [A,N]
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
-    constexpr bool NT_LOADS = STREAM || MODE == MODE_FWD;
+    constexpr bool NT_LOADS = STREAM;                       // (forward: STREAM = the logits are read once and not again soon)
+    extern __shared__ __align__(16) float s_lp[];           // FOLD: [4 waves][R4] log p of this block's rows
     const int lane = threadIdx.x & 63;
     // wave-uniform indices through readfirstlane: row/segment address arithmetic goes to the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    if (wave >= A * C) return;
+    if (wave >= A * C) return;                              // (never taken with FOLD: the grid is exactly A * C / 4 blocks)
+    const int R4 = ((B + C - 1) / C + 3) & ~3;              // rows per chunk, padded to whole float4s
     const int a = wave % A;                                 // neighbouring waves -> neighbouring dims
     const int c = wave / A;
     const int AN = A * N;
@@ -969,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     // issue slot) -- at 128 x 256 this kernel is VALU-issue bound, not HBM bound: 17 VALU slots per particle
     // before, ~10 now, 8 of them the two quarter-rate v_exp_f32.  The row maximum is taken on l*log2(e) (a product:
     // no canonicalisation instructions in front of v_max3_f32, unlike on raw loads).
-    auto group = [&](int b0, const float4 (&l)[U][M], const float (&xv)[U], const float (&gv)[U], auto full_tag) {
+    auto group = [&](int b0, int gi, const float4 (&l)[U][M], const float (&xv)[U], const float (&gv)[U], auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         v2f lp[U][M][2];                                      // l * log2(e)
         float mx[U];
@@ -1031,6 +1081,13 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             if (TANH) {
                 const float xr = ur == 0 ? xv[0] : ur == 1 ? xv[1] : ur == 2 ? xv[2] : xv[3];
                 lpr -= tanh_log_det(xr);
+            }
+            if (FOLD) {
+                // row c + (4 gi + ur) C of this chunk: kept in LDS until the block's hand-off (rows past B in the ragged
+                // last group are clamped duplicates: finite, never read back)
+                if ((lane & 15) == 0) s_lp[(threadIdx.x >> 6) * R4 + 4 * gi + ur] = lpr;
+                if (pmix_out && (FULL || b < B)) pmix_out[(size_t)b * A + a] = p;
+                return;
             }
             // 16 lanes per row store the same value to the same address: one instruction, four transactions, no branch
             if (FULL || b < B) {
@@ -1115,9 +1172,9 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         gn[u] = (MODE == MODE_BWD) ? dlogp_in[b_] : 0.f;                                           \
     }
     const int step = C * U;
-    int b0 = c;
+    int b0 = c, gi = 0;
     PFPN_WIDE_LOAD(b0)
-    for (; b0 + (U - 1) * C < B; b0 += step) {               // full groups: branch-free body
+    for (; b0 + (U - 1) * C < B; b0 += step, ++gi) {         // full groups: branch-free body
         float4 l[U][M];
         float xv[U], gv[U];
 #pragma unroll
@@ -1128,21 +1185,105 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             gv[u] = gn[u];
         }
         PFPN_WIDE_LOAD(b0 + step)                            // clamped rows: harmless beyond the end
-        group(b0, l, xv, gv, BoolTag<true>{});
+        group(b0, gi, l, xv, gv, BoolTag<true>{});
     }
-    if (b0 < B) group(b0, ln, xn, gn, BoolTag<false>{});     // ragged tail (1..U-1 live rows)
+    if (b0 < B) group(b0, gi, ln, xn, gn, BoolTag<false>{}); // ragged tail (1..U-1 live rows)
 #undef PFPN_WIDE_LOAD
+    if (MODE == MODE_FWD && FOLD) {
+        // ---- hand-off of the row sums (see the helpers above) ----
+        __shared__ unsigned s_ticket;
+        const int nb = A >> 2;                               // blocks per row chunk
+        const int jb = blockIdx.x % nb;                      // this block's place in its chunk (c = blockIdx.x / nb)
+        const int Rc = (B - c + C - 1) / C;                  // rows of chunk c
+        const int nq4 = (Rc + 3) >> 2;
+        float* part = lpseg_out + ((size_t)c * nb + jb) * R4;
+        __syncthreads();
+        for (int t = threadIdx.x; t < nq4; t += blockDim.x) {
+            const float4 w0 = *reinterpret_cast<const float4*>(s_lp + 4 * t), w1 = *reinterpret_cast<const float4*>(s_lp + R4 + 4 * t);
+            const float4 w2 = *reinterpret_cast<const float4*>(s_lp + 2 * R4 + 4 * t), w3 = *reinterpret_cast<const float4*>(s_lp + 3 * R4 + 4 * t);
+            st4_sc1(part + 4 * t, ((w0.x + w1.x) + w2.x) + w3.x, ((w0.y + w1.y) + w2.y) + w3.y,
+                    ((w0.z + w1.z) + w2.z) + w3.z, ((w0.w + w1.w) + w2.w) + w3.w);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_ticket = __hip_atomic_fetch_add(&g_wide_tick_fwd[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != (unsigned)(nb - 1)) return;
+        // the chunk's last block: logp[row] = sum over the chunk's blocks, in block order
+        const float* all = lpseg_out + (size_t)c * nb * R4;
+        for (int t = threadIdx.x; t < nq4; t += blockDim.x) {
+            f4v acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j0 = 0; j0 < nb; j0 += 8) {
+                f4v v[8];
+                ld4x8_sc1(all + (size_t)j0 * R4 + 4 * t, (size_t)R4, min(8, nb - j0), v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (j0 + i < nb) acc = (j0 + i == 0) ? v[i] : acc + v[i];
+            }
+            const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = c + (4 * t + i) * C;
+                if (b < B) fin0[b] = r[i];
+            }
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&g_wide_tick_fwd[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (MODE == MODE_BWD) {
         float* slab = partial + (size_t)c * 2 * AN + (size_t)a * N;
+        const bool fold = fin0 != nullptr;                   // wave-uniform (kernel argument)
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             if (ok[j]) {
                 const v2f d0 = acc_loc2[j][0] * (b_isc2[j][0] * PFPN_2LN2), d1 = acc_loc2[j][1] * (b_isc2[j][1] * PFPN_2LN2);
-                *reinterpret_cast<float4*>(slab + 4 * (lane + 64 * j)) = make_float4(d0.x, d0.y, d1.x, d1.y);
-                *reinterpret_cast<float4*>(slab + AN + 4 * (lane + 64 * j)) =
-                    make_float4(acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
+                if (fold) {
+                    st4_sc1(slab + 4 * (lane + 64 * j), d0.x, d0.y, d1.x, d1.y);
+                    st4_sc1(slab + AN + 4 * (lane + 64 * j), acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
+                } else {
+                    *reinterpret_cast<float4*>(slab + 4 * (lane + 64 * j)) = make_float4(d0.x, d0.y, d1.x, d1.y);
+                    *reinterpret_cast<float4*>(slab + AN + 4 * (lane + 64 * j)) =
+                        make_float4(acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
+                }
             }
         }
+        if (!fold) return;
+        // ---- hand-off: the last of this action dim's C waves adds the C slabs, in k_finalize's order (16 running sums over
+        // k = r, r + 16, ..., then those in order) so that the result is bitwise the one of the separate launch ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&g_wide_tick_bwd[a], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != (unsigned)(C - 1)) return;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const float* src = partial + (size_t)pl * AN + (size_t)a * N;
+            float* dst = (pl ? fin1 : fin0) + (size_t)a * N;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                if (!ok[j]) continue;
+                f4v run[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) run[r] = (f4v){0.f, 0.f, 0.f, 0.f};
+                for (int k0 = 0; k0 < C; k0 += 16) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f4v v[8];
+                        const int kk = k0 + 8 * h;
+                        if (kk >= C) break;
+                        ld4x8_sc1(src + (size_t)kk * 2 * AN + 4 * (lane + 64 * j), (size_t)2 * AN, min(8, C - kk), v);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (kk + i < C) run[8 * h + i] += v[i];
+                    }
+                }
+                f4v sum = run[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) sum += run[r];
+                *reinterpret_cast<float4*>(dst + 4 * (lane + 64 * j)) = make_float4(sum.x, sum.y, sum.z, sum.w);
+            }
+        }
+        if (lane == 0) __hip_atomic_store(&g_wide_tick_bwd[a], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1242,9 +1383,7 @@ static TilePlan plan_tile(int B, int A, int N, const void* logits, const void* d
     pl.threads = NC * 64;                               // compute waves; the launcher adds the service waves of the mode
     const size_t plane = (size_t)(R * AN + ((R * A + 63) & ~63) + 64) * 4;
     const int pmin = dlogits ? 3 : 2;
-    int P = 4;
-    static const int env_p = getenv("PFPN_MIX_PLANES") ? atoi(getenv("PFPN_MIX_PLANES")) : 0;     // tuning knob
-    if (env_p >= pmin && env_p <= 8) P = env_p;
+    int P = 4;                                          // (2-3 planes and > 4 measured no better: LAB_NOTEBOOK.md)
     size_t small = 0;
     for (;; --P) {
         small = (size_t)(4 * R * A + (12 * R + 3 * P) + 8 + 3 * AN) * 4;
@@ -1360,23 +1499,41 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
         const int C = wide_chunks(B, A, N);
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
+        // the row sum inside the launch (FOLD, see k_mix_wide) whenever a block is four action dims of ONE row chunk and its
+        // rows' log p fit in LDS; otherwise per-segment values + the k_row_sum launch
+        const int R4 = ((B + C - 1) / C + 3) & ~3;
+        const size_t fold_lds = (size_t)4 * R4 * sizeof(float);
+        bool fold = A % 4 == 0 && C <= 64 && fold_lds <= (size_t)WIDE_FOLD_MAX_LDS &&
+                    workspace_bytes >= (size_t)C * (A / 4) * R4 * sizeof(float);
+#ifdef PFPN_WIDE_NO_FOLD                      // build knob for same-box A/B runs (tools/ab_build.sh): the separate launches
+        fold = false;
+#endif
+        // non-temporal loads only in the streaming regime (logits larger than the 256 MiB infinity cache: 207 -> 195 us on
+        // the 1 GiB shape); below it the default policy leaves the logits in cache for the backward pass that follows
+        const bool stream = wide_stream(B, A, N);
+#define PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, SS, OO)                                                                \
+    hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, FF, SS, OO>), dim3(blocks), dim3(256), OO ? fold_lds : 0, st, \
+                       logits, x, loc, logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,  \
+                       (float*)nullptr, (float*)nullptr, logp, (float*)nullptr)
+#define PFPN_WIDE_FWD_F(MM, TT, FF)                                                                            \
+    do {                                                                                                       \
+        if (stream) { if (fold) PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, true, true); else PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, true, false); } \
+        else { if (fold) PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, false, true); else PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, false, false); } \
+    } while (0)
 #define PFPN_WIDE_FWD(MM, TT)                                                                                  \
     do {                                                                                                       \
-        if (N == 256 * MM)                                                                                     \
-            hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, true>), dim3(blocks), dim3(256), 0, st, logits, x, loc,   \
-                               logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,         \
-                               (float*)nullptr, (float*)nullptr);                                               \
-        else                                                                                                   \
-            hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, false>), dim3(blocks), dim3(256), 0, st, logits, x, loc,  \
-                               logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,         \
-                               (float*)nullptr, (float*)nullptr);                                               \
+        if (N == 256 * MM) PFPN_WIDE_FWD_F(MM, TT, true); else PFPN_WIDE_FWD_F(MM, TT, false);                  \
     } while (0)
         if (tanh_mode) { if (M == 1) PFPN_WIDE_FWD(1, true); else if (M == 2) PFPN_WIDE_FWD(2, true); else PFPN_WIDE_FWD(4, true); }
         else { if (M == 1) PFPN_WIDE_FWD(1, false); else if (M == 2) PFPN_WIDE_FWD(2, false); else PFPN_WIDE_FWD(4, false); }
 #undef PFPN_WIDE_FWD
+#undef PFPN_WIDE_FWD_F
+#undef PFPN_WIDE_FWD_LAUNCH
         PFPN_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_row_sum, dim3((B * 64 + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
-        PFPN_CHECK_LAUNCH();
+        if (!fold) {
+            hipLaunchKernelGGL(k_row_sum, dim3((B * 64 + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
+            PFPN_CHECK_LAUNCH();
+        }
         return PFPN_OK;
     }
     int C = (B < 64) ? B : 64;
@@ -1427,9 +1584,17 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         if (workspace_bytes < (size_t)C * 2 * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
+        // finalize: the last wave of an action dim adds the slabs inside the launch (k_mix_wide's hand-off) unless A exceeds
+        // the ticket array -- then, as before, the k_finalize launch
+        bool fold = finalize && A <= WIDE_FOLD_MAX_A;
+#ifdef PFPN_WIDE_NO_FOLD
+        fold = false;
+#endif
+        float* const fold0 = fold ? dloc : nullptr;
+        float* const fold1 = fold ? dlogstd : nullptr;
 #define PFPN_WIDE_BWD_LAUNCH(MM, TT, FF, SS)                                                                    \
     hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
-                       dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial)
+                       dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial, fold0, fold1)
 #define PFPN_WIDE_BWD(MM, TT)                                                                                  \
     do {                                                                                                       \
         if (N == 256 * MM) { if (stream) PFPN_WIDE_BWD_LAUNCH(MM, TT, true, true); else PFPN_WIDE_BWD_LAUNCH(MM, TT, true, false); } \
@@ -1440,7 +1605,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
 #undef PFPN_WIDE_BWD_LAUNCH
 #undef PFPN_WIDE_BWD
         PFPN_CHECK_LAUNCH();
-        if (finalize) hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
+        if (finalize && !fold) hipLaunchKernelGGL(k_finalize, dim3((2 * AN + 63) / 64), dim3(1024), 0, st, partial, C, 2 * AN, 2 * AN,
                            dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
         PFPN_CHECK_LAUNCH();
         return PFPN_OK;

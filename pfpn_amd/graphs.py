@@ -6,11 +6,34 @@ dispatch cost is comparable to the device time, so the whole device part of the 
 Host-side bookkeeping (global_step, the resample tick every `resample_interval` steps) stays outside
 the graph: the resample kernels run eagerly between replays.
 """
+import gc
 import os
+import sys
+import weakref
 
 import torch
 
 from . import kernels
+
+# Steppers whose hipGraphs hold captured RCCL collectives.  RCCL's communicator teardown waits for captured point-to-point
+# plans (all_to_all_single) that a LIVE graph still references: `destroy_process_group()` then never returns
+# (tools/capture_collective_repro.py, profiles/r04_capture_collective_repro.txt: only all-to-all, only with the graph alive;
+# deleting the graph first cures it).  So the graphs go first: `release_captured_collectives()`, called by
+# `models.distributed_model.shutdown_process_group()` and by bench.py before they destroy the group.
+_with_collectives = weakref.WeakSet()
+inject_capture_failure = False          # tests only: the next captured-exchange attempt fails (rehearses the fallback)
+
+
+def release_captured_collectives():
+    """destroy every hipGraph that captured a collective (their steppers become unusable); returns how many"""
+    n = 0
+    for g in list(_with_collectives):
+        g.close()
+        n += 1
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    return n
 
 
 def refill_noise(noise, generator):
@@ -47,48 +70,78 @@ class GraphedLearnerStep(object):
         """`gather_from` = (columns, rows [K, B] int64, losses [K, 3]), all static device tensors: step k of a replay
         first gathers rows[k] of the staged rollout `columns` into its input set (the minibatch slicing of a training
         round, inside the graph) and leaves its loss3 in losses[k].
-        `capture_exchange` (default: env PFPN_GRAPH_EXCHANGE, off): data-parallel step with the RCCL collectives INSIDE
-        the capture (one graph, K steps per replay allowed) instead of two graphs around an eagerly enqueued collective."""
+        `capture_exchange` (default: env PFPN_GRAPH_EXCHANGE, ON over RCCL with the all-reduce exchange): data-parallel step
+        with the all-reduce INSIDE the capture (one graph, K steps per replay allowed); False: two graphs around an eagerly
+        enqueued collective.  The default falls back to the two-graph form by itself (see below); an explicit True raises."""
         self.net, self.opt = net, optimizer
         self.gather_from = gather_from
-        # data parallel: the step is captured as TWO graphs around the bucket all-reduce (everything up to the
-        # per-replica clip | Adam + statistics); the collective itself is enqueued between the two replays, so the
-        # capture never contains an RCCL call and the host enqueues 3 things per step instead of ~25.
-        # Opt-in alternative (`capture_exchange`): RCCL's kernels are captured like any other (the communicator must exist
-        # before the capture starts: one tiny eager all-reduce here, which every replica runs because every replica
-        # builds its stepper), so a data-parallel step is ONE graph and K steps share a replay as on one replica.
-        # Checked on a world-size-1 RCCL group only (tests/test_gpu_dp2.py); no multi-GPU node has run it.
+        # Data parallel, two forms.  DEFAULT over RCCL (round 4; measured on a world-size-1 group: 134 us per 512-row step
+        # against 150, bench.py `strong_shard`): the bucket all-reduce is captured INSIDE the step's graph -- RCCL's kernels
+        # are captured like any other once the communicator exists (one tiny eager all-reduce below, which every replica
+        # runs because every replica builds its stepper) -- so a data-parallel step is ONE graph and K steps share a replay
+        # as on one replica.  FALLBACK, taken by every replica together when the capture fails on ANY of them (agreed
+        # through an all-reduce(MAX)), over gloo (its collectives run on the host), for the sharded exchange (its
+        # all-to-all does not belong in a long-lived graph, see `_with_collectives`) and with PFPN_GRAPH_EXCHANGE=0 /
+        # `capture_exchange=False`: TWO graphs around the eagerly enqueued collective (everything up to the per-replica
+        # clip | Adam + statistics); the host enqueues 3 things per step instead of ~25.
         exchanging = bool(getattr(optimizer, "exchange", optimizer.world > 1))
         explicit_arg = capture_exchange is not None
         if capture_exchange is None:
-            capture_exchange = os.environ.get("PFPN_GRAPH_EXCHANGE", "0") != "0"
-        self.in_graph_exchange = bool(exchanging and capture_exchange)
-        if self.in_graph_exchange and getattr(optimizer, "sharded", False):
-            # all-reduce form only: with all_to_all_single / all_gather_into_tensor captured, the process group's shutdown
-            # waits for ever on work it recorded during the capture (destroy_process_group hangs; seen on a world-size-1
-            # group).  Asked for by the environment default: the sharded step stays on two graphs; asked for by argument: refuse.
-            if explicit_arg:
-                raise ValueError("capture_exchange covers the all-reduce exchange only")
-            self.in_graph_exchange = False
-        if self.in_graph_exchange:
+            capture_exchange = os.environ.get("PFPN_GRAPH_EXCHANGE", "1") != "0"
+        want = bool(exchanging and capture_exchange)
+        if want:
             import torch.distributed as dist
-            if dist.get_backend(optimizer.pg) != "nccl":
-                raise ValueError("capture_exchange needs the RCCL backend (gloo collectives run on the host)")
-            dist.all_reduce(torch.zeros(1, device=net.device), group=optimizer.pg)
-            torch.cuda.synchronize()
-        self.split = exchanging and not self.in_graph_exchange
+            if getattr(optimizer, "sharded", False):
+                if explicit_arg:
+                    raise ValueError("capture_exchange covers the all-reduce exchange only")
+                want = False
+            elif dist.get_backend(optimizer.pg) != "nccl":
+                if explicit_arg:
+                    raise ValueError("capture_exchange needs the RCCL backend (gloo collectives run on the host)")
+                want = False
         self.K = int(steps_per_replay)
-        assert not (self.split and self.K > 1), "multi-step replays cover the single-replica step"
         assert self.K >= 1 and (self.K == 1 or noise is None), "one noise set per captured step is not built"
         self.input_sets = [tuple(inputs)] * self.K if input_sets is None else [tuple(t) for t in input_sets]
         assert len(self.input_sets) == self.K
         self.inputs = self.input_sets[0]
         self.noise = noise
+        self.exchange_fallback = None
         net._ensure_buffers(self.inputs[0].shape[0], pin=True)    # the graph keeps pointing at this size's buffers
         if hasattr(net, "sync_target_net_hard"):
             net.sync_target_net_hard()                       # SAC: the init op must not happen inside the warm-up
-        # warm up on a side stream (lazy hipBLASLt/workspace init), then restore every piece of state
         saved = [t.clone() for t in self._state_tensors()]
+        if want:
+            import torch.distributed as dist
+            failed, why = 0, None
+            try:
+                dist.all_reduce(torch.zeros(1, device=net.device), group=optimizer.pg)
+                torch.cuda.synchronize()
+                self._capture(True, exchanging, warmup, saved)
+            except Exception as e:                           # (a capture that RCCL / the runtime refuses)
+                failed, why = 1, repr(e)
+            flag = torch.tensor([failed], dtype=torch.int32, device=net.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=optimizer.pg)
+            if int(flag.item()):
+                if explicit_arg:
+                    raise RuntimeError("capturing the exchange failed on a replica: %s" % (why or "on another replica"))
+                sys.stderr.write("pfpn_amd.graphs: the all-reduce could not be captured (%s): two graphs around an eager "
+                                 "collective instead\n" % (why or "failed on another replica"))
+                self.exchange_fallback = why or "failed on another replica"
+                self.close()
+                for t, sv in zip(self._state_tensors(), saved):
+                    t.copy_(sv)
+                want = False
+        if not want:
+            assert not (exchanging and self.K > 1), "multi-step replays of a data-parallel step need the captured exchange"
+            self._capture(False, exchanging, warmup, saved)
+
+    def _capture(self, in_graph, exchanging, warmup, saved):
+        net, optimizer, gather_from = self.net, self.opt, self.gather_from
+        if in_graph and inject_capture_failure:
+            raise RuntimeError("injected capture failure")
+        self.in_graph_exchange = bool(in_graph)
+        self.split = exchanging and not in_graph
+        # warm up on a side stream (lazy hipBLASLt/workspace init), then restore every piece of state
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -113,6 +166,9 @@ class GraphedLearnerStep(object):
         for t, sv in zip(self._state_tensors(), saved):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_post = None
+        if self.in_graph_exchange:
+            _with_collectives.add(self)
         # (thread-local capture mode with collectives inside: the process group's watchdog thread may query events meanwhile)
         mode = {"capture_error_mode": "thread_local"} if self.in_graph_exchange else {}
         with torch.cuda.graph(self.graph, stream=s, **mode):      # same stream as the warm-up: per-stream workspaces exist
@@ -144,6 +200,11 @@ class GraphedLearnerStep(object):
             with torch.cuda.graph(self.graph_post, stream=s):
                 optimizer.post_reduce(net)
         # capture does not execute; state is untouched
+
+    def close(self):
+        """destroy the captured graphs (before the process group they hold collectives of goes away)"""
+        self.graph = self.graph_post = None
+        _with_collectives.discard(self)
 
     def _args(self, k):
         return self.input_sets[k] if self.noise is None else self.input_sets[k] + (self.noise,)
@@ -177,6 +238,8 @@ class GraphedLearnerStep(object):
             for dsts, srcs in zip(self.input_sets, sets):
                 for dst, src in zip(dsts, srcs):
                     dst.copy_(src, non_blocking=True)
+        if self.graph is None:
+            raise RuntimeError("this stepper was closed (release_captured_collectives)")
         if not self.can_replay():
             raise ValueError("a resample tick falls inside this %d-step replay: run one-step replays up to it" % self.K)
         if self.noise is not None:

@@ -79,7 +79,11 @@ def build(settings):
 def main(argv=None):
     settings = parse(argv)
     model = build(settings)
-    model.start({"worker": []} if settings.train else None)
+    try:
+        model.start({"worker": []} if settings.train else None)
+    finally:
+        from .models.distributed_model import shutdown_process_group
+        shutdown_process_group()
 
 
 if __name__ == "__main__":

@@ -407,6 +407,16 @@ def init_process_group(backend=None, single_rank_group=False):
     return rank, world, local_rank
 
 
+def shutdown_process_group():
+    """Orderly end of a data-parallel run: first the hipGraphs that captured collectives (RCCL's teardown waits for
+    captured point-to-point plans a live graph still references -- pfpn_amd/graphs.py), then the process group."""
+    import torch.distributed as dist
+    from ..graphs import release_captured_collectives
+    release_captured_collectives()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 class DistributedModel(object):
     """Builds the worker of THIS process (rank) and runs it: training replica, one-shot player (`test`) or the
     polling evaluator (`evaluate`).  Replaces reference :406-638 (TF cluster, parameter server, hooks)."""

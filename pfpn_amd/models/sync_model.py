@@ -57,7 +57,9 @@ class SyncReplicasApplier(object):
     reference base_worker.py:33-45)."""
 
     def __init__(self, net, groups, norm_clip=None, beta1=0.9, beta2=0.999, epsilon=1e-8,
-                 process_group=None, world_size=None, force_exchange=False, exchange_mode=None):
+                 process_group=None, world_size=None, force_exchange=False, exchange_mode=None, fused_norm=True):
+        """`fused_norm=False` (tests): the global norm's partial sums come from a launch of their own instead of the
+        step's reduction launch -- the same arithmetic in another grouping, the reference form of the bitwise tests."""
         self.net = net
         st = net.store
         self.norm_clip = norm_clip
@@ -88,13 +90,12 @@ class SyncReplicasApplier(object):
         self._g_off = (ctypes.c_longlong * G)(*[g["off"] for g in self.groups])
         self._g_len = (ctypes.c_longlong * G)(*[g["len"] for g in self.groups])
         self._g_lr = (ctypes.c_float * G)(*[g["lr"] for g in self.groups])
-        self.fused = os.environ.get("PFPN_FUSED_OPT", "1") != "0"
+        self.fused = True
         # global-norm clip: the step's reduction launch can also produce the norm's partial sums and rotate the powers
         # (ActorCriticNetwork._finish_deferred), leaving ONE launch for clip + Adam (one replica) or for the in-place clip
-        # (exchange path).  PFPN_FUSED_NORM=0: off.
+        # (exchange path).
         net._norm_hook = None
-        if self.fused and self.norm_clip and len(self.groups) <= 4 and st.device.type == "cuda" \
-                and os.environ.get("PFPN_FUSED_NORM", "1") != "0":
+        if self.norm_clip and len(self.groups) <= 4 and st.device.type == "cuda" and fused_norm:
             net._norm_hook = {"partial": torch.zeros(4096, dtype=torch.float32, device=st.device),
                               "beta_pow": self.beta_pow, "beta1": beta1, "beta2": beta2}
         # SAC: the soft target update (a train op after the apply, sac.py:67-73) becomes part of the optimiser's device
@@ -150,7 +151,6 @@ class SyncReplicasApplier(object):
             self.post_reduce(net)
             self.finish_reduce(net)
             return
-        net.join_side_stream()
         soft = net.soft_update_args() if self._soft_net else None
         if self._fused_ok():
             # clip + every group's Adam + power / step-counter advance in one launch (two without the norm hook)
@@ -184,7 +184,6 @@ class SyncReplicasApplier(object):
         `AccumulatorApplyGradient_i` receives in the reference's graph).  Sharded exchange: only the clip FACTOR is
         formed (norm_scale[1]); the gradients stay as they are and the activation statistics join them in the tail."""
         st = net.store
-        net.join_side_stream()
         if self.sharded:
             kernels.clip_scale_only(st.grad, self.norm_clip, self.norm_scale, self.beta_pow, self.beta1, self.beta2,
                                     prenorm=self._prenorm(net))

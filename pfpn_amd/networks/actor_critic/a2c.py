@@ -186,15 +186,6 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
     # -- forward -----------------------------------------------------------------------------------
     def _policy_logits(self, ha):
         """fc_policy: logits [B, A*N] = h W + b (a2c.py:541-554)."""
-        pending = getattr(self, "_pending_jobs", None) or []
-        self._pending_jobs = []
-        stack = self.trunk if self.trunk is not None else self.actor_trunk
-        if stack is not None and stack.small(ha.shape[0]):
-            # small batches: the hand-written dense kernel, with the critic head's finishing job riding in the same launch
-            kernels.dense_jobs([kernels.dense_job_nn(ha, self.policy_weight, self.logits, bias=self.policy_bias)] + pending)
-            return self.logits
-        if pending:
-            kernels.dense_jobs(pending)
         # bias through the GEMM epilogue (hipBLASLt): no separate pass over the 20 MB of logits
         torch.addmm(self.policy_bias, ha, self.policy_weight, out=self.logits)
         return self.logits
@@ -249,25 +240,6 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         w3 = st["critic/fc3/weight"].view(-1)
         dh_a, dh_c = (self.dh[0], self.dh[1]) if self.trunk is not None else (self.dh_a[0], self.dh_c[0])
         B = dlogits.shape[0]
-        if self.trunk is not None and self.trunk.small(B):
-            # small batches, ONE launch: fc_policy's dW (+ its bias gradient when the mixture kernel did not emit it) and dX
-            # -- masked by the ReLU6 of the actor trunk's output, i.e. already the gradient w.r.t. its pre-activation --
-            # and the critic head's backward (rank-1 dX, dW, db); then one launch per trunk layer
-            gb = None if fused_db else st.g("actor/fc_policy/bias")
-            jobs = [kernels.dense_job_tn(ha, dlogits, st.g("actor/fc_policy/weight"), colsum=gb),
-                    kernels.dense_job_nt(dlogits, self.policy_weight, dh_a, mask=ha)]
-            jobs += self.trunk.head_backward_jobs((1, w3, dvalue, st.g("critic/fc3/weight"), st.g("critic/fc3/bias")),
-                                                  B, out=self.dh)
-            kernels.dense_jobs(jobs)
-            final = self._final_dense_jobs(deferred, allow_norm=not self.fixed_sigma) if deferred else None
-            self.trunk.backward(self.dh, premasked=True, final=final)
-            if final is not None:
-                # the reductions rode in the trunk's last launch: nothing is left for `_finish_deferred`
-                self._norm_ready = self.trunk.norm_partials
-                del deferred[:]
-                self._deferred_done = True
-            self._dw_pending = False
-            return
         if deferred is not None:
             if not fused_db:
                 kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
@@ -275,37 +247,28 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
             torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
             self.trunk.backward(self.dh, deferred=deferred,
                                 value=(1, w3, dvalue, st.g("critic/fc3/weight"), st.g("critic/fc3/bias")))
-            self._dw_pending = False
             return
-        # critic-head backward and the fc_policy bias gradient (column sums of dlogits) are short
-        # latency-bound launches (optionally beside the two fc_policy GEMMs: PFPN_OVERLAP_AUX)
-        with self.aux():
-            kernels.value_head_bwd(hc, w3, dvalue, dh_c, st.g("critic/fc3/weight").view(-1),
-                                   st.g("critic/fc3/bias"), relu6=True)
-            if not fused_db:
-                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
-        dws = self.dw_stream if self.overlap_dw else None
+        # launch-per-piece form (steps that cannot defer: separate trunks, row counts off the float4 grid)
+        kernels.value_head_bwd(hc, w3, dvalue, dh_c, st.g("critic/fc3/weight").view(-1), st.g("critic/fc3/bias"), relu6=True)
+        if not fused_db:
+            kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
         torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
         torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
-        self.aux_join()
         if self.trunk is not None:
-            self.trunk.backward(self.dh, dw_stream=dws)
+            self.trunk.backward(self.dh)
         else:
             self.actor_trunk.backward(self.dh_a)
             self.critic_trunk.backward(self.dh_c)
-        self._dw_pending = dws is not None
 
     def _deferred_jobs(self, B, fused_mixture=False):
         """[] when this step can leave its small reductions (bias gradients, critic head, normaliser EMA and -- PPO --
         the fused mixture kernel's slabs) to ONE launch at the end of the backward pass: merged trunk, fused prologue
-        (and the packed mixture kernel for `fused_mixture`).  PFPN_DEFER_REDUCE=0 disables.  Else None."""
+        (and the packed mixture kernel for `fused_mixture`).  Else None (`self.defer_reduce = False`: never)."""
         key = (B, fused_mixture)
         ok = self._defer_ok.get(key)
         if ok is None:
-            ok = self.trunk is not None and self.trunk.L > 1 and B % 4 == 0 and not self.overlap_ema and \
-                not self.overlap_aux and not self.overlap_dw and self.state_normalizer is not None and \
-                self.normalize_state and os.environ.get("PFPN_DEFER_REDUCE", "1") != "0" and \
-                os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+            ok = self.trunk is not None and self.trunk.L > 1 and B % 4 == 0 and self.state_normalizer is not None and \
+                self.normalize_state and self.defer_reduce
             if ok and fused_mixture:
                 try:
                     for want_db in (False, True):

@@ -20,24 +20,6 @@ from ..ops import DenseStack, ParamStore
 from ..utils import OnlineNormalizer
 
 
-class _AuxScope:
-    def __init__(self, stream):
-        self.stream = stream
-        self.ctx = None
-
-    def __enter__(self):
-        if self.stream is not None:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            self.ctx = torch.cuda.stream(self.stream)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
-
-
 class ActorCriticNetwork(object):
     def __init__(self, trainable, state_shape, action_shape,
                  common_net_shape, critic_net_shape, actor_net_shape,
@@ -115,16 +97,12 @@ class ActorCriticNetwork(object):
         self.state_normalizer = OnlineNormalizer(self.S, self.device) if (self.normalize_state or self.clip_state) else None
         self.step_dev = torch.zeros(1, dtype=torch.float32, device=self.device)   # float(global_step)
         self.dp_world = 1                      # set by the optimiser (SyncReplicasApplier)
-        self.side_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        # second helper stream: the latency-bound launches of the critic head / advantage statistics / logits
-        # bias gradient run beside the policy-head GEMMs (PFPN_OVERLAP_AUX=0: everything on one stream).
-        # Running the big weight-gradient GEMMs there too (PFPN_OVERLAP_DW=1) measured SLOWER on MI355X
-        # (concurrent GEMMs thrash the L2/MALL): off.
-        self.dw_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        self.overlap_aux = os.environ.get("PFPN_OVERLAP_AUX", "0") != "0"   # measured 5 % slower: off
-        self.overlap_ema = os.environ.get("PFPN_OVERLAP_EMA", "0") != "0"   # side stream for the state-norm EMA: measured 3 % slower
-        self.overlap_dw = os.environ.get("PFPN_OVERLAP_DW", "0") != "0"
-        self._dw_pending = False
+        # ONE stream: every helper-stream overlap that was built (critic head / statistics beside the policy GEMMs, the
+        # weight-gradient GEMMs, the state-norm EMA) measured 3-8 % SLOWER on MI355X and is gone (LAB_NOTEBOOK.md).
+        # Structural switches of the learner step, fixed in the product; tests flip them on an instance to hold the fused
+        # forms against their launch-per-piece reference arithmetic bit for bit:
+        self.defer_reduce = True       # the step's small reductions wait for ONE launch (kernels.reduce_jobs)
+        self.ride_prologue = True      # multi-step captures: the next step's prologue rides in the optimiser launch
         self._B = None
         self._buf_cache, self._buf_pinned = {}, set()
         self._train_graphs, self._train_calls = {}, {}
@@ -141,7 +119,6 @@ class ActorCriticNetwork(object):
         settings: [1024, 512] both, deepmimic_base.py:4-6)."""
         if self.actor_net_shape == self.critic_net_shape:
             self.trunk = DenseStack(store, ["actor", "critic"], self.S, self.actor_net_shape)
-            self.trunk.rowdense = True
             self.actor_trunk = self.critic_trunk = None
         else:
             self.trunk = None
@@ -257,13 +234,10 @@ class ActorCriticNetwork(object):
     def _trunks_forward(self, x, value_head=None, masks=False):
         """-> (actor hidden [B,Ha], critic hidden [B,Hc]) (views of the stacks' activation buffers).
         `value_head` = (w, b, out): also evaluate the critic head inside the merged trunk's last epilogue;
-        `masks`: hidden layers leave their ReLU6 masks as bits for the deferred backward.
-        Small batches (DenseStack.small): the head's finishing job waits in `self._pending_jobs` for the policy head's
-        launch (`_policy_logits`)."""
+        `masks`: hidden layers leave their ReLU6 masks as bits for the deferred backward."""
         if self.trunk is not None:
-            self._pending_jobs = []
             h = self.trunk.forward(x, value_head=(1,) + tuple(value_head) if value_head is not None else None,
-                                   masks=masks, pending=self._pending_jobs)
+                                   masks=masks)
             return h[0], h[1]
         if value_head is not None:
             raise ValueError("the folded critic head needs the merged actor+critic trunk")
@@ -277,9 +251,6 @@ class ActorCriticNetwork(object):
         optimiser needs ONE launch (pfpn_clip_adam_prenorm) instead of two.  A step that takes this path MUST be followed
         by the optimiser's apply (the powers have moved)."""
         hook = getattr(self, "_norm_hook", None)
-        if getattr(self, "_deferred_done", False):      # (small-row path: the last dense launch carried the reductions)
-            self._deferred_done = False
-            return
         self._norm_ready = 0
         if hook is None or not allow_norm:
             kernels.reduce_jobs(deferred)
@@ -308,41 +279,6 @@ class ActorCriticNetwork(object):
             kernels.reduce_jobs(deferred)
             return
         self._norm_ready = kernels.reduce_jobs(jobs, norm=hook)
-
-    def _final_dense_jobs(self, deferred, allow_norm=True):
-        """small-row path: the step's deferred reductions as jobs of its LAST dense launch (the first trunk layer's
-        backward) -- `_finish_deferred` without a launch of its own.  -> (make_jobs(written) -> [DenseJob], norm hook) for
-        DenseStack.backward(final=...), or None when the launch cannot carry them (then `_finish_deferred` runs as usual).
-        `written`: the gradient tensors that launch itself produces; their squares are counted by the producing blocks,
-        everything else of the flat gradient buffer is final by then and is covered by square-sum jobs."""
-        hook = getattr(self, "_norm_hook", None)
-        if hook is None or not allow_norm or os.environ.get("PFPN_ROWDENSE_TAIL", "1") == "0":
-            return None
-        if any(j.kind not in (kernels.JOB_COLSUM, kernels.JOB_PPO_LOSS, kernels.JOB_NORM_EMA) for j in deferred):
-            return None
-        st = self.store
-        base, end = st.grad.data_ptr(), st.grad.data_ptr() + 4 * st.size
-        red = list(deferred)
-
-        def make_jobs(written):
-            cover = []
-            for j in red:
-                if j.kind == kernels.JOB_COLSUM and j.out is not None and base <= j.out < end:
-                    j.norm = 1
-                    cover.append((j.out, min(end, (j.out + 4 * j.n + 15) // 16 * 16)))
-            for t in written:
-                cover.append((t.data_ptr(), min(end, (t.data_ptr() + 4 * t.numel() + 15) // 16 * 16)))
-            if any(lo % 16 for lo, _ in cover):
-                raise ValueError("gradient tensors must start on 16-byte boundaries")
-            cover.sort()
-            jobs, pos = [kernels.dense_job_of_reduce(j) for j in red], base
-            for lo, hi in cover + [(end, end)]:
-                if lo > pos:
-                    nfl = (lo - pos) // 4
-                    jobs.append(kernels.dense_job_of_reduce(kernels.job_sqsum(pos, nfl, max(1, min(64, nfl // 16384)))))
-                pos = max(pos, hi)
-            return jobs
-        return make_jobs, hook
 
     def _to_dev(self, a, dtype=torch.float32):
         if isinstance(a, torch.Tensor):
@@ -405,8 +341,8 @@ class ActorCriticNetwork(object):
         those rows of `args` (the staged rollout of a training round: the gather lands in the graph's static inputs).  A worker trains on a fixed minibatch
         size (32 rows in the DPPO setting: ~40 launches of almost no work each), so after a few eager steps at
         one size the step is captured into a hipGraph (pfpn_amd/graphs.py) and replayed: identical results,
-        a third of the time.  Data-parallel steps are captured as two graphs around the RCCL all-reduce, which is
-        enqueued between their replays.  PFPN_GRAPH_TRAIN=0 keeps the eager path."""
+        a third of the time.  Data-parallel steps are captured with the RCCL all-reduce inside (or as two graphs around
+        it: pfpn_amd/graphs.py).  PFPN_GRAPH_TRAIN=0 keeps the eager path."""
         B = args[0].shape[0] if rows is None else rows.shape[0]
         key = (B, id(optimizer)) + tuple(self._graph_phase())
         g = self._train_graphs.get(key)
@@ -439,8 +375,7 @@ class ActorCriticNetwork(object):
         moments into self.adv_stats.  With the normaliser on this is two launches (fused prologue + EMA
         finalisation) instead of four or more.  `state2` -> `out2` (deferred steps): a second batch normalised with the
         same moments in the same launch (SAC's next states)."""
-        fusable = self.state_normalizer is not None and self.normalize_state and self.trainable and \
-            not self.overlap_ema and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+        fusable = self.state_normalizer is not None and self.normalize_state and self.trainable
         if state2 is not None and not (fusable and deferred is not None):
             self.state_normalizer.normalize(state2, self.clip_state or 0.0, out=out2)
             state2 = None
@@ -488,9 +423,7 @@ class ActorCriticNetwork(object):
         optimiser launch of THIS step to carry (kernels.clip_adam(rider=...)), or None where that prologue would not be the
         single fused launch.  The optimiser calls prologue_staged() once it has taken the rider; the next prologue()
         call on the same tensors then launches nothing (it still queues its EMA job)."""
-        fusable = self.state_normalizer is not None and self.normalize_state and self.trainable and \
-            not self.overlap_ema and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0" and \
-            os.environ.get("PFPN_PROLOGUE_RIDER", "1") != "0"
+        fusable = self.state_normalizer is not None and self.normalize_state and self.trainable and self.ride_prologue
         if not fusable or getattr(self, "ws_moments", None) is None or self.xn.shape[0] != state.shape[0]:
             return None
         nz = self.state_normalizer
@@ -504,40 +437,16 @@ class ActorCriticNetwork(object):
         self._prologue_staged = rider._key
 
     def update_state_normalizer(self, state):
-        """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), on a side
-        stream so the five tiny launches overlap the MLP GEMMs.  One replica: in place (visible to the NEXT
-        step's forward, the deterministic choice of DESIGN.md section 5); W replicas: into the bucket tail that is
-        averaged by the all-reduce."""
+        """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), the launch-per-piece form
+        (steps that cannot defer their reductions).  One replica: in place (visible to the NEXT step's forward, the
+        deterministic choice of DESIGN.md section 5); W replicas: into the bucket tail that is averaged by the all-reduce."""
         if not (self.normalize_state and self.trainable):
             return
         nz, tail, S = self.state_normalizer, self.store.tail, self.S
-        main = torch.cuda.current_stream()
-        side = self.side_stream if self.overlap_ema else main
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            if (self.dp_world == 1 and not getattr(self, "_stats_in_flat", False)) or \
-                    getattr(self, "_stats_in_tail", False):
-                nz.updated(state, self.step_dev, nz.mean, nz.std)
-            else:
-                nz.updated(state, self.step_dev, tail[:S], tail[S:2 * S])
-        self._side_pending = self.overlap_ema
-
-    def aux(self):
-        """context manager: run the enclosed launches on the helper stream after everything queued so far
-        on the current stream (no-op context when overlap is off)."""
-        return _AuxScope(self.dw_stream if self.overlap_aux else None)
-
-    def aux_join(self):
-        if self.overlap_aux:
-            torch.cuda.current_stream().wait_stream(self.dw_stream)
-
-    def join_side_stream(self):
-        if getattr(self, "_side_pending", False):
-            torch.cuda.current_stream().wait_stream(self.side_stream)
-            self._side_pending = False
-        if self._dw_pending:
-            torch.cuda.current_stream().wait_stream(self.dw_stream)
-            self._dw_pending = False
+        if (self.dp_world == 1 and not getattr(self, "_stats_in_flat", False)) or getattr(self, "_stats_in_tail", False):
+            nz.updated(state, self.step_dev, nz.mean, nz.std)
+        else:
+            nz.updated(state, self.step_dev, tail[:S], tail[S:2 * S])
 
     def actor_param_names(self):
         return [n for n in self.store.names() if n.startswith("actor")]

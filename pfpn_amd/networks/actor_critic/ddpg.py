@@ -231,7 +231,6 @@ def ddpg_network_wrapper(base_class):
             off, ln = st.span(self.actor_param_names())
             if not sync:                                  # policy-delay step: the actor's gradient is zero
                 st.grad[off:off + ln].zero_()
-                self.join_side_stream()
                 return out["loss3"]
             # actor gradients: through Q(s, a) to the action only (the critic's parameters are skipped)
             kernels.value_head_bwd(hq_pi[0], w3[0], out["dq_pi"][0], self.dh_pi[0], self.scratch_w3, self.scratch_b3,

@@ -9,8 +9,6 @@ One learner step = state-norm(+EMA) -> actor & critic MLP forward (PyTorch-ROCm 
 fused HIP kernel [mixture log-prob of action_hist + PPO ratio/clip/value loss + full backward of
 the mixture] -> MLP backward -> optimizer (clip, all-reduce, TF-Adam, resample tick).
 """
-import os
-
 import numpy as np
 import torch
 
@@ -52,18 +50,14 @@ def clip_ppo_network_wrapper(a2c_base_class):
             deferred = self._deferred_jobs(B, fused_mixture=True)
             x = self.prologue(state, advantage, deferred=deferred)   # normalised state, state-norm EMA, advantage moments
             w3, b3 = st["critic/fc3/weight"], st["critic/fc3/bias"]
-            if deferred is not None or (self.trunk is not None and self.trunk.small(B)):
-                # (small batches: the head always rides on the last trunk layer's launch -- one arithmetic for the
-                # deferred and the immediate step)
-                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf), masks=deferred is not None)
+            if deferred is not None:
+                ha, hc = self._trunks_forward(x, value_head=(w3, b3, self.value_buf), masks=True)
                 v = self.value_buf
             else:
                 ha, hc = self._trunks_forward(x)
-                with self.aux():                           # critic head beside the policy-head GEMM
-                    v = self._value(hc)
+                v = self._value(hc)
             policy = MixtureGaussianDistribution(self._policy_logits(ha), self.loc, self.logstd,
                                                  self.normalize_policy_output_)
-            self.aux_join()
             # without an entropy term dlogits is final when the fused kernel ends: it then also emits the
             # fc_policy bias gradient (column sums of dlogits), saving a 20 MB pass
             fused_db = not self.entropy_beta
@@ -118,14 +112,13 @@ def clip_ppo_network_wrapper(a2c_base_class):
             one-step replays leave ~10 us of idle GPU between them).  Built once the one-step graph of this minibatch
             size exists (the first steps of a run stay eager, as in graphed_train); the staged rollout lives in static
             device columns the graph's gathers read, so a round of another size gets its own graph (at most two are
-            kept).  PFPN_GRAPH_ROUND=0: one-step replays only."""
-            if (B, id(optimizer)) not in self._train_graphs or os.environ.get("PFPN_GRAPH_ROUND", "1") == "0":
+            kept).  PFPN_GRAPH_TRAIN=0 (no captured steps at all) keeps rounds eager too."""
+            if (B, id(optimizer)) not in self._train_graphs:
                 return None
             in_graph = False
             if getattr(optimizer, "exchange", optimizer.world > 1):
-                # data-parallel steps are two graphs around the all-reduce: a K-step replay cannot hold the collective,
-                # so DP rounds run one-step (split-graph) replays -- unless the step captures its collectives
-                # (PFPN_GRAPH_EXCHANGE=1: the one-step graph of this size was built that way)
+                # a K-step replay needs the collective INSIDE the graph (the default over RCCL); where the one-step graph of
+                # this size fell back to two graphs around an eager all-reduce, DP rounds run one-step replays
                 in_graph = getattr(self._train_graphs[(B, id(optimizer))], "in_graph_exchange", False)
                 if not in_graph:
                     return None
@@ -161,8 +154,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
             B0, K = len(plan[0]), self.ROUND_STEPS_PER_REPLAY
             n_rows = len(columns[names[0]])
             rg = getattr(self, "_round_graphs", {}).get((B0, n_rows, K, id(optimizer))) if len(plan) >= K else None
-            if rg is not None and os.environ.get("PFPN_GRAPH_ROUND", "1") != "0" and \
-                    all(isinstance(columns[k], np.ndarray) for k in names):
+            if rg is not None and all(isinstance(columns[k], np.ndarray) for k in names):
                 # the round's graph exists: the host columns go straight into the static columns its gathers read
                 cols = rg.gather_from[0]
                 for dst, k in zip(cols, names):

@@ -8,7 +8,6 @@ Q loss (:160-164), policy loss with target_entropy = -|A| (:166-173), soft targe
 hard sync at init (:75-86), `run` -> [action] (:91-95), `train` feed (:97-105).
 The policy sample is the Gumbel-softmax rsample branch of MixtureGaussianDistribution (utils.py:156-186).
 """
-import os
 
 import numpy as np
 import torch
@@ -34,8 +33,8 @@ def sac_network_wrapper(base_class):
                 kwargs["normalize_policy_output"] = True          # sac.py:15-16
             super().__init__(**kwargs)
             self.alpha = alpha       # replaced by exp(log_alpha) for the trainable net (sac.py:36-39)
-            self.batch_actor = os.environ.get("PFPN_SAC_BATCH_ACTOR", "1") != "0"
-            self.batch_critic = os.environ.get("PFPN_SAC_BATCH_CRITIC", "1") != "0"
+            self.batch_actor = True        # (tests flip these on an instance: the one-pass-per-input reference form)
+            self.batch_critic = True
             self.tau = tau
             self.reward, self.not_terminal = "reward", "not_terminal"
 
@@ -167,7 +166,7 @@ def sac_network_wrapper(base_class):
             self.dq_both = f(2, 2 * B)
             self.sac_out = {"dq_pi": self.dq_both[:, :B], "dq_run": self.dq_both[:, B:], "dlogp": f(B),
                             "dlog_alpha": self.store.g("alpha/log_alpha"), "loss3": f(3)}
-            # the two-pass form (PFPN_SAC_BATCH_CRITIC=0, undeferred steps) keeps contiguous [2, B] buffers of its own
+            # the two-pass form (`batch_critic = False`, undeferred steps) keeps contiguous [2, B] buffers of its own
             self.q_pi_c, self.q_run_c = f(2, B), f(2, B)
             self.sac_out_c = dict(self.sac_out, dq_pi=f(2, B), dq_run=f(2, B))
             self.scratch_w3, self.scratch_b3 = f(hc), f(1)
@@ -224,12 +223,11 @@ def sac_network_wrapper(base_class):
 
         def _deferred_jobs(self, B, fused_mixture=False):
             """[] when the step's small reductions (bias gradients, both Q heads, the normaliser EMA) can wait for ONE
-            launch at the end of the backward pass (PFPN_DEFER_REDUCE=0 disables), else None."""
+            launch at the end of the backward pass (`self.defer_reduce = False`: never), else None."""
             ok = self._defer_ok.get(B)
             if ok is None:
-                ok = B % 4 == 0 and not self.overlap_ema and not self.overlap_aux and not self.overlap_dw and \
-                    self.state_normalizer is not None and self.normalize_state and self.q_stack.L > 1 and \
-                    os.environ.get("PFPN_DEFER_REDUCE", "1") != "0" and os.environ.get("PFPN_FUSED_PROLOGUE", "1") != "0"
+                ok = B % 4 == 0 and self.state_normalizer is not None and self.normalize_state and self.q_stack.L > 1 and \
+                    self.defer_reduce
                 self._defer_ok[B] = ok
             return [] if ok else None
 
@@ -265,7 +263,7 @@ def sac_network_wrapper(base_class):
             else:
                 x = self._normalize(state)
                 x2 = self.state_normalizer.normalize(state_, self.clip_state or 0.0, out=self.xn2)
-                self.update_state_normalizer(state)        # side stream, joined in the optimiser
+                self.update_state_normalizer(state)
             fold = deferred is not None
             loc, logstd = self.loc, self.logstd
             nb = noise.get("_buf")

@@ -9,7 +9,6 @@ gradient lands directly in the flat gradient buffer (one RCCL bucket, one Adam l
 step can be captured in a hipGraph.
 """
 import math
-import os
 
 import torch
 
@@ -145,16 +144,6 @@ class DenseStack:
         self.pinned = set()       # batch sizes a captured graph points at (the network shares its set): never dropped
 
     MAX_BUFFER_SETS = 64
-    # batches of at most this many rows run on the hand-written small-row dense kernels (csrc/rowdense_kernels.hip):
-    # ONE launch per layer and direction with every epilogue fused (10 launches per DPPO step instead of 16).  Threshold
-    # by measurement (tools/rowdense_probe.py): on MI355X the family ties PyTorch-ROCm GEMMs + the
-    # streaming epilogue kernels at 32 rows (93 vs 91 us per step) and loses above (156 vs 130 us at 512 rows), so the
-    # default keeps the library path; PFPN_ROWDENSE_MAX=<rows> routes batches up to that size through the family.
-    ROW_MAX = int(os.environ.get("PFPN_ROWDENSE_MAX", "0"))
-    rowdense = False            # set by the owning network once all of its callers speak the small-row protocol
-
-    def small(self, B):
-        return self.rowdense and 0 < B <= self.ROW_MAX and self.store.device.type == "cuda"
 
     def group_view(self, t, layer, g, bias=False):
         """group g's slice of a layer tensor (parameter, gradient or Adam slot) in the reference's shape."""
@@ -245,108 +234,7 @@ class DenseStack:
         """`group_rows` of the epilogue kernels: layer 0 merged is one [B, G*H] matrix with a [G*H] bias."""
         return 0 if (i == 0 and self.merged0) else B
 
-    def _head_partials(self, buf, B, every_group):
-        key = "hpart_all" if every_group else "hpart"
-        if buf.get(key) is None:
-            P = (self.dims[-1] + 31) // 32
-            buf[key] = torch.empty((self.G, B, P) if every_group else (B, P), dtype=torch.float32,
-                                   device=self.store.device)
-        return buf[key]
-
-    def _forward_small(self, x, buf, st, value_head, pending):
-        """<= ROW_MAX rows: one launch per layer -- GEMM + bias + ReLU6 (+ the scalar head's per-32-column partial dot
-        products on the last layer) in `kernels.dense_jobs`.  The head's finishing job (partials -> value) is appended
-        to `pending` for the caller's next launch (the policy head's GEMM), or launched here when no list is given."""
-        B = x.shape[0]
-        act, act2d = buf["act"], buf["act2d"]
-        for i in range(self.L):
-            w, b = st[self.wn[i]], st[self.bn[i]]
-            head = None
-            if value_head is not None and i == self.L - 1:
-                g, vw, vb, vout = value_head
-                part = self._head_partials(buf, B, g < 0)
-                head = (g, vw.view(self.G, -1) if g < 0 else vw.view(-1), part)
-            if i == 0 and self.merged0:
-                job = kernels.dense_job_nn(x, w, act2d[0], bias=b.view(-1), relu6=True)
-            else:
-                job = kernels.dense_job_nn(x if i == 0 else act[i - 1], w, act[i], bias=b, relu6=True, head=head)
-            kernels.dense_jobs([job])
-            buf["mask_ok"][i] = False
-        if value_head is not None:
-            g, vw, vb, vout = value_head
-            fin = kernels.dense_job_head_final(part, vb, vout)
-            if pending is not None:
-                pending.append(fin)
-            else:
-                kernels.dense_jobs([fin])
-        return act[-1]
-
-    def head_backward_jobs(self, value, B, slot=0, out=None):
-        """small-row path: the backward of a scalar head on the last layer's output as two jobs for the CALLER's launch
-        (it must precede this stack's backward): dY_last[group] = dvalue (x) w * Relu6Grad, and dW / db of the head.
-        value = (group, w, dvalue, grad_w, grad_b) as in backward(); out: the [G,B,H] gradient buffer backward() gets."""
-        g, w, dv, gw, gb = value
-        act = self._bufs[(B, slot)]["act"][-1]
-        if g < 0:
-            return [kernels.dense_job_rank1(dv, w.view(self.G, -1), act, out),
-                    kernels.dense_job_head_wgrad(dv, act, gw.view(self.G, -1), gb.view(self.G, -1))]
-        return [kernels.dense_job_rank1(dv, w.view(-1), act[g], out[g]),
-                kernels.dense_job_head_wgrad(dv, act[g], gw.view(-1), gb.view(-1))]
-
-    def _backward_small(self, dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows, final=None):
-        """<= ROW_MAX rows, `dlast` = gradient w.r.t. the last layer's PRE-activation (its producer applied Relu6Grad):
-        one launch per layer -- dW = X^T dY with the bias gradient (column sums of dY) from the same operand tiles, and
-        dX = dY W^T masked by the ReLU6 of the layer below -- every result final in the flat gradient buffer (the batch
-        is the reduction length of dW: it never leaves a block, no partial slabs, nothing deferred)."""
-        act, dact, dact2d, x = buf["act"], buf["dact"], buf["dact2d"], buf["x"]
-        st = self.store
-        r0, r1 = dw_rows if dw_rows is not None else (0, B)
-        d, d2d = dlast, None
-        dx = None
-        for i in reversed(range(self.L)):
-            w, gw, gb = st[self.wn[i]], st.g(self.wn[i]), st.g(self.bn[i])
-            jobs = []
-            if i == 0:
-                merged = self.merged0
-                if merged:
-                    d2d = dact2d[0] if self.L > 1 else dlast.view(B, -1)
-                    if need_dw:
-                        jobs.append(kernels.dense_job_tn(x[r0:r1], d2d[r0:r1], gw, colsum=gb.view(-1)))
-                    if need_dx:
-                        wx = w if need_dx is True else w[need_dx[0]:need_dx[1]]
-                        a = d2d if dx_rows is None else d2d[dx_rows[0]:dx_rows[1]]
-                        dx = torch.empty(a.shape[0], wx.shape[0], dtype=torch.float32, device=st.device)
-                        jobs.append(kernels.dense_job_nt(a, wx, dx))
-                else:
-                    if need_dw:
-                        jobs.append(kernels.dense_job_tn(x[r0:r1], d[:, r0:r1], gw, colsum=gb))
-                    if need_dx:
-                        if self.G != 1:
-                            raise NotImplementedError("input gradient of an unmerged multi-group first layer")
-                        wx = w[0] if need_dx is True else w[0][need_dx[0]:need_dx[1]]
-                        a = d[0] if dx_rows is None else d[0][dx_rows[0]:dx_rows[1]]
-                        dx = torch.empty(a.shape[0], wx.shape[0], dtype=torch.float32, device=st.device)
-                        jobs.append(kernels.dense_job_nt(a, wx, dx))
-            else:
-                if need_dw:
-                    jobs.append(kernels.dense_job_tn(act[i - 1][:, r0:r1], d[:, r0:r1], gw, colsum=gb))
-                jobs.append(kernels.dense_job_nt(d, w, dact[i - 1], mask=act[i - 1]))
-                d = dact[i - 1]
-            if i == 0 and final is not None:
-                # the step's LAST dense launch also carries its deferred reductions and the gradient norm's partial sums:
-                # final = (make_jobs(written) -> extra jobs, norm hook); `written` = gradient tensors this launch writes
-                # (their squares are counted where they are produced)
-                make_jobs, hook = final
-                for jb in jobs:
-                    if jb.kind == kernels.DENSE_TN:
-                        jb.flags |= kernels.DENSE_NORM
-                extra = make_jobs([gw, gb] if need_dw else [])
-                self.norm_partials = kernels.dense_jobs(jobs + extra, norm=hook)
-            elif jobs:
-                kernels.dense_jobs(jobs)
-        return dx
-
-    def forward(self, x, slot=0, params=None, value_head=None, masks=False, pending=None):
+    def forward(self, x, slot=0, params=None, value_head=None, masks=False):
         """x: [B, in], shared by all groups.  Returns act[-1]  [G, B, H_last].
         `slot` selects an activation set (a stack evaluated on several inputs in one step keeps one
         set per input for the backward); `params` = another ParamStore with the same layout (SAC
@@ -360,8 +248,6 @@ class DenseStack:
         buf["x"] = x
         self._last = buf
         act, act2d = buf["act"], buf["act2d"]
-        if self.small(B):
-            return self._forward_small(x, buf, st, value_head, pending)
         for i in range(self.L):
             w, b = st[self.wn[i]], st[self.bn[i]]
             if i == 0 and self.merged0:
@@ -393,8 +279,8 @@ class DenseStack:
                 kernels.value_head_fwd(act[-1][g], vw.view(-1), vb, out=vout)
         return act[-1]
 
-    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, dw_stream=None, deferred=None, value=None,
-                 dw_rows=None, dx_rows=None, premasked=False, final=None):
+    def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, deferred=None, value=None,
+                 dw_rows=None, dx_rows=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output (the stack's own dact[-1] buffer
         or any contiguous tensor); masked in place.
         `deferred` (a list): the bias-gradient column sums are left as per-chunk partials and a reduce job per
@@ -408,32 +294,19 @@ class DenseStack:
         rows; the value loss reaches the critic through the second half, the policy loss only passes through the first
         half to the action).  r0 and r1 must fall on the row chunks of the partial sums.  `dx_rows` = (p0, p1): the
         rows of the input gradient to return.
-        Weight/bias gradients are written into the store's flat gradient buffer (need_dw).
-        `dw_stream`: run the weight-gradient GEMMs (independent of the dX chain) on that stream so they
-        overlap the next layer's dX GEMM; the caller joins the stream before using the gradients."""
+        Weight/bias gradients are written into the store's flat gradient buffer (need_dw).  Everything runs on the
+        current stream (weight-gradient GEMMs on a second stream measured 8 % slower: LAB_NOTEBOOK.md)."""
         if B is None:
             B = dlast.shape[1]
         buf = self._bufs[(B, slot)]
-        if premasked:
-            if not self.small(B) or value is not None or dw_stream is not None:
-                raise ValueError("a pre-masked gradient is the small-row path's input (no folded head, one stream)")
-            return self._backward_small(dlast, buf, B, need_dx, need_dw, dw_rows, dx_rows, final)
-        main = torch.cuda.current_stream() if dw_stream is not None else None
         act, act2d, dact, dact2d, x = buf["act"], buf["act2d"], buf["dact"], buf["dact2d"], buf["x"]
         d, d2d = dlast, dlast.view(self.G * B, -1)
         dx = None
 
-        def on_dw_stream(fn):
-            if dw_stream is None:
-                return fn()
-            dw_stream.wait_stream(main)
-            with torch.cuda.stream(dw_stream):
-                return fn()
-
         if value is not None and (deferred is None or not self._group_rows(self.L - 1, B)):
             raise ValueError("a folded value head needs deferred reductions on a batched last layer")
-        if dw_rows is not None and (deferred is None or dw_stream is not None):
-            raise ValueError("a row subset for the weight gradients needs deferred reductions on one stream")
+        if dw_rows is not None and deferred is None:
+            raise ValueError("a row subset for the weight gradients needs deferred reductions")
         r0, r1 = dw_rows if dw_rows is not None else (0, B)
         rsl = slice(r0, r1)
         for i in reversed(range(self.L)):
@@ -479,14 +352,15 @@ class DenseStack:
                 xt = x[rsl].t()
                 if self.merged0:
                     if need_dw:
-                        on_dw_stream(lambda: torch.mm(xt, d2d[rsl], out=gw))
+                        torch.mm(xt, d2d[rsl], out=gw)
                     if need_dx:
                         # need_dx = (c0, c1): the gradient w.r.t. input columns [c0, c1) only (SAC: the action part)
                         wx = w if need_dx is True else w[need_dx[0]:need_dx[1]]
                         dx = torch.mm(d2d[psl], wx.t())
                 else:
                     if need_dw:
-                        on_dw_stream(lambda: [torch.mm(xt, d[g][rsl], out=gw[g]) for g in range(self.G)])
+                        for g in range(self.G):
+                            torch.mm(xt, d[g][rsl], out=gw[g])
                     if need_dx:
                         rows = slice(None) if need_dx is True else slice(need_dx[0], need_dx[1])
                         dx = torch.mm(d[0][psl], w[0][rows].t())
@@ -494,7 +368,7 @@ class DenseStack:
                             dx.addmm_(d[g][psl], w[g][rows].t())
             else:
                 if need_dw:
-                    on_dw_stream(lambda: torch.bmm(act[i - 1][:, rsl].transpose(1, 2), d[:, rsl], out=gw))
+                    torch.bmm(act[i - 1][:, rsl].transpose(1, 2), d[:, rsl], out=gw)
                 torch.bmm(d, w.transpose(1, 2), out=dact[i - 1])
                 d, d2d = dact[i - 1], dact2d[i - 1]
         return dx

@@ -20,14 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_bench(extra_env=None, ranks=2):
+def run_bench(extra_args=(), ranks=2):
     port = _free_port()
     env = dict(os.environ)
-    env.update({"PFPN_BENCH_WATCHDOG": "200", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-    env.update(extra_env or {})
+    env.update({"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(ranks), "--steps", "8", "--warmup", "2", "--backend", "gloo", "--one-device"]
+           "--gpus", str(ranks), "--steps", "8", "--warmup", "2", "--backend", "gloo", "--one-device",
+           "--watchdog", "200"] + list(extra_args)
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -43,11 +43,12 @@ def test_two_rank_bench_line():
     assert d["rccl"]["ranks_seen"] == 2 and d["rccl"]["world"] == 2
     assert d["weak_scaling"]["value"] > 0 and d["weak_scaling"]["global_batch"] == 8192
     assert d["exchange_sharded"]["value"] > 0
+    assert "two hipGraphs around the RCCL all-reduce" in d["config"]["launch"]        # gloo: the fall-back form of the exchange
     assert "extras_timed_out" not in d
 
 
 def test_headline_survives_a_rank_failing_in_an_extra():
-    d = run_bench({"PFPN_BENCH_EXTRAS_DEADLINE": "30", "PFPN_BENCH_FAIL_EXTRA": "weak_block:1"})
+    d = run_bench(["--extras-deadline", "30", "--fail-extra", "weak_block:1"])
     assert d["extras_timed_out"] is True and d["value"] > 0 and d["n_gpus"] == 2
     assert d["rccl"]["ranks_seen"] == 2                           # the extra before the failing one is kept
     assert "weak_scaling" not in d
@@ -64,8 +65,9 @@ def _errors(o, path=""):
 def test_single_gpu_line_carries_every_block_without_a_swallowed_error():
     """the informational blocks of the line are built under try/except (they must not cost the headline): a block that
     failed says {"error": ...} -- which nobody reads.  Here it is read."""
-    env = dict(os.environ, PFPN_BENCH_WATCHDOG="250")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline"],
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                        "--watchdog", "250"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])

@@ -193,13 +193,17 @@ def _rccl_rank(port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["PFPN_FUSED_NORM"] = "0"             # bitwise comparison: same grouping of the norm's partial sums
+    fused_norm = [False]                            # bitwise comparison: same grouping of the norm's partial sums
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         dist.init_process_group("nccl", rank=0, world_size=1)
-        from pfpn_amd.models import SyncReplicasApplier
+        from pfpn_amd.models import SyncReplicasApplier as _Applier
+
+        def SyncReplicasApplier(*a, **kw):
+            kw.setdefault("fused_norm", fused_norm[0])
+            return _Applier(*a, **kw)
         from test_gpu_dppo_step import make_batch, make_net
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
@@ -259,9 +263,30 @@ def _rccl_rank(port, q):
         ok &= torch.equal(pair[0].store.flat, pair[1].store.flat) and torch.equal(pair[0].store.m, pair[1].store.m)
         ok &= torch.equal(pair[0].state_normalizer.mean, pair[1].state_normalizer.mean)
         ok &= pair[0].global_step == pair[1].global_step == 4
+        # the DEFAULT stepper tries the captured exchange and, when that fails on any replica, falls back to the two-graph
+        # form by itself (agreed through an all-reduce(MAX)): same bits as the eager exchange path
+        from pfpn_amd import graphs
+        fpair = [make_net(dev, seed=12, resample_interval=50) for _ in range(2)]
+        fopt = [SyncReplicasApplier(n, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True)
+                for n in fpair]
+        os.environ.pop("PFPN_GRAPH_EXCHANGE", None)
+        dflt = GraphedLearnerStep(fpair[0], fopt[0], *tin)
+        ok &= dflt.in_graph_exchange and not dflt.split and dflt.exchange_fallback is None      # the default: ONE graph
+        dflt.close()
+        graphs.inject_capture_failure = True
+        fb = GraphedLearnerStep(fpair[0], fopt[0], *tin)
+        graphs.inject_capture_failure = False
+        ok &= fb.split and not fb.in_graph_exchange and "injected" in (fb.exchange_fallback or "")
+        for _ in range(2):
+            fb()
+            fpair[1].train_device(fopt[1], *tin)
+        torch.cuda.synchronize()
+        ok &= torch.equal(fpair[0].store.flat, fpair[1].store.flat) and torch.equal(fpair[0].store.v, fpair[1].store.v)
+        ok &= graphs.release_captured_collectives() >= 2      # (nets[3]'s graph, `multi`): gone before the group is destroyed
+        os.environ["PFPN_GRAPH_EXCHANGE"] = "0"
         nets, opts = nets[:2], opts[:2]
         # with the global norm produced by the reduction launch on both paths: equal to summation-order precision
-        os.environ["PFPN_FUSED_NORM"] = "1"
+        fused_norm[0] = True
         nets = [make_net(dev, seed=10, resample_interval=50) for _ in range(2)]
         opts = [SyncReplicasApplier(nets[0], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True),
                 SyncReplicasApplier(nets[1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)]
@@ -276,7 +301,7 @@ def _rccl_rank(port, q):
             ok &= torch.equal(opts[0].beta_pow, opts[1].beta_pow)
         # SAC on the exchange path: the soft target update rides in the Adam launch of either path (pfpn_adam_groups /
         # pfpn_clip_adam_prenorm `soft_target`) -- applied exactly once, same bits
-        os.environ["PFPN_FUSED_NORM"] = "0"
+        fused_norm[0] = False
         from test_gpu_sac_step import make_net as make_sac
         snets = [make_sac(dev) for _ in range(2)]
         sopts = []

@@ -169,19 +169,19 @@ def test_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
     ONE launch produces the same bits as the step that launches each of them where the reference's graph has them."""
     from pfpn_amd.models import SyncReplicasApplier
     nets, opts = [], []
-    monkeypatch.setenv("PFPN_FUSED_NORM", "0")      # the norm's partial sums group differently when fused: own test below
+    monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
     for i in range(2):
-        monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
-        monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
         nets.append(make_net(dev, seed=5, resample_interval=3))
-        opts.append(SyncReplicasApplier(nets[-1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1))
+        nets[-1].defer_reduce = i == 0
+        # (fused_norm=False: the norm's partial sums group differently when they ride in the reduction launch: own test below)
+        opts.append(SyncReplicasApplier(nets[-1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1,
+                                        fused_norm=False))
     rng = np.random.default_rng(B)
     for it in range(4):
         b = make_batch(rng, B)
         b["log_prob"] = np.full(B, -40.0, F)
         out = []
         for i, (net, opt) in enumerate(zip(nets, opts)):
-            monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
             out.append(net.train(None, opt, ["global_step"], b["state"], b["action"], b["value"], b["log_prob"],
                                  b["advantage"]))
         assert nets[0]._defer_ok[(B, True)] is True and nets[1]._defer_ok[(B, True)] is False
@@ -228,7 +228,7 @@ def test_multi_step_graph_replay_matches_single_steps(dev):
 
 def test_next_prologue_rides_in_the_optimiser_launch(dev, monkeypatch):
     """Inside a K-step capture the optimiser launch of step k carries step k+1's prologue as extra blocks (K - 1 riders, one
-    launch less per step); PFPN_PROLOGUE_RIDER=0 keeps the separate launch.  Same bits either way."""
+    launch less per step); `net.ride_prologue = False` keeps the separate launch.  Same bits either way."""
     from pfpn_amd import kernels
     from pfpn_amd.graphs import GraphedLearnerStep
     from pfpn_amd.models import SyncReplicasApplier
@@ -243,9 +243,9 @@ def test_next_prologue_rides_in_the_optimiser_launch(dev, monkeypatch):
     monkeypatch.setattr(kernels, "clip_adam", lambda *a, **kw: (riders.append(kw.get("rider") is not None), real_adam(*a, **kw))[1])
     monkeypatch.setattr(kernels, "state_prologue", lambda *a, **kw: (plain.append(1), real_pro(*a, **kw))[1])
     finals = []
-    for flag, want_riders in (("1", K - 1), ("0", 0)):
-        monkeypatch.setenv("PFPN_PROLOGUE_RIDER", flag)
+    for flag, want_riders in ((True, K - 1), (False, 0)):
         net = make_net(dev, seed=17, resample_interval=50)
+        net.ride_prologue = flag
         opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
         g = GraphedLearnerStep(net, opt, steps_per_replay=K, input_sets=[tuple(t.clone() for t in s_) for s_ in sets],
                                warmup=1)
@@ -271,9 +271,9 @@ def test_global_norm_from_the_reduction_launch(dev, monkeypatch, B):
     nets, opts = [], []
     monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")
     for i in range(2):
-        monkeypatch.setenv("PFPN_FUSED_NORM", "1" if i == 0 else "0")
         nets.append(make_net(dev, seed=17, resample_interval=3))
-        opts.append(SyncReplicasApplier(nets[-1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1))
+        opts.append(SyncReplicasApplier(nets[-1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1,
+                                        fused_norm=i == 0))
     assert nets[0]._norm_hook is not None and nets[1]._norm_hook is None
     rng = np.random.default_rng(B + 1)
     for it in range(4):

@@ -137,6 +137,74 @@ def test_wide_kernel_config5_full_size_properties(oracle, dev):
     np.testing.assert_allclose(dl[rows].cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * np.abs(r_dl).max())
 
 
+@pytest.mark.parametrize("B,A,N", [(1030, 8, 128), (77, 12, 256), (4099, 4, 512), (517, 128, 256), (9, 16, 64)])
+def test_wide_in_launch_handoffs(oracle, dev, B, A, N):
+    """Round 4: the wide kernels finish their own reductions (no k_row_sum / k_finalize launch).  Forward: a block's four
+    waves add their rows' log p, the last block of a row chunk adds the chunk's blocks in order; backward: the last wave of an
+    action dim adds the C slabs in k_finalize's order.  Checked (a) against the oracle, (b) the backward BITWISE against the
+    slabs of the un-finalised launch summed on the host in that order, (c) over repeated launches on fresh data (the tickets
+    must come back zeroed) with ragged row counts, several float4s per lane and more blocks than CUs."""
+    from pfpn_amd import kernels
+    for it in range(3):
+        logits, x, loc, logstd = make_inputs(oracle, B, A, N, 900 + 7 * it + B, spread=1.0)
+        g = np.random.default_rng(it).normal(0, 1, B).astype(np.float32)
+        d = to_dev(dev, logits, x, loc, logstd, g)
+        ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+        lp = kernels.logprob_fwd(d[0], d[1], d[2], d[3])
+        ok = np.isfinite(ref_lp)
+        assert ok.sum() > B // 2
+        got = lp.cpu().numpy()
+        assert np.array_equal(np.isfinite(got), ok)
+        # (a row's A segment terms are of size ~5-8 each and may cancel: 3e-5 absolute is a few ulps of the terms)
+        np.testing.assert_allclose(got[ok], ref_lp[ok], rtol=RTOL, atol=3e-5)
+        assert torch.equal(lp, kernels.logprob_fwd(d[0], d[1], d[2], d[3]))                # same bits on the next launch
+        o_dl, o_dloc, o_dls = kernels.logprob_bwd(*d)
+        ws = kernels.mixture_workspace(B, A, N, dev)
+        s_dl, _, _ = kernels.logprob_bwd(*d, slabs_ws=ws)                                   # slabs left unreduced
+        assert torch.equal(o_dl, s_dl)
+        nslab, stride = kernels.logprob_bwd_slabs(d[0], s_dl, B, A, N)
+        slabs = ws.view(torch.float32)[:nslab * stride].view(nslab, stride).cpu().numpy()
+        run = np.zeros((16, 2 * A * N), np.float32)
+        for k in range(nslab):
+            run[k % 16] += slabs[k, :2 * A * N]
+        tot = run[0].copy()
+        for r in range(1, 16):
+            tot += run[r]
+        assert np.array_equal(o_dloc.cpu().numpy().reshape(-1), tot[:A * N])
+        assert np.array_equal(o_dls.cpu().numpy().reshape(-1), tot[A * N:])
+        r_dloc, r_dls = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, g)[1:3]
+        for gotp, ref in ((o_dloc, r_dloc), (o_dls, r_dls)):
+            np.testing.assert_allclose(gotp.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * (np.abs(ref).max() + 1e-30))
+
+
+def test_wide_ppo_composition_is_three_launches_into_the_callers_buffers(oracle, dev):
+    """N >= 64: ppo_mixture_fwd_bwd composes forward -> loss head -> backward; every result lands in `out` directly."""
+    from pfpn_amd import kernels
+    B, A, N = 300, 8, 128
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 77, spread=1.0)
+    rng = np.random.default_rng(3)
+    ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+    lp_old = (ref_lp + rng.normal(0, 0.15, B)).astype(np.float32)
+    adv, v, v_old = (rng.normal(0, 1, B).astype(np.float32) for _ in range(3))
+    loss, pl, vl, dlogp, dv = oracle.ppo_loss(ref_lp, lp_old, adv, v, v_old, 0.2, 0.5, normalize_adv=True)
+    r_dl, r_dloc, r_dls, _ = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, dlogp)
+    d = to_dev(dev, logits, x, loc, logstd, lp_old, adv, v, v_old)
+    stats = kernels.adv_stats(d[5])
+    out = {"logp": torch.empty(B, device=dev), "dlogits": torch.empty(B, A * N, device=dev),
+           "dloc": torch.empty(A, N, device=dev), "dlogstd": torch.empty(A, N, device=dev),
+           "dvalue": torch.empty(B, device=dev), "loss3": torch.empty(3, device=dev)}
+    ptrs = {k: t.data_ptr() for k, t in out.items()}
+    res = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5, out=out)
+    assert all(res[k].data_ptr() == ptrs[k] for k in ptrs)
+    np.testing.assert_allclose(out["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(out["loss3"].cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(out["dvalue"].cpu().numpy(), dv, rtol=1e-5, atol=1e-9)
+    sc = np.abs(r_dl).max() + 1e-30
+    np.testing.assert_allclose(out["dlogits"].cpu().numpy().reshape(B, A, N), r_dl, rtol=2e-4, atol=3e-6 * sc)
+    for k, ref in (("dloc", r_dloc), ("dlogstd", r_dls)):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref, rtol=1e-4, atol=5e-5 * (np.abs(ref).max() + 1e-30))
+
+
 def test_stream_pair_placement_changes_no_bits(dev):
     """logits / dlogits of large shapes come out of ONE allocation at a fixed distance (kernels.stream_pair: where the two
     streams of the backward sit relative to each other decides its speed); smaller shapes get two plain

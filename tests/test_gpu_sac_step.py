@@ -144,15 +144,16 @@ def test_sac_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
     from pfpn_amd.models import SyncReplicasApplier
     rng = np.random.default_rng(B)
     nets, opts = [], []
-    monkeypatch.setenv("PFPN_FUSED_NORM", "0")      # compared bit for bit: keep the norm's summation grouping the same
-    monkeypatch.setenv("PFPN_SAC_BATCH_ACTOR", "0")  # ... and the GEMMs' row counts (the deferred step would run the actor
-    monkeypatch.setenv("PFPN_SAC_BATCH_CRITIC", "0")  # and the live critic once over 2B rows: own test below)
-    for _ in range(2):
+    for i in range(2):
         net = make_net(dev)
+        # compared bit for bit: the same grouping of the norm's partial sums (fused_norm=False) and the same GEMM row counts
+        # (the deferred step would run the actor and the live critic once over 2B rows: own test below)
+        net.batch_actor = net.batch_critic = False
+        net.defer_reduce = i == 0
         nets.append(net)
         opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
                                               {"names": net.actor_param_names(), "lr": 1e-4}],
-                                        norm_clip=1.0, world_size=1))
+                                        norm_clip=1.0, world_size=1, fused_norm=False))
     for it in range(3):
         batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
                                                        rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
@@ -162,7 +163,6 @@ def test_sac_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
         noise = nets[0].make_train_noise(B)
         losses = []
         for i, (net, opt) in enumerate(zip(nets, opts)):
-            monkeypatch.setenv("PFPN_DEFER_REDUCE", "1" if i == 0 else "0")
             losses.append(net.compute_gradients(*batch, {k: t.clone() for k, t in noise.items()}).clone())
             assert net._defer_ok[B] is (i == 0)
             g = net.store.grad.clone()
@@ -186,9 +186,8 @@ def test_sac_one_pass_over_both_batches_matches_two_passes(dev, monkeypatch, B):
     rng = np.random.default_rng(B + 7)
     nets, opts = [], []
     for i in range(2):
-        monkeypatch.setenv("PFPN_SAC_BATCH_ACTOR", "1" if i == 0 else "0")
-        monkeypatch.setenv("PFPN_SAC_BATCH_CRITIC", "1" if i == 0 else "0")
         net = make_net(dev)
+        net.batch_actor = net.batch_critic = i == 0
         nets.append(net)
         opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
                                               {"names": net.actor_param_names(), "lr": 1e-4}],

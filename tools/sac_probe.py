@@ -30,9 +30,8 @@ for B in (256, 1024, 4096):
 from pfpn_amd.graphs import GraphedLearnerStep
 for B in (256, 1024, 4096):
   for both in ("0", "1", "0", "1"):
-    os.environ["PFPN_SAC_BATCH_ACTOR"] = both       # 1: the actor evaluated once over [s; s'] (2B rows)
-    os.environ["PFPN_SAC_BATCH_CRITIC"] = both      # 1: the live critic once over [(s, a_pi); (s, action_hist)]
     net = make_net(dev)
+    net.batch_actor = net.batch_critic = both == "1"   # the actor once over [s; s'], the live critic once over [(s, a_pi); (s, a_hist)]
     opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4}, {"names": net.actor_param_names(), "lr": 1e-4}],
                               norm_clip=1.0, world_size=1)
     rng = np.random.default_rng(1)

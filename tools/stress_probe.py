@@ -24,10 +24,20 @@ def timeit(f, n=10):
 L, X, V, P = 4 * B * A * N, 4 * B * A, 4 * B, 8 * A * N
 t_f = timeit(lambda: kernels.logprob_fwd(logits, x, loc, logstd))
 t_b = timeit(lambda: kernels.logprob_bwd(logits, x, loc, logstd, dl, out=bw_out))
-cp = torch.empty_like(logits)
-t_c = timeit(lambda: cp.copy_(logits))
+# the PPO composition at this shape: forward -> loss head -> backward into the caller's buffers (3L)
+lp_old = kernels.logprob_fwd(logits, x, loc, logstd).clone()
+stats = kernels.adv_stats(dl)
+zv = torch.zeros(B, device=dev)
+p_out = dict(bw_out, logp=torch.empty(B, device=dev), dvalue=torch.empty(B, device=dev), loss3=torch.empty(3, device=dev))
+t_p = timeit(lambda: kernels.ppo_mixture_fwd_bwd(logits, x, loc, logstd, lp_old, dl, zv, zv, stats, out=p_out))
+if os.environ.get("STRESS_COPY", "1") != "0":
+    cp = torch.empty_like(logits)
+    t_c = timeit(lambda: cp.copy_(logits))
+else:
+    t_c = float("nan")
 out = {"shape": [B, A, N],
        "fwd": {"us": t_f, "bytes": L + X + V + P, "GBps": (L + X + V + P) / t_f / 1e3, "frac_of_8TBps": (L + X + V + P) / t_f / 1e3 / 8000},
        "bwd": {"us": t_b, "bytes": 2 * L + X + 2 * V + 2 * P, "GBps": (2 * L + X + 2 * V + 2 * P) / t_b / 1e3, "frac_of_8TBps": (2 * L + X + 2 * V + 2 * P) / t_b / 1e3 / 8000},
+       "ppo": {"us": t_p, "bytes": 3 * L + 2 * X + 8 * V + 3 * P, "frac_of_8TBps": (3 * L + 2 * X + 8 * V + 3 * P) / t_p / 1e3 / 8000},
        "torch_copy": {"us": t_c, "GBps": 2 * L / t_c / 1e3}}
 print(json.dumps(out))

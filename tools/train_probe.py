@@ -26,8 +26,8 @@ for B in (32, 256, 4096):
 # the reference schedule: one worker's 512-step unroll, 16 minibatches of 32 (deepmimic_dppo_base.py:6-12)
 os.environ["PFPN_GRAPH_TRAIN"] = "1"
 for n, bs, rnd in ((512, 32, "1"), (512, 32, "0"), (4096, 256, "1"), (4096, 256, "0")):
-    os.environ["PFPN_GRAPH_ROUND"] = rnd            # 1: eight minibatch steps per graph replay, 0: one
     net = make_net(dev, seed=1, resample_interval=10 ** 9)
+    net.ROUND_STEPS_PER_REPLAY = 8 if rnd == "1" else 10 ** 9      # 8 minibatch steps per graph replay / one-step replays only
     opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
     b = make_batch(rng, n); b["log_prob"] = np.full(n, -40.0, np.float32)
     cols = {k: b[k] for k in names}
