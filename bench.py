@@ -490,6 +490,32 @@ def main():
         stats = net.adv_stats
         reps = 200
 
+        def time_in_graph(call, per_graph=20, replays=5):
+            """device time per call: `per_graph` calls captured in one hipGraph, replayed between two HIP events on the replay
+            stream (eager back-to-back calls measure the host: a Python wrapper call costs more than most kernels here)"""
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            side_ = torch.cuda.Stream()
+            side_.wait_stream(torch.cuda.current_stream())
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side_):
+                call()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g_, stream=side_):
+                    for _ in range(per_graph):
+                        call()
+            torch.cuda.synchronize()
+            g_.replay()
+            torch.cuda.synchronize()
+            ea_, eb_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea_.record()
+            for _ in range(replays):
+                g_.replay()
+            eb_.record()
+            torch.cuda.synchronize()
+            return ea_.elapsed_time(eb_) * 1e3 / (per_graph * replays)
+
         def time_fused(finalize):
             """device time per launch: 20 launches captured in one hipGraph and replayed 10 times between two HIP events on
             the replay stream.  (Eager back-to-back launches measure the HOST: one call of the Python wrapper costs
@@ -663,7 +689,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 u = e0.elapsed_time(e1) * 1e3 / 30
-                res[name] = {"kernel": "k_mix_wide<1,%s> (+reduce)" % name.upper(), "us_per_launch": u,
+                res[name] = {"kernel": "k_mix_wide<1,%s> (its reduction inside the launch)" % name.upper(), "us_per_launch": u,
                              "algorithmic_bytes": nbytes, "achieved": nbytes / u / 1e3, "unit": "GB/s",
                              "peak": HBM_PEAK_GBS, "frac": nbytes / u / 1e3 / HBM_PEAK_GBS}
             # the PPO composition at this shape: forward -> loss head on [B] -> backward (3L: the row log-prob couples
@@ -687,7 +713,7 @@ def main():
             torch.cuda.synchronize()
             u = e0.elapsed_time(e1) * 1e3 / 10
             nb = 3 * L_ + 2 * X_ + 8 * V_ + 3 * P_
-            res["ppo"] = {"kernel": "k_mix_wide<FWD> + k_row_sum + k_ppo_loss + k_mix_wide<BWD> (+reduce)",
+            res["ppo"] = {"kernel": "k_mix_wide<FWD> + k_ppo_loss + k_mix_wide<BWD> (three launches, results in the caller's buffers)",
                           "us_per_launch": u, "algorithmic_bytes": nb, "achieved": nb / u / 1e3, "unit": "GB/s",
                           "peak": HBM_PEAK_GBS, "frac": nb / u / 1e3 / HBM_PEAK_GBS,
                           "note": "3L composition; a fused 2L pass needs a row (128 KiB) AND the [A,N] bank (393 KB) on one CU"}
@@ -846,40 +872,77 @@ def main():
                                                "that scales" % bucket_mb}
             except Exception as e:
                 out["strong_shard"] = {"error": repr(e)}
-        # ---- sac_step: BASELINE.json config 3 (SAC-PFPN, replay batch 1024) as one hipGraph; a parity config, timed here
-        # so its rate is bench evidence and not prose
+        # ---- sac_step: BASELINE.json config 3 (SAC-PFPN, replay batch 1024; 256 = the reference's own batch,
+        # settings/deepmimic/deepmimic_sac_base.py:4-12) as one hipGraph; parity configs, timed here so their rates and
+        # rooflines are bench evidence and not prose
         if extras:
             try:
                 from pfpn_amd.networks import ParticleFilteringSACNetwork
                 sopts = dict(NET_OPTS, normalize_advantage=False, resample_interval=12000)
-                snet = ParticleFilteringSACNetwork(trainable=True, state_shape=[S], action_shape=[A],
-                                                   action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
-                                                   device=dev, seed=SEED, **sopts)
-                snet.init()
-                for op in snet.init_ops:
-                    op()
-                sopt = SyncReplicasApplier(snet, [{"names": snet.critic_param_names(), "lr": 1e-4},
-                                                  {"names": snet.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
-                srng, SB = np.random.default_rng(SEED + 3), 1024
-                sb = [torch.from_numpy(a).to(dev) for a in (
-                    (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32), np.tanh(srng.normal(0, 1, (SB, A))).astype(np.float32),
-                    srng.random(SB).astype(np.float32), (srng.random(SB) < 0.98).astype(np.float32),
-                    (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32))]
-                sstep = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB))
-                for _ in range(10):
-                    sstep()
-                torch.cuda.synchronize()
-                t_s = time.perf_counter()
-                for _ in range(100):
-                    sstep()
-                torch.cuda.synchronize()
-                sms = (time.perf_counter() - t_s) / 100 * 1e3
-                sl3 = sstep.loss3.cpu().numpy()
-                out["sac_step"] = {"workload": "DeepMimicKick-v0 SAC-PFPN 35 particles, replay batch 1024 (BASELINE.json "
-                                               "config 3), synthetic replay rows", "steps_per_s": 1e3 / sms, "ms_per_step": sms,
-                                   "launch": "hipGraph, reparameterisation draws refilled outside the graph",
-                                   "finite_loss": bool(np.all(np.isfinite(sl3)))}
-                del snet, sopt, sstep
+                AN_ = A * NP
+                # multiply-accumulates per replay row (MLP 1024 / 512): the actor runs forward over [s; s'] (2 rows per replay
+                # row) and backward over s; the twin live critics forward over [(s, a_pi); (s, a_hist)], the twin targets over
+                # (s', a'); the live critics' dX chain over both halves (first layer: the 36 action columns of the policy half
+                # only), their dW from the value-loss half
+                a_f, a_dw, a_dx = dense_macs(S, (1024, 512), AN_)
+                q_f, q_dw, q_dx = dense_macs(S + A, (1024, 512), 1)
+                sac_mac = 2 * a_f + (a_dw + a_dx) + 2 * (3 * q_f) + 2 * (2 * q_dx + A * 1024 + q_dw)
+                sac = {}
+                for SB in (1024, 256):
+                    snet = ParticleFilteringSACNetwork(trainable=True, state_shape=[S], action_shape=[A],
+                                                       action_lower_bound=-np.ones(A), action_upper_bound=np.ones(A),
+                                                       device=dev, seed=SEED, **sopts)
+                    snet.init()
+                    for op in snet.init_ops:
+                        op()
+                    sopt = SyncReplicasApplier(snet, [{"names": snet.critic_param_names(), "lr": 1e-4},
+                                                      {"names": snet.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+                    srng = np.random.default_rng(SEED + 3)
+                    sb = [torch.from_numpy(a_).to(dev) for a_ in (
+                        (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32), np.tanh(srng.normal(0, 1, (SB, A))).astype(np.float32),
+                        srng.random(SB).astype(np.float32), (srng.random(SB) < 0.98).astype(np.float32),
+                        (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32))]
+                    sstep = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB), debug_nodes=True)
+                    for _ in range(10):
+                        sstep()
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    for _ in range(100):
+                        sstep()
+                    torch.cuda.synchronize()
+                    sms = (time.perf_counter() - t_s) / 100 * 1e3
+                    sl3 = sstep.loss3.cpu().numpy()
+                    sflops = 2.0 * SB * sac_mac
+                    # the step's HBM-bound hand-written kernels on their own (launches replayed from a hipGraph): the
+                    # reparameterised sample over the 2B rows [s; s'] (reads logits, Gumbel, normal draws: 3L) and its backward
+                    # over B rows (reads the same three, adds into dlogits: 3L + 2L)
+                    Ls = 4 * SB * AN_
+                    nz_ = sstep.noise["_buf"]
+                    us_rf = time_in_graph(lambda: kernels.rsample_fwd(snet.logits_both, snet.loc, snet.logstd,
+                                                                      nz_[0:2].view(2 * SB, -1), nz_[2:4].view(2 * SB, -1)))
+                    da_ = torch.zeros(SB, A, device=dev)
+                    us_rb = time_in_graph(lambda: kernels.rsample_bwd(snet.logits, snet.loc, snet.logstd, nz_[0], nz_[2], da_, da_,
+                                                                      snet.dlogits, snet.store.g("actor/samples"),
+                                                                      snet.store.g("actor/samples_std")))
+                    sac[SB] = {"steps_per_s": 1e3 / sms, "ms_per_step": sms, "finite_loss": bool(np.all(np.isfinite(sl3))),
+                               "roofline": {"bound": "mfma", "gemm_flops": sflops, "achieved": sflops / (sms * 1e-3) / 1e12,
+                                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                            "launches_per_step": sstep.kernel_nodes(),
+                                            "launches_source": "kernel nodes of the captured hipGraph (+ 1 eager launch: the noise "
+                                                               "draw before each replay)",
+                                            "note": "frac = the step's GEMM flops / its WHOLE time / the fp32 MFMA peak: a step of ~%d "
+                                                    "launches at ~5 us each is launch-bound, not MFMA-bound, at these row counts"
+                                                    % ((sstep.kernel_nodes() or 37) + 1),
+                                            "hbm_kernels": {
+                                                "k_rsample_fwd_quad (2B rows)": {"us": us_rf, "algorithmic_bytes": 6 * Ls,
+                                                                                 "frac": 6 * Ls / us_rf / 1e3 / HBM_PEAK_GBS},
+                                                "k_rsample_bwd_quad + k_rsample_param_partial": {
+                                                    "us": us_rb, "algorithmic_bytes": 5 * Ls, "frac": 5 * Ls / us_rb / 1e3 / HBM_PEAK_GBS}}}}
+                    del snet, sopt, sstep
+                out["sac_step"] = dict(sac[1024], workload="DeepMimicKick-v0 SAC-PFPN 35 particles, replay batch 1024 (BASELINE.json "
+                                                            "config 3), synthetic replay rows",
+                                       launch="hipGraph, reparameterisation draws refilled outside the graph",
+                                       batch_256=sac[256])
             except Exception as e:
                 out["sac_step"] = {"error": repr(e)}
         # ---- config5_step: BASELINE.json config 5 as a learner step on ONE GPU's shard (8192 rows over 8 GPUs = 1024 rows
@@ -907,7 +970,7 @@ def main():
                 torch.cuda.synchronize()
                 claunch = "hipGraph"
                 try:
-                    cstep = graphs.GraphedLearnerStep(cnet, copt, *[t.clone() for t in cargs])
+                    cstep = graphs.GraphedLearnerStep(cnet, copt, *[t.clone() for t in cargs], debug_nodes=True)
                 except Exception:                       # (capture refused: time the eager launches)
                     claunch, cstep = "eager", (lambda: cnet.train_device(copt, *cargs))
                 for _ in range(3):
@@ -921,11 +984,31 @@ def main():
                 cl3 = cnet.train_out["loss3"].cpu().numpy()
                 mac = S * 2048 + 2 * 1024 * 512 + 512 * cA * cN
                 flops = 2.0 * cB * (mac + S * 2048 + 2 * 2 * 1024 * 512 + 2 * 512 * cA * cN)
+                # the step's HBM-bound kernels on their own at this shard's shape (128 MiB of logits: inside the infinity cache)
+                cL, cX, cV, cP = 4 * cB * cA * cN, 4 * cB * cA, 4 * cB, 8 * cA * cN
+                us_cf = time_in_graph(lambda: kernels.logprob_fwd(cnet.logits, ct["action"], cnet.loc, cnet.logstd,
+                                                                  out=cnet.train_out["logp"]), per_graph=10)
+                cdl = torch.randn(cB, device=dev)
+                us_cb = time_in_graph(lambda: kernels.logprob_bwd(cnet.logits, ct["action"], cnet.loc, cnet.logstd, cdl,
+                                                                  out=cnet.train_out), per_graph=10)
                 out["config5_step"] = {"workload": "128 action dims x 256 particles, %d rows (one GPU's shard of the 8192-row "
                                                    "batch over 8 GPUs), head 512 -> 32768" % cB,
                                        "ms_per_step": cms, "steps_per_s": 1e3 / cms, "launch": claunch, "gemm_flops": flops,
-                                       "gemm_tflops_if_all_time_were_gemm": flops / (cms * 1e-3) / 1e12,
-                                       "finite_loss": bool(np.all(np.isfinite(cl3)))}
+                                       "finite_loss": bool(np.all(np.isfinite(cl3))),
+                                       "roofline": {"bound": "mfma", "gemm_flops": flops, "achieved": flops / (cms * 1e-3) / 1e12,
+                                                    "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                                    "frac": flops / (cms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                                    "launches_per_step": cstep.kernel_nodes() if claunch == "hipGraph" else None,
+                                                    "note": "frac = the step's GEMM flops / its WHOLE time / the fp32 MFMA peak",
+                                                    "hbm_kernels": {
+                                                        "k_mix_wide<FWD> (row sums inside)": {
+                                                            "us": us_cf, "algorithmic_bytes": cL + cX + cV + cP,
+                                                            "frac": (cL + cX + cV + cP) / us_cf / 1e3 / HBM_PEAK_GBS},
+                                                        "k_mix_wide<BWD> (slab sums inside)": {
+                                                            "us": us_cb, "algorithmic_bytes": 2 * cL + cX + 2 * cV + 2 * cP,
+                                                            "frac": (2 * cL + cX + 2 * cV + 2 * cP) / us_cb / 1e3 / HBM_PEAK_GBS},
+                                                        "note": "128 MiB of logits fit the 256 MiB infinity cache: a fraction above "
+                                                                "the HBM figure of the 1 GiB shape is cache, not HBM"}}}
                 del cnet, copt
             except Exception as e:
                 out["config5_step"] = {"error": repr(e)}

@@ -66,7 +66,7 @@ class GraphedLearnerStep(object):
     runs after the replay, so a K-step replay is only legal while no resample falls inside it: `can_replay()`."""
 
     def __init__(self, net, optimizer, *inputs, warmup=3, noise=None, steps_per_replay=1, input_sets=None,
-                 gather_from=None, capture_exchange=None):
+                 gather_from=None, capture_exchange=None, debug_nodes=False):
         """`gather_from` = (columns, rows [K, B] int64, losses [K, 3]), all static device tensors: step k of a replay
         first gathers rows[k] of the staged rollout `columns` into its input set (the minibatch slicing of a training
         round, inside the graph) and leaves its loss3 in losses[k].
@@ -75,6 +75,7 @@ class GraphedLearnerStep(object):
         enqueued collective.  The default falls back to the two-graph form by itself (see below); an explicit True raises."""
         self.net, self.opt = net, optimizer
         self.gather_from = gather_from
+        self.debug_nodes = bool(debug_nodes)               # keep the graph's node list (kernel_nodes(): launches per replay)
         # Data parallel, two forms.  DEFAULT over RCCL (round 4; measured on a world-size-1 group: 134 us per 512-row step
         # against 150, bench.py `strong_shard`): the bucket all-reduce is captured INSIDE the step's graph -- RCCL's kernels
         # are captured like any other once the communicator exists (one tiny eager all-reduce below, which every replica
@@ -166,6 +167,8 @@ class GraphedLearnerStep(object):
         for t, sv in zip(self._state_tensors(), saved):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
+        if self.debug_nodes:
+            self.graph.enable_debug_mode()
         self.graph_post = None
         if self.in_graph_exchange:
             _with_collectives.add(self)
@@ -200,6 +203,23 @@ class GraphedLearnerStep(object):
             with torch.cuda.graph(self.graph_post, stream=s):
                 optimizer.post_reduce(net)
         # capture does not execute; state is untouched
+
+    def kernel_nodes(self):
+        """kernel launches per replay of the main graph, counted in the runtime's own dump of the captured graph
+        (`debug_nodes=True` at construction); None where the runtime cannot print it"""
+        if not self.debug_nodes:
+            raise ValueError("construct the stepper with debug_nodes=True")
+        import re
+        import tempfile
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "graph.dot")
+                self.graph.debug_dump(path)
+                txt = open(path).read()
+            n = len(re.findall(r"label=\"[^\"]*(?:KERNEL|kernel)", txt))
+            return n or None
+        except Exception:
+            return None
 
     def close(self):
         """destroy the captured graphs (before the process group they hold collectives of goes away)"""
