@@ -902,15 +902,19 @@ def main():
                         (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32), np.tanh(srng.normal(0, 1, (SB, A))).astype(np.float32),
                         srng.random(SB).astype(np.float32), (srng.random(SB) < 0.98).astype(np.float32),
                         (srng.normal(0, 1, (SB, S)) * 2 + 0.3).astype(np.float32))]
-                    sstep = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB), debug_nodes=True)
-                    for _ in range(10):
+                    SK = max(1, args.steps_per_graph)      # learner steps per replay, like the headline
+                    sstep = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB), debug_nodes=True,
+                                                      steps_per_replay=SK)
+                    for _ in range(4):
                         sstep()
                     torch.cuda.synchronize()
                     t_s = time.perf_counter()
-                    for _ in range(100):
+                    for _ in range(25):
                         sstep()
                     torch.cuda.synchronize()
-                    sms = (time.perf_counter() - t_s) / 100 * 1e3
+                    sms = (time.perf_counter() - t_s) / (25 * SK) * 1e3
+                    s_nodes = sstep.kernel_nodes()
+                    s_launches = (s_nodes / SK) if s_nodes else None
                     sl3 = sstep.loss3.cpu().numpy()
                     sflops = 2.0 * SB * sac_mac
                     # the step's HBM-bound hand-written kernels on their own (launches replayed from a hipGraph): the
@@ -927,12 +931,13 @@ def main():
                     sac[SB] = {"steps_per_s": 1e3 / sms, "ms_per_step": sms, "finite_loss": bool(np.all(np.isfinite(sl3))),
                                "roofline": {"bound": "mfma", "gemm_flops": sflops, "achieved": sflops / (sms * 1e-3) / 1e12,
                                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                                            "launches_per_step": sstep.kernel_nodes(),
-                                            "launches_source": "kernel nodes of the captured hipGraph (+ 1 eager launch: the noise "
-                                                               "draw before each replay)",
+                                            "launches_per_step": s_launches,
+                                            "launches_source": "kernel nodes of the captured %d-step hipGraph / %d (the noise draw "
+                                                               "and the next step's prologue ride in the optimiser launch: %s)"
+                                                               % (SK, SK, sstep.noise_in_graph),
                                             "note": "frac = the step's GEMM flops / its WHOLE time / the fp32 MFMA peak: a step of ~%d "
                                                     "launches at ~5 us each is launch-bound, not MFMA-bound, at these row counts"
-                                                    % ((sstep.kernel_nodes() or 37) + 1),
+                                                    % round(s_launches or 36),
                                             "hbm_kernels": {
                                                 "k_rsample_fwd_quad (2B rows)": {"us": us_rf, "algorithmic_bytes": 6 * Ls,
                                                                                  "frac": 6 * Ls / us_rf / 1e3 / HBM_PEAK_GBS},
@@ -941,7 +946,7 @@ def main():
                     del snet, sopt, sstep
                 out["sac_step"] = dict(sac[1024], workload="DeepMimicKick-v0 SAC-PFPN 35 particles, replay batch 1024 (BASELINE.json "
                                                             "config 3), synthetic replay rows",
-                                       launch="hipGraph, reparameterisation draws refilled outside the graph",
+                                       launch="hipGraph, %d learner steps per replay, noise drawn inside the graph" % SK,
                                        batch_256=sac[256])
             except Exception as e:
                 out["sac_step"] = {"error": repr(e)}

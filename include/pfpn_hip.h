@@ -127,7 +127,9 @@ int pfpn_sac_noise_from_uniform(float* u, size_t n, void* stream);
 /* The same four tensors drawn on the device in one launch: element i of buf [4][n] takes its four uniforms from the
  * Philox4x32-10 block {counter = (i, offset), key = seed} (the role of tf.random.uniform / tf.random.normal behind
  * utils.py:156-161; the stream itself cannot match TensorFlow's and is the caller's to choose: a new `offset` per step). */
-int pfpn_sac_noise_fill(float* buf, size_t n, uint64_t seed, uint64_t offset, void* stream);
+int pfpn_sac_noise_fill(float* buf, size_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream);
+/* (offset_dev != NULL: the offset is read from device memory when the launch RUNS, so a captured launch draws fresh noise
+ * on every replay) */
 
 /* SAC reparameterised sample (K4) -- utils.py:156-186.  gumbel [B,A*N] = -log(-log u), eps [B,A*N]:
  * k = argmax(logits+gumbel), s_out = p_k = loc+exp(logstd)*eps, a_out = tanh(p_k).
@@ -294,12 +296,23 @@ typedef struct {
     float* adv_stats;        /* [4] or NULL */
     void* workspace;         /* pfpn_learner_workspace_bytes(B, S): the float64 column moments */
     size_t workspace_bytes;
+    /* SAC (sac.py:141-153): a second batch normalised with the same moments (the next states) */
+    const float* s2;         /* [B,S] or NULL */
+    float* x2;               /* [B,S] or NULL */
+    /* SAC: the NEXT step's four noise tensors drawn by extra blocks of the same launch (as pfpn_sac_noise_fill with
+     * offset_dev = noise_epoch); NULL: none.  `s` may then be NULL (noise only: the last step of a captured replay). */
+    float* noise;            /* [4][noise_n] or NULL */
+    size_t noise_n;
+    uint64_t noise_seed;
+    const uint64_t* noise_epoch;
 } PfpnStatePrologue;
+/* soft_target != NULL: the SAC soft target update of the parameters just written, as in pfpn_clip_adam_prenorm. */
 int pfpn_clip_adam_prenorm_prologue(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                                     const long long* group_off, const long long* group_len, const float* group_lr,
                                     float beta1, float beta2, float eps, const float* beta_pow, float clip_norm,
                                     float* norm_scale, float* step_counter, const float* sq_partial, int n_partials,
-                                    const PfpnStatePrologue* next, void* stream);
+                                    const PfpnStatePrologue* next, float* soft_target, long long soft_off,
+                                    long long soft_len, float soft_tau, void* stream);
 int pfpn_clip_adam_prenorm(float* params, const float* grads, float* m, float* v, size_t n, int n_groups,
                            const long long* group_off, const long long* group_len, const float* group_lr, float beta1,
                            float beta2, float eps, const float* beta_pow, float clip_norm, float* norm_scale,
@@ -385,7 +398,9 @@ int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size
 int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, const float* logp, const float* logp_t,
                   const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
                   float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
-                  float* dlog_alpha, float* loss3, int q_ld, void* stream);
+                  float* dlog_alpha, float* loss3, int q_ld, uint64_t* noise_epoch, void* stream);
+/* (noise_epoch, optional: a device counter this launch advances by one -- the offset the step's NEXT noise draw reads,
+ * pfpn_sac_noise_fill(offset_dev) / PfpnStatePrologue.noise_epoch; its readers run in other launches) */
 /* The three critic inputs of a SAC step in one launch -- sac.py:108-121 (tf.concat([state, action], -1) for Q(s, a_pi),
  * Q(s, action_hist) and the target Q'(s', a')): x, x_next [B,S] normalised states, a_* [B,A]; outputs [B,S+A]. */
 int pfpn_sac_q_inputs(const float* x, const float* x_next, const float* a_pi, const float* a_hist, const float* a_next,

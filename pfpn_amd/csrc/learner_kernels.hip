@@ -805,11 +805,18 @@ __global__ __launch_bounds__(256) void k_clip_adam(float* __restrict__ p, const 
 // batch.  The two touch disjoint data (the prologue reads the normaliser statistics the reduction launch BEFORE this one
 // updated, and writes buffers -- normalised state, moment workspace, advantage moments -- whose last readers of step k ran
 // before that launch too), so one launch less per step in a single chain of kernels.
+// SAC (round 4): the rider may also carry a second batch for the prologue (the next states, normalised with the same
+// moments), the soft target update rides in the optimiser part as in k_clip_adam, and a third block role draws the NEXT
+// step's four noise tensors (sac_noise_element; the offset is the step's device-resident draw counter, which this step's
+// loss head advanced in an earlier launch: no reader races its writer).  pro_blocks = 0: noise only (the last step of a replay).
 struct PrologueRider {
     const float* s; const float* mean; const float* std;
     int B, S, chunk_len, C, gx;
     float clip;
     float* x; double* partial; const float* adv; int normalize_adv; float* adv_stats;
+    const float* s2; float* x2;
+    unsigned pro_blocks;
+    float* noise; size_t noise_n; unsigned long long noise_seed; const unsigned long long* noise_epoch; unsigned noise_blocks;
 };
 __global__ __launch_bounds__(256) void k_clip_adam_prologue(float* __restrict__ p, const float* __restrict__ g,
                                                             float* __restrict__ m, float* __restrict__ v, AdamGroups gr,
@@ -817,14 +824,21 @@ __global__ __launch_bounds__(256) void k_clip_adam_prologue(float* __restrict__ 
                                                             const float* __restrict__ beta_pow,
                                                             const float* __restrict__ partial, int nblk, float clip_norm,
                                                             float* __restrict__ norm_scale, float* __restrict__ step,
-                                                            unsigned adam_blocks, PrologueRider r) {
+                                                            unsigned adam_blocks, PrologueRider r,
+                                                            float* __restrict__ soft_t, size_t soft_o4, size_t soft_n4,
+                                                            float tau) {
     if (blockIdx.x < adam_blocks) {
         clip_adam_block(p, g, m, v, gr, b1, b2, eps, beta_pow, partial, nblk, clip_norm, 1.0f, norm_scale, step, nullptr, 0,
-                        1.f, nullptr, 0, 0, 0.f, blockIdx.x, adam_blocks);
-    } else {
+                        1.f, soft_t, soft_o4, soft_n4, tau, blockIdx.x, adam_blocks);
+    } else if (blockIdx.x < adam_blocks + r.pro_blocks) {
         const int lin = (int)(blockIdx.x - adam_blocks);
         state_prologue_block(r.s, r.mean, r.std, r.B, r.S, r.chunk_len, r.C, r.clip, r.x, r.partial, r.adv, r.normalize_adv,
-                             r.adv_stats, nullptr, nullptr, lin % r.gx, lin / r.gx);
+                             r.adv_stats, r.s2, r.x2, lin % r.gx, lin / r.gx);
+    } else {
+        const unsigned long long offset = r.noise_epoch[0];
+        const size_t first = (size_t)(blockIdx.x - adam_blocks - r.pro_blocks) * blockDim.x + threadIdx.x;
+        for (size_t i = first; i < r.noise_n; i += (size_t)r.noise_blocks * blockDim.x)
+            sac_noise_element(r.noise, r.noise_n, i, r.noise_seed, offset);
     }
 }
 
@@ -974,9 +988,11 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
     const float* __restrict__ not_terminal, const float* __restrict__ log_alpha, int B, float gamma,
     float value_coef, float target_entropy,
     float* __restrict__ dq_pi, float* __restrict__ dq_run, float* __restrict__ dlogp,
-    float* __restrict__ dlog_alpha, float* __restrict__ loss3, int ld)      // ld: row stride of q_pi, q_run, dq_pi, dq_run
+    float* __restrict__ dlog_alpha, float* __restrict__ loss3, int ld,      // ld: row stride of q_pi, q_run, dq_pi, dq_run
+    unsigned long long* __restrict__ noise_epoch)   // the step's draw counter: += 1 (its readers sit in other launches)
 {
     __shared__ float red[16];
+    if (noise_epoch && threadIdx.x == 0) noise_epoch[0] += 1ull;
     const float la = log_alpha[0];
     const float alpha = expf(la);
     const float inv_B = 1.0f / (float)B;
@@ -1823,15 +1839,24 @@ int pfpn_clip_adam_prenorm_prologue(float* params, const float* grads, float* m,
                                     const long long* group_off, const long long* group_len, const float* group_lr,
                                     float beta1, float beta2, float eps, const float* beta_pow, float clip_norm,
                                     float* norm_scale, float* step_counter, const float* sq_partial, int n_partials,
-                                    const PfpnStatePrologue* next, void* stream) {
+                                    const PfpnStatePrologue* next, float* soft_target, long long soft_off,
+                                    long long soft_len, float soft_tau, void* stream) {
     PFPN_BEGIN();
     if (!params || !grads || !m || !v || !beta_pow || !group_off || !group_len || !group_lr || !sq_partial || n < 1 ||
         n_groups < 1 || n_groups > 4 || n_partials < 1 || !next)
         return PFPN_ERR_ARG;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15) return PFPN_ERR_ARG;
-    if (!next->s || !next->mean || !next->std || !next->x || next->B < 1 || next->S < 1 || (next->adv_stats && !next->adv))
+    if (soft_target && (soft_off < 0 || soft_len < 0 || (soft_off & 3) || (soft_len & 3) ||
+                        (size_t)(soft_off + soft_len) > n || ((uintptr_t)soft_target & 15)))
         return PFPN_ERR_ARG;
-    if (!next->workspace || next->workspace_bytes < pfpn_learner_workspace_bytes(next->B, next->S)) return PFPN_ERR_WORKSPACE;
+    const bool has_pro = next->s != nullptr, has_noise = next->noise != nullptr;
+    if (!has_pro && !has_noise) return PFPN_ERR_ARG;
+    if (has_pro && (!next->mean || !next->std || !next->x || next->B < 1 || next->S < 1 || (next->adv_stats && !next->adv) ||
+                    ((next->s2 != nullptr) != (next->x2 != nullptr))))
+        return PFPN_ERR_ARG;
+    if (has_pro && (!next->workspace || next->workspace_bytes < pfpn_learner_workspace_bytes(next->B, next->S)))
+        return PFPN_ERR_WORKSPACE;
+    if (has_noise && (!next->noise_epoch || next->noise_n < 1)) return PFPN_ERR_ARG;
     AdamGroups gr{};
     gr.n = n_groups;
     size_t longest = 0;
@@ -1843,17 +1868,26 @@ int pfpn_clip_adam_prenorm_prologue(float* params, const float* grads, float* m,
         if ((size_t)group_len[k] > longest) longest = (size_t)group_len[k];
     }
     PrologueRider r{};
-    r.s = next->s; r.mean = next->mean; r.std = next->std; r.B = next->B; r.S = next->S; r.clip = next->clip;
-    r.x = next->x; r.partial = (double*)next->workspace; r.adv = next->adv; r.normalize_adv = next->normalize_adv;
-    r.adv_stats = next->adv_stats;
-    int C = row_chunks(next->B);
-    if (C > 256) C = 256;
-    r.C = C; r.chunk_len = (next->B + C - 1) / C; r.gx = (next->S + 63) / 64;
+    if (has_pro) {
+        r.s = next->s; r.mean = next->mean; r.std = next->std; r.B = next->B; r.S = next->S; r.clip = next->clip;
+        r.x = next->x; r.partial = (double*)next->workspace; r.adv = next->adv; r.normalize_adv = next->normalize_adv;
+        r.adv_stats = next->adv_stats; r.s2 = next->s2; r.x2 = next->x2;
+        int C = row_chunks(next->B);
+        if (C > 256) C = 256;
+        r.C = C; r.chunk_len = (next->B + C - 1) / C; r.gx = (next->S + 63) / 64;
+        r.pro_blocks = (unsigned)(r.gx * (C + 1));
+    }
+    if (has_noise) {
+        r.noise = next->noise; r.noise_n = next->noise_n; r.noise_seed = next->noise_seed;
+        r.noise_epoch = (const unsigned long long*)next->noise_epoch;
+        size_t nb = (next->noise_n + 255) / 256;
+        r.noise_blocks = (unsigned)(nb > 1024 ? 1024 : nb);
+    }
     const unsigned adam_blocks = (unsigned)stream_grid(longest >> 2);
-    const unsigned pro_blocks = (unsigned)(r.gx * (C + 1));
-    hipLaunchKernelGGL(k_clip_adam_prologue, dim3(adam_blocks + pro_blocks), dim3(256), 0, (hipStream_t)stream, params, grads,
-                       m, v, gr, beta1, beta2, eps, beta_pow, sq_partial, n_partials, clip_norm, norm_scale, step_counter,
-                       adam_blocks, r);
+    hipLaunchKernelGGL(k_clip_adam_prologue, dim3(adam_blocks + r.pro_blocks + r.noise_blocks), dim3(256), 0,
+                       (hipStream_t)stream, params, grads, m, v, gr, beta1, beta2, eps, beta_pow, sq_partial, n_partials,
+                       clip_norm, norm_scale, step_counter, adam_blocks, r, soft_target, (size_t)soft_off >> 2,
+                       (size_t)soft_len >> 2, soft_tau);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }
@@ -2001,14 +2035,14 @@ int pfpn_adam_groups(float* params, const float* grads, float* m, float* v, size
 int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, const float* logp, const float* logp_t,
                   const float* reward, const float* not_terminal, const float* log_alpha, int B, float gamma,
                   float value_coef, float target_entropy, float* dq_pi, float* dq_run, float* dlogp,
-                  float* dlog_alpha, float* loss3, int q_ld, void* stream) {
+                  float* dlog_alpha, float* loss3, int q_ld, uint64_t* noise_epoch, void* stream) {
     PFPN_BEGIN();
     if (!q_pi || !q_run || !q_tgt || !logp || !logp_t || !reward || !not_terminal || !log_alpha || !dq_pi ||
         !dq_run || !dlogp || !dlog_alpha || !loss3 || B < 1 || (q_ld != 0 && q_ld < B))
         return PFPN_ERR_ARG;
     hipLaunchKernelGGL(k_sac_loss, dim3(1), dim3(1024), 0, (hipStream_t)stream, q_pi, q_run, q_tgt, logp, logp_t,
                        reward, not_terminal, log_alpha, B, gamma, value_coef, target_entropy, dq_pi, dq_run, dlogp,
-                       dlog_alpha, loss3, q_ld ? q_ld : B);
+                       dlog_alpha, loss3, q_ld ? q_ld : B, (unsigned long long*)noise_epoch);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

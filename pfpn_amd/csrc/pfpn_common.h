@@ -223,6 +223,38 @@ __device__ __forceinline__ float slab_reduce_1024(const float* __restrict__ slab
     return s;          // valid on k-lane 0
 }
 
+// Philox4x32-10 (Salmon et al., SC'11: the counter-based generator TF and PyTorch use) and the SAC learner step's four
+// noise values of element i drawn from ONE block {counter = (i, offset), key = seed}: rows 0, 1 of u [4][n] become Gumbel
+// noise -log(-log u), rows 2, 3 a Box-Muller pair of independent standard normals (utils.py:156-161 for s and s').
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ void sac_noise_element(float* __restrict__ u, size_t n, size_t i, unsigned long long seed,
+                                                  unsigned long long offset) {
+    unsigned r[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
+                  (unsigned)(seed >> 32), r);
+    // 24-bit uniforms in [0, 1), as torch's uniform_() makes them for float32
+    const float u0 = (r[0] >> 8) * 5.9604644775390625e-08f, u1 = (r[1] >> 8) * 5.9604644775390625e-08f;
+    const float u2 = (r[2] >> 8) * 5.9604644775390625e-08f, u3 = (r[3] >> 8) * 5.9604644775390625e-08f;
+    u[i] = -logf(-logf(fmaxf(u0, 1.17549435e-38f)));
+    u[n + i] = -logf(-logf(fmaxf(u1, 1.17549435e-38f)));
+    const float rr = sqrtf(-2.f * logf(fmaxf(u2, 1.17549435e-38f)));
+    float sn, cs;
+    sincosf(6.28318530717958647692f * u3, &sn, &cs);
+    u[2 * n + i] = rr * cs;
+    u[3 * n + i] = rr * sn;
+}
+
 // tf.clip_by_value of the normalised advantage (actor_critic.py:158-170); bounds -inf / +inf = no clipping.  Written
 // with comparisons so a NaN advantage stays NaN, as Minimum/Maximum leave it in TensorFlow.
 __device__ __forceinline__ float clip_adv(float a, float lo, float hi) {

@@ -575,39 +575,15 @@ __global__ __launch_bounds__(256) void k_sac_noise_inplace(float* __restrict__ u
 }
 
 // The same four tensors WITHOUT the uniform fill: element i draws its four uniforms from one Philox4x32-10 block
-// (counter = {i, offset}, key = seed; Salmon et al., SC'11 -- the counter-based generator TF and PyTorch use) and writes
-// the transformed values: one launch and 16 B per element instead of a 16-B fill plus a 32-B in-place pass.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
-                                              unsigned (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
+// (sac_noise_element, pfpn_common.h) and writes the transformed values: one launch and 16 B per element instead of a 16-B fill
+// plus a 32-B in-place pass.  `epoch` != nullptr: the offset is read from device memory (the learner step's own draw
+// counter, advanced by its loss head: the same launch can then be replayed from a hipGraph).
 __global__ __launch_bounds__(256) void k_sac_noise_fill(float* __restrict__ u, size_t n, unsigned long long seed,
-                                                        unsigned long long offset) {
+                                                        unsigned long long offset,
+                                                        const unsigned long long* __restrict__ epoch) {
+    if (epoch) offset = epoch[0];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        unsigned r[4];
-        philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed,
-                      (unsigned)(seed >> 32), r);
-        // 24-bit uniforms in [0, 1), as torch's uniform_() makes them for float32
-        const float u0 = (r[0] >> 8) * 5.9604644775390625e-08f, u1 = (r[1] >> 8) * 5.9604644775390625e-08f;
-        const float u2 = (r[2] >> 8) * 5.9604644775390625e-08f, u3 = (r[3] >> 8) * 5.9604644775390625e-08f;
-        u[i] = -logf(-logf(fmaxf(u0, 1.17549435e-38f)));
-        u[n + i] = -logf(-logf(fmaxf(u1, 1.17549435e-38f)));
-        const float rr = sqrtf(-2.f * logf(fmaxf(u2, 1.17549435e-38f)));
-        float sn, cs;
-        sincosf(6.28318530717958647692f * u3, &sn, &cs);
-        u[2 * n + i] = rr * cs;
-        u[3 * n + i] = rr * sn;
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) sac_noise_element(u, n, i, seed, offset);
 }
 
 __global__ __launch_bounds__(256) void k_gumbel_inplace(float* __restrict__ u, size_t n) {
@@ -740,14 +716,14 @@ int pfpn_sac_noise_from_uniform(float* u, size_t n, void* stream) {
     return PFPN_OK;
 }
 
-int pfpn_sac_noise_fill(float* buf, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+int pfpn_sac_noise_fill(float* buf, size_t n, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* stream) {
     PFPN_BEGIN();
     if (!buf) return PFPN_ERR_ARG;
     if (n == 0) return PFPN_OK;
     size_t g = (n + 255) / 256;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_sac_noise_fill, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, buf, n,
-                       (unsigned long long)seed, (unsigned long long)offset);
+                       (unsigned long long)seed, (unsigned long long)offset, (const unsigned long long*)offset_dev);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

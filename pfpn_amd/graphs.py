@@ -101,7 +101,9 @@ class GraphedLearnerStep(object):
                     raise ValueError("capture_exchange needs the RCCL backend (gloo collectives run on the host)")
                 want = False
         self.K = int(steps_per_replay)
-        assert self.K >= 1 and (self.K == 1 or noise is None), "one noise set per captured step is not built"
+        # (K > 1 with noise: every step's draw must happen INSIDE the replay -- as a rider of the previous optimiser launch)
+        assert self.K >= 1 and (self.K == 1 or noise is None or hasattr(net, "stage_next_noise")), \
+            "several captured steps need a network that draws its noise inside the graph"
         self.input_sets = [tuple(inputs)] * self.K if input_sets is None else [tuple(t) for t in input_sets]
         assert len(self.input_sets) == self.K
         self.inputs = self.input_sets[0]
@@ -184,8 +186,12 @@ class GraphedLearnerStep(object):
                     # step's prologue as extra blocks (one launch less per step: SyncReplicasApplier.apply_device)
                     if gather_from is not None:
                         kernels.gather_columns(list(gather_from[0]), list(self.input_sets[k + 1]), gather_from[1][k + 1])
-                    if self.noise is None and hasattr(net, "stage_next_prologue"):
+                    if hasattr(net, "stage_next_prologue"):
                         net.stage_next_prologue(*self.input_sets[k + 1])
+                if self.noise is not None and hasattr(net, "stage_next_noise"):
+                    # the NEXT step's noise (the next replay's first step after the last one) is drawn by extra blocks of
+                    # this step's optimiser launch: no draw launch between replays
+                    net.stage_next_noise(self.noise)
                 if self.split:
                     optimizer.pre_reduce(net)
                 elif self.in_graph_exchange:
@@ -237,6 +243,8 @@ class GraphedLearnerStep(object):
     def _state_tensors(self):
         net, opt, st = self.net, self.opt, self.net.store
         ts = [st.flat, st.m, st.v, st.bucket, net.step_dev, opt.beta_pow]
+        if getattr(net, "noise_epoch", None) is not None:
+            ts.append(net.noise_epoch)
         if getattr(net, "target_store", None) is not None:
             ts.append(net.target_store.flat)
         if net.state_normalizer is not None:
@@ -262,9 +270,9 @@ class GraphedLearnerStep(object):
             raise RuntimeError("this stepper was closed (release_captured_collectives)")
         if not self.can_replay():
             raise ValueError("a resample tick falls inside this %d-step replay: run one-step replays up to it" % self.K)
-        if self.noise is not None:
-            refill_noise(self.noise, self.net.rng)
+        self.ensure_noise()
         self.graph.replay()
+        self._noise_fresh = self.noise_in_graph            # (the replay's last optimiser launch left the next draw)
         self.replays = getattr(self, "replays", 0) + 1
         if self.split:
             self.opt.reduce(self.net)

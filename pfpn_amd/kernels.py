@@ -364,14 +364,18 @@ def gumbel_from_uniform_(u):
     return u
 
 
-def sac_noise_fill_(buf, seed, offset):
+def sac_noise_fill_(buf, seed, offset, epoch=None):
     """buf [4, ...]: rows 0,1 <- Gumbel(0,1), rows 2,3 <- N(0,1), drawn on the device (Philox4x32-10 keyed by `seed`,
-    block counter (element, `offset`)) -- one launch, no uniform fill."""
+    block counter (element, `offset`)) -- one launch, no uniform fill.  `epoch` (an int64 device scalar): the offset is read
+    from it when the launch runs (the learner step's own draw counter, kernels.sac_loss(noise_epoch=...) advances it)."""
     lib = _lib.load()
     if buf.shape[0] != 4:
         raise ValueError("buf must be [4, ...]")
+    if epoch is not None and (epoch.dtype != torch.int64 or not epoch.is_cuda or epoch.numel() != 1):
+        raise ValueError("epoch must be a one-element int64 device tensor")
     _lib.check(lib.pfpn_sac_noise_fill(_f32(buf), buf.numel() // 4, int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                       int(offset) & 0xFFFFFFFFFFFFFFFF, _stream()), "pfpn_sac_noise_fill")
+                                       int(offset) & 0xFFFFFFFFFFFFFFFF, epoch.data_ptr() if epoch is not None else None,
+                                       _stream()), "pfpn_sac_noise_fill")
     return buf
 
 
@@ -696,18 +700,35 @@ class StatePrologue(ctypes.Structure):
     _fields_ = [("s", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("std", ctypes.c_void_p), ("B", ctypes.c_int),
                 ("S", ctypes.c_int), ("clip", ctypes.c_float), ("x", ctypes.c_void_p), ("adv", ctypes.c_void_p),
                 ("normalize_adv", ctypes.c_int), ("adv_stats", ctypes.c_void_p), ("workspace", ctypes.c_void_p),
-                ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace_bytes", ctypes.c_size_t), ("s2", ctypes.c_void_p), ("x2", ctypes.c_void_p),
+                ("noise", ctypes.c_void_p), ("noise_n", ctypes.c_size_t), ("noise_seed", ctypes.c_uint64),
+                ("noise_epoch", ctypes.c_void_p)]
+    _key = None          # set by the network: which prologue call this rider stands for (None: no prologue part)
 
 
-def state_prologue_rider(s, mean, std, clip, out_x, adv, normalize_adv, adv_stats, ws):
-    """the arguments of state_prologue(..., want_moments=True, ws=ws) as a rider for clip_adam(rider=...)"""
+def state_prologue_rider(s, mean, std, clip, out_x, adv, normalize_adv, adv_stats, ws, s2=None, out_x2=None):
+    """the arguments of state_prologue(..., want_moments=True, ws=ws[, s2, out_x2]) as a rider for clip_adam(rider=...)"""
     B, S = s.shape
     r = StatePrologue(s=_f32(s, B, S), mean=_f32(mean, S), std=_f32(std, S), B=B, S=S, clip=float(clip or 0.0),
                       x=_f32(out_x, B, S), adv=_f32(adv, B) if adv_stats is not None else None,
                       normalize_adv=int(normalize_adv), adv_stats=_f32(adv_stats, 4) if adv_stats is not None else None,
-                      workspace=ws.data_ptr(), workspace_bytes=ws.numel())
-    r._keep = (s, mean, std, out_x, adv, adv_stats, ws)
+                      workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+                      s2=_f32(s2, B, S) if s2 is not None else None, x2=_f32(out_x2, B, S) if s2 is not None else None)
+    r._keep = (s, mean, std, out_x, adv, adv_stats, ws, s2, out_x2)
     return r
+
+
+def noise_rider(rider, buf, seed, epoch):
+    """add the SAC step's noise draw (sac_noise_fill_(buf, seed, epoch=epoch)) to `rider` (None: a rider of the noise alone)"""
+    if rider is None:
+        rider = StatePrologue()
+        rider._keep = ()
+    if buf.dim() != 3 or buf.shape[0] != 4 or not buf.is_contiguous() or epoch.dtype != torch.int64:
+        raise ValueError("noise buffer [4, B, A*N] contiguous and an int64 device counter expected")
+    rider.noise, rider.noise_n = _f32(buf), buf.shape[1] * buf.shape[2]
+    rider.noise_seed, rider.noise_epoch = int(seed) & 0xFFFFFFFFFFFFFFFF, epoch.data_ptr()
+    rider._keep = tuple(rider._keep) + (buf, epoch)
+    return rider
 
 
 def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, clip_norm, norm_scale, beta1=0.9,
@@ -715,20 +736,21 @@ def clip_adam(params, grads, m, v, group_off, group_len, group_lr, beta_pow, cli
     """One-replica optimiser step in two launches (global-norm clip folded into TF-Adam).  group_* are ctypes
     arrays (host); beta_pow is [G,4] (see include/pfpn_hip.h).
     prenorm = (partial, count) from reduce_jobs(norm=...): the norm's partial sums exist and the powers are rotated
-    already -- ONE launch.  rider (with prenorm, without soft): a StatePrologue -- the NEXT learner step's prologue runs as
-    extra blocks of this launch (multi-step captures)."""
+    already -- ONE launch.  rider (with prenorm): a StatePrologue -- the NEXT learner step's prologue (and, SAC, its noise
+    draw) runs as extra blocks of this launch (captured steps)."""
     lib = _lib.load()
     n = params.numel()
     G = len(group_lr)
     if rider is not None:
-        if prenorm is None or soft is not None:
-            raise ValueError("the prologue rider needs the one-launch optimiser (prenorm) without a soft target update")
+        if prenorm is None:
+            raise ValueError("the prologue rider needs the one-launch optimiser (prenorm)")
         _lib.check(lib.pfpn_clip_adam_prenorm_prologue(_f32(params), _f32(grads), _f32(m), _f32(v), n, G,
                                                        ctypes.addressof(group_off), ctypes.addressof(group_len),
                                                        ctypes.addressof(group_lr), float(beta1), float(beta2), float(eps),
                                                        _f32(beta_pow, G, 4), float(clip_norm), _f32(norm_scale, 2),
                                                        _f32(step_counter, 1) if step_counter is not None else None,
-                                                       _f32(prenorm[0]), int(prenorm[1]), ctypes.addressof(rider), _stream()),
+                                                       _f32(prenorm[0]), int(prenorm[1]), ctypes.addressof(rider),
+                                                       *_soft_args(soft), _stream()),
                    "pfpn_clip_adam_prenorm_prologue")
         return
     if prenorm is not None:
@@ -855,7 +877,7 @@ def _f32_rows(t, rows, cols, name="tensor"):
 
 
 def sac_loss(q_pi, q_run, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, gamma, value_coef, target_entropy,
-             out):
+             out, noise_epoch=None):
     """out: dict(dq_pi [2,B], dq_run [2,B], dlogp [B], dlog_alpha [1], loss3 [3]).  q_pi, q_run, dq_pi, dq_run may be
     row-strided views with one common row stride (the halves of [2, 2B] buffers)."""
     lib = _lib.load()
@@ -868,7 +890,8 @@ def sac_loss(q_pi, q_run, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, 
                                  _f32(logp_t, B), _f32(reward, B), _f32(not_terminal, B), _f32(log_alpha),
                                  B, float(gamma), float(value_coef), float(target_entropy),
                                  ptrs[2][0], ptrs[3][0], _f32(out["dlogp"], B),
-                                 _f32(out["dlog_alpha"]), _f32(out["loss3"], 3), int(ld), _stream()), "pfpn_sac_loss")
+                                 _f32(out["dlog_alpha"]), _f32(out["loss3"], 3), int(ld),
+                                 noise_epoch.data_ptr() if noise_epoch is not None else None, _stream()), "pfpn_sac_loss")
     return out
 
 

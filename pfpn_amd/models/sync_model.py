@@ -158,7 +158,7 @@ class SyncReplicasApplier(object):
             # (multi-step captures: the next step's prologue as extra blocks of this launch -- graphs.py stages it)
             rider = getattr(net, "_next_prologue", None)
             net._next_prologue = None
-            if rider is not None and (pre is None or soft is not None):
+            if rider is not None and pre is None:
                 rider = None
             kernels.clip_adam(st.flat, st.grad, st.m, st.v, self._g_off, self._g_len, self._g_lr, self.beta_pow,
                               self.norm_clip, self.norm_scale, self.beta1, self.beta2, self.epsilon,

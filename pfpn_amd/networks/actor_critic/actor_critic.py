@@ -395,7 +395,7 @@ class ActorCriticNetwork(object):
             # (its result is first read by the NEXT step's prologue)
             staged = getattr(self, "_prologue_staged", None)
             self._prologue_staged = None
-            if staged is not None and state2 is None and staged == self._prologue_key(state, advantage):
+            if staged is not None and staged == self._prologue_key(state, advantage, state2):
                 pass        # this launch already ran, as a rider of the previous captured step's optimiser launch
             else:
                 kernels.state_prologue(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, True, advantage,
@@ -415,10 +415,11 @@ class ActorCriticNetwork(object):
         return self.xn
 
     @staticmethod
-    def _prologue_key(state, advantage):
-        return (state.data_ptr(), tuple(state.shape), advantage.data_ptr() if advantage is not None else 0)
+    def _prologue_key(state, advantage, state2=None):
+        return (state.data_ptr(), tuple(state.shape), advantage.data_ptr() if advantage is not None else 0,
+                state2.data_ptr() if state2 is not None else 0)
 
-    def prologue_rider(self, state, advantage=None):
+    def prologue_rider(self, state, advantage=None, state2=None, out2=None):
         """Multi-step captures (pfpn_amd/graphs.py): the arguments of the NEXT step's deferred fused prologue, for the
         optimiser launch of THIS step to carry (kernels.clip_adam(rider=...)), or None where that prologue would not be the
         single fused launch.  The optimiser calls prologue_staged() once it has taken the rider; the next prologue()
@@ -429,12 +430,15 @@ class ActorCriticNetwork(object):
         nz = self.state_normalizer
         r = kernels.state_prologue_rider(state, nz.mean, nz.std, self.clip_state or 0.0, self.xn, advantage,
                                          self.normalize_advantage, self.adv_stats if advantage is not None else None,
-                                         self.ws_moments)
-        r._key = self._prologue_key(state, advantage)
+                                         self.ws_moments, s2=state2, out_x2=out2)
+        r._key = self._prologue_key(state, advantage, state2)
         return r
 
     def prologue_staged(self, rider):
-        self._prologue_staged = rider._key
+        if rider._key is not None:
+            self._prologue_staged = rider._key
+        if rider.noise:
+            self._noise_rode = True       # (SAC: the optimiser launch drew the next step's noise)
 
     def update_state_normalizer(self, state):
         """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), the launch-per-piece form

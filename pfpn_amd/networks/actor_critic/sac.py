@@ -240,13 +240,35 @@ def sac_network_wrapper(base_class):
             noise.refill = self._draw_train_noise
             return noise
 
+        def _noise_counter(self):
+            """the step's draw counter: an int64 device scalar the loss head advances by one per learner step and every
+            noise draw reads when its launch RUNS -- so a captured draw (a rider of the optimiser launch, graphs.py) is
+            fresh on every replay.  It starts at the learner step count (a run resumed from a checkpoint does not replay
+            the draws of the run's beginning)."""
+            if getattr(self, "noise_epoch", None) is None:
+                self.noise_epoch = torch.full((1,), int(self.global_step), dtype=torch.int64, device=self.device)
+            return self.noise_epoch
+
         def _draw_train_noise(self, buf):
             """fresh draws into buf [4, B, A*N] in ONE launch: a Philox block per element, keyed by the network generator's
-            seed, counted by the learner step and the number of draws so far (no uniform fill + transform pass)."""
-            self._noise_draws = getattr(self, "_noise_draws", 0) + 1
-            # (the learner step count restored from a checkpoint is part of the counter: a resumed run does not replay
-            # the draws of the run's beginning)
-            return kernels.sac_noise_fill_(buf, self.rng.initial_seed(), (int(self.global_step) << 24) + self._noise_draws)
+            seed and the step's draw counter (no uniform fill + transform pass)."""
+            return kernels.sac_noise_fill_(buf, self.rng.initial_seed(), 0, epoch=self._noise_counter())
+
+        def stage_next_prologue(self, state, action, reward, not_terminal, state_):
+            """captured steps (graphs.py): the NEXT step's prologue (s and s' normalised, the moments of s) as a rider of
+            this step's optimiser launch"""
+            B = state.shape[0]
+            if self._deferred_jobs(B) is None:
+                return
+            self._next_prologue = self.prologue_rider(state, None, state2=state_, out2=self.xn2)
+
+        def stage_next_noise(self, noise):
+            """captured steps: the NEXT step's four noise tensors drawn by extra blocks of this step's optimiser launch"""
+            buf = noise.get("_buf") if isinstance(noise, dict) else None
+            if buf is None or not buf.is_contiguous() or buf.dim() != 3:
+                return
+            self._next_prologue = kernels.noise_rider(getattr(self, "_next_prologue", None), buf, self.rng.initial_seed(),
+                                                      self._noise_counter())
 
         def compute_gradients(self, state, action, reward, not_terminal, state_, noise=None):
             B, S, A = state.shape[0], self.S, self.n_actions
@@ -304,7 +326,8 @@ def sac_network_wrapper(base_class):
             self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
             self.last["q_pi"] = q_pi
             out = kernels.sac_loss(q_pi, q_run, self.q_tgt, logp, logp2, reward, not_terminal,
-                                   self.log_alpha, self.gamma, self.value_loss_coef, -float(A), sout)
+                                   self.log_alpha, self.gamma, self.value_loss_coef, -float(A), sout,
+                                   noise_epoch=self._noise_counter())
             # critic gradients (value loss through Q(s, action_hist))
             gw3, gb3 = st.g("critic/q1+critic/q2|fc3/weight"), st.g("critic/q1+critic/q2|fc3/bias")
             if not fold:

@@ -126,15 +126,60 @@ def test_sac_step_as_graph_matches_eager(dev):
                                                    (rng.uniform(size=B) > 0.05).astype(F),
                                                    (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
     g = GraphedLearnerStep(nets[0], opts[0], *[t.clone() for t in batch], noise=nets[0].make_train_noise(B))
+    assert g.noise_in_graph                  # every replay's optimiser launch draws the next step's noise (no launch between)
     for it in range(3):
-        l_g = g().clone()
+        g.ensure_noise()                      # (a no-op after the first replay: the previous optimiser launch drew it)
         noise = {k: t.clone() for k, t in g.noise.items()}
+        l_g = g().clone()
         l_e = nets[1].compute_gradients(*batch, noise).clone()
         opts[1].apply(nets[1])
         assert torch.equal(l_g, l_e), it
         assert torch.equal(nets[0].store.flat, nets[1].store.flat) and torch.equal(nets[0].store.v, nets[1].store.v)
         assert torch.equal(nets[0].target_store.flat, nets[1].target_store.flat)
         assert nets[0].global_step == nets[1].global_step == it + 1
+
+
+def test_sac_multi_step_replay_draws_its_noise_inside_the_graph(dev):
+    """K SAC learner steps in ONE hipGraph: step k's optimiser launch carries step k+1's prologue (s and s' normalised) AND
+    draws step k+1's four noise tensors (Philox keyed by the step's device-resident draw counter, which the loss head
+    advances), so nothing is launched between the steps or between replays.  Equal, bit for bit, to K eager steps that draw
+    their noise with the same generator before each step."""
+    from pfpn_amd.graphs import GraphedLearnerStep
+    from pfpn_amd.models import SyncReplicasApplier
+    rng = np.random.default_rng(5)
+    B, K = 64, 3
+    nets, opts = [], []
+    for _ in range(2):
+        net = make_net(dev)
+        nets.append(net)
+        opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                              {"names": net.actor_param_names(), "lr": 1e-4}],
+                                        norm_clip=1.0, world_size=1))
+    sets = [[torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                   rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                   rng.normal(0.5, 0.3, B).astype(F),
+                                                   (rng.uniform(size=B) > 0.05).astype(F),
+                                                   (rng.normal(0, 1, (B, 197)) * 2).astype(F))] for _ in range(K)]
+    g = GraphedLearnerStep(nets[0], opts[0], steps_per_replay=K, input_sets=[[t.clone() for t in s_] for s_ in sets],
+                           noise=nets[0].make_train_noise(B), debug_nodes=True)
+    assert g.K == K and g.noise_in_graph
+    one = GraphedLearnerStep(nets[1], opts[1], *[t.clone() for t in sets[0]], noise=nets[1].make_train_noise(B),
+                             debug_nodes=True)
+    nk, n1 = g.kernel_nodes(), one.kernel_nodes()
+    if nk and n1:
+        assert nk <= K * n1 - (K - 1), (nk, n1)             # the K - 1 prologues inside the replay launch nothing
+    for rep in range(2):
+        g()
+        for s_ in sets:
+            noise = nets[1].make_train_noise(B)
+            nets[1].compute_gradients(*s_, noise)
+            opts[1].apply(nets[1])
+        torch.cuda.synchronize()
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat), rep
+        assert torch.equal(nets[0].target_store.flat, nets[1].target_store.flat)
+        assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
+        assert torch.equal(nets[0].noise_epoch, nets[1].noise_epoch) and int(nets[0].noise_epoch.item()) == K * (rep + 1)
+        assert nets[0].global_step == nets[1].global_step == K * (rep + 1)
 
 
 @pytest.mark.parametrize("B", [64, 1024])
@@ -270,3 +315,7 @@ def test_sac_noise_fill_philox(dev):
     for seed, off in ((0, 1), (1, 0), (1 << 40, 0), (0, 1 << 33)):
         z2 = kernels.sac_noise_fill_(torch.empty(4, n, device=dev), seed, off)
         assert not torch.equal(z2, z) and abs((z2[2] * z[2]).mean().item()) < 3e-3
+    # the offset read from device memory when the launch runs (the learner step's draw counter) == the same offset by value
+    ep = torch.tensor([1 << 33], dtype=torch.int64, device=dev)
+    assert torch.equal(kernels.sac_noise_fill_(torch.empty(4, n, device=dev), 0, 12345, epoch=ep),
+                       kernels.sac_noise_fill_(torch.empty(4, n, device=dev), 0, 1 << 33))
