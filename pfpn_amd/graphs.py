@@ -209,6 +209,17 @@ class GraphedLearnerStep(object):
             with torch.cuda.graph(self.graph_post, stream=s):
                 optimizer.post_reduce(net)
         # capture does not execute; state is untouched
+        # True: every captured step's optimiser launch took the noise rider, so only the FIRST replay needs a draw from outside
+        self.noise_in_graph = bool(self.noise is not None and getattr(net, "_noise_rode", False))
+        net._noise_rode = False
+        self._noise_fresh = False
+
+    def ensure_noise(self):
+        """the noise the NEXT replay will use is in `self.noise` after this call (drawn here unless the previous replay's
+        last optimiser launch drew it)"""
+        if self.noise is not None and not (self.noise_in_graph and self._noise_fresh):
+            refill_noise(self.noise, self.net.rng)
+            self._noise_fresh = True
 
     def kernel_nodes(self):
         """kernel launches per replay of the main graph, counted in the runtime's own dump of the captured graph

@@ -1,5 +1,6 @@
 """The SAC-PFPN learner step (replay batch 1024) as a hipGraph, a few dozen replays: the program to put under
-`rocprofv3 --kernel-trace` for a kernel-by-kernel timeline (`tools/step_timeline.py <trace> k_sac_noise_fill`)."""
+`rocprofv3 --kernel-trace` for a kernel-by-kernel timeline (`tools/step_timeline.py <trace> k_sac_loss`: since round 4 the
+noise draw and the next step's prologue ride in the optimiser launch, eight steps per replay; the loss head marks a step)."""
 import os, sys
 import numpy as np, torch
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
@@ -20,8 +21,8 @@ b = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).asty
                                            rng.normal(0.5, 0.3, B).astype(np.float32),
                                            (rng.uniform(size=B) > 0.02).astype(np.float32),
                                            (rng.normal(0, 1, (B, 197)) * 2).astype(np.float32))]
-step = GraphedLearnerStep(net, opt, *b, noise=net.make_train_noise(B))
-for _ in range(40):
+step = GraphedLearnerStep(net, opt, *b, noise=net.make_train_noise(B), steps_per_replay=8)
+for _ in range(12):
     step()
 torch.cuda.synchronize()
 print("done", step.loss3.cpu().numpy())
