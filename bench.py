@@ -88,6 +88,16 @@ def rocprof_kernel_us(kernel_substring):
     return None
 
 
+def timeline_launches(suffix):
+    """launch count of one step in the newest committed rocprofv3 timeline profiles/rNN_<suffix> -> (n, file) or (None, None)"""
+    import re
+    path, _ = latest_profile(suffix)
+    if not path:
+        return None, None
+    m = re.search(r"(\d+) launches", open(path).read().strip().splitlines()[-1])
+    return (int(m.group(1)), "profiles/" + os.path.basename(path)) if m else (None, None)
+
+
 def dense_macs(S_in, hidden, head):
     """multiply-accumulates per row of an MLP S_in -> hidden... -> head: (forward, dW, dX below the first layer)"""
     dims = [S_in] + list(hidden) + [head]
@@ -913,8 +923,11 @@ def main():
                         sstep()
                     torch.cuda.synchronize()
                     sms = (time.perf_counter() - t_s) / (25 * SK) * 1e3
-                    s_nodes = sstep.kernel_nodes()
-                    s_launches = (s_nodes / SK) if s_nodes else None
+                    s_nodes = sstep.kernel_nodes()         # (None where the runtime cannot print a captured graph: this image)
+                    s_launches, s_src = (s_nodes / SK, "kernel nodes of the captured %d-step hipGraph / %d" % (SK, SK)) \
+                        if s_nodes else timeline_launches("sac_step_timeline.txt")
+                    if not s_nodes and s_src:
+                        s_src += " (committed rocprofv3 --kernel-trace of tools/sac_trace.py at replay batch 1024; NOT counted in this run)"
                     sl3 = sstep.loss3.cpu().numpy()
                     sflops = 2.0 * SB * sac_mac
                     # the step's HBM-bound hand-written kernels on their own (launches replayed from a hipGraph): the
@@ -932,9 +945,8 @@ def main():
                                "roofline": {"bound": "mfma", "gemm_flops": sflops, "achieved": sflops / (sms * 1e-3) / 1e12,
                                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                                             "launches_per_step": s_launches,
-                                            "launches_source": "kernel nodes of the captured %d-step hipGraph / %d (the noise draw "
-                                                               "and the next step's prologue ride in the optimiser launch: %s)"
-                                                               % (SK, SK, sstep.noise_in_graph),
+                                            "launches_source": s_src,
+                                            "noise_and_next_prologue_ride_in_the_optimiser_launch": sstep.noise_in_graph,
                                             "note": "frac = the step's GEMM flops / its WHOLE time / the fp32 MFMA peak: a step of ~%d "
                                                     "launches at ~5 us each is launch-bound, not MFMA-bound, at these row counts"
                                                     % round(s_launches or 36),

@@ -900,15 +900,40 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 template <bool NT>
 __device__ __forceinline__ float4 ld4_stream(const float* p) {
     if (NT) {
+#if defined(PFPN_WIDE_LD_POLICY) && PFPN_WIDE_LD_POLICY == 1          // A/B build knobs (tools/ab_build.sh)
+        return ld4(p);
+#elif defined(PFPN_WIDE_LD_POLICY) && PFPN_WIDE_LD_POLICY == 2
+        const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));      // (placeholder: same as default)
+        return make_float4(v.x, v.y, v.z, v.w);
+#else
         const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
         return make_float4(v.x, v.y, v.z, v.w);
+#endif
     }
     return ld4(p);
 }
+// Streaming stores of the backward's dlogits (round 4): WRITE-THROUGH (`sc1`: the line leaves the XCD's L2 for memory and is
+// dropped) instead of non-temporal -- 384 us against 394 us for the 2 GiB pass on one box, a tie (389 / 391) on another, in
+// alternating runs (profiles/r04_wide_handoff_ab.txt; `sc0 sc1` the same, `sc0 sc1 nt` 388).  Issued as a raw BUFFER store
+// whose resource descriptor is the (wave-uniform) row segment: the builtin takes the cache policy as an argument (16 = sc1 on
+// gfx940+) and is visible to hipcc's waitcnt pass (an asm store is not; a volatile store, `sc0 sc1`, makes hipcc drain
+// vmcnt(0) in front of every store).
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 template <bool NT>
-__device__ __forceinline__ void st4_stream(float* p, float a, float b, float c, float d) {
-    if (NT) __builtin_nontemporal_store((f4v){a, b, c, d}, reinterpret_cast<f4v*>(p));
-    else *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+__device__ __forceinline__ void st4_row(float* row, int seg_bytes, int q, float a, float b, float c, float d) {
+    if (NT) {
+        const f4v v = {a, b, c, d};
+#if defined(PFPN_WIDE_ST_POLICY) && PFPN_WIDE_ST_POLICY == 0           // A/B build knobs (tools/ab_build.sh)
+        __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(row + 4 * q));
+#elif defined(PFPN_WIDE_ST_POLICY) && PFPN_WIDE_ST_POLICY == 1
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(row + 4 * q), "v"(v) : "memory");
+#else
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(row, 0, seg_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), rsrc, 16 * q, 0, 16);
+#endif
+        return;
+    }
+    *reinterpret_cast<float4*>(row + 4 * q) = make_float4(a, b, c, d);
 }
 
 template <bool V> struct BoolTag { static constexpr bool value = V; };
@@ -1137,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                                 acc_ls2[j][h]);
                             if (dx_out) dx2 = __builtin_elementwise_fma(tt * z, b_isc2[j][h] * PFPN_2LN2, dx2);
                         }
-                        if (live) st4_stream<STREAM>(drow + 4 * (lane + 64 * j), d[0].x, d[0].y, d[1].x, d[1].y);
+                        if (live) st4_row<STREAM>(drow, 4 * N, lane + 64 * j, d[0].x, d[0].y, d[1].x, d[1].y);
                     }
                 }
                 dxa[u] = dx2.x + dx2.y;
@@ -1163,18 +1188,19 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     // forward unchanged, backward 388 -> 414 us: the exit test between the two bodies costs the counted vmcnt waits.)
     float4 ln[U][M];
     float xn[U], gn[U];
-#define PFPN_WIDE_LOAD(b0_)                                                                        \
+#define PFPN_WIDE_LOAD_INTO(L_, X_, G_, b0_)                                                       \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                \
         const int b_ = min((b0_) + u * C, B - 1);            /* clamped: loads unconditional */     \
         const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;                              \
-        _Pragma("unroll") for (int j = 0; j < M; ++j) ln[u][j] = ld4_stream<NT_LOADS>(row_ + 4 * (ok[j] ? lane + 64 * j : 0)); \
-        xn[u] = x[(size_t)b_ * A + a];                                                             \
-        gn[u] = (MODE == MODE_BWD) ? dlogp_in[b_] : 0.f;                                           \
+        _Pragma("unroll") for (int j = 0; j < M; ++j) L_[u][j] = ld4_stream<NT_LOADS>(row_ + 4 * (ok[j] ? lane + 64 * j : 0)); \
+        X_[u] = x[(size_t)b_ * A + a];                                                             \
+        G_[u] = (MODE == MODE_BWD) ? dlogp_in[b_] : 0.f;                                           \
     }
+#define PFPN_WIDE_LOAD(b0_) PFPN_WIDE_LOAD_INTO(ln, xn, gn, b0_)
     const int step = C * U;
     int b0 = c, gi = 0;
     PFPN_WIDE_LOAD(b0)
-    for (; b0 + (U - 1) * C < B; b0 += step, ++gi) {         // full groups: branch-free body
+    auto full_group = [&]() {                                // one full group: branch-free body
         float4 l[U][M];
         float xv[U], gv[U];
 #pragma unroll
@@ -1186,9 +1212,14 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         }
         PFPN_WIDE_LOAD(b0 + step)                            // clamped rows: harmless beyond the end
         group(b0, gi, l, xv, gv, BoolTag<true>{});
-    }
+    };
+    // (hipcc's waits for a group's rows at the loop top are vmcnt(3..0): it counts the loads younger than the awaited row but
+    // not the previous group's stores, which are younger too, so every iteration also waits for those stores.  Peeling the
+    // first group, two groups of prefetch (432 us against 389) and hand-written store forms did not change that or lost.)
+    for (; b0 + (U - 1) * C < B; b0 += step, ++gi) full_group();
     if (b0 < B) group(b0, gi, ln, xn, gn, BoolTag<false>{}); // ragged tail (1..U-1 live rows)
 #undef PFPN_WIDE_LOAD
+#undef PFPN_WIDE_LOAD_INTO
     if (MODE == MODE_FWD && FOLD) {
         // ---- hand-off of the row sums (see the helpers above) ----
         __shared__ unsigned s_ticket;
