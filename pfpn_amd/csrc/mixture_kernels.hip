@@ -1046,8 +1046,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     // no canonicalisation instructions in front of v_max3_f32, unlike on raw loads).
     auto group = [&](int b0, int gi, const float4 (&l)[U][M], const float (&xv)[U], const float (&gv)[U], auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        v2f lp[U][M][2];                                      // l * log2(e)
         float mx[U];
+        v2f lp[U][M][2];                                      // l * log2(e)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             mx[u] = -INFINITY;
@@ -1073,6 +1073,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 for (int h = 0; h < 2; ++h) {
                     e[u][j][h] = ef[u][j][h] = zq[u][j][h] = (v2f){0.f, 0.f};
                     if (ok[j]) {
+                        // (the maximum on the raw logits + l c - max c as one packed fma -- 8 VALU instructions fewer per
+                        // group -- measured no faster: 176 vs 177 us, round 4)
                         const v2f le = lp[u][j][h] - mx[u];
                         const v2f z = (xv[u] - b_loc2[j][h]) * b_isc2[j][h];
                         const v2f arg = le + __builtin_elementwise_fma(-z, z, b_ct2[j][h]);
@@ -1213,9 +1215,22 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         PFPN_WIDE_LOAD(b0 + step)                            // clamped rows: harmless beyond the end
         group(b0, gi, l, xv, gv, BoolTag<true>{});
     };
-    // (hipcc's waits for a group's rows at the loop top are vmcnt(3..0): it counts the loads younger than the awaited row but
-    // not the previous group's stores, which are younger too, so every iteration also waits for those stores.  Peeling the
-    // first group, two groups of prefetch (432 us against 389) and hand-written store forms did not change that or lost.)
+    // Backward: the FIRST group runs outside the loop and the loop sits INSIDE that branch.  hipcc's waitcnt pass merges the
+    // states of a loop header's predecessors conservatively: coming from the prologue only the prefetch loads are outstanding,
+    // coming round the loop the loads AND the younger stores are -- merged, the header waited vmcnt(3..0) for its rows, i.e.
+    // every iteration also waited for the previous group's stores to be acknowledged.  This way both predecessors end in
+    // [loads, stores] and the header waits vmcnt(6..5): the stores stay in flight across the iteration (CDNA4 counts stores
+    // in vmcnt).  388 us against 395 us (alternating, three rounds) with write-through stores; with non-temporal stores the
+    // counted form is SLOWER (417-427 us).  -DPFPN_WIDE_NO_PEEL: the plain loop (A/B).
+#if !defined(PFPN_WIDE_NO_PEEL)
+    if (MODE == MODE_BWD) {
+        if (b0 + (U - 1) * C < B) {
+            full_group();
+            b0 += step; ++gi;
+            while (b0 + (U - 1) * C < B) { full_group(); b0 += step; ++gi; }
+        }
+    } else
+#endif
     for (; b0 + (U - 1) * C < B; b0 += step, ++gi) full_group();
     if (b0 < B) group(b0, gi, ln, xn, gn, BoolTag<false>{}); // ragged tail (1..U-1 live rows)
 #undef PFPN_WIDE_LOAD
