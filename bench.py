@@ -723,7 +723,7 @@ def main():
             torch.cuda.synchronize()
             u = e0.elapsed_time(e1) * 1e3 / 10
             nb = 3 * L_ + 2 * X_ + 8 * V_ + 3 * P_
-            res["ppo"] = {"kernel": "k_mix_wide<FWD> + k_ppo_loss + k_mix_wide<BWD> (three launches, results in the caller's buffers)",
+            res["ppo"] = {"kernel": "k_mix_wide<FWD + PPO head> + k_mix_wide<BWD> (two launches, results in the caller's buffers)",
                           "us_per_launch": u, "algorithmic_bytes": nb, "achieved": nb / u / 1e3, "unit": "GB/s",
                           "peak": HBM_PEAK_GBS, "frac": nb / u / 1e3 / HBM_PEAK_GBS,
                           "note": "3L composition; a fused 2L pass needs a row (128 KiB) AND the [A,N] bank (393 KB) on one CU"}

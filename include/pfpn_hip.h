@@ -52,6 +52,16 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
                      int B, int A, int N, int tanh_mode, float* logp, float* pmix,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* N >= 64 shapes (where pfpn_ppo_mixture_fwd_bwd does not apply): the forward above AND the clipped-PPO head of
+ * pfpn_ppo_loss (reference ppo.py:31-54, actor_critic.py:132-184) in ONE launch -- the block that finishes a row chunk's
+ * log-probs runs the head on those rows; loss3 = {loss, policy_loss, value_loss*coef} is complete when the launch ends.
+ * PFPN_ERR_ARG where that form does not apply (N < 64 shapes, A % 4 != 0, ...): call the two entry points instead. */
+int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* loc, const float* logstd,
+                         const float* logp_old, const float* adv, const float* value, const float* value_old,
+                         const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
+                         float* logp, float* dlogp, float* dvalue, float* loss3,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* TF autodiff of the above incl. the NaN/Inf guard of utils.py:109-117.
  * dlogp [B] in; dlogits [B,A*N], dloc [A,N], dlogstd [A,N] out (overwritten, not accumulated);
  * dx [B,A] optional (needed by SAC where x depends on the parameters). */

@@ -948,6 +948,7 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // The counters live in the code object, are zero at load and are handed back zeroed by the last arriver; launches of a
 // wide kernel on two streams AT THE SAME TIME would share them (the package launches on one stream).
 __device__ unsigned g_wide_tick_fwd[64];             // one per row chunk c (C <= 64)
+__device__ unsigned g_wide_tick_ppo;                 // the chunks whose PPO head is done (forward + PPO head in one launch)
 __device__ unsigned g_wide_tick_bwd[4096];           // one per action dim
 constexpr int WIDE_FOLD_MAX_A = 4096;
 constexpr int WIDE_FOLD_MAX_LDS = 32 * 1024;
@@ -979,6 +980,15 @@ __device__ __forceinline__ void ld4x8_sc1(const float* p, size_t stride, int n, 
         : "memory");
 }
 
+// The clipped-PPO head (k_ppo_loss's arithmetic, reference ppo.py:31-54) for the rows a chunk's last block has just finished:
+// dlogp / dvalue per row, the two loss sums per chunk; the chunk that finishes last adds the C pairs in chunk order.
+struct WidePpo {
+    const float* logp_old; const float* adv; const float* value; const float* value_old; const float* stats;
+    float clip_lo, clip_hi, value_coef, inv_B;
+    float* dlogp; float* dvalue; float* loss3;
+    float* sums;                                      // [C][2] in the workspace
+};
+
 // FOLD (forward): the row sum over the A segments happens inside the launch -- a wave keeps its rows' log p in LDS, the
 // block (4 consecutive action dims of ONE row chunk: A % 4 == 0) adds its four waves' values per row and publishes ONE
 // partial per row ([C][A/4][R4] in `lpseg_out`, whole float4s), the last block of a chunk adds the A/4 partials in block
@@ -996,7 +1006,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     float* __restrict__ dx_out,              // BWD optional
     float* __restrict__ partial,             // [C][2*A*N]  (BWD)
     float* __restrict__ fin0 = nullptr,      // FWD FOLD: logp [B];  BWD: dloc [A,N] (null: slabs left for the caller)
-    float* __restrict__ fin1 = nullptr)      // BWD: dlogstd [A,N]
+    float* __restrict__ fin1 = nullptr,      // BWD: dlogstd [A,N]
+    WidePpo ppo = WidePpo{})                 // FWD FOLD: logp_old != nullptr -> the PPO head runs in the hand-off tail
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
     constexpr bool NT_LOADS = STREAM;                       // (forward: STREAM = the logits are read once and not again soon)
@@ -1258,6 +1269,9 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         if (s_ticket != (unsigned)(nb - 1)) return;
         // the chunk's last block: logp[row] = sum over the chunk's blocks, in block order
         const float* all = lpseg_out + (size_t)c * nb * R4;
+        const bool head = ppo.logp_old != nullptr;           // block-uniform (kernel argument)
+        float hm = 0.f, hr = 1.f, hlo = 0.f, hhi = 0.f, ps = 0.f, vs = 0.f;
+        if (head) { hm = ppo.stats[0]; hr = ppo.stats[1]; hlo = ppo.stats[2]; hhi = ppo.stats[3]; }
         for (int t = threadIdx.x; t < nq4; t += blockDim.x) {
             f4v acc = {0.f, 0.f, 0.f, 0.f};
             for (int j0 = 0; j0 < nb; j0 += 8) {
@@ -1271,10 +1285,44 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int b = c + (4 * t + i) * C;
-                if (b < B) fin0[b] = r[i];
+                if (b >= B) continue;
+                fin0[b] = r[i];
+                if (head) {                                  // k_ppo_loss, term for term
+                    const float av = ppo.adv[b];
+                    const float nadv = clip_adv((av - hm) * hr, hlo, hhi);
+                    const float ratio = expf(r[i] - ppo.logp_old[b]);
+                    const float sur = ratio * nadv;
+                    const float csur = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo) * nadv;
+                    ps += fminf(sur, csur);
+                    const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+                    ppo.dlogp[b] = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+                    const float dvv = ppo.value[b] - (av + ppo.value_old[b]);
+                    vs += dvv * dvv;
+                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                }
             }
         }
         if (threadIdx.x == 0) __hip_atomic_store(&g_wide_tick_fwd[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (head) {
+            __shared__ float hred[4];
+            ps = block_sum(ps, hred);
+            vs = block_sum(vs, hred);
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(ppo.sums + 2 * c, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (sc1 stores)
+                __hip_atomic_store(ppo.sums + 2 * c + 1, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (__hip_atomic_fetch_add(&g_wide_tick_ppo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(C - 1)) {
+                    float tp = 0.f, tv = 0.f;                // the last chunk: the C pairs in chunk order
+                    for (int k = 0; k < C; ++k) {
+                        tp += __hip_atomic_load(ppo.sums + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tv += __hip_atomic_load(ppo.sums + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const float pl = -tp * ppo.inv_B, vl = tv * ppo.inv_B * ppo.value_coef;
+                    ppo.loss3[0] = pl + vl; ppo.loss3[1] = pl; ppo.loss3[2] = vl;
+                    __hip_atomic_store(&g_wide_tick_ppo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
     if (MODE == MODE_BWD) {
         float* slab = partial + (size_t)c * 2 * AN + (size_t)a * N;
@@ -1524,15 +1572,17 @@ size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
     return (slabs + (size_t)B * A + 64) * sizeof(float);
 }
 
-int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, const float* logstd,
-                     int B, int A, int N, int tanh_mode, float* logp, float* pmix,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+// forward of every path; `ppo` (wide path with the in-launch hand-off only, else PFPN_ERR_ARG): the PPO head in the same launch
+static int logprob_fwd_impl(const float* logits, const float* x, const float* loc, const float* logstd,
+                            int B, int A, int N, int tanh_mode, float* logp, float* pmix,
+                            void* workspace, size_t workspace_bytes, void* stream, const WidePpo* ppo) {
     PFPN_BEGIN();
     if (!logits || !x || !loc || !logstd || !logp || B < 0 || A < 1 || N < 1) return PFPN_ERR_ARG;
     if (B == 0) return PFPN_OK;
     hipStream_t st = (hipStream_t)stream;
     TilePlan pl = plan_tile(B, A, N, logits, nullptr);
     if (pl.ok && tile_has(N)) {
+        if (ppo) return PFPN_ERR_ARG;                      // (the tile path has its own fused PPO kernel)
         PpoArgs none{};
         launch_tile<MODE_FWD>(N, pl, st, logits, x, loc, logstd, nullptr, B, A, tanh_mode, logp, pmix,
                                 nullptr, nullptr, nullptr, none);
@@ -1549,18 +1599,22 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
         // rows' log p fit in LDS; otherwise per-segment values + the k_row_sum launch
         const int R4 = ((B + C - 1) / C + 3) & ~3;
         const size_t fold_lds = (size_t)4 * R4 * sizeof(float);
+        const size_t part_floats = (size_t)C * (A / 4) * R4;
         bool fold = A % 4 == 0 && C <= 64 && fold_lds <= (size_t)WIDE_FOLD_MAX_LDS &&
-                    workspace_bytes >= (size_t)C * (A / 4) * R4 * sizeof(float);
+                    workspace_bytes >= (part_floats + 2 * 64) * sizeof(float);
 #ifdef PFPN_WIDE_NO_FOLD                      // build knob for same-box A/B runs (tools/ab_build.sh): the separate launches
         fold = false;
 #endif
+        if (ppo && !fold) return PFPN_ERR_ARG;
+        WidePpo head{};
+        if (ppo) { head = *ppo; head.sums = lpseg + part_floats; }
         // non-temporal loads only in the streaming regime (logits larger than the 256 MiB infinity cache: 207 -> 195 us on
         // the 1 GiB shape); below it the default policy leaves the logits in cache for the backward pass that follows
         const bool stream = wide_stream(B, A, N);
 #define PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, SS, OO)                                                                \
     hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, FF, SS, OO>), dim3(blocks), dim3(256), OO ? fold_lds : 0, st, \
                        logits, x, loc, logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,  \
-                       (float*)nullptr, (float*)nullptr, logp, (float*)nullptr)
+                       (float*)nullptr, (float*)nullptr, logp, (float*)nullptr, head)
 #define PFPN_WIDE_FWD_F(MM, TT, FF)                                                                            \
     do {                                                                                                       \
         if (stream) { if (fold) PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, true, true); else PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, true, false); } \
@@ -1582,6 +1636,7 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
         }
         return PFPN_OK;
     }
+    if (ppo) return PFPN_ERR_ARG;
     int C = (B < 64) ? B : 64;
     while ((size_t)A * C < 2048 && C < B) C = (C * 2 < B) ? C * 2 : B;
     const int waves = A * C;
@@ -1593,6 +1648,25 @@ int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, cons
     hipLaunchKernelGGL(k_row_sum, dim3((B * 64 + 255) / 256), dim3(256), 0, st, lpseg, B, A, logp);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
+}
+
+int pfpn_logprob_fwd(const float* logits, const float* x, const float* loc, const float* logstd,
+                     int B, int A, int N, int tanh_mode, float* logp, float* pmix,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return logprob_fwd_impl(logits, x, loc, logstd, B, A, N, tanh_mode, logp, pmix, workspace, workspace_bytes, stream, nullptr);
+}
+
+int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* loc, const float* logstd,
+                         const float* logp_old, const float* adv, const float* value, const float* value_old,
+                         const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
+                         float* logp, float* dlogp, float* dvalue, float* loss3,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!logp_old || !adv || !value || !value_old || !adv_stats || !dlogp || !dvalue || !loss3 || B < 1) return PFPN_ERR_ARG;
+    WidePpo p{};
+    p.logp_old = logp_old; p.adv = adv; p.value = value; p.value_old = value_old; p.stats = adv_stats;
+    p.clip_lo = 1.0f - clip_eps; p.clip_hi = 1.0f + clip_eps; p.value_coef = value_coef; p.inv_B = 1.0f / (float)B;
+    p.dlogp = dlogp; p.dvalue = dvalue; p.loss3 = loss3;
+    return logprob_fwd_impl(logits, action, loc, logstd, B, A, N, 0, logp, nullptr, workspace, workspace_bytes, stream, &p);
 }
 
 int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, const float* logstd,

@@ -139,6 +139,16 @@ def adv_stats(adv, normalize=True, out=None):
     return out
 
 
+_dlogp_bufs = {}
+
+
+def _dlogp_scratch(B, device):
+    key = (B, device.index)
+    if key not in _dlogp_bufs:
+        _dlogp_bufs[key] = torch.empty(B, dtype=torch.float32, device=device)
+    return _dlogp_bufs[key]
+
+
 def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value_old, stats,
                         clip_eps=0.2, value_coef=0.5, out=None, dbias=None, finalize=True, ws=None):
     """Fused learner kernel.  Returns dict(logp, dlogits, dloc, dlogstd, dvalue, loss3).
@@ -178,14 +188,21 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
         # documented composition of the three HIP entry points (include/pfpn_hip.h)
         # (the row log-prob couples all A segments of a row; at N >= 64 a row and the [A,N] bank no longer fit on one
         # CU, so the second pass over the logits is structural: 3L of traffic)
-        # THREE launches (round 4): the forward's row sums and the backward's slab sums happen inside their launches, and
-        # every result lands in the caller's buffers (no copies)
+        # TWO launches (round 4): the forward's row sums AND the PPO head happen inside the forward launch, the backward's slab
+        # sums inside the backward launch, and every result lands in the caller's buffers (no copies)
         # (walking a > 256 MiB batch in row chunks that fit the infinity cache, so that a chunk's backward re-reads its logits
         # from cache, was built and measured in round 4: 806 us against 570 us on the 1 GiB shape -- 33 launches of
         # 96-MiB chunks cost more in start-up and tail than the cache gives back: LAB_NOTEBOOK.md)
-        logprob_fwd(logits, action, loc, logstd, out=out["logp"])
-        dlogp, _, _ = ppo_loss(out["logp"], logp_old, adv, value, value_old, stats, clip_eps, value_coef,
-                               dvalue=out["dvalue"], loss3=out["loss3"])
+        dlogp = _dlogp_scratch(B, dev)
+        rc = lib.pfpn_logprob_fwd_ppo(pl, pa, ploc, pls, *ptrs, B, A, N, float(clip_eps), float(value_coef),
+                                      out["logp"].data_ptr(), dlogp.data_ptr(), out["dvalue"].data_ptr(),
+                                      out["loss3"].data_ptr(), ws, wsn, _stream())
+        if rc == 1:        # (A % 4 != 0, very long row chunks: forward and loss head as launches of their own)
+            logprob_fwd(logits, action, loc, logstd, out=out["logp"])
+            dlogp, _, _ = ppo_loss(out["logp"], logp_old, adv, value, value_old, stats, clip_eps, value_coef,
+                                   dvalue=out["dvalue"], loss3=out["loss3"])
+        else:
+            _lib.check(rc, "pfpn_logprob_fwd_ppo")
         logprob_bwd(logits, action, loc, logstd, dlogp, out=out)          # straight into the caller's buffers
         if dbias is not None:
             act_bwd_bias_grad(None, out["dlogits"].view(B, A * N), dbias.view(1, -1), relu6=False)

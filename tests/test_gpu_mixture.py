@@ -177,8 +177,9 @@ def test_wide_in_launch_handoffs(oracle, dev, B, A, N):
             np.testing.assert_allclose(gotp.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * (np.abs(ref).max() + 1e-30))
 
 
-def test_wide_ppo_composition_is_three_launches_into_the_callers_buffers(oracle, dev):
-    """N >= 64: ppo_mixture_fwd_bwd composes forward -> loss head -> backward; every result lands in `out` directly."""
+def test_wide_ppo_composition_is_two_launches_into_the_callers_buffers(oracle, dev):
+    """N >= 64: ppo_mixture_fwd_bwd composes [forward + PPO head in one launch] -> backward; every result lands in `out`
+    directly; the in-launch head gives the per-row outputs of the stand-alone head bit for bit."""
     from pfpn_amd import kernels
     B, A, N = 300, 8, 128
     logits, x, loc, logstd = make_inputs(oracle, B, A, N, 77, spread=1.0)
@@ -203,6 +204,13 @@ def test_wide_ppo_composition_is_three_launches_into_the_callers_buffers(oracle,
     np.testing.assert_allclose(out["dlogits"].cpu().numpy().reshape(B, A, N), r_dl, rtol=2e-4, atol=3e-6 * sc)
     for k, ref in (("dloc", r_dloc), ("dlogstd", r_dls)):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref, rtol=1e-4, atol=5e-5 * (np.abs(ref).max() + 1e-30))
+    # the head inside the forward launch == the stand-alone head on the same log-probs (sums: another order)
+    h_dlogp, h_dv, h_l3 = kernels.ppo_loss(out["logp"], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    assert torch.equal(kernels._dlogp_scratch(B, dev), h_dlogp) and torch.equal(out["dvalue"], h_dv)
+    np.testing.assert_allclose(out["loss3"].cpu().numpy(), h_l3.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    again = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    for k in out:
+        assert torch.equal(out[k], again[k]), k                # the tickets came back zeroed; fixed-order sums
 
 
 def test_stream_pair_placement_changes_no_bits(dev):
