@@ -81,3 +81,29 @@ def test_single_gpu_line_carries_every_block_without_a_swallowed_error():
     assert 0 < d["roofline_gemm"]["frac"] < 1
     for k in ("sac_step", "config5_step"):
         assert k not in d or d[k]["finite_loss"]
+
+
+def _single(extra_args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                        "--watchdog", "250", "--force-exchange"] + list(extra_args),
+                       cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_rccl_line_times_the_safe_exchange_form_first_and_reports_the_default_one():
+    """Data parallel over RCCL (here: a world-size-1 group, `--force-exchange`): the two-graph form is timed first and stands
+    as the line until the default form -- the all-reduce captured inside the step's graph -- has been timed too."""
+    d = _single([])
+    assert "captured inside" in d["config"]["launch"] and d["value"] > 0 and d["windows"] == 5
+    assert d["exchange_two_graphs"]["value"] > 0 and "two hipGraphs" in d["exchange_two_graphs"]["launch"]
+    assert "headline_form" not in d and "extras_timed_out" not in d
+    assert d["rccl"]["ranks_seen"] == 1
+
+
+def test_rccl_line_survives_a_default_exchange_form_that_never_finishes():
+    d = _single(["--fail-extra", "default_form:0", "--extras-deadline", "15"])
+    assert d["extras_timed_out"] is True and d["value"] > 0
+    assert "two hipGraphs" in d["config"]["launch"] and "headline_form" in d
