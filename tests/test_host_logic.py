@@ -397,3 +397,34 @@ def test_stream_pair_layout_on_host_tensors(monkeypatch):
     assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.is_contiguous() and b.is_contiguous()
     gap = b.data_ptr() - a.data_ptr()
     assert gap == (256 << 20) + 4096 and gap >= a.numel() * 4 and a.shape == b.shape == (64, 100)
+
+
+def test_bench_reads_the_committed_profiles():
+    """bench.py quotes three numbers from committed rocprofv3 summaries (never measured in the run that prints them): the
+    headline kernel's begin-to-end duration, the GEMM kernels' MFMA-busy share and the SAC step's launch count.  The files it
+    picks must exist, be the newest round's, and parse."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    path, tag = bench.latest_profile("bench_kernel_stats.csv")
+    assert path and os.path.basename(path).startswith(tag) and tag >= "r04"
+    us, calls, src = bench.rocprof_kernel_us("k_mix_tile<35, 2>")
+    assert 8.0 < us < 20.0 and calls > 100 and src.startswith("profiles/")
+    n, src = bench.timeline_launches("sac_step_timeline.txt")
+    assert 20 <= n <= 60 and src.endswith("sac_step_timeline.txt")
+    n, _ = bench.timeline_launches("step_timeline.txt")
+    assert n == 15
+    mpath, _ = bench.latest_profile("gemm_mfma.json")
+    mj = json.load(open(mpath))
+    assert 0.5 < mj["mfma_busy_all_gemm_kernels"] < 1.0 and len([k for k, v in mj["kernels"].items() if "mfma_busy" in v]) >= 8
+    tpath, _ = bench.latest_profile("pmc_traffic.json")
+    t = json.load(open(tpath))["kernels"]["k_mix_tile<35,PPO>"]["traffic_bytes"]
+    assert bench.algorithmic_bytes_fused(4096) <= t <= 1.2 * bench.algorithmic_bytes_fused(4096)
+    # multiply-accumulates per row of the DeepMimic MLPs (SURVEY 8d: 5,889,536 per row forward + backward incl. the critic's
+    # 512-wide fc3, which runs inside an epilogue here and is not counted as GEMM work)
+    f, dw, dx = bench.dense_macs(197, (1024, 512), 1260)
+    assert f == 197 * 1024 + 1024 * 512 + 512 * 1260 and dx == f - 197 * 1024
+    assert bench.gemm_flops(4096) == 2.0 * 4096 * (5889536 - 3 * 512)
