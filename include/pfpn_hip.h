@@ -415,6 +415,26 @@ int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, con
  * Q(s, action_hist) and the target Q'(s', a')): x, x_next [B,S] normalised states, a_* [B,A]; outputs [B,S+A]. */
 int pfpn_sac_q_inputs(const float* x, const float* x_next, const float* a_pi, const float* a_hist, const float* a_next,
                       int B, int S, int A, float* xa_pi, float* xa_hist, float* xa_next, void* stream);
+/* The SAC actor side of a learner step as two launches (sac.py:108-175 with utils.py:108-134, :156-186) -- what
+ * pfpn_rsample_fwd + pfpn_logprob_fwd(tanh_mode) + pfpn_sac_q_inputs, and pfpn_logprob_bwd + pfpn_rsample_bwd + the
+ * column sums of dlogits (fc_policy's bias gradient) compute in seven, for N <= 64 particles and A <= 256 action dims
+ * (pfpn_sac_actor_supported: 1 / 0; other shapes keep the piece-wise entry points).
+ * fwd: rows [0, R) of logits / gumbel / eps [R, A*N] (R = 2B: the actor on [s; s']); k, a_out = tanh(p_k), s_out = p_k
+ * [R, A], logp [R].  xq_both != NULL: the critic inputs too -- x [R, S] normalised states of the same rows, a_hist [B, A];
+ * row r < B -> xq_both[r] = [x_r | a_r], xq_both[B + r] = [x_r | a_hist_r]; row r >= B -> xq_next[r - B] = [x_r | a_r].
+ * bwd: rows [0, B); x [B, A] = s_out, dlogp [B], da [B, A] upstream of a_out (the upstream of s_out is the log-prob's own
+ * dx); dlogits [B, A*N] is written; the workspace receives *nslab slabs of *stride = 3 A N floats {dloc | dlogstd |
+ * d fc_policy bias}, each summed over one block's rows -- the caller adds them in slab order (PFPN_JOB_COLSUM). */
+int pfpn_sac_actor_supported(int A, int N);
+int pfpn_sac_actor_fwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
+                       const float* eps, int R, int A, int N, int32_t* k, float* a_out, float* s_out, float* logp,
+                       const float* x, const float* a_hist, int B, int S, float* xq_both, float* xq_next,
+                       void* stream);
+int pfpn_sac_actor_bwd_slabs(int B, int A, int N, int* nslab, int* stride);
+size_t pfpn_sac_actor_workspace_bytes(int B, int A, int N);
+int pfpn_sac_actor_bwd(const float* logits, const float* loc, const float* logstd, const float* gumbel,
+                       const float* eps, const float* x, const float* dlogp, const float* da, int B, int A, int N,
+                       float* dlogits, void* workspace, size_t workspace_bytes, void* stream);
 /* SAC soft target update -- sac.py:67-73. */
 int pfpn_soft_update(float* target, const float* source, size_t n, float tau, void* stream);
 

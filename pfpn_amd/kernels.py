@@ -922,6 +922,62 @@ def sac_q_inputs(x, x_next, a_pi, a_hist, a_next, xa_pi, xa_hist, xa_next):
                                      _f32(xa_next, B, S + A), _stream()), "pfpn_sac_q_inputs")
 
 
+def sac_actor_supported(A, N):
+    """whether the two-launch actor side of the SAC step (sac_actor_fwd / sac_actor_bwd) covers this particle grid"""
+    return bool(_lib.load().pfpn_sac_actor_supported(int(A), int(N)))
+
+
+def sac_actor_fwd(logits, loc, logstd, gumbel, eps, x=None, a_hist=None, xq_both=None, xq_next=None):
+    """reparameterised sample + its log-prob (tanh mode) over the R rows of logits, and -- with x [R, S], a_hist [B, A],
+    xq_both [2B, S + A], xq_next [R - B, S + A] -- the three critic inputs, in ONE launch.  -> a, s_, k [R, A], logp [R]."""
+    lib = _lib.load()
+    A, N = loc.shape
+    R = logits.shape[0]
+    dev = logits.device
+    k = torch.empty(R, A, dtype=torch.int32, device=dev)
+    a = torch.empty(R, A, dtype=torch.float32, device=dev)
+    s_ = torch.empty(R, A, dtype=torch.float32, device=dev)
+    logp = torch.empty(R, dtype=torch.float32, device=dev)
+    B = S = 0
+    px = pa = pq = pn = None
+    if xq_both is not None:
+        B, S = a_hist.shape[0], x.shape[1]
+        px, pa = _f32(x, R, S), _f32(a_hist, B, A)
+        pq, pn = _f32(xq_both, 2 * B, S + A), _f32(xq_next, R - B, S + A)
+    _lib.check(lib.pfpn_sac_actor_fwd(_f32(logits.view(R, A * N), R, A * N), _f32(loc, A, N), _f32(logstd, A, N),
+                                      _f32(gumbel.view(R, A * N), R, A * N), _f32(eps.view(R, A * N), R, A * N), R, A, N,
+                                      k.data_ptr(), a.data_ptr(), s_.data_ptr(), logp.data_ptr(), px, pa, B, S, pq, pn,
+                                      _stream()), "pfpn_sac_actor_fwd")
+    return a, s_, k, logp
+
+
+def sac_actor_workspace(B, A, N, device):
+    return torch.empty(int(_lib.load().pfpn_sac_actor_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
+
+
+def sac_actor_bwd_slabs(B, A, N):
+    """(nslab, stride) of the {dloc | dlogstd | d head bias} partial sums sac_actor_bwd leaves in its workspace"""
+    n, st = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.load().pfpn_sac_actor_bwd_slabs(B, A, N, ctypes.addressof(n), ctypes.addressof(st)),
+               "pfpn_sac_actor_bwd_slabs")
+    return n.value, st.value
+
+
+def sac_actor_bwd(logits, loc, logstd, gumbel, eps, s_, dlogp, da, dlogits, ws):
+    """log-prob backward (at the sample s_, upstream dlogp [B]) + sample backward (upstream da [B, A] of tanh(s_); the
+    upstream of s_ is the log-prob's own dx) in ONE launch: dlogits [B, A*N] written, the particle-grid and head-bias
+    partial sums left in `ws` (sac_actor_workspace; sac_actor_bwd_slabs)."""
+    lib = _lib.load()
+    A, N = loc.shape
+    B = logits.shape[0]
+    _lib.check(lib.pfpn_sac_actor_bwd(_f32(logits.view(B, A * N), B, A * N), _f32(loc, A, N), _f32(logstd, A, N),
+                                      _f32(gumbel.view(B, A * N), B, A * N), _f32(eps.view(B, A * N), B, A * N),
+                                      _f32(s_, B, A), _f32(dlogp, B), _f32(da, B, A), B, A, N,
+                                      _f32(dlogits.view(B, A * N), B, A * N), ws.data_ptr(), ws.numel(), _stream()),
+               "pfpn_sac_actor_bwd")
+    return dlogits
+
+
 STREAM_PAIR_MIN_BYTES = 256 << 20          # = the wide backward's streaming regime (dlogits beyond the infinity cache)
 
 

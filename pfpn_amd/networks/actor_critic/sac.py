@@ -35,6 +35,7 @@ def sac_network_wrapper(base_class):
             self.alpha = alpha       # replaced by exp(log_alpha) for the trainable net (sac.py:36-39)
             self.batch_actor = True        # (tests flip these on an instance: the one-pass-per-input reference form)
             self.batch_critic = True
+            self.fuse_actor = True         # sample + log-prob + critic inputs | their backward as ONE launch each
             self.tau = tau
             self.reward, self.not_terminal = "reward", "not_terminal"
 
@@ -175,6 +176,8 @@ def sac_network_wrapper(base_class):
             # step's reduction launch
             self.ws_mixbwd = kernels.mixture_workspace(B, A, self.particles, dev)
             self.ws_rsbwd = kernels.rollout_workspace(B, A, self.particles, dev)
+            self.ws_actor = kernels.sac_actor_workspace(B, A, self.particles, dev) \
+                if kernels.sac_actor_supported(A, self.particles) else None
 
         # -- rollout ----------------------------------------------------------------------------------
         def _actor_logits(self, x, slot, out, masks=False):
@@ -292,6 +295,7 @@ def sac_network_wrapper(base_class):
             both = fold and self.batch_actor and nb is not None and nb.is_contiguous() and \
                 tuple(nb.shape) == (4, B, A * self.particles) and x.data_ptr() == self.xn_both.data_ptr()
             actor_slot = 0
+            fused = both and self.fuse_actor and self.ws_actor is not None
             if both:
                 # eval actor on s and the shared actor on s' (sac.py:141-153) are the same network: ONE pass over the
                 # 2B rows [s; s'] -- trunk, head, reparameterised sample and log-prob are 7 launches instead of 14; the
@@ -299,9 +303,15 @@ def sac_network_wrapper(base_class):
                 hb = self._actor_logits(self.xn_both, 0, self.logits_both, masks=True)
                 self.actor_trunk.share_prefix(2 * B, B, 0, 3)
                 actor_slot, ha = 3, hb[:B]
-                ab, sb, kb = kernels.rsample_fwd(self.logits_both, loc, logstd, nb[0:2].view(2 * B, -1),
-                                                 nb[2:4].view(2 * B, -1))
-                lb = kernels.logprob_fwd(self.logits_both, sb, loc, logstd, True)
+                if fused:
+                    # sample, log-prob at the sample and the three critic inputs: one launch (csrc/sac_actor_kernels.hip)
+                    ab, sb, kb, lb = kernels.sac_actor_fwd(self.logits_both, loc, logstd, nb[0:2].view(2 * B, -1),
+                                                           nb[2:4].view(2 * B, -1), x=self.xn_both, a_hist=action,
+                                                           xq_both=self.xq_both, xq_next=self.xa2)
+                else:
+                    ab, sb, kb = kernels.rsample_fwd(self.logits_both, loc, logstd, nb[0:2].view(2 * B, -1),
+                                                     nb[2:4].view(2 * B, -1))
+                    lb = kernels.logprob_fwd(self.logits_both, sb, loc, logstd, True)
                 a, s_, k, logp, a2, logp2 = ab[:B], sb[:B], kb[:B], lb[:B], ab[B:], lb[B:]
             else:
                 ha = self._actor_logits(x, 0, self.logits, masks=fold)
@@ -312,7 +322,8 @@ def sac_network_wrapper(base_class):
                 logp2 = kernels.logprob_fwd(self.logits2, s2, loc, logstd, True)
             self.last = {"a": a, "s_": s_, "k": k, "logp": logp}
             # Q inputs
-            kernels.sac_q_inputs(x, x2, a, action, a2, self.xa, self.xh, self.xa2)
+            if not fused:
+                kernels.sac_q_inputs(x, x2, a, action, a2, self.xa, self.xh, self.xa2)
             # (the second half's rows must start on a row chunk of the partial sums: 16-row chunks up to 8192 rows)
             both_q = fold and self.batch_critic and B % 16 == 0 and 2 * B <= 8192
             if both_q:
@@ -358,28 +369,40 @@ def sac_network_wrapper(base_class):
             # the particle-grid gradients land straight in the flat gradient buffer: log-prob backward writes them, the
             # reparameterised-sample backward adds its part in place
             dloc, dlogstd = st.g("actor/samples"), st.g("actor/samples_std")
-            wm, wr = (self.ws_mixbwd, self.ws_rsbwd) if fold else (None, None)
-            dlogits, _, _, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True,
-                                                     out={"dlogits": self.dlogits, "dloc": dloc, "dlogstd": dlogstd},
-                                                     slabs_ws=wm)
-            dlogits = dlogits.view(B, -1)
-            kernels.rsample_bwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"], da, dxs,
-                                dlogits, dloc, dlogstd, slabs_ws=wr)
-            if fold:
-                # dloc / dlogstd = (slab sum of the log-prob backward) + (slab sum of the sample backward): two jobs of the
-                # reduction launch instead of two finalize launches (same sums, same order)
-                AN = dlogits.shape[1]
-                n1, s1 = kernels.logprob_bwd_slabs(self.logits, self.dlogits, B, A, self.particles)
-                n2, s2, o2 = kernels.rsample_bwd_slabs(B, A, self.particles)
-                deferred.append(kernels.job_colsum(wm, 0, n1, s1, AN, dloc.view(-1), second=(wr, o2, n2, s2)))
-                deferred.append(kernels.job_colsum(wm, AN, n1, s1, AN, dlogstd.view(-1), second=(wr, o2 + AN, n2, s2)))
-            torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
             gpb = st.g("actor/fc_policy/bias")
-            if fold:
-                cpg = kernels.act_bwd_partial(None, dlogits, 0, self.ws_pbias, relu6=False)
-                deferred.append(kernels.job_colsum(self.ws_pbias, 0, cpg, dlogits.shape[1], dlogits.shape[1], gpb))
+            if fused:
+                # log-prob backward + sample backward + the particle-grid and head-bias partial sums: one launch; the three
+                # slab sums are jobs of the step's reduction launch
+                AN = A * self.particles
+                dlogits = kernels.sac_actor_bwd(self.logits, loc, logstd, nb[0], nb[2], s_, out["dlogp"], da,
+                                                self.dlogits, self.ws_actor)
+                ns, ss = kernels.sac_actor_bwd_slabs(B, A, self.particles)
+                deferred.append(kernels.job_colsum(self.ws_actor, 0, ns, ss, AN, dloc.view(-1)))
+                deferred.append(kernels.job_colsum(self.ws_actor, AN, ns, ss, AN, dlogstd.view(-1)))
+                deferred.append(kernels.job_colsum(self.ws_actor, 2 * AN, ns, ss, AN, gpb))
+                torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
             else:
-                kernels.act_bwd_bias_grad(None, dlogits, gpb, relu6=False)
+                wm, wr = (self.ws_mixbwd, self.ws_rsbwd) if fold else (None, None)
+                dlogits, _, _, dxs = kernels.logprob_bwd(self.logits, s_, loc, logstd, out["dlogp"], True, True,
+                                                         out={"dlogits": self.dlogits, "dloc": dloc, "dlogstd": dlogstd},
+                                                         slabs_ws=wm)
+                dlogits = dlogits.view(B, -1)
+                kernels.rsample_bwd(self.logits, loc, logstd, noise["gumbel"], noise["eps"], da, dxs,
+                                    dlogits, dloc, dlogstd, slabs_ws=wr)
+                if fold:
+                    # dloc / dlogstd = (slab sum of the log-prob backward) + (slab sum of the sample backward): two jobs of
+                    # the reduction launch instead of two finalize launches (same sums, same order)
+                    AN = dlogits.shape[1]
+                    n1, s1 = kernels.logprob_bwd_slabs(self.logits, self.dlogits, B, A, self.particles)
+                    n2, s2, o2 = kernels.rsample_bwd_slabs(B, A, self.particles)
+                    deferred.append(kernels.job_colsum(wm, 0, n1, s1, AN, dloc.view(-1), second=(wr, o2, n2, s2)))
+                    deferred.append(kernels.job_colsum(wm, AN, n1, s1, AN, dlogstd.view(-1), second=(wr, o2 + AN, n2, s2)))
+                torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
+                if fold:
+                    cpg = kernels.act_bwd_partial(None, dlogits, 0, self.ws_pbias, relu6=False)
+                    deferred.append(kernels.job_colsum(self.ws_pbias, 0, cpg, dlogits.shape[1], dlogits.shape[1], gpb))
+                else:
+                    kernels.act_bwd_bias_grad(None, dlogits, gpb, relu6=False)
             torch.mm(dlogits, self.policy_weight.t(), out=self.dha[0])
             self.actor_trunk.backward(self.dha, slot=actor_slot, deferred=deferred)
             if fold:

@@ -1,0 +1,95 @@
+"""The two-launch actor side of the SAC step (csrc/sac_actor_kernels.hip) against the piece-wise kernels it stands for
+(reparameterised sample, log-prob, critic inputs | log-prob backward, sample backward, column sums) and the NumPy oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+
+
+def _inputs(rng, R, A, N, dev, tanh_grid=True):
+    loc = np.tile(np.linspace(-1.6, 1.6, N, dtype=F), (A, 1)) + rng.normal(0, 0.02, (A, N)).astype(F)
+    logstd = np.log(np.full((A, N), 3.2 / N, F)) + rng.normal(0, 0.05, (A, N)).astype(F)
+    logits = rng.normal(0, 1.5, (R, A * N)).astype(F)
+    gumbel = (-np.log(-np.log(rng.uniform(1e-10, 1, (R, A * N))))).astype(F)
+    eps = rng.normal(0, 1, (R, A * N)).astype(F)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return t(logits), t(loc), t(logstd), t(gumbel), t(eps)
+
+
+@pytest.mark.parametrize("B,A,N,S", [(256, 36, 35, 197), (37, 36, 35, 197), (1024, 36, 35, 197), (50, 5, 7, 11),
+                                     (33, 3, 64, 9), (18, 150, 4, 6)])
+def test_actor_forward_matches_the_three_launches(dev, oracle, B, A, N, S):
+    from pfpn_amd import kernels
+    assert kernels.sac_actor_supported(A, N)
+    rng = np.random.default_rng(B * 131 + A)
+    R = 2 * B
+    logits, loc, logstd, gumbel, eps = _inputs(rng, R, A, N, dev)
+    x = torch.from_numpy(rng.normal(0, 1, (R, S)).astype(F)).to(dev)
+    a_hist = torch.from_numpy(np.tanh(rng.normal(0, 1, (B, A))).astype(F)).to(dev)
+    xq_both = torch.full((2 * B, S + A), float("nan"), device=dev)
+    xq_next = torch.full((B, S + A), float("nan"), device=dev)
+    a, s_, k, logp = kernels.sac_actor_fwd(logits, loc, logstd, gumbel, eps, x=x, a_hist=a_hist, xq_both=xq_both,
+                                           xq_next=xq_next)
+    a0, s0, k0 = kernels.rsample_fwd(logits, loc, logstd, gumbel, eps)
+    lp0 = kernels.logprob_fwd(logits, s0, loc, logstd, True)
+    assert torch.equal(k, k0) and torch.equal(a, a0) and torch.equal(s_, s0)            # same arithmetic: same bits
+    torch.testing.assert_close(logp, lp0, rtol=1e-5, atol=1e-5 * float(lp0.abs().max()))
+    xa, xh, xn = (torch.empty(B, S + A, device=dev) for _ in range(3))
+    kernels.sac_q_inputs(x[:B], x[B:], a0[:B], a_hist, a0[B:], xa, xh, xn)
+    assert torch.equal(xq_both[:B], xa) and torch.equal(xq_both[B:], xh) and torch.equal(xq_next, xn)
+    # the oracle's log-prob at the same samples (float64 inside)
+    ref, _ = oracle.mixture_log_prob(logits.cpu().numpy().reshape(R, A, N), s_.cpu().numpy(), loc.cpu().numpy(),
+                                     logstd.cpu().numpy(), tanh_mode=True)
+    np.testing.assert_allclose(logp.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    # without the critic inputs (rollout-style use): same sample, same log-prob
+    a1, s1, k1, lp1 = kernels.sac_actor_fwd(logits, loc, logstd, gumbel, eps)
+    assert torch.equal(k1, k) and torch.equal(lp1, logp)
+
+
+@pytest.mark.parametrize("B,A,N", [(256, 36, 35), (37, 36, 35), (1024, 36, 35), (4096, 36, 35), (50, 5, 7), (33, 3, 64),
+                                   (18, 150, 4)])
+def test_actor_backward_matches_the_piecewise_launches(dev, B, A, N):
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(B * 17 + N)
+    logits, loc, logstd, gumbel, eps = _inputs(rng, B, A, N, dev)
+    a0, s0, k0 = kernels.rsample_fwd(logits, loc, logstd, gumbel, eps)
+    dlogp = torch.from_numpy((rng.normal(0, 1, B) * 0.01).astype(F)).to(dev)
+    da = torch.from_numpy(rng.normal(0, 0.02, (B, A)).astype(F)).to(dev)
+    AN = A * N
+    # piece-wise: log-prob backward writes, sample backward accumulates
+    dl0, dloc0, dls0, dxs = kernels.logprob_bwd(logits, s0, loc, logstd, dlogp, True, True)
+    dl0 = dl0.view(B, AN).clone()
+    dloc0, dls0 = dloc0.clone(), dls0.clone()
+    kernels.rsample_bwd(logits, loc, logstd, gumbel, eps, da, dxs, dl0, dloc0, dls0)
+    # fused
+    ws = kernels.sac_actor_workspace(B, A, N, dev)
+    dl1 = torch.full((B, AN), float("nan"), device=dev)
+    kernels.sac_actor_bwd(logits, loc, logstd, gumbel, eps, s0, dlogp, da, dl1, ws)
+    ns, ss = kernels.sac_actor_bwd_slabs(B, A, N)
+    assert ss == 3 * AN and ws.numel() == 4 * ns * ss
+    slabs = ws.view(torch.float32).view(ns, 3, AN).double().sum(0).cpu().numpy()
+    d0 = dl0.cpu().numpy().astype(np.float64)
+    d1 = dl1.cpu().numpy().astype(np.float64)
+    sc = np.abs(d0).max()
+    np.testing.assert_allclose(d1, d0, rtol=2e-5, atol=2e-6 * sc)
+    for got, ref, name in ((slabs[0], dloc0.cpu().numpy().reshape(-1), "dloc"),
+                           (slabs[1], dls0.cpu().numpy().reshape(-1), "dlogstd"),
+                           (slabs[2], d0.sum(0), "dbias")):
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg=name)
+    # run to run: the same bits (fixed-order sums, no atomics)
+    ws2 = kernels.sac_actor_workspace(B, A, N, dev)
+    dl2 = torch.empty(B, AN, device=dev)
+    kernels.sac_actor_bwd(logits, loc, logstd, gumbel, eps, s0, dlogp, da, dl2, ws2)
+    assert torch.equal(dl2, dl1) and torch.equal(ws2, ws)
+
+
+def test_actor_kernels_refuse_what_they_do_not_cover(dev):
+    from pfpn_amd import kernels, _lib
+    assert not kernels.sac_actor_supported(36, 65) and not kernels.sac_actor_supported(300, 8)
+    assert not kernels.sac_actor_supported(128, 256)          # (3 staged rows of 128 x 256 do not fit 64 KiB)
+    rng = np.random.default_rng(0)
+    logits, loc, logstd, gumbel, eps = _inputs(rng, 8, 4, 65, dev)
+    with pytest.raises(_lib.PfpnLibraryError):
+        kernels.sac_actor_fwd(logits, loc, logstd, gumbel, eps)
