@@ -44,20 +44,26 @@ __device__ __forceinline__ void sa_stage_out(float* __restrict__ dst, const floa
     for (int i = 4 * nq + tid; i < count; i += nthr) dst[base + i] = lds[i];
 }
 
-// The particle bank of one lane: loc, scale, isc = sqrt(.5 log2 e) / scale, ct = 64 - (0.5 log 2 pi + log scale) log2 e
-// (k_mix_tile's constants: e * phi = exp2(l log2 e - max - z'^2 + ct) * 2^-64 in ONE v_exp_f32).
+// The particle bank of one lane: loc, logstd, scale, isc = sqrt(.5 log2 e) / scale, ct = 64 - (0.5 log 2 pi + log scale) log2 e
+// (k_mix_tile's constants: e * phi = exp2(l log2 e - max - z'^2 + ct) * 2^-64 in ONE v_exp_f32).  The scale comes from one
+// v_exp_f32 and its reciprocal from one v_rcp_f32 (2e-7 relative; log scale = logstd as it stands): a block is alive for
+// ONE or two row groups, so the bank is not amortised -- with libm's expf / logf / division it was a third of the launch.
+__device__ __forceinline__ float sa_fast_tanh(float v) {      // 1 - 2 / (1 + e^(2v)): v_exp_f32 + v_rcp_f32, |error| ~1e-7
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * (2.f * PFPN_LOG2E)));
+}
 template <int NP>
 struct SaBank {
-    float loc[NP], sc[NP], isc[NP], ct[NP];
+    float loc[NP], ls[NP], sc[NP], isc[NP], ct[NP];
     __device__ __forceinline__ void load(const float* __restrict__ locp, const float* __restrict__ lsp, int a, int N, int g) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int n = g + SA_G * i;
             const int o = a * N + (n < N ? n : 0);
             loc[i] = locp[o];
-            sc[i] = expf(lsp[o]);
-            isc[i] = (1.0f / sc[i]) * PFPN_SQRT_HALF_LOG2E;
-            ct[i] = 64.f - (PFPN_HALF_LOG_2PI + logf(sc[i])) * PFPN_LOG2E;
+            ls[i] = lsp[o];
+            sc[i] = __builtin_amdgcn_exp2f(ls[i] * PFPN_LOG2E);
+            isc[i] = __builtin_amdgcn_rcpf(sc[i]) * PFPN_SQRT_HALF_LOG2E;
+            ct[i] = 64.f - (PFPN_HALF_LOG_2PI + ls[i]) * PFPN_LOG2E;
         }
     }
 };
@@ -84,18 +90,52 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_fwd(
     float* ll = sa_lds;
     float* lg = ll + span;
     float* s_lp = lg + span;                             // [Rb][A] per-segment log p
-    float* s_a = s_lp + Rb * A;                          // [Rb][A] tanh(p_k)
-    sa_stage_in(ll, logits, (size_t)r0 * AN, rows * AN, tid, nthr);
-    sa_stage_in(lg, gumbel, (size_t)r0 * AN, rows * AN, tid, nthr);
-    __syncthreads();
+    const int W = S + A;
     const int q = tid >> 2, g = tid & 3;
     const int rq_ = q / A, a = q - rq_ * A;
+    // Everything that depends on nothing computed here is REQUESTED first -- the state columns of the critic inputs (up to
+    // XR per thread in registers), then the staged tensors, then the bank: one memory round trip, not three.
+    constexpr int XR = 4;
+    float xr[XR];
+    const int nx = xq_both ? rows * S : 0;
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+        const int idx = tid + j * nthr;
+        xr[j] = idx < nx ? x[(size_t)r0 * S + idx] : 0.f;  // (the block's rows of x are one contiguous span)
+    }
+    sa_stage_in(ll, logits, (size_t)r0 * AN, rows * AN, tid, nthr);
+    sa_stage_in(lg, gumbel, (size_t)r0 * AN, rows * AN, tid, nthr);
+    SaBank<NP> bk;
+    bk.load(loc, logstd, a, N, g);
+    if (xq_both) {                                       // the replayed actions: the action columns of Q(s, action_hist)
+        for (int idx = tid; idx < rows * A; idx += nthr) {
+            const int rr = idx / A, c = idx - rr * A;
+            const int r = r0 + rr;
+            if (r < B) xq_both[(size_t)(B + r) * W + S + c] = a_hist[(size_t)r * A + c];
+        }
+    }
+    for (int idx0 = 0; idx0 < nx; idx0 += nthr * XR) {    // (one trip unless Rb * S > XR * blockDim)
+#pragma unroll
+        for (int j = 0; j < XR; ++j) {
+            const int idx = idx0 + tid + j * nthr;
+            if (idx < nx) {
+                const float v = idx0 == 0 ? xr[j] : x[(size_t)r0 * S + idx];
+                const int rr = idx / S, c = idx - rr * S;
+                const int r = r0 + rr;
+                if (r < B) {
+                    xq_both[(size_t)r * W + c] = v;
+                    xq_both[(size_t)(B + r) * W + c] = v;
+                } else {
+                    xq_next[(size_t)(r - B) * W + c] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
     if (rq_ < rows) {                                    // (a quad is live or dead as a whole: the DPP steps stay inside it)
         const int rq = rq_;
         const float* row = ll + (rq * A + a) * N;
         const float* gr = lg + (rq * A + a) * N;
-        SaBank<NP> bk;
-        bk.load(loc, logstd, a, N, g);
         float l[NP];
         float mx = -INFINITY, mxl = -INFINITY;
         int k = 0x7fffffff;
@@ -111,20 +151,33 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_fwd(
             }
         }
         sa_quad_argmax(mx, k);
-        mxl = quad_max(mxl);
         const size_t seg = (size_t)(r0 + rq) * A + a;
-        const float pk = loc[a * N + k] + expf(logstd[a * N + k]) * eps[seg * N + k];
-        float sum = 0.f, num = 0.f;
+        const float ek = eps[seg * N + k];               // the one draw this segment uses: requested as soon as k is known,
+        mxl = quad_max(mxl);                             // the softmax denominator runs under its round trip
+        float e[NP];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            e[i] = l[i] - mxl;
+            if (g + SA_G * i < N) sum += __builtin_amdgcn_exp2f(e[i]);
+        }
+        sum = quad_sum(sum);
+        // p_k = loc_k + exp(logstd_k) * eps_k from the lane that owns particle k (libm's expf: the bits of the piece-wise
+        // kernel, which the backward recomputes); x + 0 + 0 + 0 is exact
+        float lock = 0.f, lsk = 0.f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            if (g + SA_G * i == k) { lock = bk.loc[i]; lsk = bk.ls[i]; }
+        float pk = (k & 3) == g ? lock + expf(lsk) * ek : 0.f;
+        pk = quad_sum(pk);
+        float num = 0.f;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (g + SA_G * i < N) {
-                const float le = l[i] - mxl;
                 const float z = (pk - bk.loc[i]) * bk.isc[i];
-                sum += __builtin_amdgcn_exp2f(le);
-                num += __builtin_amdgcn_exp2f(le + fmaf(-z, z, bk.ct[i]));
+                num += __builtin_amdgcn_exp2f(e[i] + fmaf(-z, z, bk.ct[i]));
             }
         }
-        sum = quad_sum(sum);
         num = quad_sum(num);
         float p = (num * 5.421010862427522e-20f) * __builtin_amdgcn_rcpf(sum);
         if (p < 1.401298464324817e-45f) p = 0.f;         // below the smallest fp32 denormal: the reference's p is 0
@@ -135,7 +188,11 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_fwd(
             s_out[seg] = pk;
             a_out[seg] = ta;
             s_lp[rq * A + a] = lp;
-            s_a[rq * A + a] = ta;
+            if (xq_both) {                                // the sample's column of its critic input
+                const int r = r0 + rq;
+                if (r < B) xq_both[(size_t)r * W + S + a] = ta;
+                else xq_next[(size_t)(r - B) * W + S + a] = ta;
+            }
         }
     }
     __syncthreads();
@@ -145,19 +202,6 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_fwd(
         for (int aa = lane; aa < A; aa += 64) s += s_lp[rr * A + aa];
         s = wave_sum(s);
         if (lane == 0) logp[r0 + rr] = s;
-    }
-    if (!xq_both) return;
-    const int W = S + A;
-    for (int idx = tid; idx < rows * W; idx += nthr) {
-        const int rr = idx / W, c = idx - rr * W;
-        const int r = r0 + rr;
-        const float v = c < S ? x[(size_t)r * S + c] : s_a[rr * A + (c - S)];
-        if (r < B) {
-            xq_both[(size_t)r * W + c] = v;
-            xq_both[(size_t)(B + r) * W + c] = c < S ? v : a_hist[(size_t)r * A + (c - S)];
-        } else {
-            xq_next[(size_t)(r - B) * W + c] = v;
-        }
     }
 }
 
@@ -184,13 +228,20 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_bwd(
     const int rq_ = q / A, a = q - rq_ * A;
     SaBank<NP> bk;
     bk.load(loc, logstd, a, N, g);
-    float acc_loc[NP], acc_ls[NP], acc_b[NP], acc_lk[NP];
+    float acc_loc[NP], acc_ls[NP], acc_b[NP];
 #pragma unroll
-    for (int i = 0; i < NP; ++i) acc_loc[i] = acc_ls[i] = acc_b[i] = acc_lk[i] = 0.f;
+    for (int i = 0; i < NP; ++i) acc_loc[i] = acc_ls[i] = acc_b[i] = 0.f;
     const float two_m64 = 5.421010862427522e-20f;
     for (int it = 0; it < iters; ++it) {
         const int r0 = (blockIdx.x * iters + it) * Rb;
         const int rows = max(0, min(Rb, B - r0));
+        float xval = 0.f, gv = 0.f, gda = 0.f;           // (issued before the staging: one round trip, not two)
+        if (rq_ < rows) {
+            const size_t seg = (size_t)(r0 + rq_) * A + a;
+            xval = x[seg];
+            gv = dlogp[r0 + rq_];
+            gda = da[seg];
+        }
         if (it) __syncthreads();                         // the previous group's dlogits have left the LDS
         if (rows > 0) {
             sa_stage_in(ll, logits, (size_t)r0 * AN, rows * AN, tid, nthr);
@@ -203,25 +254,20 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_bwd(
             float* row = ll + (rq * A + a) * N;
             const float* gr = lg + (rq * A + a) * N;
             const float* er = le_ + (rq * A + a) * N;
-            const size_t seg = (size_t)(r0 + rq) * A + a;
-            const float xval = x[seg];
-            const float gv = dlogp[r0 + rq];
-            const float gda = da[seg];
             // -- log-prob part (k_mix_tile's arithmetic) and the softmax of logits + Gumbel, one pass over the registers
-            float lp[NP], y[NP], th[NP];
+            float lp[NP], y[NP];
             float mxl = -INFINITY, mxy = -INFINITY;
             int k = 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int n = g + SA_G * i;
-                lp[i] = 0.f; y[i] = -INFINITY; th[i] = 0.f;
+                lp[i] = 0.f; y[i] = -INFINITY;
                 if (n < N) {
                     const float lv = row[n];
                     lp[i] = lv * PFPN_LOG2E;
                     mxl = fmaxf(mxl, lp[i]);
                     y[i] = lv + gr[n];
                     if (y[i] > mxy) { mxy = y[i]; k = n; }
-                    th[i] = tanhf(bk.loc[i] + bk.sc[i] * er[n]);      // tanh of every particle's candidate sample
                 }
             }
             mxl = quad_max(mxl);
@@ -238,7 +284,7 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_bwd(
                     ef[i] = __builtin_amdgcn_exp2f(le + fmaf(-z, z, bk.ct[i]));
                     sum += e[i];
                     num += ef[i];
-                    y[i] = expf(y[i] - mxy);                          // y <- softmax numerator of logits + Gumbel
+                    y[i] = __builtin_amdgcn_exp2f((y[i] - mxy) * PFPN_LOG2E);   // y <- softmax numerator of logits + Gumbel
                     sumy += y[i];
                 } else {
                     y[i] = 0.f;
@@ -265,25 +311,31 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_bwd(
                 acc_ls[i] = fmaf(tt, fmaf(z * z, PFPN_2LN2, -1.f), acc_ls[i]);
                 dxp = fmaf(tt * z, bk.isc[i] * PFPN_2LN2, dxp);
             }
-            const float gds = -quad_sum(dxp) + gv * 2.f * tanhf(xval);     // d L / d p_k through the log-prob
-            // -- sample part (k_rsample_bwd_quad's arithmetic)
-            const float inv = 1.0f / sumy;
-            const float sck = expf(logstd[a * N + k]);
-            const float ek = er[k];
-            const float tk = tanhf(loc[a * N + k] + sck * ek);
+            // -- sample part (k_rsample_bwd_quad's arithmetic).  tanh(p_k) from libm at x = p_k (the forward's value); the
+            // other particles' candidates through v_exp / v_rcp (|error| ~1e-7 against gaps of >= 0.05); scale_k * eps_k
+            // from the lane that owns particle k.  (eps is read HERE, not with the logits: nine registers fewer live across
+            // the log-prob part, which otherwise spills)
+            const float tk = tanhf(xval);
+            const float gds = -quad_sum(dxp) + gv * 2.f * tk;         // d L / d p_k through the log-prob
+            const float inv = __builtin_amdgcn_rcpf(sumy);
             const float one_m = 1.f - tk * tk;
             const float cs = gds / fmaxf(1e-6f, one_m);
-            float dot = 0.f;
+            float th[NP];
+            float sek = 0.f, dot = 0.f;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                const float gap = th[i] - tk;
-                th[i] = gap * gda + gap * cs;                         // th <- gw_n
+                const int n = g + SA_G * i;
+                const float se = n < N ? bk.sc[i] * er[n] : 0.f;      // scale * eps
+                if (n == k) sek = se;
+                const float gap = sa_fast_tanh(bk.loc[i] + se) - tk;
+                th[i] = gap * gda + gap * cs;                         // gw_n
                 y[i] *= inv;                                          // y <- w_n
                 dot += th[i] * y[i];
             }
+            sek = quad_sum(sek);
             dot = quad_sum(dot);
             const float gp = gda * one_m + gds;                       // d L / d p_k
-            const float gs = gp * sck * ek;                           // d L / d logstd_k
+            const float gs = gp * sek;                                // d L / d logstd_k
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 const int n = g + SA_G * i;
@@ -291,7 +343,8 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_bwd(
                     const float dt = d[i] + y[i] * (th[i] - dot);
                     row[n] = dt;
                     acc_b[i] += dt;
-                    if (n == k) { acc_lk[i] += gp; acc_ls[i] += gs; }
+                    // (the sample's own d / d loc_k joins the log-prob's sum pre-divided by the factor that sum is finished with)
+                    if (n == k) { acc_loc[i] = fmaf(gp, bk.sc[i] * (1.0f / PFPN_SQRT_2LN2), acc_loc[i]); acc_ls[i] += gs; }
                 }
             }
         }
@@ -306,7 +359,7 @@ __global__ __launch_bounds__(MAXT) void k_sac_actor_bwd(
             const int n = g + SA_G * i;
             if (n < N) {
                 float* pl = sa_lds + (size_t)rq_ * 3 * AN + a * N + n;
-                pl[0] = fmaf(acc_loc[i], bk.isc[i] * PFPN_2LN2, acc_lk[i]);
+                pl[0] = acc_loc[i] * (bk.isc[i] * PFPN_2LN2);
                 pl[AN] = acc_ls[i];
                 pl[2 * AN] = acc_b[i];
             }
@@ -331,9 +384,25 @@ static inline int sa_rows_per_block(int A, int N) {
     if (rb > cap) rb = cap;
     return rb;                                            // 0: unsupported shape (the caller keeps the piece-wise launches)
 }
-static inline int sa_bwd_iters(int B, int Rb) {
-    const int it = (B + Rb * 256 - 1) / (Rb * 256);      // <= 256 blocks = slabs
-    return it < 1 ? 1 : it;
+// The launch is latency-bound (one block = one pass: stage, compute, write): small batches take FEWER rows per block so
+// that the blocks spread over more CUs and a SIMD hosts one wave instead of three (backward at 256 rows: 10.8 -> 8.0 us;
+// forward over 512 rows: 7.9 -> 6.7 us; forward over 2048 rows: 11.2 us at 4 rows per block, 10.9 at 2, 11.8 at 1).
+// Backward: at most 256 blocks = slabs; beyond Rb_max * 256 rows a block walks `it` row groups.
+static inline void sa_bwd_geom(int B, int A, int N, int* Rb, int* it) {
+    const int rbmax = sa_rows_per_block(A, N);
+    int rb = (B + 255) / 256;
+    if (rb > rbmax) rb = rbmax;
+    if (rb < 1) rb = rbmax > 0 ? 1 : 0;
+    *Rb = rb;
+    *it = rb > 0 ? (B + rb * 256 - 1) / (rb * 256) : 0;
+    if (*it < 1) *it = 1;
+}
+static inline int sa_fwd_rows(int R, int A, int N) {
+    const int rbmax = sa_rows_per_block(A, N);
+    int rb = (R + 1023) / 1024;
+    if (rb > rbmax) rb = rbmax;
+    if (rb < 1) rb = rbmax > 0 ? 1 : 0;
+    return rb;
 }
 
 }  // namespace pfpn
@@ -351,11 +420,11 @@ int pfpn_sac_actor_fwd(const float* logits, const float* loc, const float* logst
     PFPN_BEGIN();
     if (!logits || !loc || !logstd || !gumbel || !eps || !k || !a_out || !s_out || !logp || R < 0) return PFPN_ERR_ARG;
     if (xq_both && (!x || !a_hist || !xq_next || B < 0 || B > R || S < 1)) return PFPN_ERR_ARG;
-    const int Rb = sa_rows_per_block(A, N);
+    const int Rb = sa_fwd_rows(R, A, N);
     if (Rb < 1) return PFPN_ERR_ARG;
     if (R == 0) return PFPN_OK;
     const int threads = (Rb * A * SA_G + 63) & ~63;
-    const size_t lds = ((size_t)2 * ((Rb * A * N + 3) & ~3) + 2 * Rb * A) * sizeof(float);
+    const size_t lds = ((size_t)2 * ((Rb * A * N + 3) & ~3) + Rb * A) * sizeof(float);
     const dim3 grid((R + Rb - 1) / Rb), block(threads);
 #define PFPN_SA_FWD(NP_, MT_)                                                                                        \
     hipLaunchKernelGGL((k_sac_actor_fwd<NP_, MT_>), grid, block, lds, (hipStream_t)stream, logits, loc, logstd, gumbel, \
@@ -370,9 +439,9 @@ int pfpn_sac_actor_fwd(const float* logits, const float* loc, const float* logst
 }
 
 int pfpn_sac_actor_bwd_slabs(int B, int A, int N, int* nslab, int* stride) {
-    const int Rb = sa_rows_per_block(A, N);
+    int Rb = 0, it = 0;
+    sa_bwd_geom(B, A, N, &Rb, &it);
     if (!nslab || !stride || B < 1 || Rb < 1) return PFPN_ERR_ARG;
-    const int it = sa_bwd_iters(B, Rb);
     *nslab = (B + Rb * it - 1) / (Rb * it);
     *stride = 3 * A * N;
     return PFPN_OK;
@@ -389,10 +458,10 @@ int pfpn_sac_actor_bwd(const float* logits, const float* loc, const float* logst
                        float* dlogits, void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
     if (!logits || !loc || !logstd || !gumbel || !eps || !x || !dlogp || !da || !dlogits || B < 1) return PFPN_ERR_ARG;
-    const int Rb = sa_rows_per_block(A, N);
+    int Rb = 0, it = 0;
+    sa_bwd_geom(B, A, N, &Rb, &it);
     if (Rb < 1) return PFPN_ERR_ARG;
     if (!workspace || workspace_bytes < pfpn_sac_actor_workspace_bytes(B, A, N)) return PFPN_ERR_WORKSPACE;
-    const int it = sa_bwd_iters(B, Rb);
     const int threads = (Rb * A * SA_G + 63) & ~63;
     const size_t lds = (size_t)3 * ((Rb * A * N + 3) & ~3) * sizeof(float);
     const dim3 grid((B + Rb * it - 1) / (Rb * it)), block(threads);
