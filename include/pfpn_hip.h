@@ -411,6 +411,30 @@ int pfpn_sac_loss(const float* q_pi, const float* q_run, const float* q_tgt, con
                   float* dlog_alpha, float* loss3, int q_ld, uint64_t* noise_epoch, void* stream);
 /* (noise_epoch, optional: a device counter this launch advances by one -- the offset the step's NEXT noise draw reads,
  * pfpn_sac_noise_fill(offset_dev) / PfpnStatePrologue.noise_epoch; its readers run in other launches) */
+/* pfpn_sac_loss riding in the first launch of the critics' backward pass -- for the step that evaluates the twin live critics
+ * ONCE over the 2B rows [(s, a_pi); (s, action_hist)] (q_both / dq_both [2, 2B]: [g][0:B] = Q_g(s, a_pi), [g][B:2B] =
+ * Q_g(s, action_hist)).  = pfpn_act_bwd_partial(rows = 4B, group_rows = 2B, relu6, value_group = -1) on dvalue = the dQ of
+ * pfpn_sac_loss(q_ld = 2B), which every block forms for its own rows (a row's dQ depends on that row alone) and the first
+ * column tile writes to dq_both; one block adds loss3, dlog_alpha, dlogp [B] and the draw counter.  dQ: the bits of
+ * pfpn_sac_loss; the three losses: equal to rounding (256 threads sum them here, 1024 there). */
+typedef struct PfpnSacLoss {
+    const float* q_both;
+    const float* q_tgt;          /* [2, B] */
+    const float* logp;
+    const float* logp_t;
+    const float* reward;
+    const float* not_terminal;
+    const float* log_alpha;
+    int B;
+    float gamma, value_coef, target_entropy;
+    float* dq_both;
+    float* dlogp;
+    float* dlog_alpha;
+    float* loss3;
+    uint64_t* noise_epoch;       /* optional */
+} PfpnSacLoss;
+int pfpn_act_bwd_partial_sac(const float* y, float* dy, int H, const float* value_w, float* value_partial, float* partial,
+                             size_t partial_floats, int* chunks_per_group, const PfpnSacLoss* loss, void* stream);
 /* The three critic inputs of a SAC step in one launch -- sac.py:108-121 (tf.concat([state, action], -1) for Q(s, a_pi),
  * Q(s, action_hist) and the target Q'(s', a')): x, x_next [B,S] normalised states, a_* [B,A]; outputs [B,S+A]. */
 int pfpn_sac_q_inputs(const float* x, const float* x_next, const float* a_pi, const float* a_hist, const float* a_next,

@@ -1180,20 +1180,69 @@ __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, c
 // k_act_bwd_partial with the critic head's backward folded in: on group `vgroup` the incoming gradient is not read
 // but formed as dv[b] * w[c] (k_value_head_bwd_partial's arithmetic), masked and written like any other row, and a
 // second accumulator collects the head's weight-gradient partials sum_b y[b,c] dv[b] into vpartial[chunk][H].
+// SAC = the SAC loss head rides along (PfpnSacLoss, one pass of the twin critics over [(s, a_pi); (s, a_hist)]: grows = 2B,
+// a head on both groups): the upstream dQ of a row is a function of that row alone (k_sac_loss's expressions, same order ->
+// same bits), so every block forms the values it needs instead of reading them from a launch of their own; the blocks of
+// the first column tile write them to dq_both (the head-bias job reads them), block (0, 0, 0) adds what a loss head
+// leaves besides: the three losses, d log_alpha, dlogp [B] and the step's draw counter.
+__device__ __forceinline__ float sac_dq(const PfpnSacLoss& L, int z, int b, float alpha, float inv_B) {
+    if (b < L.B) {                                                // Q_z(s, a_pi): tf.minimum routes its gradient to x where x <= y
+        const bool sel1 = L.q_both[b] <= L.q_both[2 * L.B + b];
+        return (z == 0) == sel1 ? -inv_B : 0.f;
+    }
+    const int r = b - L.B;                                        // Q_z(s, a_hist): the value loss
+    const float vft = fminf(L.q_tgt[r], L.q_tgt[L.B + r]) - alpha * L.logp_t[r];
+    const float qt = L.reward[r] + L.gamma * L.not_terminal[r] * vft;
+    const float d = qt - L.q_both[(size_t)z * 2 * L.B + L.B + r];
+    return -2.f * d * L.value_coef * inv_B;
+}
+
+template <bool SAC>
 __global__ __launch_bounds__(256) void k_act_bwd_partial_value(const float* __restrict__ y, float* __restrict__ dy,
                                                                int grows, int H, int chunk_len,
                                                                float* __restrict__ partial, int vgroup,
                                                                const float* __restrict__ vw,
                                                                const float* __restrict__ dv,
-                                                               float* __restrict__ vpartial) {
+                                                               float* __restrict__ vpartial, PfpnSacLoss L) {
     __shared__ float4 red[4][64];
+    float sac_alpha = 0.f, sac_inv_B = 0.f;
+    if (SAC) { sac_alpha = expf(L.log_alpha[0]); sac_inv_B = 1.0f / (float)L.B; }
+    const int nchunk = SAC ? gridDim.y - 1 : gridDim.y;           // SAC: one more row of blocks, of which ONE is the loss head
+    if (SAC && (int)blockIdx.y == nchunk) {
+        if (blockIdx.x || blockIdx.z) return;
+        // what k_sac_loss leaves besides dQ, next to (not after) the blocks that do the pass (sums over 256 threads here,
+        // 1024 there: the losses agree to rounding)
+        float* redf = reinterpret_cast<float*>(red);
+        if (L.noise_epoch && threadIdx.x == 0) L.noise_epoch[0] += 1ull;
+        const float la = L.log_alpha[0];
+        float ps = 0.f, vs = 0.f, es = 0.f;
+        for (int b = threadIdx.x; b < L.B; b += blockDim.x) {
+            const float vft = fminf(L.q_tgt[b], L.q_tgt[L.B + b]) - sac_alpha * L.logp_t[b];
+            const float qt = L.reward[b] + L.gamma * L.not_terminal[b] * vft;
+            const float d1 = qt - L.q_both[L.B + b], d2 = qt - L.q_both[3 * L.B + b];
+            vs += d1 * d1 + d2 * d2;
+            const float lp = L.logp[b];
+            ps += sac_alpha * lp - fminf(L.q_both[b], L.q_both[2 * L.B + b]) - la * (lp + L.target_entropy);
+            es += lp + L.target_entropy;
+            L.dlogp[b] = sac_alpha * sac_inv_B;
+        }
+        ps = block_sum(ps, redf);
+        vs = block_sum(vs, redf);
+        es = block_sum(es, redf);
+        if (threadIdx.x == 0) {
+            const float pl = ps * sac_inv_B, vl = vs * sac_inv_B * L.value_coef;
+            L.loss3[0] = pl + vl; L.loss3[1] = pl; L.loss3[2] = vl;
+            L.dlog_alpha[0] = -es * sac_inv_B;
+        }
+        return;
+    }
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c4 = blockIdx.x * 64 + cl;
     const int H4 = H >> 2;
     const int ch = blockIdx.y;
     const bool all = vgroup < 0;                                  // every group has a head: vw [G,H], dv [G*grows],
     const bool head = all || (int)blockIdx.z == vgroup;           // vpartial [G][chunks][H]
-    if (all) { vw += (size_t)blockIdx.z * H; dv += (size_t)blockIdx.z * grows; vpartial += (size_t)blockIdx.z * gridDim.y * H; }
+    if (all) { vw += (size_t)blockIdx.z * H; dv += (size_t)blockIdx.z * grows; vpartial += (size_t)blockIdx.z * nchunk * H; }
     const size_t goff = (size_t)blockIdx.z * grows * H4;
     const int b0 = ch * chunk_len, b1 = min(grows, b0 + chunk_len);
     const float4* y4 = reinterpret_cast<const float4*>(y) + goff;
@@ -1212,7 +1261,8 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial_value(const float* __re
                 const size_t i = (size_t)rc * H4 + c4;
                 v[j] = y4[i];
                 if (head) {
-                    gs[j] = dv[rc];
+                    gs[j] = SAC ? sac_dq(L, (int)blockIdx.z, rc, sac_alpha, sac_inv_B) : dv[rc];
+                    if (SAC && blockIdx.x == 0 && cl == 0 && r < b1) L.dq_both[(size_t)blockIdx.z * grows + r] = gs[j];
                     g[j] = make_float4(gs[j] * wv.x, gs[j] * wv.y, gs[j] * wv.z, gs[j] * wv.w);
                 } else {
                     gs[j] = 0.f;
@@ -1240,7 +1290,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial_value(const float* __re
     if (rl == 0 && c4 < H4) {
         float4 t = red[0][cl];
         for (int k = 1; k < 4; ++k) { const float4 u = red[k][cl]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        reinterpret_cast<float4*>(partial + ((size_t)blockIdx.z * gridDim.y + ch) * H)[c4] = t;
+        reinterpret_cast<float4*>(partial + ((size_t)blockIdx.z * nchunk + ch) * H)[c4] = t;
     }
     if (!head) return;
     __syncthreads();
@@ -1649,12 +1699,35 @@ int pfpn_act_bwd_partial(const float* y, float* dy, int rows, int H, int group_r
     if (value_w) {
         if (!dvalue || !value_partial || !relu6 || value_group >= G || ((uintptr_t)value_w & 15))
             return PFPN_ERR_ARG;
-        hipLaunchKernelGGL(k_act_bwd_partial_value, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy, grows,
-                           H, len, partial, value_group, value_w, dvalue, value_partial);
+        hipLaunchKernelGGL(k_act_bwd_partial_value<false>, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy,
+                           grows, H, len, partial, value_group, value_w, dvalue, value_partial, PfpnSacLoss{});
     } else {
         hipLaunchKernelGGL(k_act_bwd_partial, dim3(((H >> 2) + 63) / 64, cpg, G), dim3(256), 0, st, y, dy, grows, H, len,
                            relu6, partial);
     }
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_act_bwd_partial_sac(const float* y, float* dy, int H, const float* value_w, float* value_partial, float* partial,
+                             size_t partial_floats, int* chunks_per_group, const PfpnSacLoss* loss, void* stream) {
+    PFPN_BEGIN();
+    if (!y || !dy || !value_w || !value_partial || !partial || !chunks_per_group || !loss || H < 4 || (H & 3) ||
+        ((uintptr_t)dy & 15) || ((uintptr_t)value_w & 15))
+        return PFPN_ERR_ARG;
+    const PfpnSacLoss& L = *loss;
+    if (!L.q_both || !L.q_tgt || !L.logp || !L.logp_t || !L.reward || !L.not_terminal || !L.log_alpha || !L.dq_both ||
+        !L.dlogp || !L.dlog_alpha || !L.loss3 || L.B < 1)
+        return PFPN_ERR_ARG;
+    const int G = 2, grows = 2 * L.B;
+    int cpg = row_chunks(grows);
+    if (cpg * G > PFPN_MAX_CHUNKS) cpg = PFPN_MAX_CHUNKS / G;
+    if (cpg < 1) return PFPN_ERR_ARG;
+    if (partial_floats < (size_t)G * cpg * H) return PFPN_ERR_WORKSPACE;
+    const int len = (grows + cpg - 1) / cpg;
+    *chunks_per_group = cpg;
+    hipLaunchKernelGGL(k_act_bwd_partial_value<true>, dim3(((H >> 2) + 63) / 64, cpg + 1, G), dim3(256), 0, (hipStream_t)stream,
+                       y, dy, grows, H, len, partial, -1, value_w, (const float*)nullptr, value_partial, L);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -551,13 +551,50 @@ def bias_act_value(y, bias, group_rows, value_group, value_w, value_b, v, relu6=
     return v
 
 
+class SacLoss(ctypes.Structure):
+    """mirror of PfpnSacLoss (include/pfpn_hip.h): the SAC loss head as a rider of the critics' first backward launch"""
+    _fields_ = [("q_both", ctypes.c_void_p), ("q_tgt", ctypes.c_void_p), ("logp", ctypes.c_void_p),
+                ("logp_t", ctypes.c_void_p), ("reward", ctypes.c_void_p), ("not_terminal", ctypes.c_void_p),
+                ("log_alpha", ctypes.c_void_p), ("B", ctypes.c_int), ("gamma", ctypes.c_float),
+                ("value_coef", ctypes.c_float), ("target_entropy", ctypes.c_float), ("dq_both", ctypes.c_void_p),
+                ("dlogp", ctypes.c_void_p), ("dlog_alpha", ctypes.c_void_p), ("loss3", ctypes.c_void_p),
+                ("noise_epoch", ctypes.c_void_p)]
+
+
+def sac_loss_rider(q_both, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, gamma, value_coef, target_entropy,
+                   dq_both, out, noise_epoch=None):
+    """sac_loss() for the one-pass critic step (q_both / dq_both [2, 2B]) as an argument of act_bwd_partial(value=(-1, w,
+    None, ws_value, rider)): no launch of its own."""
+    B = logp.shape[0]
+    if noise_epoch is not None and (noise_epoch.dtype != torch.int64 or not noise_epoch.is_cuda or noise_epoch.numel() != 1):
+        raise ValueError("noise_epoch must be a one-element int64 device tensor")
+    r = SacLoss(_f32(q_both, 2, 2 * B), _f32(q_tgt, 2, B), _f32(logp, B), _f32(logp_t, B), _f32(reward, B),
+                _f32(not_terminal, B), _f32(log_alpha.view(-1), 1), B, float(gamma), float(value_coef),
+                float(target_entropy), _f32(dq_both, 2, 2 * B), _f32(out["dlogp"], B), _f32(out["dlog_alpha"].view(-1), 1),
+                _f32(out["loss3"], 3), noise_epoch.data_ptr() if noise_epoch is not None else None)
+    r._keep = (q_both, q_tgt, logp, logp_t, reward, not_terminal, log_alpha, dq_both, out, noise_epoch)
+    return r
+
+
 def act_bwd_partial(y, dy, group_rows, ws, relu6=True, value=None, mask=None):
     """Relu6Grad in place + per-chunk bias-gradient partials left in `ws` (float view [G*cpg, H]); returns cpg.
     value = (group, w [H], dvalue [group_rows], ws_value): fold the critic head's backward into that group.
+    value = (-1, w [2, H], None, ws_value, SacLoss): the twin critics' heads with the SAC loss head riding (sac_loss_rider).
     mask (from bias_act_mask, H % 256 == 0): read the mask bits instead of the activations `y`."""
     lib = _lib.load()
     rows, H = dy.shape
     cpg = ctypes.c_int(0)
+    if value is not None and len(value) > 4 and value[4] is not None:
+        rider = value[4]
+        if mask is not None or not relu6 or value[0] >= 0 or rows != 4 * rider.B or group_rows != 2 * rider.B:
+            raise ValueError("the SAC loss rides on the twin heads of a [2, 2B]-row pass only")
+        if value[3].numel() < 4 * 2 * 1024 * H:
+            raise ValueError("value-head partial workspace too small")
+        _lib.check(lib.pfpn_act_bwd_partial_sac(_f32(y, rows, H), _f32(dy, rows, H), H, _f32(value[1].view(-1), 2 * H),
+                                                value[3].data_ptr(), ws.data_ptr(), ws.numel() // 4,
+                                                ctypes.addressof(cpg), ctypes.addressof(rider), _stream()),
+                   "pfpn_act_bwd_partial_sac")
+        return cpg.value
     if mask is not None:
         if value is not None or not relu6:
             raise ValueError("the mask-bit form has no folded head and is ReLU6 only")

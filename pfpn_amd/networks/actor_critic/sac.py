@@ -36,6 +36,7 @@ def sac_network_wrapper(base_class):
             self.batch_actor = True        # (tests flip these on an instance: the one-pass-per-input reference form)
             self.batch_critic = True
             self.fuse_actor = True         # sample + log-prob + critic inputs | their backward as ONE launch each
+            self.ride_loss = True          # the loss head inside the first launch of the critics' backward pass
             self.tau = tau
             self.reward, self.not_terminal = "reward", "not_terminal"
 
@@ -336,9 +337,17 @@ def sac_network_wrapper(base_class):
                 hq_run = self._q_forward(self.xh, 1, q_run, fold=fold)
             self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
             self.last["q_pi"] = q_pi
-            out = kernels.sac_loss(q_pi, q_run, self.q_tgt, logp, logp2, reward, not_terminal,
-                                   self.log_alpha, self.gamma, self.value_loss_coef, -float(A), sout,
-                                   noise_epoch=self._noise_counter())
+            rider = ()
+            if both_q and self.ride_loss:
+                # the loss head rides in the first launch of the critics' backward pass (every block forms the dQ of its rows)
+                out = sout
+                rider = (kernels.sac_loss_rider(self.q_both, self.q_tgt, logp, logp2, reward, not_terminal, self.log_alpha,
+                                                self.gamma, self.value_loss_coef, -float(A), self.dq_both, sout,
+                                                noise_epoch=self._noise_counter()),)
+            else:
+                out = kernels.sac_loss(q_pi, q_run, self.q_tgt, logp, logp2, reward, not_terminal,
+                                       self.log_alpha, self.gamma, self.value_loss_coef, -float(A), sout,
+                                       noise_epoch=self._noise_counter())
             # critic gradients (value loss through Q(s, action_hist))
             gw3, gb3 = st.g("critic/q1+critic/q2|fc3/weight"), st.g("critic/q1+critic/q2|fc3/bias")
             if not fold:
@@ -348,7 +357,7 @@ def sac_network_wrapper(base_class):
                 # half (weight / bias / head gradients from rows [B, 2B) only), the policy loss passes through the first
                 # half to the action alone (Q parameters are skipped, sac.py:167): 6 launches instead of 9
                 da = self.q_stack.backward(self.dh_both, slot=0, need_dw=True, need_dx=(S, S + A), deferred=deferred,
-                                           value=(-1, self.q_w3, self.dq_both, gw3, gb3),
+                                           value=(-1, self.q_w3, self.dq_both, gw3, gb3) + rider,
                                            dw_rows=(B, 2 * B), dx_rows=(0, B))
             elif fold:
                 # both heads' backward inside the trunks' last-layer passes; bias-gradient sums become jobs

@@ -287,6 +287,7 @@ class DenseStack:
         tensor is appended instead of being launched (the caller runs `kernels.reduce_jobs(deferred)` once).
         `value` = (group, w, dvalue [B], grad_w, grad_b) (with `deferred` only): the backward of a scalar head on that
         group's output is folded into the last layer's pass -- dlast[group] is formed as dvalue (x) w, not read.
+        A sixth entry (kernels.sac_loss_rider) makes that launch ALSO the loss head that produces dvalue.
         group = -1: a head on EVERY group (w [G,H], dvalue [G,B], grad_w [G,H], grad_b [G,1]; twin Q networks).
         With need_dw=False the partial sums are left unreduced (no jobs; grad_w / grad_b may be None).
         `dw_rows` = (r0, r1) (with `deferred`): only these rows of the batch enter the weight / bias / head gradients --
@@ -317,7 +318,7 @@ class DenseStack:
                 grows, H = self._group_rows(i, B), act2d[i].shape[1]
                 fold = None
                 if value is not None and i == self.L - 1:
-                    fold = (value[0], value[1], value[2], ws_value)
+                    fold = (value[0], value[1], value[2], ws_value) + tuple(value[5:6])     # (+ a loss-head rider)
                 if fold is None and buf["mask_ok"][i]:
                     cpg = kernels.act_bwd_partial(None, d2d, grows, ws[i], mask=buf["mask"][i])
                 else:

@@ -261,6 +261,39 @@ def test_sac_one_pass_over_both_batches_matches_two_passes(dev, monkeypatch, B):
         assert torch.equal(nets[0].state_normalizer.std, nets[1].state_normalizer.std)
 
 
+@pytest.mark.parametrize("B", [64, 1024])
+def test_sac_loss_head_rides_in_the_critics_backward_launch(dev, B):
+    """`net.ride_loss`: the loss head has no launch of its own -- the first launch of the critics' backward pass forms the
+    dQ of its rows itself.  Against the step with the stand-alone loss head: dQ, dlogp and every gradient that descends from
+    them bit for bit; the three losses and d log_alpha (block sums over 256 instead of 1024 threads) to rounding; the draw
+    counter advanced alike."""
+    from pfpn_amd.models import SyncReplicasApplier
+    rng = np.random.default_rng(B + 3)
+    nets = []
+    for i in range(2):
+        net = make_net(dev)
+        net.ride_loss = i == 0
+        nets.append(net)
+    for it in range(2):
+        batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                       rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                       rng.normal(0.5, 0.3, B).astype(F),
+                                                       (rng.uniform(size=B) > 0.05).astype(F),
+                                                       (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
+        noise = nets[0].make_train_noise(B)
+        l3 = [net.compute_gradients(*batch, {k: t.clone() for k, t in noise.items()}).clone() for net in nets]
+        assert torch.equal(nets[0].dq_both, nets[1].dq_both)
+        assert torch.equal(nets[0].sac_out["dlogp"], nets[1].sac_out["dlogp"])
+        torch.testing.assert_close(l3[0], l3[1], rtol=2e-6, atol=1e-6)
+        assert int(nets[0].noise_epoch) == int(nets[1].noise_epoch) == it + 1
+        g0, g1 = nets[0].gradients(), nets[1].gradients()
+        for name in g1:
+            if "log_alpha" in name:
+                torch.testing.assert_close(g0[name], g1[name], rtol=2e-6, atol=1e-7)
+            else:
+                assert torch.equal(g0[name], g1[name]), name
+
+
 def test_gumbel_transform_matches_tensor_ops(dev):
     from pfpn_amd import kernels
     u = torch.rand(1000, 1260, device=dev)
