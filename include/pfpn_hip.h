@@ -243,6 +243,23 @@ int pfpn_act_bwd_partial_mask(float* dy, const void* mask, int rows, int H, int 
  * group g's bias at value_b[g*value_b_stride], v [G*B]. */
 int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_rows, int relu6, int value_group,
                         const float* value_w, const float* value_b, int value_b_stride, float* v, void* stream);
+/* Two epilogue passes of one width H in ONE launch -- a SAC step evaluates the live twin critics (2B rows, mask bits for the
+ * backward) and the target twin critics (B rows) on unrelated inputs, and a dependent launch costs ~5 us whatever it does.
+ * pfpn_bias_act_mask_pair: per pass what pfpn_bias_act_mask (mask != NULL) or pfpn_bias_act(relu6) (mask NULL) does;
+ * pfpn_bias_act_value_pair: per pass pfpn_bias_act_value(relu6, value_group = -1).  Same arithmetic, same bits. */
+typedef struct PfpnEpilogueJob {
+    float* y;
+    const float* bias;
+    int rows, group_rows;
+    void* mask;               /* optional (pfpn_bias_act_mask_pair) */
+    size_t mask_bytes;
+    const float* value_w;     /* pfpn_bias_act_value_pair: [G, H], [G * value_b_stride], v [G, group_rows] */
+    const float* value_b;
+    int value_b_stride;
+    float* v;
+} PfpnEpilogueJob;
+int pfpn_bias_act_mask_pair(const PfpnEpilogueJob* a, const PfpnEpilogueJob* b, int H, void* stream);
+int pfpn_bias_act_value_pair(const PfpnEpilogueJob* a, const PfpnEpilogueJob* b, int H, void* stream);
 /* Relu6Grad + per-chunk BiasAddGrad partials only: like pfpn_act_bwd_bias_grad but the column sums stay as
  * partial[G][chunks_per_group][H] (chunks_per_group is returned) for pfpn_reduce_jobs.  With value_w != NULL the critic
  * head's backward is folded in: on group value_group, dy is FORMED as dvalue[b]*value_w[c] (not read), masked and

@@ -21,6 +21,7 @@ _CT = {
     "const uint64_t*": ctypes.c_void_p, "uint64_t*": ctypes.c_void_p,
     "const long long*": ctypes.c_void_p, "long long*": ctypes.c_void_p, "const PfpnReduceJob*": ctypes.c_void_p,
     "const PfpnStatePrologue*": ctypes.c_void_p, "const PfpnSacLoss*": ctypes.c_void_p,
+    "const PfpnEpilogueJob*": ctypes.c_void_p,
     "const void* const*": ctypes.c_void_p, "void* const*": ctypes.c_void_p,
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
     "long long": ctypes.c_longlong, "size_t": ctypes.c_size_t, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,

@@ -1029,13 +1029,15 @@ __global__ __launch_bounds__(1024) void k_sac_loss(
 // element instead of re-reading the activations (33.5 MB -> 1 MB for the merged first layer).  A wave's 64 lanes own 64
 // consecutive float4s, so the four words of a chunk are four wave ballots, stored by every lane to the same address
 // (one transaction, no branch).
-__global__ __launch_bounds__(256) void k_bias_act_mask(float* __restrict__ y, const float* __restrict__ bias, int rows,
-                                                       int H, int group_rows, unsigned long long* __restrict__ mask) {
+// (body: block `blk` of `nblk`; mask == nullptr: the plain BiasAdd + Relu6 -- k_bias_act's results, bit for bit)
+__device__ __forceinline__ void bias_act_mask_body(float* __restrict__ y, const float* __restrict__ bias, int rows, int H,
+                                                   int group_rows, unsigned long long* __restrict__ mask, int blk,
+                                                   int nblk) {
     const int H4 = H >> 2;
     const size_t n4 = (size_t)rows * H4;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t stride = (size_t)nblk * blockDim.x;
     const size_t nround = (n4 + 63) & ~(size_t)63;             // whole waves: every lane of a live chunk takes part
-    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < nround; i0 += 4 * stride) {
+    for (size_t i0 = (size_t)blk * blockDim.x + threadIdx.x; i0 < nround; i0 += 4 * stride) {
         float4 v[4], bb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1060,12 +1062,26 @@ __global__ __launch_bounds__(256) void k_bias_act_mask(float* __restrict__ y, co
             t.x = fminf(fmaxf(t.x, 0.f), 6.f); t.y = fminf(fmaxf(t.y, 0.f), 6.f);
             t.z = fminf(fmaxf(t.z, 0.f), 6.f); t.w = fminf(fmaxf(t.w, 0.f), 6.f);
             if (live) reinterpret_cast<float4*>(y)[i] = t;
-            if (i < nround) {                                   // wave-uniform: the whole chunk or nothing
+            if (mask && i < nround) {                           // wave-uniform: the whole chunk or nothing
                 unsigned long long* mw = mask + (i >> 6) * 4;
                 mw[0] = m0; mw[1] = m1; mw[2] = m2; mw[3] = m3;
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_bias_act_mask(float* __restrict__ y, const float* __restrict__ bias, int rows,
+                                                       int H, int group_rows, unsigned long long* __restrict__ mask) {
+    bias_act_mask_body(y, bias, rows, H, group_rows, mask, blockIdx.x, gridDim.x);
+}
+// Two epilogue passes of one width in ONE launch (SAC: the live critics' layer over 2B rows with mask bits and the target
+// critics' layer over B rows without): blocks [0, nb_a) are pass a's grid, the rest pass b's.  A dependent launch costs
+// ~5 us on this chip whatever it does; the two passes have nothing to do with each other.
+__global__ __launch_bounds__(256) void k_bias_act_mask_pair(PfpnEpilogueJob a, PfpnEpilogueJob b, int H, int nb_a) {
+    if ((int)blockIdx.x < nb_a)
+        bias_act_mask_body(a.y, a.bias, a.rows, H, a.group_rows, (unsigned long long*)a.mask, blockIdx.x, nb_a);
+    else
+        bias_act_mask_body(b.y, b.bias, b.rows, H, b.group_rows, (unsigned long long*)b.mask, blockIdx.x - nb_a,
+                           gridDim.x - nb_a);
 }
 
 // k_act_bwd_partial reading the mask bits of k_bias_act_mask instead of the activations (H/4 a multiple of 64, so a
@@ -1127,12 +1143,12 @@ __global__ __launch_bounds__(256) void k_act_bwd_partial_mask(float* __restrict_
 #ifndef PFPN_BAV_ROWS
 #define PFPN_BAV_ROWS 2
 #endif
-__global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, const float* __restrict__ bias, int rows,
-                                                        int H, int group_rows, int relu6, int vgroup,
-                                                        const float* __restrict__ vw, const float* __restrict__ vb,
-                                                        int vb_stride, float* __restrict__ v) {
+__device__ __forceinline__ void bias_act_value_body(float* __restrict__ y, const float* __restrict__ bias, int rows,
+                                                    int H, int group_rows, int relu6, int vgroup,
+                                                    const float* __restrict__ vw, const float* __restrict__ vb,
+                                                    int vb_stride, float* __restrict__ v, int blk) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int wave = (blk * blockDim.x + threadIdx.x) >> 6;
     constexpr int RW = PFPN_BAV_ROWS;                             // rows per wave (group_rows % 4 == 0 covers 2 and 4)
     const int r0 = wave * RW;
     if (r0 >= rows) return;
@@ -1175,6 +1191,21 @@ __global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, c
         const int r = r0 + j;
         if (lane == 0 && r < rows) v[all ? r : r - vgroup * group_rows] = sacc + b0;
     }
+}
+__global__ __launch_bounds__(256) void k_bias_act_value(float* __restrict__ y, const float* __restrict__ bias, int rows,
+                                                        int H, int group_rows, int relu6, int vgroup,
+                                                        const float* __restrict__ vw, const float* __restrict__ vb,
+                                                        int vb_stride, float* __restrict__ v) {
+    bias_act_value_body(y, bias, rows, H, group_rows, relu6, vgroup, vw, vb, vb_stride, v, blockIdx.x);
+}
+// two last-layer passes with a head on every group (the live and the target twin critics of a SAC step) in ONE launch
+__global__ __launch_bounds__(256) void k_bias_act_value_pair(PfpnEpilogueJob a, PfpnEpilogueJob b, int H, int nb_a) {
+    if ((int)blockIdx.x < nb_a)
+        bias_act_value_body(a.y, a.bias, a.rows, H, a.group_rows, 1, -1, a.value_w, a.value_b, a.value_b_stride, a.v,
+                            blockIdx.x);
+    else
+        bias_act_value_body(b.y, b.bias, b.rows, H, b.group_rows, 1, -1, b.value_w, b.value_b, b.value_b_stride, b.v,
+                            blockIdx.x - nb_a);
 }
 
 // k_act_bwd_partial with the critic head's backward folded in: on group `vgroup` the incoming gradient is not read
@@ -1676,6 +1707,36 @@ int pfpn_bias_act_value(float* y, const float* bias, int rows, int H, int group_
     const int waves = (rows + PFPN_BAV_ROWS - 1) / PFPN_BAV_ROWS;
     hipLaunchKernelGGL(k_bias_act_value, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, bias, rows, H,
                        group_rows, relu6, value_group, value_w, value_b, value_b_stride, v);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+static bool epilogue_job_ok(const PfpnEpilogueJob* j, int H, bool value) {
+    if (!j || !j->y || !j->bias || j->rows < 1 || ((uintptr_t)j->y & 15) || ((uintptr_t)j->bias & 15) ||
+        (j->group_rows > 0 && j->rows % j->group_rows))
+        return false;
+    if (j->mask && (((uintptr_t)j->mask & 7) || j->mask_bytes < pfpn_relu6_mask_bytes(j->rows, H))) return false;
+    if (value && (!j->value_w || !j->value_b || !j->v || ((uintptr_t)j->value_w & 15) || j->group_rows < 4 ||
+                  (j->group_rows & 3) || j->value_b_stride < 1))
+        return false;
+    return true;
+}
+
+int pfpn_bias_act_mask_pair(const PfpnEpilogueJob* a, const PfpnEpilogueJob* b, int H, void* stream) {
+    PFPN_BEGIN();
+    if (H < 4 || (H & 3) || !epilogue_job_ok(a, H, false) || !epilogue_job_ok(b, H, false)) return PFPN_ERR_ARG;
+    const int na = stream_grid((size_t)a->rows * (H >> 2)), nb = stream_grid((size_t)b->rows * (H >> 2));
+    hipLaunchKernelGGL(k_bias_act_mask_pair, dim3(na + nb), dim3(256), 0, (hipStream_t)stream, *a, *b, H, na);
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
+}
+
+int pfpn_bias_act_value_pair(const PfpnEpilogueJob* a, const PfpnEpilogueJob* b, int H, void* stream) {
+    PFPN_BEGIN();
+    if (H < 4 || (H & 3) || !epilogue_job_ok(a, H, true) || !epilogue_job_ok(b, H, true)) return PFPN_ERR_ARG;
+    const int na = (((a->rows + PFPN_BAV_ROWS - 1) / PFPN_BAV_ROWS) + 3) / 4;
+    const int nb = (((b->rows + PFPN_BAV_ROWS - 1) / PFPN_BAV_ROWS) + 3) / 4;
+    hipLaunchKernelGGL(k_bias_act_value_pair, dim3(na + nb), dim3(256), 0, (hipStream_t)stream, *a, *b, H, na);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

@@ -551,6 +551,47 @@ def bias_act_value(y, bias, group_rows, value_group, value_w, value_b, v, relu6=
     return v
 
 
+class EpilogueJob(ctypes.Structure):
+    """mirror of PfpnEpilogueJob (include/pfpn_hip.h): one of the two passes of a paired epilogue launch"""
+    _fields_ = [("y", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("rows", ctypes.c_int), ("group_rows", ctypes.c_int),
+                ("mask", ctypes.c_void_p), ("mask_bytes", ctypes.c_size_t), ("value_w", ctypes.c_void_p),
+                ("value_b", ctypes.c_void_p), ("value_b_stride", ctypes.c_int), ("v", ctypes.c_void_p)]
+
+
+def epilogue_job(y, bias, group_rows=0, mask=None, value=None):
+    """a pass of bias_act_mask_pair (mask: the bit buffer or None) / bias_act_value_pair (value = (w [G,H], b [G(,pad)],
+    v [G, group_rows]): a head on every group)."""
+    rows, H = y.shape
+    j = EpilogueJob(_f32(y, rows, H), _f32(bias), rows, int(group_rows), mask.data_ptr() if mask is not None else None,
+                    mask.numel() if mask is not None else 0, None, None, 0, None)
+    j._keep = (y, bias, mask, value)
+    if value is not None:
+        vw, vb, v = value
+        nh = rows // group_rows
+        bstride = vb.stride(0) if vb.dim() == 2 else 1
+        if vb.numel() < (nh - 1) * bstride + 1:
+            raise ValueError("value_b too short")
+        j.value_w, j.value_b, j.value_b_stride = _f32(vw.view(-1), nh * H), _f32(vb), int(bstride)
+        j.v = _f32(v.view(-1), nh * group_rows)
+    return j, H
+
+
+def bias_act_mask_pair(a, b):
+    """two BiasAdd + Relu6 passes of one width (each with or without mask bits) in one launch; a, b = epilogue_job(...)"""
+    if a[1] != b[1]:
+        raise ValueError("the two passes must have one width")
+    _lib.check(_lib.load().pfpn_bias_act_mask_pair(ctypes.addressof(a[0]), ctypes.addressof(b[0]), a[1], _stream()),
+               "pfpn_bias_act_mask_pair")
+
+
+def bias_act_value_pair(a, b):
+    """two last-layer passes (BiasAdd + Relu6 + a scalar head on every group) in one launch; a, b = epilogue_job(value=...)"""
+    if a[1] != b[1]:
+        raise ValueError("the two passes must have one width")
+    _lib.check(_lib.load().pfpn_bias_act_value_pair(ctypes.addressof(a[0]), ctypes.addressof(b[0]), a[1], _stream()),
+               "pfpn_bias_act_value_pair")
+
+
 class SacLoss(ctypes.Structure):
     """mirror of PfpnSacLoss (include/pfpn_hip.h): the SAC loss head as a rider of the critics' first backward launch"""
     _fields_ = [("q_both", ctypes.c_void_p), ("q_tgt", ctypes.c_void_p), ("logp", ctypes.c_void_p),

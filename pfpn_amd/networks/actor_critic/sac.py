@@ -37,6 +37,7 @@ def sac_network_wrapper(base_class):
             self.batch_critic = True
             self.fuse_actor = True         # sample + log-prob + critic inputs | their backward as ONE launch each
             self.ride_loss = True          # the loss head inside the first launch of the critics' backward pass
+            self.pair_critics = True       # live and target critics layer by layer, one epilogue launch for both
             self.tau = tau
             self.reward, self.not_terminal = "reward", "not_terminal"
 
@@ -329,13 +330,20 @@ def sac_network_wrapper(base_class):
             both_q = fold and self.batch_critic and B % 16 == 0 and 2 * B <= 8192
             if both_q:
                 # the live critic on [(s, a_pi); (s, action_hist)] in ONE pass of 2B rows (4 launches instead of 8)
-                self._q_forward(self.xq_both, 0, self.q_both, fold=True)
+                # ... next to the target critics on (s', a'): GEMM, GEMM, ONE epilogue launch for both, per layer
+                hw, hb = "critic/q1+critic/q2|fc3/weight", "critic/q1+critic/q2|fc3/bias"
+                paired = self.pair_critics and self.q_stack.forward_pair(
+                    self.xq_both, 0, (st[hw], st[hb], self.q_both),
+                    self.xa2, 2, self.target_store, (self.target_store[hw], self.target_store[hb], self.q_tgt))
+                if not paired:
+                    self._q_forward(self.xq_both, 0, self.q_both, fold=True)
                 q_pi, q_run, sout = self.q_pi, self.q_run, self.sac_out
             else:
                 q_pi, q_run, sout = self.q_pi_c, self.q_run_c, self.sac_out_c
                 hq_pi = self._q_forward(self.xa, 0, q_pi, fold=fold)
                 hq_run = self._q_forward(self.xh, 1, q_run, fold=fold)
-            self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
+            if not (both_q and paired):
+                self._q_forward(self.xa2, 2, self.q_tgt, target=True, fold=fold)
             self.last["q_pi"] = q_pi
             rider = ()
             if both_q and self.ride_loss:

@@ -279,6 +279,47 @@ class DenseStack:
                 kernels.value_head_fwd(act[-1][g], vw.view(-1), vb, out=vout)
         return act[-1]
 
+    def forward_pair(self, x_a, slot_a, head_a, x_b, slot_b, params_b, head_b):
+        """Two forward passes of this stack in lock step: pass a with the live parameters and mask bits (a backward
+        follows), pass b with `params_b` (SAC: the target critics) -- GEMM a, GEMM b, then ONE epilogue launch for both,
+        layer by layer; head_* = (w [G,H], b [G(,pad)], out [G,B]): a scalar head on every group inside the last layer's
+        epilogue.  Same results, bit for bit, as forward(x_a, slot_a, value_head=(-1,) + head_a, masks=True) and
+        forward(x_b, slot_b, params=params_b, value_head=(-1,) + head_b); two launches fewer per layer pair.
+        Returns False (nothing done) when a layer does not fit the paired kernels."""
+        Ba, Bb = x_a.shape[0], x_b.shape[0]
+        if self.L < 2 or Ba % 4 or Bb % 4 or any(self.dims[i + 1] % 256 for i in range(self.L - 1)) or self.dims[-1] % 4:
+            return False
+        bufs = [self._buffers(Ba, slot_a), self._buffers(Bb, slot_b)]
+        bufs[0]["x"], bufs[1]["x"] = x_a, x_b
+        self._last = bufs[0]
+        stores = (self.store, params_b)
+        xs = (x_a, x_b)
+        Bs = (Ba, Bb)
+        for i in range(self.L):
+            for buf, st, x in zip(bufs, stores, xs):
+                w = st[self.wn[i]]
+                if i == 0 and self.merged0:
+                    torch.mm(x, w, out=buf["act2d"][0])
+                elif i == 0:
+                    for g in range(self.G):
+                        torch.mm(x, w[g], out=buf["act"][0][g])
+                else:
+                    torch.bmm(buf["act"][i - 1], w, out=buf["act"][i])
+            if i < self.L - 1:
+                a2d = bufs[0]["act2d"][i]
+                if bufs[0]["mask"][i] is None:
+                    bufs[0]["mask"][i] = kernels.relu6_mask(a2d.shape[0], a2d.shape[1], self.store.device)
+                kernels.bias_act_mask_pair(
+                    kernels.epilogue_job(a2d, stores[0][self.bn[i]], self._group_rows(i, Ba), mask=bufs[0]["mask"][i]),
+                    kernels.epilogue_job(bufs[1]["act2d"][i], stores[1][self.bn[i]], self._group_rows(i, Bb)))
+                bufs[0]["mask_ok"][i], bufs[1]["mask_ok"][i] = True, False
+            else:
+                kernels.bias_act_value_pair(
+                    kernels.epilogue_job(bufs[0]["act2d"][i], stores[0][self.bn[i]], Ba, value=head_a),
+                    kernels.epilogue_job(bufs[1]["act2d"][i], stores[1][self.bn[i]], Bb, value=head_b))
+                bufs[0]["mask_ok"][i] = bufs[1]["mask_ok"][i] = False
+        return True
+
     def backward(self, dlast, need_dx=False, slot=0, need_dw=True, B=None, deferred=None, value=None,
                  dw_rows=None, dx_rows=None):
         """dlast: [G, B, H_last] gradient w.r.t. the (post-ReLU6) output (the stack's own dact[-1] buffer

@@ -294,6 +294,36 @@ def test_sac_loss_head_rides_in_the_critics_backward_launch(dev, B):
                 assert torch.equal(g0[name], g1[name]), name
 
 
+@pytest.mark.parametrize("B", [64, 1024])
+def test_sac_live_and_target_critics_share_their_epilogue_launches(dev, B):
+    """`net.pair_critics`: the live critics' pass over [(s, a_pi); (s, a_hist)] and the target critics' pass over (s', a')
+    run layer by layer with ONE epilogue launch for both -- same Q values, losses, gradients and parameters, bit for bit."""
+    from pfpn_amd.models import SyncReplicasApplier
+    rng = np.random.default_rng(B + 11)
+    nets, opts = [], []
+    for i in range(2):
+        net = make_net(dev)
+        net.pair_critics = i == 0
+        nets.append(net)
+        opts.append(SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                              {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1))
+    for it in range(3):
+        batch = [torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                       rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                       rng.normal(0.5, 0.3, B).astype(F),
+                                                       (rng.uniform(size=B) > 0.05).astype(F),
+                                                       (rng.normal(0, 1, (B, 197)) * 2).astype(F))]
+        noise = nets[0].make_train_noise(B)
+        l3 = [net.compute_gradients(*batch, {k: t.clone() for k, t in noise.items()}).clone() for net in nets]
+        assert torch.equal(nets[0].q_both, nets[1].q_both) and torch.equal(nets[0].q_tgt, nets[1].q_tgt)
+        assert torch.equal(l3[0], l3[1])
+        assert torch.equal(nets[0].store.grad, nets[1].store.grad)
+        for net, opt in zip(nets, opts):
+            opt.apply(net)
+        assert torch.equal(nets[0].store.flat, nets[1].store.flat)
+        assert torch.equal(nets[0].target_store.flat, nets[1].target_store.flat)
+
+
 def test_gumbel_transform_matches_tensor_ops(dev):
     from pfpn_amd import kernels
     u = torch.rand(1000, 1260, device=dev)
