@@ -967,17 +967,18 @@ def main():
                         s_src += " (committed rocprofv3 --kernel-trace of tools/sac_trace.py at replay batch 1024; NOT counted in this run)"
                     sl3 = sstep.loss3.cpu().numpy()
                     sflops = 2.0 * SB * sac_mac
-                    # the step's HBM-bound hand-written kernels on their own (launches replayed from a hipGraph): the
-                    # reparameterised sample over the 2B rows [s; s'] (reads logits, Gumbel, normal draws: 3L) and its backward
-                    # over B rows (reads the same three, adds into dlogits: 3L + 2L)
+                    # the step's hand-written actor-side launches on their own (replayed from a hipGraph): sample + log-prob +
+                    # critic inputs over the 2B rows [s; s'] (reads logits and Gumbel draws: 4L, L = one B-row tensor) and
+                    # their backward over B rows (reads logits, Gumbel, normal draws, writes dlogits: 4L)
                     Ls = 4 * SB * AN_
                     nz_ = sstep.noise["_buf"]
-                    us_rf = time_in_graph(lambda: kernels.rsample_fwd(snet.logits_both, snet.loc, snet.logstd,
-                                                                      nz_[0:2].view(2 * SB, -1), nz_[2:4].view(2 * SB, -1)))
+                    us_rf = time_in_graph(lambda: kernels.sac_actor_fwd(
+                        snet.logits_both, snet.loc, snet.logstd, nz_[0:2].view(2 * SB, -1), nz_[2:4].view(2 * SB, -1),
+                        x=snet.xn_both, a_hist=sb[1], xq_both=snet.xq_both, xq_next=snet.xa2))
                     da_ = torch.zeros(SB, A, device=dev)
-                    us_rb = time_in_graph(lambda: kernels.rsample_bwd(snet.logits, snet.loc, snet.logstd, nz_[0], nz_[2], da_, da_,
-                                                                      snet.dlogits, snet.store.g("actor/samples"),
-                                                                      snet.store.g("actor/samples_std")))
+                    s_smp = snet.last["s_"].contiguous()
+                    us_rb = time_in_graph(lambda: kernels.sac_actor_bwd(snet.logits, snet.loc, snet.logstd, nz_[0], nz_[2], s_smp,
+                                                                        snet.sac_out["dlogp"], da_, snet.dlogits, snet.ws_actor))
                     sac[SB] = {"steps_per_s": 1e3 / sms, "ms_per_step": sms, "finite_loss": bool(np.all(np.isfinite(sl3))),
                                "roofline": {"bound": "mfma", "gemm_flops": sflops, "achieved": sflops / (sms * 1e-3) / 1e12,
                                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
@@ -986,12 +987,14 @@ def main():
                                             "noise_and_next_prologue_ride_in_the_optimiser_launch": sstep.noise_in_graph,
                                             "note": "frac = the step's GEMM flops / its WHOLE time / the fp32 MFMA peak: a step of ~%d "
                                                     "launches at ~5 us each is launch-bound, not MFMA-bound, at these row counts"
-                                                    % round(s_launches or 36),
+                                                    % round(s_launches or 28),
                                             "hbm_kernels": {
-                                                "k_rsample_fwd_quad (2B rows)": {"us": us_rf, "algorithmic_bytes": 6 * Ls,
-                                                                                 "frac": 6 * Ls / us_rf / 1e3 / HBM_PEAK_GBS},
-                                                "k_rsample_bwd_quad + k_rsample_param_partial": {
-                                                    "us": us_rb, "algorithmic_bytes": 5 * Ls, "frac": 5 * Ls / us_rb / 1e3 / HBM_PEAK_GBS}}}}
+                                                "k_sac_actor_fwd (2B rows)": {"us": us_rf, "algorithmic_bytes": 4 * Ls,
+                                                                              "frac": 4 * Ls / us_rf / 1e3 / HBM_PEAK_GBS},
+                                                "k_sac_actor_bwd": {"us": us_rb, "algorithmic_bytes": 4 * Ls,
+                                                                    "frac": 4 * Ls / us_rb / 1e3 / HBM_PEAK_GBS},
+                                                "note": "latency-bound single-pass launches (stage, compute, write): 7-13 us each, "
+                                                        "not HBM-bound at these sizes"}}}
                     del snet, sopt, sstep
                 out["sac_step"] = dict(sac[1024], workload="DeepMimicKick-v0 SAC-PFPN 35 particles, replay batch 1024 (BASELINE.json "
                                                             "config 3), synthetic replay rows",

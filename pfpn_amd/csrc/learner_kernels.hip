@@ -827,18 +827,22 @@ __global__ __launch_bounds__(256) void k_clip_adam_prologue(float* __restrict__ 
                                                             unsigned adam_blocks, PrologueRider r,
                                                             float* __restrict__ soft_t, size_t soft_o4, size_t soft_n4,
                                                             float tau) {
-    if (blockIdx.x < adam_blocks) {
+    // The draw's blocks come FIRST in the grid: they are arithmetic (Philox, logs, sin / cos: ~1,300 instructions per thread)
+    // next to an optimiser pass that waits on memory; dispatched last they ran as its tail (the grid is larger than what
+    // the chip holds at once), dispatched first they run under it.
+    const unsigned nz = r.noise_blocks;
+    if (blockIdx.x < nz) {
+        const unsigned long long offset = r.noise_epoch[0];
+        const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (size_t i = first; i < r.noise_n; i += (size_t)nz * blockDim.x)
+            sac_noise_element(r.noise, r.noise_n, i, r.noise_seed, offset);
+    } else if (blockIdx.x < nz + adam_blocks) {
         clip_adam_block(p, g, m, v, gr, b1, b2, eps, beta_pow, partial, nblk, clip_norm, 1.0f, norm_scale, step, nullptr, 0,
-                        1.f, soft_t, soft_o4, soft_n4, tau, blockIdx.x, adam_blocks);
-    } else if (blockIdx.x < adam_blocks + r.pro_blocks) {
-        const int lin = (int)(blockIdx.x - adam_blocks);
+                        1.f, soft_t, soft_o4, soft_n4, tau, blockIdx.x - nz, adam_blocks);
+    } else {
+        const int lin = (int)(blockIdx.x - nz - adam_blocks);
         state_prologue_block(r.s, r.mean, r.std, r.B, r.S, r.chunk_len, r.C, r.clip, r.x, r.partial, r.adv, r.normalize_adv,
                              r.adv_stats, r.s2, r.x2, lin % r.gx, lin / r.gx);
-    } else {
-        const unsigned long long offset = r.noise_epoch[0];
-        const size_t first = (size_t)(blockIdx.x - adam_blocks - r.pro_blocks) * blockDim.x + threadIdx.x;
-        for (size_t i = first; i < r.noise_n; i += (size_t)r.noise_blocks * blockDim.x)
-            sac_noise_element(r.noise, r.noise_n, i, r.noise_seed, offset);
     }
 }
 

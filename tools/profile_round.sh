@@ -28,7 +28,7 @@ echo "bench done" >> $O/progress.log
 rm -rf pfpn_amd/build && PFPN_BUILD_STAMPS=1 python3 -m pfpn_amd.build > $O/stamp_build.log 2>&1 && python3 tools/stamp_probe.py 2>&1 | grep -v amdgpu.ids > $O/stamps.txt
 python3 tools/profile_collect.py $O gpurun_out/prof_summary $TAG > $O/collect.log 2>&1
 python3 tools/gemm_mfma_pmc.py $O/gemm_mfma gpurun_out/prof_summary/${TAG}_gemm_mfma.json >> $O/collect.log 2>&1
-python3 tools/step_timeline.py $(ls $O/sac_trace/*/*kernel_trace.csv | head -1) k_sac_loss > gpurun_out/prof_summary/${TAG}_sac_step_timeline.txt 2>> $O/collect.log
+python3 tools/step_timeline.py $(ls $O/sac_trace/*/*kernel_trace.csv | head -1) k_act_bwd_partial_value > gpurun_out/prof_summary/${TAG}_sac_step_timeline.txt 2>> $O/collect.log
 for d in stats timeline probe_trace sac_trace gemm_mfma fetch write sq1 sq2 sfetch swrite; do rm -rf $O/$d; done   # raw traces: large; the summaries are what is kept
 tail -3 $O/collect.log
 

@@ -35,3 +35,12 @@ for B in (1024, 256):
     t_f_mm = time_in_graph(f_mm)
     print("B %4d  dW: bmm %.1f us, 2 x mm %.1f us | dX: bmm %.1f, 2 x mm %.1f | forward: bmm %.1f, 2 x mm %.1f"
           % (B, t_dw_bmm, t_dw_mm, t_dx_bmm, t_dx_mm, t_f_bmm, t_f_mm), flush=True)
+# the policy head: bias inside the GEMM (torch.addmm -> a hipBLASLt bias-epilogue kernel) against a plain mm
+for R in (2048, 512, 4096):
+    hh = torch.randn(R, 512, device=dev)
+    wp = torch.randn(512, 1260, device=dev)
+    bp = torch.randn(1260, device=dev)
+    out = torch.empty(R, 1260, device=dev)
+    t_add = time_in_graph(lambda: torch.addmm(bp, hh, wp, out=out))
+    t_mm = time_in_graph(lambda: torch.mm(hh, wp, out=out))
+    print("head %4d rows: addmm %.1f us, mm %.1f us" % (R, t_add, t_mm), flush=True)

@@ -1,6 +1,7 @@
 """The SAC-PFPN learner step (replay batch 1024) as a hipGraph, a few dozen replays: the program to put under
-`rocprofv3 --kernel-trace` for a kernel-by-kernel timeline (`tools/step_timeline.py <trace> k_sac_loss`: since round 4 the
-noise draw and the next step's prologue ride in the optimiser launch, eight steps per replay; the loss head marks a step)."""
+`rocprofv3 --kernel-trace` for a kernel-by-kernel timeline (`tools/step_timeline.py <trace> k_act_bwd_partial_value`: since
+round 4 the noise draw and the next step's prologue ride in the optimiser launch and the loss head in the first launch of the
+critics' backward pass, eight steps per replay; that launch marks a step)."""
 import os, sys
 import numpy as np, torch
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
