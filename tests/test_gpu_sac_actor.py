@@ -19,6 +19,7 @@ def _inputs(rng, R, A, N, dev, tanh_grid=True):
 
 
 @pytest.mark.parametrize("B,A,N,S", [(256, 36, 35, 197), (37, 36, 35, 197), (1024, 36, 35, 197), (50, 5, 7, 11),
+                                     (1027, 36, 35, 197),      # 2054 rows in blocks of 3: a ragged last block
                                      (33, 3, 64, 9), (18, 150, 4, 6)])
 def test_actor_forward_matches_the_three_launches(dev, oracle, B, A, N, S):
     from pfpn_amd import kernels
@@ -49,6 +50,7 @@ def test_actor_forward_matches_the_three_launches(dev, oracle, B, A, N, S):
 
 
 @pytest.mark.parametrize("B,A,N", [(256, 36, 35), (37, 36, 35), (1024, 36, 35), (4096, 36, 35), (50, 5, 7), (33, 3, 64),
+                                   (1027, 36, 35),             # two row groups of 4 per block, the last block ragged
                                    (18, 150, 4)])
 def test_actor_backward_matches_the_piecewise_launches(dev, B, A, N):
     from pfpn_amd import kernels
