@@ -1025,19 +1025,21 @@ def main():
                 for _ in range(5):
                     cnet.train_device(copt, *cargs)
                 torch.cuda.synchronize()
-                claunch = "hipGraph"
+                CK = max(1, args.steps_per_graph)       # learner steps per replay, like the headline
+                claunch = "hipGraph, %d learner steps per replay" % CK
                 try:
-                    cstep = graphs.GraphedLearnerStep(cnet, copt, *[t.clone() for t in cargs], debug_nodes=True)
+                    cstep = graphs.GraphedLearnerStep(cnet, copt, *[t.clone() for t in cargs], debug_nodes=True,
+                                                      steps_per_replay=CK)
                 except Exception:                       # (capture refused: time the eager launches)
-                    claunch, cstep = "eager", (lambda: cnet.train_device(copt, *cargs))
+                    CK, claunch, cstep = 1, "eager", (lambda: cnet.train_device(copt, *cargs))
                 for _ in range(3):
                     cstep()
                 torch.cuda.synchronize()
                 t_c = time.perf_counter()
-                for _ in range(30):
+                for _ in range(8):
                     cstep()
                 torch.cuda.synchronize()
-                cms = (time.perf_counter() - t_c) / 30 * 1e3
+                cms = (time.perf_counter() - t_c) / (8 * CK) * 1e3
                 cl3 = cnet.train_out["loss3"].cpu().numpy()
                 mac = S * 2048 + 2 * 1024 * 512 + 512 * cA * cN
                 flops = 2.0 * cB * (mac + S * 2048 + 2 * 2 * 1024 * 512 + 2 * 512 * cA * cN)
@@ -1055,7 +1057,8 @@ def main():
                                        "roofline": {"bound": "mfma", "gemm_flops": flops, "achieved": flops / (cms * 1e-3) / 1e12,
                                                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                                     "frac": flops / (cms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
-                                                    "launches_per_step": cstep.kernel_nodes() if claunch == "hipGraph" else None,
+                                                    "launches_per_step": (cstep.kernel_nodes() or 0) / CK or None
+                                                    if claunch != "eager" else None,
                                                     "note": "frac = the step's GEMM flops / its WHOLE time / the fp32 MFMA peak",
                                                     "hbm_kernels": {
                                                         "k_mix_wide<FWD> (row sums inside)": {

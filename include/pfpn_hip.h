@@ -69,6 +69,14 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
                      const float* dlogp, int B, int A, int N, int tanh_mode,
                      float* dlogits, float* dloc, float* dlogstd, float* dx, int finalize,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* pfpn_logprob_bwd(finalize = 1) that also leaves dbias [A*N] = the column sums of dlogits (fc_policy's bias gradient,
+ * a2c.py:554 BiasAdd) -- for particle grids the wide kernel serves (N >= 64, A <= 4096; else PFPN_ERR_ARG and the caller
+ * sums the columns in a pass of its own): a third plane of the kernel's slabs, finished in its hand-off.  Workspace:
+ * pfpn_mixture_workspace_bytes. */
+int pfpn_logprob_bwd_bias(const float* logits, const float* x, const float* loc, const float* logstd,
+                          const float* dlogp, int B, int A, int N, int tanh_mode,
+                          float* dlogits, float* dloc, float* dlogstd, float* dx, float* dbias,
+                          void* workspace, size_t workspace_bytes, void* stream);
 /* finalize = 0: the per-block partial sums of dloc / dlogstd stay in the workspace (dloc, dlogstd may be NULL) as
  * *nslab slabs of *stride floats [dloc A*N | dlogstd A*N | ..]; a PFPN_JOB_COLSUM job sums them in the same order. */
 int pfpn_logprob_bwd_slabs(const float* logits, const float* dlogits, int B, int A, int N, int* nslab, int* stride);

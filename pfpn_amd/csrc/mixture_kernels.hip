@@ -1041,10 +1041,17 @@ __global__ __launch_bounds__(256) void k_mix_wide(
             b_ct2[j][k >> 1][k & 1] = 64.f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
         }
     }
-    v2f acc_loc2[M][2], acc_ls2[M][2];
+    // BWD + FOLD = the backward that ALSO leaves the column sums of dlogits (the head's bias gradient: a third plane of the
+    // slabs, finished into `lpseg_out`, which the backward does not otherwise use) -- one register set more, and the
+    // 134-MB pass that re-read dlogits for it is gone (config 5's 1024-row shard: 21 us)
+    constexpr bool DBIAS = MODE == MODE_BWD && FOLD;
+    constexpr int PL = DBIAS ? 3 : 2;                       // planes per slab
+    v2f acc_loc2[M][2], acc_ls2[M][2], acc_b2[M][2];
 #pragma unroll
     for (int j = 0; j < M; ++j)
-        for (int h = 0; h < 2; ++h) { acc_loc2[j][h] = (v2f){0.f, 0.f}; acc_ls2[j][h] = (v2f){0.f, 0.f}; }
+        for (int h = 0; h < 2; ++h) {
+            acc_loc2[j][h] = (v2f){0.f, 0.f}; acc_ls2[j][h] = (v2f){0.f, 0.f}; acc_b2[j][h] = (v2f){0.f, 0.f};
+        }
     const float two_m64 = 5.421010862427522e-20f;           // 2^-64
 
     // One group of U rows.  FULL = every row of the group exists: the body is then BRANCH-FREE straight-line
@@ -1169,6 +1176,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                             const v2f tt = ef[u][j][h] * qs64;
                             const v2f z = zq[u][j][h];
                             d[h] = __builtin_elementwise_fma(-e[u][j][h], (v2f){qp, qp}, tt);
+                            if (DBIAS) acc_b2[j][h] += d[h];                 // (q = 0 on rows past B: nothing added)
                             acc_loc2[j][h] = __builtin_elementwise_fma(tt, z, acc_loc2[j][h]);
                             acc_ls2[j][h] = __builtin_elementwise_fma(
                                 tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}),
@@ -1325,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         }
     }
     if (MODE == MODE_BWD) {
-        float* slab = partial + (size_t)c * 2 * AN + (size_t)a * N;
+        float* slab = partial + (size_t)c * PL * AN + (size_t)a * N;
         const bool fold = fin0 != nullptr;                   // wave-uniform (kernel argument)
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -1334,6 +1342,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 if (fold) {
                     st4_sc1(slab + 4 * (lane + 64 * j), d0.x, d0.y, d1.x, d1.y);
                     st4_sc1(slab + AN + 4 * (lane + 64 * j), acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
+                    if (DBIAS)
+                        st4_sc1(slab + 2 * AN + 4 * (lane + 64 * j), acc_b2[j][0].x, acc_b2[j][0].y, acc_b2[j][1].x, acc_b2[j][1].y);
                 } else {
                     *reinterpret_cast<float4*>(slab + 4 * (lane + 64 * j)) = make_float4(d0.x, d0.y, d1.x, d1.y);
                     *reinterpret_cast<float4*>(slab + AN + 4 * (lane + 64 * j)) =
@@ -1350,9 +1360,9 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket != (unsigned)(C - 1)) return;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
+        for (int pl = 0; pl < PL; ++pl) {
             const float* src = partial + (size_t)pl * AN + (size_t)a * N;
-            float* dst = (pl ? fin1 : fin0) + (size_t)a * N;
+            float* dst = (pl == 0 ? fin0 : pl == 1 ? fin1 : lpseg_out) + (size_t)a * N;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 if (!ok[j]) continue;
@@ -1365,7 +1375,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                         f4v v[8];
                         const int kk = k0 + 8 * h;
                         if (kk >= C) break;
-                        ld4x8_sc1(src + (size_t)kk * 2 * AN + 4 * (lane + 64 * j), (size_t)2 * AN, min(8, C - kk), v);
+                        ld4x8_sc1(src + (size_t)kk * PL * AN + 4 * (lane + 64 * j), (size_t)PL * AN, min(8, C - kk), v);
 #pragma unroll
                         for (int i = 0; i < 8; ++i)
                             if (kk + i < C) run[8 * h + i] += v[i];
@@ -1669,10 +1679,10 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
     return logprob_fwd_impl(logits, action, loc, logstd, B, A, N, 0, logp, nullptr, workspace, workspace_bytes, stream, &p);
 }
 
-int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, const float* logstd,
-                     const float* dlogp, int B, int A, int N, int tanh_mode,
-                     float* dlogits, float* dloc, float* dlogstd, float* dx, int finalize,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+static int logprob_bwd_impl(const float* logits, const float* x, const float* loc, const float* logstd,
+                            const float* dlogp, int B, int A, int N, int tanh_mode,
+                            float* dlogits, float* dloc, float* dlogstd, float* dx, int finalize,
+                            void* workspace, size_t workspace_bytes, void* stream, float* dbias) {
     PFPN_BEGIN();
     if (!logits || !x || !loc || !logstd || !dlogp || !dlogits || (finalize && (!dloc || !dlogstd)) || B < 0 || A < 1 ||
         N < 1 || (!finalize && B == 0))
@@ -1687,6 +1697,8 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     if (!workspace) return PFPN_ERR_WORKSPACE;
     float* partial = (float*)workspace;
     TilePlan pl = plan_tile(B, A, N, logits, dlogits);
+    if (dbias && !(wide_ok(A, N, logits, dlogits) && !(pl.ok && tile_has(N)) && finalize && A <= WIDE_FOLD_MAX_A))
+        return PFPN_ERR_ARG;                                 // (the bias-gradient plane exists in the wide kernel's hand-off only)
     if (pl.ok && tile_has(N)) {
         if (workspace_bytes < (size_t)pl.grid * (2 * AN + 4) * sizeof(float)) return PFPN_ERR_WORKSPACE;
         PpoArgs none{};
@@ -1701,7 +1713,7 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
     if (wide_ok(A, N, logits, dlogits)) {
         const int C = wide_chunks(B, A, N, true);
         const bool stream = wide_stream(B, A, N);
-        if (workspace_bytes < (size_t)C * 2 * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
+        if (workspace_bytes < (size_t)C * (dbias ? 3 : 2) * AN * sizeof(float)) return PFPN_ERR_WORKSPACE;
         const int blocks = (A * C * 64 + 255) / 256;
         const int M = (N / 4 + 63) / 64;
         // finalize: the last wave of an action dim adds the slabs inside the launch (k_mix_wide's hand-off) unless A exceeds
@@ -1709,12 +1721,20 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
         bool fold = finalize && A <= WIDE_FOLD_MAX_A;
 #ifdef PFPN_WIDE_NO_FOLD
         fold = false;
+        if (dbias) return PFPN_ERR_ARG;
 #endif
         float* const fold0 = fold ? dloc : nullptr;
         float* const fold1 = fold ? dlogstd : nullptr;
 #define PFPN_WIDE_BWD_LAUNCH(MM, TT, FF, SS)                                                                    \
-    hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS>), dim3(blocks), dim3(256), 0, st, logits, x, loc, logstd, \
-                       dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial, fold0, fold1)
+    do {                                                                                                        \
+        if (dbias)                                                                                              \
+            hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS, true>), dim3(blocks), dim3(256), 0, st, logits, x, loc, \
+                               logstd, dlogp, B, A, N, C, dbias, (float*)nullptr, dlogits, dx, partial, fold0, fold1); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS>), dim3(blocks), dim3(256), 0, st, logits, x, loc, \
+                               logstd, dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial, fold0,  \
+                               fold1);                                                                          \
+    } while (0)
 #define PFPN_WIDE_BWD(MM, TT)                                                                                  \
     do {                                                                                                       \
         if (N == 256 * MM) { if (stream) PFPN_WIDE_BWD_LAUNCH(MM, TT, true, true); else PFPN_WIDE_BWD_LAUNCH(MM, TT, true, false); } \
@@ -1741,6 +1761,23 @@ int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, cons
                        dloc, dlogstd, AN, (float*)nullptr, 0.f, 0.f);
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
+}
+
+int pfpn_logprob_bwd(const float* logits, const float* x, const float* loc, const float* logstd,
+                     const float* dlogp, int B, int A, int N, int tanh_mode,
+                     float* dlogits, float* dloc, float* dlogstd, float* dx, int finalize,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    return logprob_bwd_impl(logits, x, loc, logstd, dlogp, B, A, N, tanh_mode, dlogits, dloc, dlogstd, dx, finalize, workspace,
+                            workspace_bytes, stream, nullptr);
+}
+
+int pfpn_logprob_bwd_bias(const float* logits, const float* x, const float* loc, const float* logstd,
+                          const float* dlogp, int B, int A, int N, int tanh_mode,
+                          float* dlogits, float* dloc, float* dlogstd, float* dx, float* dbias,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dbias || B < 1) return PFPN_ERR_ARG;
+    return logprob_bwd_impl(logits, x, loc, logstd, dlogp, B, A, N, tanh_mode, dlogits, dloc, dlogstd, dx, 1, workspace,
+                            workspace_bytes, stream, dbias);
 }
 
 // Slab geometry of pfpn_logprob_bwd(finalize = 0): `nslab` slabs of `stride` floats at the start of its workspace, each

@@ -67,9 +67,11 @@ def logprob_fwd(logits, x, loc, logstd, tanh_mode=False, want_pmix=False, out=No
     return (logp, pmix) if want_pmix else logp
 
 
-def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, out=None, slabs_ws=None):
+def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, out=None, slabs_ws=None, dbias=None):
     """-> dlogits [B,A,N], dloc [A,N], dlogstd [A,N] (, dx [B,A]).  `out`: dict with preallocated `dlogits`, `dloc`,
     `dlogstd` to write into (no 1-GiB temporaries at the 128 x 256 shape).
+    `dbias` [A*N] (not with `slabs_ws`): also the column sums of dlogits -- inside the launch where the wide kernel serves
+    the grid (N >= 64), by a pass over dlogits otherwise.
     `slabs_ws` (a private uint8 workspace, mixture_workspace()): dloc / dlogstd are NOT finalised -- their per-block
     partial sums stay in it (logprob_bwd_slabs() gives the geometry) for a deferred column-sum job."""
     lib = _lib.load()
@@ -88,9 +90,20 @@ def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, o
         dlogstd = torch.empty(A, N, dtype=torch.float32, device=x.device)
     dx = torch.empty(B, A, dtype=torch.float32, device=x.device) if want_dx else None
     ws, wsn = _mix_ws(B, A, N, x.device) if slabs_ws is None else (slabs_ws.data_ptr(), slabs_ws.numel())
+    if dbias is not None:
+        if slabs_ws is not None:
+            raise ValueError("dbias needs the finished form (no slabs_ws)")
+        rc = lib.pfpn_logprob_bwd_bias(pl, px, ploc, pls, pg, B, A, N, int(tanh_mode), dlogits.data_ptr(), dloc.data_ptr(),
+                                       dlogstd.data_ptr(), dx.data_ptr() if want_dx else None,
+                                       _f32(dbias.view(-1), A * N, name="dbias"), ws, wsn, _stream())
+        if rc != 1:
+            _lib.check(rc, "pfpn_logprob_bwd_bias")
+            return (dlogits, dloc, dlogstd, dx) if want_dx else (dlogits, dloc, dlogstd)
     _lib.check(lib.pfpn_logprob_bwd(pl, px, ploc, pls, pg, B, A, N, int(tanh_mode), dlogits.data_ptr(),
                                     dloc.data_ptr(), dlogstd.data_ptr(), dx.data_ptr() if want_dx else None,
                                     int(slabs_ws is None), ws, wsn, _stream()), "pfpn_logprob_bwd")
+    if dbias is not None:           # (a grid outside the wide kernel: the column sums as a pass of their own)
+        act_bwd_bias_grad(None, dlogits.view(B, A * N), dbias.view(1, -1), relu6=False)
     return (dlogits, dloc, dlogstd, dx) if want_dx else (dlogits, dloc, dlogstd)
 
 
@@ -203,9 +216,8 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
                                    dvalue=out["dvalue"], loss3=out["loss3"])
         else:
             _lib.check(rc, "pfpn_logprob_fwd_ppo")
-        logprob_bwd(logits, action, loc, logstd, dlogp, out=out)          # straight into the caller's buffers
-        if dbias is not None:
-            act_bwd_bias_grad(None, out["dlogits"].view(B, A * N), dbias.view(1, -1), relu6=False)
+        # straight into the caller's buffers; the head's bias gradient inside the backward launch (a third slab plane)
+        logprob_bwd(logits, action, loc, logstd, dlogp, out=out, dbias=dbias)
         return out
     _lib.check(rc, "pfpn_ppo_mixture_fwd_bwd")
     return out

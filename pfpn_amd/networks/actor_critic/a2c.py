@@ -160,6 +160,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         self.adv_stats = kernels.new_adv_stats(dev, self.clip_advantage)     # {mean, rstd | clip bounds}
         self.ws_mix = kernels.mixture_workspace(B, self.n_actions, self.particles, dev)   # private: deferred finalize
         self._mix_slabs = {}
+        self._pbias_ws = {}
         if self.trunk is not None:
             self.dh = torch.empty(2, B, hc, dtype=torch.float32, device=dev)
         else:
@@ -242,7 +243,13 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
         B = dlogits.shape[0]
         if deferred is not None:
             if not fused_db:
-                kernels.act_bwd_bias_grad(None, dlogits, st.g("actor/fc_policy/bias"), relu6=False)
+                # the head's bias gradient (column sums of dlogits) as per-chunk partials + a job of the reduction launch
+                AN = dlogits.shape[1]
+                ws = self._pbias_ws.get(B)
+                if ws is None:
+                    ws = self._pbias_ws[B] = kernels.learner_workspace(B, AN, dlogits.device)
+                cpg = kernels.act_bwd_partial(None, dlogits, 0, ws, relu6=False)
+                deferred.append(kernels.job_colsum(ws, 0, cpg, AN, AN, st.g("actor/fc_policy/bias").view(-1)))
             torch.mm(ha.t(), dlogits, out=st.g("actor/fc_policy/weight"))
             torch.mm(dlogits, self.policy_weight.t(), out=dh_a)
             self.trunk.backward(self.dh, deferred=deferred,
@@ -274,8 +281,11 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
                     for want_db in (False, True):
                         self._mix_slabs[want_db] = kernels.ppo_mixture_slabs(
                             B, self.n_actions, self.particles, want_db, self.logits, self.train_out["dlogits"])
+                    self._mix_slabs["composed"] = False
                 except Exception:
-                    ok = False
+                    # a particle grid outside the one-launch kernel (N > 64): the two-launch composition finishes its own
+                    # sums; everything else of the step is deferred all the same
+                    self._mix_slabs["composed"] = True
             self._defer_ok[key] = ok
         return [] if ok else None
 

@@ -60,14 +60,17 @@ def clip_ppo_network_wrapper(a2c_base_class):
                                                  self.normalize_policy_output_)
             # without an entropy term dlogits is final when the fused kernel ends: it then also emits the
             # fc_policy bias gradient (column sums of dlogits), saving a 20 MB pass
+            # (N > 64: the two-launch composition leaves dloc / dlogstd / dbias / loss3 final, nothing of it is deferred)
+            composed = deferred is not None and self._mix_slabs.get("composed", False)
             fused_db = not self.entropy_beta
             gbias = st.g("actor/fc_policy/bias")
+            slabs = deferred is not None and not composed
             out = kernels.ppo_mixture_fwd_bwd(policy.logits, action, self.loc, self.logstd, log_prob, advantage, v,
                                               value, self.adv_stats, self.epsilon, self.value_loss_coef,
                                               out=self.train_out, dbias=gbias if fused_db else None,
-                                              finalize=deferred is None, ws=self.ws_mix if deferred is not None else None)
+                                              finalize=not slabs, ws=self.ws_mix if slabs else None)
             dlogits = out["dlogits"]
-            if deferred is not None:
+            if slabs:
                 # dloc / dlogstd / dbias / loss3 stay as per-block slabs until the step's single reduce launch
                 AN = self.n_actions * self.particles
                 nslab, stride = self._mix_slabs[fused_db]

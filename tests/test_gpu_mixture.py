@@ -175,6 +175,16 @@ def test_wide_in_launch_handoffs(oracle, dev, B, A, N):
         r_dloc, r_dls = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, g)[1:3]
         for gotp, ref in ((o_dloc, r_dloc), (o_dls, r_dls)):
             np.testing.assert_allclose(gotp.cpu().numpy(), ref, rtol=1e-4, atol=2e-5 * (np.abs(ref).max() + 1e-30))
+        # the backward that also leaves the head's bias gradient (a third slab plane): every other output keeps its bits,
+        # dbias = the column sums of dlogits
+        dbias = torch.full((A * N,), float("nan"), device=dev)
+        b_dl, b_dloc, b_dls = kernels.logprob_bwd(*d, dbias=dbias)
+        assert torch.equal(b_dl, o_dl) and torch.equal(b_dloc, o_dloc) and torch.equal(b_dls, o_dls)
+        r_db = o_dl.view(B, A * N).double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(dbias.cpu().numpy(), r_db, rtol=1e-4, atol=2e-5 * (np.abs(r_db).max() + 1e-30))
+        dbias2 = torch.empty_like(dbias)
+        kernels.logprob_bwd(*d, dbias=dbias2)
+        assert torch.equal(dbias, dbias2)
 
 
 def test_wide_ppo_composition_is_two_launches_into_the_callers_buffers(oracle, dev):
