@@ -960,6 +960,18 @@ def main():
                         sstep()
                     torch.cuda.synchronize()
                     sms = (time.perf_counter() - t_s) / (25 * SK) * 1e3
+                    # the same step as ONE step per replay with its noise drawn by a launch of its own between replays -- the
+                    # form the off-policy worker runs (one learner step per environment step, `workers/ddpg.py`)
+                    s1 = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB))
+                    for _ in range(5):
+                        s1()
+                    torch.cuda.synchronize()
+                    t_s = time.perf_counter()
+                    for _ in range(100):
+                        s1()
+                    torch.cuda.synchronize()
+                    sms1 = (time.perf_counter() - t_s) / 100 * 1e3
+                    del s1
                     s_nodes = sstep.kernel_nodes()         # (None where the runtime cannot print a captured graph: this image)
                     s_launches, s_src = (s_nodes / SK, "kernel nodes of the captured %d-step hipGraph / %d" % (SK, SK)) \
                         if s_nodes else timeline_launches("sac_step_timeline.txt")
@@ -979,7 +991,8 @@ def main():
                     s_smp = snet.last["s_"].contiguous()
                     us_rb = time_in_graph(lambda: kernels.sac_actor_bwd(snet.logits, snet.loc, snet.logstd, nz_[0], nz_[2], s_smp,
                                                                         snet.sac_out["dlogp"], da_, snet.dlogits, snet.ws_actor))
-                    sac[SB] = {"steps_per_s": 1e3 / sms, "ms_per_step": sms, "finite_loss": bool(np.all(np.isfinite(sl3))),
+                    sac[SB] = {"steps_per_s": 1e3 / sms, "ms_per_step": sms, "ms_per_step_one_step_per_replay": sms1,
+                               "finite_loss": bool(np.all(np.isfinite(sl3))),
                                "roofline": {"bound": "mfma", "gemm_flops": sflops, "achieved": sflops / (sms * 1e-3) / 1e12,
                                             "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                                             "launches_per_step": s_launches,
