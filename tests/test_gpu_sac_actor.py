@@ -87,6 +87,55 @@ def test_actor_backward_matches_the_piecewise_launches(dev, B, A, N):
     assert torch.equal(dl2, dl1) and torch.equal(ws2, ws)
 
 
+def test_actor_kernels_random_shapes(dev):
+    """24 random particle grids (B 1..700, A 1..60, N 1..64: ragged blocks, partial quads' worth of particles, both register
+    layouts, more than 640 threads per block) through both launches against the piece-wise kernels."""
+    from pfpn_amd import kernels
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        B, A, N = int(rng.integers(1, 700)), int(rng.integers(1, 61)), int(rng.integers(1, 65))
+        if case == 0:
+            B, A, N = 3, 200, 5            # one row of 800 threads per block
+        if not kernels.sac_actor_supported(A, N):
+            continue
+        S = int(rng.integers(1, 40))
+        R = 2 * B
+        logits, loc, logstd, gumbel, eps = _inputs(rng, R, A, N, dev)
+        x = torch.from_numpy(rng.normal(0, 1, (R, S)).astype(F)).to(dev)
+        a_hist = torch.from_numpy(np.tanh(rng.normal(0, 1, (B, A))).astype(F)).to(dev)
+        xq_both, xq_next = torch.empty(2 * B, S + A, device=dev), torch.empty(B, S + A, device=dev)
+        a, s_, k, logp = kernels.sac_actor_fwd(logits, loc, logstd, gumbel, eps, x=x, a_hist=a_hist, xq_both=xq_both,
+                                               xq_next=xq_next)
+        a0, s0, k0 = kernels.rsample_fwd(logits, loc, logstd, gumbel, eps)
+        lp0 = kernels.logprob_fwd(logits, s0, loc, logstd, True)
+        tag = "case %d: B %d A %d N %d S %d" % (case, B, A, N, S)
+        assert torch.equal(k, k0) and torch.equal(a, a0) and torch.equal(s_, s0), tag
+        fin = torch.isfinite(lp0)
+        assert torch.equal(torch.isfinite(logp), fin), tag
+        torch.testing.assert_close(logp[fin], lp0[fin], rtol=1e-5, atol=2e-5 * float(lp0[fin].abs().max()), msg=tag)
+        xa, xh, xn = (torch.empty(B, S + A, device=dev) for _ in range(3))
+        kernels.sac_q_inputs(x[:B], x[B:], a0[:B], a_hist, a0[B:], xa, xh, xn)
+        assert torch.equal(xq_both[:B], xa) and torch.equal(xq_both[B:], xh) and torch.equal(xq_next, xn), tag
+        # backward over the first B rows
+        lg, gm, ep, sB = logits[:B].contiguous(), gumbel[:B].contiguous(), eps[:B].contiguous(), s0[:B].contiguous()
+        dlogp = torch.from_numpy((rng.normal(0, 1, B) * 0.01).astype(F)).to(dev)
+        da = torch.from_numpy(rng.normal(0, 0.02, (B, A)).astype(F)).to(dev)
+        AN = A * N
+        dl0, dloc0, dls0, dxs = kernels.logprob_bwd(lg, sB, loc, logstd, dlogp, True, True)
+        dl0 = dl0.view(B, AN).clone(); dloc0 = dloc0.clone(); dls0 = dls0.clone()
+        kernels.rsample_bwd(lg, loc, logstd, gm, ep, da, dxs, dl0, dloc0, dls0)
+        ws = kernels.sac_actor_workspace(B, A, N, dev)
+        dl1 = torch.full((B, AN), float("nan"), device=dev)
+        kernels.sac_actor_bwd(lg, loc, logstd, gm, ep, sB, dlogp, da, dl1, ws)
+        ns, ss = kernels.sac_actor_bwd_slabs(B, A, N)
+        slabs = ws.view(torch.float32).view(ns, 3, AN).double().sum(0).cpu().numpy()
+        d0 = dl0.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(dl1.cpu().numpy(), d0, rtol=3e-5, atol=3e-6 * (np.abs(d0).max() + 1e-30), err_msg=tag)
+        for got, ref, name in ((slabs[0], dloc0.cpu().numpy().reshape(-1), "dloc"),
+                               (slabs[1], dls0.cpu().numpy().reshape(-1), "dlogstd"), (slabs[2], d0.sum(0), "dbias")):
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5 * (np.abs(ref).max() + 1e-30), err_msg=tag + " " + name)
+
+
 def test_actor_kernels_refuse_what_they_do_not_cover(dev):
     from pfpn_amd import kernels, _lib
     assert not kernels.sac_actor_supported(36, 65) and not kernels.sac_actor_supported(300, 8)
