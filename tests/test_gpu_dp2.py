@@ -406,7 +406,8 @@ def _rccl_sharded_rank(port, q):
                 SyncReplicasApplier(nets[1], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1, force_exchange=True,
                                     exchange_mode="sharded"),
                 SyncReplicasApplier(nets[2], [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)]
-        ok = opts[0].sharded and opts[1].sharded and not opts[2].exchange and nets[0]._stats_in_flat
+        ok = _Checks()
+        ok &= opts[0].sharded and opts[1].sharded and not opts[2].exchange and nets[0]._stats_in_flat
         rng = np.random.default_rng(4)
         for it in range(9):
             b = make_batch(rng, 256)
