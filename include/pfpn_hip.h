@@ -19,6 +19,19 @@
  *  - return value: PFPN_OK (0), PFPN_ERR_ARG (1: null pointer / bad shape), PFPN_ERR_LAUNCH (2:
  *    HIP launch error), PFPN_ERR_WORKSPACE (3: workspace missing or too small).
  *  - reductions over the batch use fixed-order partial slabs: results are bitwise reproducible.
+ *
+ * Concurrency (what may be in flight at the same time, on different streams of one process)
+ *  - NO entry point keeps state in the library: every intermediate (partial slabs, in-launch hand-off tickets, staging)
+ *    lives in memory the caller hands in -- the outputs and `workspace`.  Two calls are independent, and may run
+ *    concurrently on two streams, exactly when they share no output and no workspace; a workspace is exclusive to one
+ *    call at a time (calls that reuse it must be ordered: same stream, or events).  Read-only inputs may be shared.
+ *  - A workspace needs no initialisation and keeps no meaning between calls: the mixture entry points zero the hand-off
+ *    tickets they use (the last words of a pfpn_mixture_workspace_bytes() workspace) stream-ordered in front of their
+ *    launch, so an uninitialised, reused or poisoned workspace gives the same bits as a fresh one.  A workspace smaller
+ *    than pfpn_*_workspace_bytes() asks for is refused with PFPN_ERR_WORKSPACE (or, where a launch-per-piece form needs
+ *    less, served by that form).
+ *  - The exceptions are documented at their prototypes: pfpn_debug_stamps() and pfpn_sac_noise_fill()'s draw counter
+ *    are explicit caller-owned device state; environment knobs (PFPN_WIDE_C, PFPN_WIDE_STREAM) are read once.
  */
 #ifndef PFPN_HIP_H_
 #define PFPN_HIP_H_

@@ -945,13 +945,15 @@ template <bool V> struct BoolTag { static constexpr bool value = V; };
 // adds them in a FIXED order -- bitwise the result the separate launch gave.  No fence: an agent-scope release would write
 // back this XCD's whole L2, which holds the kernel's 1 GiB dlogits stream (MI355X_MICROARCH.md, inter-workgroup
 // visibility: `sc1` payload -> vmcnt(0) -> atomic ticket -> `sc1` loads by the wave whose add returned last).
-// The counters live in the code object, are zero at load and are handed back zeroed by the last arriver; launches of a
-// wide kernel on two streams AT THE SAME TIME would share them (the package launches on one stream).
-__device__ unsigned g_wide_tick_fwd[64];             // one per row chunk c (C <= 64)
-__device__ unsigned g_wide_tick_ppo;                 // the chunks whose PPO head is done (forward + PPO head in one launch)
-__device__ unsigned g_wide_tick_bwd[4096];           // one per action dim
+// The counters live in the CALLER'S workspace (its last WIDE_TICK_WORDS words, see wide_tickets()): two launches in flight on two
+// streams with two workspaces share nothing.  The entry point zeroes the counters a launch uses stream-ordered in front of it
+// (hipMemsetAsync: a memset node under capture), so a fresh (uninitialised) or poisoned workspace is repaired, not trusted.
+constexpr int WIDE_TICK_FWD = 0;                     // [64]   one per row chunk c (C <= 64)
+constexpr int WIDE_TICK_PPO = 64;                    // [1]    the chunks whose PPO head is done (forward + PPO head in one launch)
+constexpr int WIDE_TICK_BWD = 128;                   // [4096] one per action dim
 constexpr int WIDE_FOLD_MAX_A = 4096;
 constexpr int WIDE_FOLD_MAX_LDS = 32 * 1024;
+constexpr size_t WIDE_TICK_WORDS = WIDE_TICK_BWD + WIDE_FOLD_MAX_A;
 
 __device__ __forceinline__ void st4_sc1(float* p, float a, float b, float c, float d) {
     const f4v v = {a, b, c, d};
@@ -1007,7 +1009,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     float* __restrict__ partial,             // [C][2*A*N]  (BWD)
     float* __restrict__ fin0 = nullptr,      // FWD FOLD: logp [B];  BWD: dloc [A,N] (null: slabs left for the caller)
     float* __restrict__ fin1 = nullptr,      // BWD: dlogstd [A,N]
-    WidePpo ppo = WidePpo{})                 // FWD FOLD: logp_old != nullptr -> the PPO head runs in the hand-off tail
+    WidePpo ppo = WidePpo{},                 // FWD FOLD: logp_old != nullptr -> the PPO head runs in the hand-off tail
+    unsigned* __restrict__ tick = nullptr)   // the hand-off tickets (caller's workspace, zeroed in front of the launch)
 {
     constexpr int U = 4;                                    // rows in flight per wave (reduced together)
     constexpr bool NT_LOADS = STREAM;                       // (forward: STREAM = the logits are read once and not again soon)
@@ -1272,7 +1275,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
-            s_ticket = __hip_atomic_fetch_add(&g_wide_tick_fwd[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = __hip_atomic_fetch_add(&tick[WIDE_TICK_FWD + c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != (unsigned)(nb - 1)) return;
         // the chunk's last block: logp[row] = sum over the chunk's blocks, in block order
@@ -1310,7 +1313,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 }
             }
         }
-        if (threadIdx.x == 0) __hip_atomic_store(&g_wide_tick_fwd[c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(&tick[WIDE_TICK_FWD + c], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (head) {
             __shared__ float hred[4];
             ps = block_sum(ps, hred);
@@ -1319,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 __hip_atomic_store(ppo.sums + 2 * c, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (sc1 stores)
                 __hip_atomic_store(ppo.sums + 2 * c + 1, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (__hip_atomic_fetch_add(&g_wide_tick_ppo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(C - 1)) {
+                if (__hip_atomic_fetch_add(&tick[WIDE_TICK_PPO], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(C - 1)) {
                     float tp = 0.f, tv = 0.f;                // the last chunk: the C pairs in chunk order
                     for (int k = 0; k < C; ++k) {
                         tp += __hip_atomic_load(ppo.sums + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1327,7 +1330,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                     }
                     const float pl = -tp * ppo.inv_B, vl = tv * ppo.inv_B * ppo.value_coef;
                     ppo.loss3[0] = pl + vl; ppo.loss3[1] = pl; ppo.loss3[2] = vl;
-                    __hip_atomic_store(&g_wide_tick_ppo, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&tick[WIDE_TICK_PPO], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
@@ -1356,7 +1359,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
         // k = r, r + 16, ..., then those in order) so that the result is bitwise the one of the separate launch ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned ticket = 0;
-        if (lane == 0) ticket = __hip_atomic_fetch_add(&g_wide_tick_bwd[a], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) ticket = __hip_atomic_fetch_add(&tick[WIDE_TICK_BWD + a], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket != (unsigned)(C - 1)) return;
 #pragma unroll
@@ -1387,7 +1390,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
                 *reinterpret_cast<float4*>(dst + 4 * (lane + 64 * j)) = make_float4(sum.x, sum.y, sum.z, sum.w);
             }
         }
-        if (lane == 0) __hip_atomic_store(&g_wide_tick_bwd[a], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(&tick[WIDE_TICK_BWD + a], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1579,7 +1582,25 @@ size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
     // slabs: tile path <= 1024 blocks x (3AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]
     const size_t AN = (size_t)A * N;
     const size_t slabs = (N <= 64 ? (size_t)1024 : (size_t)64) * (3 * AN + 4);
-    return (slabs + (size_t)B * A + 64) * sizeof(float);
+    // ... + the wide kernels' hand-off tickets as the LAST WIDE_TICK_WORDS words (wide_tickets())
+    return (((slabs + (size_t)B * A + 64) * sizeof(float) + 15) & ~(size_t)15) + WIDE_TICK_WORDS * sizeof(unsigned);
+}
+
+// the ticket area of a caller's workspace: at a place that depends on (B, A, N) alone -- the end of the size
+// pfpn_mixture_workspace_bytes() asks for -- or nullptr when the workspace is smaller than that (no in-launch hand-off then)
+static unsigned* wide_tickets(void* workspace, size_t workspace_bytes, int B, int A, int N) {
+    const size_t need = pfpn_mixture_workspace_bytes(B, A, N);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 3)) return nullptr;
+    return (unsigned*)((char*)workspace + need - WIDE_TICK_WORDS * sizeof(unsigned));
+}
+// zero `n` tickets from `first` on, stream-ordered in front of the launch that draws them (-DPFPN_WIDE_TRUST_TICKETS, A/B build
+// knob only: rely on the last arriver having handed them back zeroed)
+static bool wide_zero_tickets(unsigned* tick, int first, int n, hipStream_t st) {
+#ifdef PFPN_WIDE_TRUST_TICKETS
+    return true;
+#else
+    return hipMemsetAsync(tick + first, 0, (size_t)n * sizeof(unsigned), st) == hipSuccess;
+#endif
 }
 
 // forward of every path; `ppo` (wide path with the in-launch hand-off only, else PFPN_ERR_ARG): the PPO head in the same launch
@@ -1610,21 +1631,23 @@ static int logprob_fwd_impl(const float* logits, const float* x, const float* lo
         const int R4 = ((B + C - 1) / C + 3) & ~3;
         const size_t fold_lds = (size_t)4 * R4 * sizeof(float);
         const size_t part_floats = (size_t)C * (A / 4) * R4;
-        bool fold = A % 4 == 0 && C <= 64 && fold_lds <= (size_t)WIDE_FOLD_MAX_LDS &&
-                    workspace_bytes >= (part_floats + 2 * 64) * sizeof(float);
+        unsigned* const tick = wide_tickets(workspace, workspace_bytes, B, A, N);
+        bool fold = A % 4 == 0 && C <= 64 && fold_lds <= (size_t)WIDE_FOLD_MAX_LDS && tick != nullptr &&
+                    (part_floats + 2 * 64) * sizeof(float) <= (size_t)((char*)tick - (char*)workspace);
 #ifdef PFPN_WIDE_NO_FOLD                      // build knob for same-box A/B runs (tools/ab_build.sh): the separate launches
         fold = false;
 #endif
         if (ppo && !fold) return PFPN_ERR_ARG;
         WidePpo head{};
         if (ppo) { head = *ppo; head.sums = lpseg + part_floats; }
+        if (fold && !wide_zero_tickets(tick, WIDE_TICK_FWD, WIDE_TICK_PPO + 1, st)) return PFPN_ERR_LAUNCH;
         // non-temporal loads only in the streaming regime (logits larger than the 256 MiB infinity cache: 207 -> 195 us on
         // the 1 GiB shape); below it the default policy leaves the logits in cache for the backward pass that follows
         const bool stream = wide_stream(B, A, N);
 #define PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, SS, OO)                                                                \
     hipLaunchKernelGGL((k_mix_wide<MM, MODE_FWD, TT, FF, SS, OO>), dim3(blocks), dim3(256), OO ? fold_lds : 0, st, \
                        logits, x, loc, logstd, (const float*)nullptr, B, A, N, C, lpseg, pmix, (float*)nullptr,  \
-                       (float*)nullptr, (float*)nullptr, logp, (float*)nullptr, head)
+                       (float*)nullptr, (float*)nullptr, logp, (float*)nullptr, head, tick)
 #define PFPN_WIDE_FWD_F(MM, TT, FF)                                                                            \
     do {                                                                                                       \
         if (stream) { if (fold) PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, true, true); else PFPN_WIDE_FWD_LAUNCH(MM, TT, FF, true, false); } \
@@ -1718,22 +1741,25 @@ static int logprob_bwd_impl(const float* logits, const float* x, const float* lo
         const int M = (N / 4 + 63) / 64;
         // finalize: the last wave of an action dim adds the slabs inside the launch (k_mix_wide's hand-off) unless A exceeds
         // the ticket array -- then, as before, the k_finalize launch
-        bool fold = finalize && A <= WIDE_FOLD_MAX_A;
+        unsigned* const tick = wide_tickets(workspace, workspace_bytes, B, A, N);
+        bool fold = finalize && A <= WIDE_FOLD_MAX_A && tick != nullptr;
 #ifdef PFPN_WIDE_NO_FOLD
         fold = false;
-        if (dbias) return PFPN_ERR_ARG;
 #endif
+        if (dbias && !fold) return tick ? PFPN_ERR_ARG : PFPN_ERR_WORKSPACE;
+        if (fold && !wide_zero_tickets(tick, WIDE_TICK_BWD, A, st)) return PFPN_ERR_LAUNCH;
         float* const fold0 = fold ? dloc : nullptr;
         float* const fold1 = fold ? dlogstd : nullptr;
 #define PFPN_WIDE_BWD_LAUNCH(MM, TT, FF, SS)                                                                    \
     do {                                                                                                        \
         if (dbias)                                                                                              \
             hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS, true>), dim3(blocks), dim3(256), 0, st, logits, x, loc, \
-                               logstd, dlogp, B, A, N, C, dbias, (float*)nullptr, dlogits, dx, partial, fold0, fold1); \
+                               logstd, dlogp, B, A, N, C, dbias, (float*)nullptr, dlogits, dx, partial, fold0, fold1, \
+                               WidePpo{}, tick);                                                                \
         else                                                                                                    \
             hipLaunchKernelGGL((k_mix_wide<MM, MODE_BWD, TT, FF, SS>), dim3(blocks), dim3(256), 0, st, logits, x, loc, \
                                logstd, dlogp, B, A, N, C, (float*)nullptr, (float*)nullptr, dlogits, dx, partial, fold0,  \
-                               fold1);                                                                          \
+                               fold1, WidePpo{}, tick);                                                         \
     } while (0)
 #define PFPN_WIDE_BWD(MM, TT)                                                                                  \
     do {                                                                                                       \

@@ -187,6 +187,97 @@ def test_wide_in_launch_handoffs(oracle, dev, B, A, N):
         assert torch.equal(dbias, dbias2)
 
 
+@pytest.mark.parametrize("B,A,N", [(1030, 8, 128), (517, 128, 256)])
+def test_wide_handoff_is_reentrant_across_streams(oracle, dev, B, A, N):
+    """Round 5 (SURVEY 8b "re-entrant"; include/pfpn_hip.h "Concurrency"): the hand-off tickets of the wide kernels live in the
+    CALLER'S workspace, not in the code object.  Forward (+ PPO head) and backward launched on two streams at once, each with
+    its own workspace and outputs, 50 rounds, interleaved from the host so that launches of the two streams overlap on the
+    chip: every result of every round is bitwise the single-stream one (compared on the device, stream-ordered, no host sync
+    inside the rounds)."""
+    from pfpn_amd import kernels
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 4242 + B, spread=1.0)
+    rng = np.random.default_rng(B)
+    g = rng.normal(0, 1, B).astype(np.float32)
+    sets = []
+    for k in range(2):                                          # two independent problems (same shape, different data)
+        lg = logits if k == 0 else np.roll(logits, 1, axis=0).copy()
+        d = to_dev(dev, lg, x, loc, logstd, g)
+        ref_lp = kernels.logprob_fwd(d[0], d[1], d[2], d[3]).clone()
+        ref = [t.clone() for t in kernels.logprob_bwd(*d)]
+        dbias_ref = torch.empty(A * N, device=dev)
+        kernels.logprob_bwd(*d, dbias=dbias_ref)
+        sets.append((d, ref_lp, ref, dbias_ref))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    outs, bad, wss = [], [], []
+    for k, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            outs.append({"lp": torch.empty(B, device=dev), "dlogits": torch.empty(B, A, N, device=dev),
+                         "dloc": torch.empty(A, N, device=dev), "dlogstd": torch.empty(A, N, device=dev),
+                         "dbias": torch.empty(A * N, device=dev)})
+            bad.append(torch.zeros(1, dtype=torch.int64, device=dev))
+            d = sets[k][0]
+            kernels.logprob_fwd(d[0], d[1], d[2], d[3], out=outs[k]["lp"])     # (sizes this stream's workspace)
+            wss.append(kernels.workspace(1, dev))
+    assert wss[0].data_ptr() != wss[1].data_ptr()              # one workspace per stream
+    torch.cuda.synchronize()
+    for it in range(50):
+        for k, st in enumerate(streams):
+            d, ref_lp, ref, dbias_ref = sets[k]
+            o = outs[k]
+            with torch.cuda.stream(st):
+                kernels.logprob_fwd(d[0], d[1], d[2], d[3], out=o["lp"])
+                bad[k] += (o["lp"] != ref_lp).sum()
+                kernels.logprob_bwd(*d, out=o, dbias=o["dbias"] if it % 2 else None)
+                bad[k] += (o["dlogits"] != ref[0]).sum() + (o["dloc"] != ref[1]).sum() + (o["dlogstd"] != ref[2]).sum()
+                if it % 2:
+                    bad[k] += (o["dbias"] != dbias_ref).sum()
+    torch.cuda.synchronize()
+    assert int(bad[0].item()) == 0 and int(bad[1].item()) == 0, (int(bad[0].item()), int(bad[1].item()))
+
+
+def test_wide_handoff_repairs_a_poisoned_workspace_and_refuses_a_short_one(oracle, dev):
+    """The ticket area needs no initialisation: a workspace full of 0xFF bytes (what torch.empty may hand out, or what a launch
+    that died mid-way leaves) gives the bits of a clean one -- the entry point zeroes the tickets it uses in front of its
+    launch.  A workspace shorter than pfpn_mixture_workspace_bytes(): the forward still answers (launch-per-piece form, same
+    bits to 1e-6), the bias-plane backward -- which exists in the hand-off only -- is refused with PFPN_ERR_WORKSPACE."""
+    import ctypes
+    from pfpn_amd import _lib, kernels
+    B, A, N = 517, 12, 256
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 99, spread=1.0)
+    g = np.random.default_rng(9).normal(0, 1, B).astype(np.float32)
+    d = to_dev(dev, logits, x, loc, logstd, g)
+    lp0 = kernels.logprob_fwd(d[0], d[1], d[2], d[3]).clone()
+    r0 = [t.clone() for t in kernels.logprob_bwd(*d)]
+    db0 = torch.empty(A * N, device=dev)
+    kernels.logprob_bwd(*d, dbias=db0)
+    for fill in (0xFF, 0x01):
+        kernels.workspace(1, dev).fill_(fill)                   # the current stream's workspace, tickets included
+        assert torch.equal(kernels.logprob_fwd(d[0], d[1], d[2], d[3]), lp0)
+        kernels.workspace(1, dev).fill_(fill)
+        db = torch.empty(A * N, device=dev)
+        r = kernels.logprob_bwd(*d, dbias=db)
+        assert all(torch.equal(a, b) for a, b in zip(r, r0)) and torch.equal(db, db0)
+    lib = _lib.load()
+    need = int(lib.pfpn_mixture_workspace_bytes(B, A, N))
+    short = torch.empty(need - 64, dtype=torch.uint8, device=dev)
+    lp = torch.empty(B, device=dev)
+    st = kernels._stream()
+    assert lib.pfpn_logprob_fwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), B, A, N, 0, lp.data_ptr(),
+                                None, short.data_ptr(), short.numel(), st) == 0
+    np.testing.assert_allclose(lp.cpu().numpy(), lp0.cpu().numpy(), rtol=2e-6, atol=2e-5)
+    dl, dloc, dls, db = (torch.empty(B, A * N, device=dev), torch.empty(A, N, device=dev), torch.empty(A, N, device=dev),
+                         torch.empty(A * N, device=dev))
+    rc = lib.pfpn_logprob_bwd_bias(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), B, A, N,
+                                   0, dl.data_ptr(), dloc.data_ptr(), dls.data_ptr(), None, db.data_ptr(), short.data_ptr(),
+                                   short.numel(), st)
+    assert rc == 3                                              # PFPN_ERR_WORKSPACE
+    # ... and the plain backward with the short workspace takes the k_finalize launch: same bits (same summation order)
+    assert lib.pfpn_logprob_bwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), B, A, N, 0,
+                                dl.data_ptr(), dloc.data_ptr(), dls.data_ptr(), None, 1, short.data_ptr(), short.numel(), st) == 0
+    assert torch.equal(dl.view(B, A, N), r0[0]) and torch.equal(dloc, r0[1]) and torch.equal(dls, r0[2])
+
+
 def test_wide_ppo_composition_is_two_launches_into_the_callers_buffers(oracle, dev):
     """N >= 64: ppo_mixture_fwd_bwd composes [forward + PPO head in one launch] -> backward; every result lands in `out`
     directly; the in-launch head gives the per-row outputs of the stand-alone head bit for bit."""

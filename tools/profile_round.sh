@@ -5,13 +5,14 @@
 # Outputs under gpurun_out/prof/ ; tools/profile_collect.py turns them into the files committed under profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
-TAG=${1:-r04}
+TAG=${1:-r05}
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-tune --no-graph > $O/stats.log 2>&1
 echo "stats done" > $O/progress.log
 rocprofv3 --kernel-trace --output-format csv -d $O/timeline -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline > $O/timeline.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/probe_trace -- python3 tools/mix_probe.py > $O/probe_trace.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/sac_trace -- python3 tools/sac_trace.py > $O/sac_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/c5_trace -- python3 tools/config5_trace.py > $O/c5_trace.log 2>&1
 echo "traces done" >> $O/progress.log
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/gemm_mfma -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/gemm_mfma.log 2>&1
 echo "gemm mfma pmc done" >> $O/progress.log
@@ -29,7 +30,8 @@ rm -rf pfpn_amd/build && PFPN_BUILD_STAMPS=1 python3 -m pfpn_amd.build > $O/stam
 python3 tools/profile_collect.py $O gpurun_out/prof_summary $TAG > $O/collect.log 2>&1
 python3 tools/gemm_mfma_pmc.py $O/gemm_mfma gpurun_out/prof_summary/${TAG}_gemm_mfma.json >> $O/collect.log 2>&1
 python3 tools/step_timeline.py $(ls $O/sac_trace/*/*kernel_trace.csv | head -1) k_act_bwd_partial_value > gpurun_out/prof_summary/${TAG}_sac_step_timeline.txt 2>> $O/collect.log
-for d in stats timeline probe_trace sac_trace gemm_mfma fetch write sq1 sq2 sfetch swrite; do rm -rf $O/$d; done   # raw traces: large; the summaries are what is kept
+python3 tools/step_timeline.py $(ls $O/c5_trace/*/*kernel_trace.csv | head -1) k_clip_adam > gpurun_out/prof_summary/${TAG}_config5_step_timeline.txt 2>> $O/collect.log
+for d in stats timeline probe_trace sac_trace c5_trace gemm_mfma fetch write sq1 sq2 sfetch swrite; do rm -rf $O/$d; done   # raw traces: large; the summaries are what is kept
 tail -3 $O/collect.log
 
 # leave the DEFAULT library behind: later bench / test runs must not silently measure a diagnostic or flagged build
