@@ -75,6 +75,18 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
                          float* logp, float* dlogp, float* dvalue, float* loss3,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* EXPERIMENTAL (round 5 probe; tools/f2l_probe.py): pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias) of an N = 256 / 512 / 1024
+ * particle grid as ONE launch that reads the logits once (reference networks/utils.py:108-134 + its autodiff, ppo.py:31-54): the
+ * A waves of a row chunk exchange their per-dimension log p through memory once per four rows.  All of the chunk's waves must be
+ * resident together: the entry point sizes the grid to the device (*chunks_out, optional, receives the chunk count) and every
+ * in-kernel wait is bounded (on expiry word WIDE_TICK_PPO + 1 of the workspace's ticket area is set: results invalid).
+ * dbias optional (NULL: no bias plane).  PFPN_ERR_ARG for shapes outside the form. */
+int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* loc, const float* logstd,
+                        const float* logp_old, const float* adv, const float* value, const float* value_old,
+                        const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
+                        float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue, float* dlogp,
+                        float* dbias, float* loss3, int* chunks_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* TF autodiff of the above incl. the NaN/Inf guard of utils.py:109-117.
  * dlogp [B] in; dlogits [B,A*N], dloc [A,N], dlogstd [A,N] out (overwritten, not accumulated);
  * dx [B,A] optional (needed by SAC where x depends on the parameters). */

@@ -427,4 +427,6 @@ def restore(prefix, net, optimizer=None, strict=True):
         net.global_step = int(rd.get("step/global_step"))
         if hasattr(net, "step_dev"):
             net.step_dev.fill_(float(net.global_step))
+        if getattr(net, "noise_epoch", None) is not None:      # SAC: the learner's noise draws continue, they do not restart
+            net.noise_epoch.fill_(int(net.global_step))
     return rd

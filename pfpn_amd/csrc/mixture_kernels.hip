@@ -1394,6 +1394,312 @@ __global__ __launch_bounds__(256) void k_mix_wide(
     }
 }
 
+// =====================================================================================================================
+// EXPERIMENTAL (round 5 probe, tools/f2l_probe.py): the clipped-PPO learner pass of the wide shapes as ONE launch that reads
+// the logits once and writes dlogits once (2L instead of the 3L of [forward + head] -> backward).
+// The obstacle is the row sum: log p of a row = the sum over its A action dims, and the wide kernels give every action dim
+// to its own wave (bank + gradient accumulators of ONE dim in registers while it walks the rows) -- A = 128 waves on 32
+// blocks.  Here the A waves of a row chunk MEET once per group of four rows, through memory: a wave publishes its four
+// per-dim log p (write-through, `sc1`), takes a ticket on the chunk's arrival counter, and -- one group later -- finds the
+// counter complete, adds the A partials in a fixed order, runs the PPO head on the four row totals (every wave redundantly:
+// uniform scalar work) and finishes the backward of THAT group from the e / e*phi / z it kept in registers.  The pipeline is
+// two groups deep (forward of group k, then backward of group k - 1) so that a group's exchange has a whole iteration to
+// complete; the next-but-one group's loads are in flight meanwhile.  The waves of a chunk must be co-resident (they wait for
+// each other): the host sizes C so that the whole grid is resident at once; every wait is bounded and raises `err`.
+// Ordering of a publish: payload `sc1` store -> s_waitcnt vmcnt(0) -> relaxed agent-scope add; of a read: relaxed agent-scope
+// load of the counter >= target -> `sc1` loads of the payload (the protocol of the hand-off above).
+struct WideF2L {
+    float* part;        // [C][2][A][4]: log p of (chunk, group parity, action dim) for the group's four rows
+    unsigned* count;    // [C][2] arrivals, monotonic per parity (zeroed in front of the launch)
+    unsigned* err;      // [1]
+    float* logp;        // [B] out
+};
+
+__device__ __forceinline__ bool f2l_wait(const unsigned* cnt, unsigned target, unsigned* err) {
+    int it = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++it > (1 << 20)) {                              // ~1 s: the grid was not co-resident (or a wave died)
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+// four `sc1` loads (entries past `n` re-read entry n - 1: ignored by the caller) and the wait for EVERYTHING outstanding, as
+// one asm statement (see ld4x8_sc1)
+__device__ __forceinline__ void ld4x4_sc1_drain(const float* p, size_t stride, int n, f4v (&v)[4]) {
+    const float* q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = p + (size_t)min(i, n - 1) * stride;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3])
+        : "memory");
+}
+
+template <int M, bool STREAM, bool DBIAS>
+__global__ __launch_bounds__(256) void k_mix_wide_f2l(
+    const float* __restrict__ logits, const float* __restrict__ x,
+    const float* __restrict__ loc, const float* __restrict__ logstd,
+    int B, int A, int N, int C,
+    float* __restrict__ dlogits,
+    float* __restrict__ partial,             // [C][PL * A * N] slabs
+    float* __restrict__ fin0, float* __restrict__ fin1, float* __restrict__ finb,      // dloc, dlogstd, dbias [A, N]
+    WidePpo ppo, WideF2L sy, unsigned* __restrict__ tick)
+{
+    constexpr int U = 4;
+    constexpr int PL = DBIAS ? 3 : 2;
+    const int lane = threadIdx.x & 63;
+    const int nb = A >> 2;                                   // blocks per row chunk (A % 4 == 0)
+    // chunk <-> XCD: blocks are dealt to the 8 XCDs round-robin; the blocks of one chunk all carry the same blockIdx % 8, so a
+    // chunk's exchange stays among the CUs of one XCD where the chunk count allows (C % 8 == 0)
+    int c, jb;
+    if ((C & 7) == 0) { const int i = blockIdx.x >> 3; c = (blockIdx.x & 7) + 8 * (i / nb); jb = i % nb; }
+    else { c = blockIdx.x / nb; jb = blockIdx.x % nb; }
+    c = __builtin_amdgcn_readfirstlane(c);
+    const int a = __builtin_amdgcn_readfirstlane(4 * jb + (int)(threadIdx.x >> 6));
+    const int AN = A * N;
+    v2f b_loc2[M][2], b_isc2[M][2], b_ct2[M][2];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const int o = a * N + 4 * (lane + 64 * j);
+        const float4 lo = ld4(loc + o), ls = ld4(logstd + o);
+        const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, ls_[4] = {ls.x, ls.y, ls.z, ls.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sc = expf(ls_[k]);
+            b_loc2[j][k >> 1][k & 1] = lo_[k];
+            b_isc2[j][k >> 1][k & 1] = (1.0f / sc) * PFPN_SQRT_HALF_LOG2E;
+            b_ct2[j][k >> 1][k & 1] = 64.f - (PFPN_HALF_LOG_2PI + logf(sc)) * PFPN_LOG2E;
+        }
+    }
+    v2f acc_loc2[M][2], acc_ls2[M][2], acc_b2[M][2];
+#pragma unroll
+    for (int j = 0; j < M; ++j)
+        for (int h = 0; h < 2; ++h) {
+            acc_loc2[j][h] = (v2f){0.f, 0.f}; acc_ls2[j][h] = (v2f){0.f, 0.f}; acc_b2[j][h] = (v2f){0.f, 0.f};
+        }
+    const float two_m64 = 5.421010862427522e-20f;
+    const float hm = ppo.stats[0], hr = ppo.stats[1], hlo = ppo.stats[2], hhi = ppo.stats[3];
+    const int Rc = (B - c + C - 1) / C;                      // rows of chunk c
+    const int G = (Rc + U - 1) / U;                          // its groups of four rows
+    float ps = 0.f, vs = 0.f;                                // loss sums of this chunk's rows (kept by its wave a == 0)
+    bool alive = true;
+
+    struct St { v2f e[U][M][2], ef[U][M][2], zq[U][M][2]; float p[U], inv_sum[U]; };
+    struct Ld { float4 l[U][M]; float x[U]; };
+    auto load = [&](int g, Ld& d) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b_ = min(c + (U * g + u) * C, B - 1);  // clamped: loads unconditional
+            const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;
+#pragma unroll
+            for (int j = 0; j < M; ++j) d.l[u][j] = ld4_stream<STREAM>(row_ + 4 * (lane + 64 * j));
+            d.x[u] = x[(size_t)b_ * A + a];
+        }
+    };
+    // forward of one group: e, e*phi, z kept; -> the group's four per-dim log p
+    auto fwd = [&](const Ld& d, St& s, float (&lpr)[U]) {
+        float mx[U];
+        v2f lp[U][M][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            mx[u] = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                lp[u][j][0] = (v2f){d.l[u][j].x, d.l[u][j].y} * PFPN_LOG2E;
+                lp[u][j][1] = (v2f){d.l[u][j].z, d.l[u][j].w} * PFPN_LOG2E;
+                mx[u] = fmaxf(fmaxf(lp[u][j][0].x, lp[u][j][0].y), mx[u]);
+                mx[u] = fmaxf(fmaxf(lp[u][j][1].x, lp[u][j][1].y), mx[u]);
+            }
+        }
+        wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
+        float sum[U], num[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v2f s2 = {0.f, 0.f}, n2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2f le = lp[u][j][h] - mx[u];
+                    const v2f z = (d.x[u] - b_loc2[j][h]) * b_isc2[j][h];
+                    const v2f arg = le + __builtin_elementwise_fma(-z, z, b_ct2[j][h]);
+                    s.zq[u][j][h] = z;
+                    s.e[u][j][h] = (v2f){__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
+                    s.ef[u][j][h] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                    if (j == 0 && h == 0) { s2 = s.e[u][j][h]; n2 = s.ef[u][j][h]; }
+                    else { s2 += s.e[u][j][h]; n2 += s.ef[u][j][h]; }
+                }
+            }
+            sum[u] = s2.x + s2.y;
+            num[u] = n2.x + n2.y;
+        }
+        wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
+        wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s.inv_sum[u] = __builtin_amdgcn_rcpf(sum[u]);
+            float p = (num[u] * two_m64) * s.inv_sum[u];
+            if (p < 1.401298464324817e-45f) p = 0.f;
+            s.p[u] = p;
+            lpr[u] = __builtin_amdgcn_logf(p) * 0.6931471805599453f;
+        }
+    };
+    auto publish = [&](int g, const float (&lpr)[U]) {
+        float* slot = sy.part + (((size_t)c * 2 + (g & 1)) * A + a) * 4;
+        if (lane == 0) st4_sc1(slot, lpr[0], lpr[1], lpr[2], lpr[3]);
+    };
+    auto ticket = [&](int g) {
+        if (lane == 0) __hip_atomic_fetch_add(&sy.count[c * 2 + (g & 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // the group's four row totals (every lane: the same bits) -- wait for the chunk's A arrivals, add the A partials in a
+    // fixed order: lane l takes dims l, l + 64, ... in turn, then the transposing butterfly
+    auto totals = [&](int g, float (&tot)[U]) {
+        if (alive) alive = f2l_wait(&sy.count[c * 2 + (g & 1)], (unsigned)((g >> 1) + 1) * (unsigned)A, sy.err);
+        const float* base = sy.part + ((size_t)c * 2 + (g & 1)) * A * 4;
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+        for (int a0 = 0; a0 < A; a0 += 256) {
+            f4v v[4];
+            const int n = min(4, (A - a0 - lane + 63) / 64);             // dims a0 + lane + 64 i < A
+            ld4x4_sc1_drain(base + (size_t)(a0 + min(lane, max(A - a0 - 1, 0))) * 4, (size_t)64 * 4, max(n, 1), v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < n) acc += v[i];
+        }
+        tot[0] = acc.x; tot[1] = acc.y; tot[2] = acc.z; tot[3] = acc.w;
+        wave_reduce4<false>(tot[0], tot[1], tot[2], tot[3], lane);
+    };
+    // PPO head on a group's four rows (k_ppo_loss, term for term) + the backward of the group
+    auto bwd = [&](int g, const St& s, const float (&tot)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = c + (U * g + u) * C;
+            const bool live = b < B;
+            const int bb = live ? b : B - 1;
+            const float av = ppo.adv[bb];
+            const float nadv = clip_adv((av - hm) * hr, hlo, hhi);
+            const float ratio = expf(tot[u] - ppo.logp_old[bb]);
+            const float sur = ratio * nadv;
+            const float csur = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo) * nadv;
+            const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+            const float gdl = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+            const float dvv = ppo.value[bb] - (av + ppo.value_old[bb]);
+            if (a == 0 && live) {
+                ps += fminf(sur, csur);
+                vs += dvv * dvv;
+                if (lane == 0) {
+                    sy.logp[b] = tot[u];
+                    ppo.dlogp[b] = gdl;
+                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+                }
+            }
+            const float q_ = live ? guard_finite(gdl * __builtin_amdgcn_rcpf(s.p[u])) : 0.f;
+            const float qs = q_ * s.inv_sum[u];
+            const float qp = qs * s.p[u];
+            const float qs64 = qs * two_m64;
+            float* drow = dlogits + (size_t)bb * AN + (size_t)a * N;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                v2f d[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const v2f tt = s.ef[u][j][h] * qs64;
+                    const v2f z = s.zq[u][j][h];
+                    d[h] = __builtin_elementwise_fma(-s.e[u][j][h], (v2f){qp, qp}, tt);
+                    if (DBIAS) acc_b2[j][h] += d[h];
+                    acc_loc2[j][h] = __builtin_elementwise_fma(tt, z, acc_loc2[j][h]);
+                    acc_ls2[j][h] = __builtin_elementwise_fma(
+                        tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}), acc_ls2[j][h]);
+                }
+                if (live) st4_row<STREAM>(drow, 4 * N, lane + 64 * j, d[0].x, d[0].y, d[1].x, d[1].y);
+            }
+        }
+    };
+
+    Ld ln, lf;
+    St sc, sp;
+    float lpr[U], tot[U];
+    load(0, ln);
+    load(1, lf);
+    for (int k = 0; k < G; ++k) {
+        fwd(ln, sc, lpr);
+        publish(k, lpr);
+        if (k > 0) totals(k - 1, tot);                       // (its last asm drains: lf and the publish have landed)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket(k);
+        ln = lf;
+        load(k + 2, lf);
+        if (k > 0) bwd(k - 1, sp, tot);
+        sp = sc;
+    }
+    totals(G - 1, tot);
+    bwd(G - 1, sp, tot);
+
+    // ---- the chunk's loss sums; the last chunk adds the C pairs in chunk order (the tail of the forward's hand-off) ----
+    if (a == 0 && lane == 0) {
+        __hip_atomic_store(ppo.sums + 2 * c, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ppo.sums + 2 * c + 1, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (__hip_atomic_fetch_add(&tick[WIDE_TICK_PPO], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(C - 1)) {
+            float tp = 0.f, tv = 0.f;
+            for (int k = 0; k < C; ++k) {
+                tp += __hip_atomic_load(ppo.sums + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tv += __hip_atomic_load(ppo.sums + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const float pl = -tp * ppo.inv_B, vl = tv * ppo.inv_B * ppo.value_coef;
+            ppo.loss3[0] = pl + vl; ppo.loss3[1] = pl; ppo.loss3[2] = vl;
+        }
+    }
+    // ---- slabs + the last wave of an action dim adds the C slabs (k_mix_wide's backward hand-off, same order) ----
+    float* slab = partial + (size_t)c * PL * AN + (size_t)a * N;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const v2f d0 = acc_loc2[j][0] * (b_isc2[j][0] * PFPN_2LN2), d1 = acc_loc2[j][1] * (b_isc2[j][1] * PFPN_2LN2);
+        st4_sc1(slab + 4 * (lane + 64 * j), d0.x, d0.y, d1.x, d1.y);
+        st4_sc1(slab + AN + 4 * (lane + 64 * j), acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
+        if (DBIAS) st4_sc1(slab + 2 * AN + 4 * (lane + 64 * j), acc_b2[j][0].x, acc_b2[j][0].y, acc_b2[j][1].x, acc_b2[j][1].y);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(&tick[WIDE_TICK_BWD + a], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if (tk != (unsigned)(C - 1)) return;
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) {
+        const float* src = partial + (size_t)pl * AN + (size_t)a * N;
+        float* dst = (pl == 0 ? fin0 : pl == 1 ? fin1 : finb) + (size_t)a * N;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            f4v run[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) run[r] = (f4v){0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < C; k0 += 16) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f4v v[8];
+                    const int kk = k0 + 8 * h;
+                    if (kk >= C) break;
+                    ld4x8_sc1(src + (size_t)kk * PL * AN + 4 * (lane + 64 * j), (size_t)PL * AN, min(8, C - kk), v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (kk + i < C) run[8 * h + i] += v[i];
+                }
+            }
+            f4v sum = run[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) sum += run[r];
+            *reinterpret_cast<float4*>(dst + 4 * (lane + 64 * j)) = make_float4(sum.x, sum.y, sum.z, sum.w);
+        }
+    }
+}
+
 // logp[b] = sum_a lpseg[b,a]: one wavefront per row, lanes read the row coalesced, fixed-order
 // butterfly (deterministic).  (A serial per-thread loop here costs A dependent-load latencies.)
 __global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ lpseg, int B, int A,
@@ -1700,6 +2006,76 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
     p.clip_lo = 1.0f - clip_eps; p.clip_hi = 1.0f + clip_eps; p.value_coef = value_coef; p.inv_B = 1.0f / (float)B;
     p.dlogp = dlogp; p.dvalue = dvalue; p.loss3 = loss3;
     return logprob_fwd_impl(logits, action, loc, logstd, B, A, N, 0, logp, nullptr, workspace, workspace_bytes, stream, &p);
+}
+
+// EXPERIMENTAL (round 5 probe): clipped-PPO forward + head + backward of a wide shape in ONE launch, logits read once
+// (k_mix_wide_f2l).  PFPN_ERR_ARG where the form does not apply (the caller composes pfpn_logprob_fwd_ppo + pfpn_logprob_bwd).
+int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* loc, const float* logstd,
+                        const float* logp_old, const float* adv, const float* value, const float* value_old,
+                        const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
+                        float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue, float* dlogp,
+                        float* dbias, float* loss3, int* chunks_out, void* workspace, size_t workspace_bytes, void* stream) {
+    PFPN_BEGIN();
+    if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats || !logp ||
+        !dlogits || !dloc || !dlogstd || !dvalue || !dlogp || !loss3 || B < 1 || A < 4 || N < 1)
+        return PFPN_ERR_ARG;
+    const int M = N / 256;
+    if (!wide_ok(A, N, logits, dlogits) || N != 256 * M || !(M == 1 || M == 2 || M == 4) || (A & 3) || A > WIDE_FOLD_MAX_A)
+        return PFPN_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* const tick = wide_tickets(workspace, workspace_bytes, B, A, N);
+    if (!tick) return PFPN_ERR_WORKSPACE;
+    const bool stream_policy = wide_stream(B, A, N);
+    const int nb = A / 4;
+    // every wave of a chunk waits for the others: the WHOLE grid must be resident at once
+    int per_cu = 0;
+#define PFPN_F2L_KERNEL(MM, SS, DD) k_mix_wide_f2l<MM, SS, DD>
+#define PFPN_F2L_DISPATCH(WHAT)                                                                              \
+    do {                                                                                                     \
+        if (M == 1) { if (stream_policy) { if (dbias) WHAT(1, true, true); else WHAT(1, true, false); }     \
+                      else { if (dbias) WHAT(1, false, true); else WHAT(1, false, false); } }               \
+        else if (M == 2) { if (stream_policy) { if (dbias) WHAT(2, true, true); else WHAT(2, true, false); } \
+                           else { if (dbias) WHAT(2, false, true); else WHAT(2, false, false); } }          \
+        else { if (stream_policy) { if (dbias) WHAT(4, true, true); else WHAT(4, true, false); }            \
+               else { if (dbias) WHAT(4, false, true); else WHAT(4, false, false); } }                      \
+    } while (0)
+#define PFPN_F2L_OCC(MM, SS, DD) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PFPN_F2L_KERNEL(MM, SS, DD), 256, 0)
+    PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
+#undef PFPN_F2L_OCC
+    int C = (per_cu * cu_count()) / nb;
+    if (wide_c_env() > 0 && wide_c_env() < C) C = wide_c_env();
+    if (C > 32) C = 32;
+    if (C >= 8) C &= ~7;
+    if (C > (B + 3) / 4) C = (B + 3) / 4;
+    if (C < 1) return PFPN_ERR_ARG;
+    if (chunks_out) *chunks_out = C;
+    const int AN = A * N;
+    const int PLn = dbias ? 3 : 2;
+    float* partial = (float*)workspace;
+    const size_t slab_floats = (size_t)C * PLn * AN;
+    const size_t sync_floats = (size_t)C * 2 * A * 4 + 2 * (size_t)C;
+    if ((slab_floats + sync_floats) * sizeof(float) > (size_t)((char*)tick - (char*)workspace)) return PFPN_ERR_WORKSPACE;
+    WideF2L sy{};
+    sy.part = partial + slab_floats;
+    sy.count = tick + WIDE_TICK_FWD;                         // [C][2] <= 64 words
+    sy.err = tick + WIDE_TICK_PPO + 1;
+    sy.logp = logp;
+    WidePpo p{};
+    p.logp_old = logp_old; p.adv = adv; p.value = value; p.value_old = value_old; p.stats = adv_stats;
+    p.clip_lo = 1.0f - clip_eps; p.clip_hi = 1.0f + clip_eps; p.value_coef = value_coef; p.inv_B = 1.0f / (float)B;
+    p.dlogp = dlogp; p.dvalue = dvalue; p.loss3 = loss3;
+    p.sums = sy.part + (size_t)C * 2 * A * 4;
+    if (hipMemsetAsync(tick, 0, (size_t)(WIDE_TICK_BWD + A) * sizeof(unsigned), st) != hipSuccess) return PFPN_ERR_LAUNCH;
+    const int blocks = C * nb;
+#define PFPN_F2L_LAUNCH(MM, SS, DD)                                                                          \
+    hipLaunchKernelGGL((PFPN_F2L_KERNEL(MM, SS, DD)), dim3(blocks), dim3(256), 0, st, logits, action, loc, logstd, B, A, N, C, \
+                       dlogits, partial, dloc, dlogstd, dbias, p, sy, tick)
+    PFPN_F2L_DISPATCH(PFPN_F2L_LAUNCH);
+#undef PFPN_F2L_LAUNCH
+#undef PFPN_F2L_DISPATCH
+#undef PFPN_F2L_KERNEL
+    PFPN_CHECK_LAUNCH();
+    return PFPN_OK;
 }
 
 static int logprob_bwd_impl(const float* logits, const float* x, const float* loc, const float* logstd,

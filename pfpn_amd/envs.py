@@ -62,7 +62,47 @@ class SyntheticDeepMimicEnv(object):
         pass
 
 
+class SyntheticReachEnv(object):
+    """A control problem with a KNOWN optimum and an immediate reward, for the learning tests (tests/test_gpu_learning.py):
+    DeepMimic's spaces (S = 197, A = 36), reward_t = exp(-(4 / A) |a_t - g(s_t)|^2) with the target g(s) = 0.5 tanh(s[:A]),
+    action-independent AR(1) state (s' = 0.9 s + sqrt(1 - 0.81) noise: unit stationary variance), 200-step episodes that end
+    by the time limit only.  Returns: optimum 200 (a = g(s)); the best state-blind policy (a = 0) ~ 134; uniform random
+    actions ~ 36.  Q(s, a) = reward(s, a) + a function of s alone, so an off-policy critic sees the action's effect in ONE
+    step -- unlike SyntheticDeepMimicEnv, whose reward answers an action only through the next states."""
+
+    def __init__(self, state_dim=197, action_dim=36, episode_length=200, seed=0):
+        self.observation_space = Box(-np.inf * np.ones(state_dim), np.inf * np.ones(state_dim))
+        self.action_space = Box(-np.ones(action_dim), np.ones(action_dim))
+        self.episode_length = episode_length
+        self.rng = np.random.RandomState(seed)
+        self.t = 0
+
+    def seed(self, s):
+        self.rng = np.random.RandomState(s)
+
+    def target(self, s):
+        return 0.5 * np.tanh(s[:self.action_space.shape[0]])
+
+    def reset(self):
+        self.t = 0
+        self.s = self.rng.randn(self.observation_space.shape[0]).astype(np.float32)
+        return self.s.copy()
+
+    def step(self, a):
+        self.t += 1
+        d = np.asarray(a, np.float32) - self.target(self.s)
+        reward = float(np.exp(-4.0 / d.shape[0] * np.square(d).sum()))
+        self.s = (0.9 * self.s + np.sqrt(1 - 0.81) * self.rng.randn(self.s.shape[0])).astype(np.float32)
+        timeout = self.t >= self.episode_length
+        return self.s.copy(), reward, timeout, ({"TimeLimit.truncated": True} if timeout else {})
+
+    def render(self):
+        pass
+
+
 def make_env(name, render=False, seed=0):
+    if str(name).startswith("SyntheticReach"):
+        return SyntheticReachEnv(seed=seed)
     try:
         import gym  # noqa: F401
         import envs  # noqa: F401  (the reference's PyBullet package, if on sys.path)

@@ -21,7 +21,9 @@ from . import kernels
 # deleting the graph first cures it).  So the graphs go first: `release_captured_collectives()`, called by
 # `models.distributed_model.shutdown_process_group()` and by bench.py before they destroy the group.
 _with_collectives = weakref.WeakSet()
-inject_capture_failure = False          # tests only: the next captured-exchange attempt fails (rehearses the fallback)
+# tests only: the next captured-exchange attempt fails INSIDE the capture region (rehearses the fall-back) -- True: on every
+# replica; an int r: only on the replica whose optimiser carries `rank_for_tests == r` (the others learn of it through the flag)
+inject_capture_failure = False
 
 
 def release_captured_collectives():
@@ -34,6 +36,24 @@ def release_captured_collectives():
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     return n
+
+
+def _capture_mode(force=False):
+    """keyword arguments of torch.cuda.graph(): thread-local error mode while a torch.distributed group lives in the process"""
+    try:
+        import torch.distributed as dist
+        alive = dist.is_available() and dist.is_initialized()
+    except Exception:
+        alive = False
+    return {"capture_error_mode": "thread_local"} if (force or alive) else {}
+
+
+def any_replica(flag, group=None, device="cpu"):
+    """logical OR of `flag` over the replicas of `group` (one all-reduce(MAX) every replica must reach)"""
+    import torch.distributed as dist
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
 
 
 def refill_noise(noise, generator):
@@ -116,15 +136,19 @@ class GraphedLearnerStep(object):
         if want:
             import torch.distributed as dist
             failed, why = 0, None
+            # The replicas agree on the fall-back through an all-reduce(MAX) of `failed` -- which pairs up only if every
+            # replica has issued the SAME collectives before it.  The warm-up runs real bucket all-reduces: it happens
+            # OUTSIDE the try (a replica that fails there aborts with its exception; it must not walk into the flag's
+            # all-reduce while the others are still summing buckets).  Only the capture region itself -- in which
+            # collectives are recorded, not executed -- may fail on one replica alone and fall back.
+            dist.all_reduce(torch.zeros(1, device=net.device), group=optimizer.pg)
+            torch.cuda.synchronize()
+            self._warm_up(True, exchanging, warmup, saved)
             try:
-                dist.all_reduce(torch.zeros(1, device=net.device), group=optimizer.pg)
-                torch.cuda.synchronize()
-                self._capture(True, exchanging, warmup, saved)
+                self._record(True)
             except Exception as e:                           # (a capture that RCCL / the runtime refuses)
                 failed, why = 1, repr(e)
-            flag = torch.tensor([failed], dtype=torch.int32, device=net.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=optimizer.pg)
-            if int(flag.item()):
+            if any_replica(failed, optimizer.pg, net.device):
                 if explicit_arg:
                     raise RuntimeError("capturing the exchange failed on a replica: %s" % (why or "on another replica"))
                 sys.stderr.write("pfpn_amd.graphs: the all-reduce could not be captured (%s): two graphs around an eager "
@@ -139,9 +163,11 @@ class GraphedLearnerStep(object):
             self._capture(False, exchanging, warmup, saved)
 
     def _capture(self, in_graph, exchanging, warmup, saved):
-        net, optimizer, gather_from = self.net, self.opt, self.gather_from
-        if in_graph and inject_capture_failure:
-            raise RuntimeError("injected capture failure")
+        self._warm_up(in_graph, exchanging, warmup, saved)
+        self._record(in_graph)
+
+    def _warm_up(self, in_graph, exchanging, warmup, saved):
+        net, optimizer = self.net, self.opt
         self.in_graph_exchange = bool(in_graph)
         self.split = exchanging and not in_graph
         # warm up on a side stream (lazy hipBLASLt/workspace init), then restore every piece of state
@@ -168,14 +194,22 @@ class GraphedLearnerStep(object):
         self.capture_stream = s
         for t, sv in zip(self._state_tensors(), saved):
             t.copy_(sv)
+
+    def _record(self, in_graph):
+        net, optimizer, gather_from, s = self.net, self.opt, self.gather_from, self.capture_stream
+        want_fail = inject_capture_failure
+        if in_graph and (want_fail is True or want_fail == getattr(optimizer, "rank_for_tests", None)):
+            raise RuntimeError("injected capture failure")
         self.graph = torch.cuda.CUDAGraph()
         if self.debug_nodes:
             self.graph.enable_debug_mode()
         self.graph_post = None
         if self.in_graph_exchange:
             _with_collectives.add(self)
-        # (thread-local capture mode with collectives inside: the process group's watchdog thread may query events meanwhile)
-        mode = {"capture_error_mode": "thread_local"} if self.in_graph_exchange else {}
+        # (thread-local capture mode whenever a process group is alive: its watchdog thread queries events at any time, and in
+        # the default -- global -- mode a query from ANOTHER thread invalidates this thread's capture: the "operation failed
+        # due to a previous error during capture" that one full-suite run in seven died of in round 4)
+        mode = _capture_mode(self.in_graph_exchange)
         with torch.cuda.graph(self.graph, stream=s, **mode):      # same stream as the warm-up: per-stream workspaces exist
             if gather_from is not None:
                 kernels.gather_columns(list(gather_from[0]), list(self.input_sets[0]), gather_from[1][0])
@@ -206,13 +240,21 @@ class GraphedLearnerStep(object):
                     gather_from[2][k].copy_(self.loss3)
         if self.split:
             self.graph_post = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_post, stream=s):
+            with torch.cuda.graph(self.graph_post, stream=s, **mode):
                 optimizer.post_reduce(net)
         # capture does not execute; state is untouched
-        # True: every captured step's optimiser launch took the noise rider, so only the FIRST replay needs a draw from outside
-        self.noise_in_graph = bool(self.noise is not None and getattr(net, "_noise_rode", False))
-        net._noise_rode = False
+        # True: EVERY captured step's optimiser launch took the noise rider, so only the FIRST replay needs a draw from outside.
+        # A K-step replay in which some step did not take it (the exchange path, no norm hook, > 4 Adam groups, a noise
+        # dict without a contiguous `_buf`: SyncReplicasApplier.apply_device drops the rider there) would run those steps
+        # on the PREVIOUS step's Gumbel / normal draws, silently: refused.
+        takers = int(getattr(net, "_noise_rode", 0)) if self.noise is not None else 0
+        net._noise_rode = 0
         self._noise_fresh = False
+        self.noise_in_graph = bool(self.noise is not None and takers == self.K)
+        if self.noise is not None and self.K > 1 and takers != self.K:
+            self.close()
+            raise RuntimeError("a %d-step capture drew its noise inside the graph in %d of its steps: this optimiser path does "
+                               "not carry the draw (steps_per_replay=1 refills the noise between replays)" % (self.K, takers))
 
     def ensure_noise(self):
         """the noise the NEXT replay will use is in `self.noise` after this call (drawn here unless the previous replay's
@@ -326,7 +368,7 @@ class GraphedRollout(object):
         for t, sv in zip(stats, saved):
             t.copy_(sv)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):
+        with torch.cuda.graph(self.graph, stream=s, **_capture_mode()):
             self.out = net.run_batch(self.states, noise=self.noise)
         self.policy = net.policy
 

@@ -156,7 +156,8 @@ _dlogp_bufs = {}
 
 
 def _dlogp_scratch(B, device):
-    key = (B, device.index)
+    # (per stream, like workspace(): two steps in flight on two streams must not share d loss / d logp)
+    key = (B, device.index, _stream())
     if key not in _dlogp_bufs:
         _dlogp_bufs[key] = torch.empty(B, dtype=torch.float32, device=device)
     return _dlogp_bufs[key]
@@ -526,11 +527,6 @@ def learner_workspace(rows, H, device):
     whose reductions are deferred to `reduce_jobs` each need their own."""
     lib = _lib.load()
     return torch.empty(int(max(lib.pfpn_learner_workspace_bytes(rows, H), 4096 * 4)), dtype=torch.uint8, device=device)
-
-
-def mixture_workspace(B, A, N, device):
-    lib = _lib.load()
-    return torch.empty(int(lib.pfpn_mixture_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
 
 
 def relu6_mask(rows, H, device):

@@ -438,7 +438,8 @@ class ActorCriticNetwork(object):
         if rider._key is not None:
             self._prologue_staged = rider._key
         if rider.noise:
-            self._noise_rode = True       # (SAC: the optimiser launch drew the next step's noise)
+            # (SAC: the optimiser launch drew the next step's noise; graphs.py requires one taker per captured step)
+            self._noise_rode = getattr(self, "_noise_rode", 0) + 1
 
     def update_state_normalizer(self, state):
         """UPDATE_OPS on the training minibatch (reference sync_model.py:123-138, utils.py:60-68), the launch-per-piece form

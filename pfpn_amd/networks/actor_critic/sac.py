@@ -68,6 +68,8 @@ def sac_network_wrapper(base_class):
             self.q_w3 = st["critic/q1+critic/q2|fc3/weight"]
             self.q_b3 = st["critic/q1+critic/q2|fc3/bias"]
             self.log_alpha = st["alpha/log_alpha"]
+            # the noise draws' counter exists from the start (a stepper's state snapshot lists it; checkpoint.restore resets it)
+            self.noise_epoch = torch.full((1,), int(self.global_step), dtype=torch.int64, device=self.device)
             if self.trainable:
                 # target net = own copies of the Q tensors only; actor + normaliser are shared (sac.py:141-153)
                 self.target_store = ParamStore(self.device)
@@ -248,10 +250,8 @@ def sac_network_wrapper(base_class):
         def _noise_counter(self):
             """the step's draw counter: an int64 device scalar the loss head advances by one per learner step and every
             noise draw reads when its launch RUNS -- so a captured draw (a rider of the optimiser launch, graphs.py) is
-            fresh on every replay.  It starts at the learner step count (a run resumed from a checkpoint does not replay
-            the draws of the run's beginning)."""
-            if getattr(self, "noise_epoch", None) is None:
-                self.noise_epoch = torch.full((1,), int(self.global_step), dtype=torch.int64, device=self.device)
+            fresh on every replay.  It starts at the learner step count and `checkpoint.restore` sets it to the restored
+            count (a run resumed from a checkpoint does not replay the draws of the run's beginning)."""
             return self.noise_epoch
 
         def _draw_train_noise(self, buf):

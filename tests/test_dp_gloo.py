@@ -100,6 +100,10 @@ def _rank_main(rank, world, port, q):
         # max_active is AVERAGED, not max-reduced (reference quirk, sync_model.py:85-87)
         mx = np.maximum(shards[0]["max_active"], shards[1]["max_active"]).reshape(-1)
         ok &= not np.allclose(net.max_active.numpy(), mx)
+        # the stepper's fall-back agreement (pfpn_amd/graphs.py): ONE replica whose capture failed takes every replica
+        # to the two-graph form; nobody failing leaves everybody where they are
+        from pfpn_amd.graphs import any_replica
+        ok &= any_replica(rank == world - 1) is True and any_replica(False) is False
         q.put((rank, bool(ok), float(net.store.bucket.sum())))
     except Exception as e:                 # report instead of leaving the parent waiting for its timeout
         import traceback

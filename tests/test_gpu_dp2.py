@@ -301,6 +301,19 @@ def _rccl_rank(port, q):
         fb = GraphedLearnerStep(fpair[0], fopt[0], *tin)
         graphs.inject_capture_failure = False
         ok &= fb.split and not fb.in_graph_exchange and "injected" in (fb.exchange_fallback or "")
+        # the injection can name ONE replica (round 5: the failure sits inside the capture region, behind the warm-up's real
+        # collectives, so that a replica failing alone still reaches the flag's all-reduce in step with the others): another
+        # replica's id leaves this one in the captured form, its own id makes it fall back
+        fopt[0].rank_for_tests = 0
+        graphs.inject_capture_failure = 1
+        other = GraphedLearnerStep(fpair[0], fopt[0], *tin)
+        ok &= other.in_graph_exchange and other.exchange_fallback is None
+        other.close()
+        graphs.inject_capture_failure = 0
+        mine = GraphedLearnerStep(fpair[0], fopt[0], *tin)
+        graphs.inject_capture_failure = False
+        ok &= mine.split and "injected" in (mine.exchange_fallback or "")
+        mine.close()
         for _ in range(2):
             fb()
             fpair[1].train_device(fopt[1], *tin)

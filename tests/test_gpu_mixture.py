@@ -137,6 +137,53 @@ def test_wide_kernel_config5_full_size_properties(oracle, dev):
     np.testing.assert_allclose(dl[rows].cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * np.abs(r_dl).max())
 
 
+def test_wide_ppo_composition_config5_full_size_vs_oracle(oracle, dev):
+    """Round 5: the N >= 64 learner composition -- [forward + clipped-PPO head in ONE launch] -> backward
+    (+ the head's bias plane) -- at BASELINE.json config 5's FULL shape, 8192 x 128 x 256 (1 GiB of logits), against the
+    oracle: log-prob and d loss / d value on EVERY row (oracle log-probs computed in 256-row chunks; reference
+    networks/utils.py:108-134), the loss sums against oracle.ppo_loss on those log-probs (networks/actor_critic/ppo.py:31-54,
+    actor_critic.py:132-184), d loss / d logp on every row, and the backward (utils.py autodiff) on 128 rows spread over the
+    batch with the oracle fed the oracle's own d loss / d logp."""
+    from _parity import away_from_clip
+    from pfpn_amd import kernels
+    B, A, N = 8192, 128, 256
+    logits, x, loc, logstd, _ = _config5_inputs(dev, B, seed=8)
+    loc_h, ls_h, x_h = loc.cpu().numpy(), logstd.cpu().numpy(), x.cpu().numpy()
+    ref_lp = np.concatenate([oracle.mixture_log_prob(logits[i:i + 256].cpu().numpy(), x_h[i:i + 256], loc_h, ls_h)[0]
+                             for i in range(0, B, 256)])
+    assert np.isfinite(ref_lp).all()
+    rng = np.random.default_rng(85)
+    lp_old = away_from_clip(ref_lp, (ref_lp + rng.normal(0, 0.15, B)).astype(np.float32))
+    adv, v, v_old = (rng.normal(0, 1, B).astype(np.float32) for _ in range(3))
+    loss, pl, vl, r_dlogp, r_dv = oracle.ppo_loss(ref_lp, lp_old, adv, v, v_old, 0.2, 0.5, normalize_adv=True)
+    d = to_dev(dev, lp_old, adv, v, v_old)
+    stats = kernels.adv_stats(d[1])
+    lg2, dl2 = logits.view(B, A * N), torch.empty(B, A * N, device=dev)
+    out = {"logp": torch.empty(B, device=dev), "dlogits": dl2, "dloc": torch.empty(A, N, device=dev),
+           "dlogstd": torch.empty(A, N, device=dev), "dvalue": torch.empty(B, device=dev), "loss3": torch.empty(3, device=dev)}
+    dbias = torch.empty(A * N, device=dev)
+    kernels.ppo_mixture_fwd_bwd(lg2, x, loc, logstd, d[0], d[1], d[2], d[3], stats, 0.2, 0.5, out=out, dbias=dbias)
+    np.testing.assert_allclose(out["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=0)              # every row, pure rtol
+    np.testing.assert_allclose(out["loss3"].cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["dvalue"].cpu().numpy(), r_dv, rtol=1e-5, atol=1e-10)
+    got_dlogp = kernels._dlogp_scratch(B, dev).cpu().numpy()
+    # d loss / d logp = -(A_norm / B) * ratio on the rows whose surrogate passes: the ratio carries the log-prob's 1e-5
+    np.testing.assert_allclose(got_dlogp, r_dlogp, rtol=2e-3, atol=1e-9)
+    assert np.array_equal(got_dlogp != 0, r_dlogp != 0)                                           # same clip decisions
+    rows = torch.arange(0, B, 64, device=dev)
+    h = [logits[rows].cpu().numpy(), x_h[::64], loc_h, ls_h, r_dlogp[::64]]
+    r_dl = oracle.mixture_log_prob_bwd(*h)[0]
+    got = out["dlogits"].view(B, A, N)[rows].cpu().numpy()
+    np.testing.assert_allclose(got, r_dl, rtol=2e-3, atol=3e-6 * np.abs(r_dl).max())
+    # ... and with the kernel's own d loss / d logp (so that only the backward's arithmetic is in the comparison)
+    r_dl2 = oracle.mixture_log_prob_bwd(h[0], h[1], h[2], h[3], got_dlogp[::64])[0]
+    np.testing.assert_allclose(got, r_dl2, rtol=1e-4, atol=3e-6 * np.abs(r_dl2).max())
+    # the sums over the batch: column sums of dlogits == dbias (float64 on the device), softmax Jacobian rows sum to zero
+    cs = out["dlogits"].double().sum(0)
+    assert (dbias.double() - cs).abs().max().item() <= 1e-4 * cs.abs().max().item()
+    assert bool(torch.isfinite(out["dloc"]).all()) and bool(torch.isfinite(out["dlogstd"]).all())
+
+
 @pytest.mark.parametrize("B,A,N", [(1030, 8, 128), (77, 12, 256), (4099, 4, 512), (517, 128, 256), (9, 16, 64)])
 def test_wide_in_launch_handoffs(oracle, dev, B, A, N):
     """Round 4: the wide kernels finish their own reductions (no k_row_sum / k_finalize launch).  Forward: a block's four

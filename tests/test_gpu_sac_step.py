@@ -182,6 +182,44 @@ def test_sac_multi_step_replay_draws_its_noise_inside_the_graph(dev):
         assert nets[0].global_step == nets[1].global_step == K * (rep + 1)
 
 
+def test_sac_multi_step_capture_without_the_noise_rider_is_refused(dev, tmp_path):
+    """Round 5: the draw for step k + 1 rides in step k's optimiser launch ONLY on the fused one-replica path with
+    the norm hook.  Where the optimiser drops the rider (here: `fused_norm=False`, no hook) a K-step replay would run K steps
+    on ONE set of Gumbel / normal draws: the stepper counts the takers and refuses; a one-step stepper (noise refilled between
+    replays) is fine.  Also: `noise_epoch` exists from construction and a restored checkpoint sets it to the restored step."""
+    from pfpn_amd import checkpoint as ck
+    from pfpn_amd.graphs import GraphedLearnerStep
+    from pfpn_amd.models import SyncReplicasApplier
+    rng = np.random.default_rng(6)
+    B, K = 64, 2
+    net = make_net(dev)
+    assert int(net.noise_epoch.item()) == 0
+    opt = SyncReplicasApplier(net, [{"names": net.critic_param_names(), "lr": 1e-4},
+                                    {"names": net.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1,
+                              fused_norm=False)
+    sets = [[torch.from_numpy(a).to(dev) for a in ((rng.normal(0, 1, (B, 197)) * 2).astype(F),
+                                                   rng.uniform(-0.9, 0.9, (B, 36)).astype(F),
+                                                   rng.normal(0.5, 0.3, B).astype(F),
+                                                   (rng.uniform(size=B) > 0.05).astype(F),
+                                                   (rng.normal(0, 1, (B, 197)) * 2).astype(F))] for _ in range(K)]
+    flat0 = net.store.flat.clone()
+    with pytest.raises(RuntimeError, match="drew its noise inside the graph in 0 of its steps"):
+        GraphedLearnerStep(net, opt, steps_per_replay=K, input_sets=sets, noise=net.make_train_noise(B))
+    assert torch.equal(net.store.flat, flat0) and net.global_step == 0       # the refused capture left the state alone
+    one = GraphedLearnerStep(net, opt, *sets[0], noise=net.make_train_noise(B))
+    assert not one.noise_in_graph
+    one(); one()
+    assert net.global_step == 2 and int(net.noise_epoch.item()) == 2
+    prefix = str(tmp_path / "model.ckpt-2")
+    ck.save(prefix, net, opt)
+    net2 = make_net(dev)
+    opt2 = SyncReplicasApplier(net2, [{"names": net2.critic_param_names(), "lr": 1e-4},
+                                      {"names": net2.actor_param_names(), "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    net2.make_train_noise(B)                                  # a draw BEFORE the restore must not pin the counter at 0
+    ck.restore(prefix, net2, opt2)
+    assert net2.global_step == 2 and int(net2.noise_epoch.item()) == 2
+
+
 @pytest.mark.parametrize("B", [64, 1024])
 def test_sac_deferred_reduce_step_matches_immediate_step(dev, monkeypatch, B):
     """SAC step with both Q heads folded into the trunk epilogues and ONE deferred reduction launch == the step that
