@@ -180,7 +180,9 @@ def digest(out):
     """<= 600 bytes: the figures the review reads first"""
     d = {"stress_fwd": _dig(out, "roofline_stress", "fwd", "frac"), "stress_bwd": _dig(out, "roofline_stress", "bwd", "frac"),
          "stress_ppo": _dig(out, "roofline_stress", "ppo", "frac"),
-         "stress_ppo_2l": _dig(out, "roofline_stress", "ppo_2l", "frac"),
+         "stress_ppo_on_3l_bytes": _dig(out, "roofline_stress", "ppo", "frac_on_3l_bytes"),
+         "stress_ppo_3l_form": _dig(out, "roofline_stress", "ppo_3l", "frac"),
+         "stress_ppo_us": _dig(out, "roofline_stress", "ppo", "us_per_launch"),
          "tile_frac": _dig(out, "roofline", "frac"), "tile_frac_events": _dig(out, "roofline", "frac_events"),
          "sac_ms_1024": _dig(out, "sac_step", "ms_per_step"), "sac_ms_256": _dig(out, "sac_step", "batch_256", "ms_per_step"),
          "config5_ms": _dig(out, "config5_step", "ms_per_step"), "value_200": _dig(out, "value_200"),
@@ -849,19 +851,37 @@ def main():
 
             def ppo_composed():
                 kernels.ppo_mixture_fwd_bwd(sl, sx, sloc, sls, s_lp_old, sg, s_v, s_v, s_stats, out=s_out)
-            ppo_composed(); ppo_composed()
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(10):
-                ppo_composed()
-            e1.record()
-            torch.cuda.synchronize()
-            u = e0.elapsed_time(e1) * 1e3 / 10
-            nb = 3 * L_ + 2 * X_ + 8 * V_ + 3 * P_
-            res["ppo"] = {"kernel": "k_mix_wide<FWD + PPO head> + k_mix_wide<BWD> (two launches, results in the caller's buffers)",
-                          "us_per_launch": u, "algorithmic_bytes": nb, "achieved": nb / u / 1e3, "unit": "GB/s",
-                          "peak": HBM_PEAK_GBS, "frac": nb / u / 1e3 / HBM_PEAK_GBS,
-                          "note": "3L composition; a fused 2L pass needs a row (128 KiB) AND the [A,N] bank (393 KB) on one CU"}
+
+            def time_ppo():
+                ppo_composed(); ppo_composed()
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    ppo_composed()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / 10
+            nb3, nb2 = 3 * L_ + 2 * X_ + 8 * V_ + 3 * P_, 2 * L_ + X_ + 6 * V_ + 2 * P_
+            fused_default = kernels.WIDE_FUSED
+            # the two-launch composition (3L: the backward reads the logits again) ...
+            kernels.WIDE_FUSED = False
+            u3 = time_ppo()
+            res["ppo_3l"] = {"kernel": "k_mix_wide<FWD + PPO head> + k_mix_wide<BWD> (two launches, results in the caller's buffers)",
+                             "us_per_launch": u3, "algorithmic_bytes": nb3, "achieved": nb3 / u3 / 1e3, "unit": "GB/s",
+                             "peak": HBM_PEAK_GBS, "frac": nb3 / u3 / 1e3 / HBM_PEAK_GBS}
+            # ... and what the learner composition runs (round 5): ONE launch, the logits read once (2L), the waves of a row
+            # chunk exchanging their per-dimension log p through the XCD's L2 once per four rows
+            kernels.WIDE_FUSED = fused_default
+            if fused_default:
+                u2 = time_ppo()
+                res["ppo"] = {"kernel": "k_mix_wide_f2l (forward + PPO head + backward in one launch, logits read once)",
+                              "us_per_launch": u2, "algorithmic_bytes": nb2, "achieved": nb2 / u2 / 1e3, "unit": "GB/s",
+                              "peak": HBM_PEAK_GBS, "frac": nb2 / u2 / 1e3 / HBM_PEAK_GBS,
+                              "frac_on_3l_bytes": nb3 / u2 / 1e3 / HBM_PEAK_GBS, "speedup_vs_3l_form": u3 / u2,
+                              "note": "frac: on its own (2L) algorithmic bytes; frac_on_3l_bytes: the bytes of the two-launch "
+                                      "form it replaces over this launch's time"}
+            else:
+                res["ppo"] = dict(res["ppo_3l"])
             del s_out
             # this box's roof for the two access patterns, in the same run, from the build's OWN streaming kernels
             # (pfpn_stream_copy: float4 grid-stride; the few launch shapes that won tools/copy_probe.py's sweep, best taken):
@@ -898,12 +918,12 @@ def main():
             res["device_read"] = dict(best_of(lambda u_, nt_, bl_: (lambda: kernels.stream_copy(sinks[bl_], sl, 0, nt_, bl_)),
                                               [(0, 1, 2048), (0, 1, 8192), (0, 1, 32768), (0, 0, 8192)], L_),
                                       kernel="pfpn_stream_copy, read-only (own float4 grid-stride sum of the same logits: read L)")
-            for k_, ref_ in (("fwd", "device_read"), ("bwd", "device_copy"), ("ppo", "device_copy")):
+            for k_, ref_ in (("fwd", "device_read"), ("bwd", "device_copy"), ("ppo", "device_copy"), ("ppo_3l", "device_copy")):
                 res[k_]["frac_of_box_copy"] = res[k_]["achieved"] / res[ref_]["achieved"]
                 res[k_]["box_copy"] = ref_
             res["note"] = ("frac: of the 8 TB/s spec; frac_of_box_copy: of what this box's memory system moves for the same "
                            "access pattern with NO arithmetic (device_read for the forward, device_copy for the backward and "
-                           "the 3L composition).  fwd is bound by its arithmetic -- two v_exp_f32 per particle: with the rows "
+                           "the PPO passes).  fwd is bound by its arithmetic -- two v_exp_f32 per particle: with the rows "
                            "already in LDS (LDS-DMA ring, tools/bw_probe8.hip) the same math takes ~203 us")
             out["roofline_stress"] = {"shape": [sB, sA, sN], "bound": "hbm", **res}
             del sl, sx, sg

@@ -31,7 +31,8 @@
  *    than pfpn_*_workspace_bytes() asks for is refused with PFPN_ERR_WORKSPACE (or, where a launch-per-piece form needs
  *    less, served by that form).
  *  - The exceptions are documented at their prototypes: pfpn_debug_stamps() and pfpn_sac_noise_fill()'s draw counter
- *    are explicit caller-owned device state; environment knobs (PFPN_WIDE_C, PFPN_WIDE_STREAM) are read once.
+ *    are explicit caller-owned device state; pfpn_ppo_wide_fused() needs the device to itself while it runs (grid-wide
+ *    co-residency); environment knobs (PFPN_WIDE_C, PFPN_WIDE_STREAM) are read once, PFPN_WIDE_F2L_SAFE (tests) at every call.
  */
 #ifndef PFPN_HIP_H_
 #define PFPN_HIP_H_
@@ -75,12 +76,17 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
                          float* logp, float* dlogp, float* dvalue, float* loss3,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* EXPERIMENTAL (round 5 probe; tools/f2l_probe.py): pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias) of an N = 256 / 512 / 1024
- * particle grid as ONE launch that reads the logits once (reference networks/utils.py:108-134 + its autodiff, ppo.py:31-54): the
- * A waves of a row chunk exchange their per-dimension log p through memory once per four rows.  All of the chunk's waves must be
- * resident together: the entry point sizes the grid to the device (*chunks_out, optional, receives the chunk count) and every
- * in-kernel wait is bounded (on expiry word WIDE_TICK_PPO + 1 of the workspace's ticket area is set: results invalid).
- * dbias optional (NULL: no bias plane).  PFPN_ERR_ARG for shapes outside the form. */
+/* pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias) of a 256-particle grid (N == 256, A % 4 == 0, A <= 128, a batch of at least 8
+ * row chunks of 4 rows) as ONE launch that reads the logits once and writes dlogits once (reference networks/utils.py:108-134 +
+ * its autodiff, ppo.py:31-54, actor_critic.py:132-184): the waves of a row chunk exchange their per-dimension log p through
+ * memory once per four rows (k_mix_wide_f2l; 448 us against 598 us for 8192 x 128 x 256).  Same outputs as the two entry points
+ * (+ dlogp [B] = d loss / d logp); sums in a fixed order: bitwise reproducible run to run, equal to the two-launch composition to
+ * summation order.  dbias optional (NULL: no bias plane).  *chunks_out (optional) receives the chunk count.
+ * CONCURRENCY: the launch's waves wait for each other, so its whole grid must be resident at once: the entry point sizes the
+ * grid to the device's occupancy, and NOTHING else may occupy the device while it runs (not a second call on another stream,
+ * not another kernel).  Every in-kernel wait is bounded (~0.2 s): on expiry the gradients come out NaN and word 65 of the
+ * workspace's ticket area is set -- a loud failure, not a hang.  PFPN_ERR_ARG for shapes outside the form (compose the two
+ * entry points). */
 int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* loc, const float* logstd,
                         const float* logp_old, const float* adv, const float* value, const float* value_old,
                         const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,

@@ -1395,56 +1395,46 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 }
 
 // =====================================================================================================================
-// EXPERIMENTAL (round 5 probe, tools/f2l_probe.py): the clipped-PPO learner pass of the wide shapes as ONE launch that reads
-// the logits once and writes dlogits once (2L instead of the 3L of [forward + head] -> backward).
-// The obstacle is the row sum: log p of a row = the sum over its A action dims, and the wide kernels give every action dim
-// to its own wave (bank + gradient accumulators of ONE dim in registers while it walks the rows) -- A = 128 waves on 32
-// blocks.  Here the A waves of a row chunk MEET once per group of four rows, through memory: a wave publishes its four
-// per-dim log p (write-through, `sc1`), takes a ticket on the chunk's arrival counter, and -- one group later -- finds the
-// counter complete, adds the A partials in a fixed order, runs the PPO head on the four row totals (every wave redundantly:
-// uniform scalar work) and finishes the backward of THAT group from the e / e*phi / z it kept in registers.  The pipeline is
-// two groups deep (forward of group k, then backward of group k - 1) so that a group's exchange has a whole iteration to
-// complete; the next-but-one group's loads are in flight meanwhile.  The waves of a chunk must be co-resident (they wait for
-// each other): the host sizes C so that the whole grid is resident at once; every wait is bounded and raises `err`.
-// Ordering of a publish: payload `sc1` store -> s_waitcnt vmcnt(0) -> relaxed agent-scope add; of a read: relaxed agent-scope
-// load of the counter >= target -> `sc1` loads of the payload (the protocol of the hand-off above).
+// The clipped-PPO learner pass of the 256-particle shapes as ONE launch that reads the logits once and writes dlogits once
+// (2L; round 5).  The composition [forward + PPO head] -> backward reads the logits twice (3L): 598 us for 8192 x 128 x 256;
+// this kernel: 448 us (tools/f2l_probe.py, profiles/r05_wide_2l_probe.txt).
+//
+// The obstacle is the row sum: log p of a row = the sum over its A action dims, and the wide kernels give every action dim to
+// its own wave (bank + gradient accumulators of ONE dim in registers while it walks the rows): A = 128 waves on 32 blocks.  Here
+// the waves of a row chunk MEET once per group of four rows, through memory, without atomics and without fences:
+//   * a block's four waves add their per-dim log p in LDS (fixed order); wave 0 publishes ONE 32-byte entry per block -- two
+//     16-byte stores {l0, l1, tag, 0 | l2, l3, tag, 0}, tag = the group's sequence number.  A half is valid exactly when its
+//     own tag says so: no ordering between stores is needed (16-byte stores are observed untorn on gfx950);
+//   * every wave sweeps the chunk's A / 4 entries (1 KiB at A = 128) with `sc1` loads (they bypass the CU's L1), finds every
+//     tag equal to the sequence it waits for (else polls again, bounded), adds the partials in a fixed order, runs the PPO head
+//     on the four row totals (redundantly: uniform scalar work) and finishes the backward of THAT group from the e / e*phi it
+//     kept in registers;
+//   * two groups are in flight per wave: forward of group k, then the backward of group k - 1 with the poll issued at the end
+//     of iteration k - 1 (compiler-visible raw buffer loads: waited for with a counted vmcnt exactly where first used, behind
+//     the forward math).  Four slots per (chunk, block), group g in slot g % 4: a wave that writes group k has passed its wait
+//     for group k - 1, so every wave of the chunk has published k - 1, i.e. finished reading k - 2 -- and k - 4.
+// Where the exchange lives decides everything (measured, same kernel): write-through stores + memory-side loads -- correct
+// under any placement -- 704-850 us (every wave of a chunk re-reads the chunk's partials from the memory side once per group:
+// 1 GiB of loads on a few hot lines; a tagged hand-off costs ~3 us under streaming load, MI355X_MICROARCH.md row
+// handoff-1to1); the same with atomics on one arrival counter per chunk: 6.8 ms (128 arrivals serialise).  Plain stores + `sc1`
+// loads keep the exchange INSIDE the chunk's XCD (the stores stay in that XCD's L2, which serves the loads): 448 us.  That
+// needs all waves of a chunk on one XCD.  Blocks are dealt to the XCDs round-robin (observed, not promised), so a chunk takes
+// the blocks of one blockIdx % 8 class -- and the kernel CHECKS: before the first group every block publishes its XCC id the
+// safe way (`sc1` store, memory-side); a chunk whose blocks do not all report the same id runs the safe exchange (slow,
+// correct) instead.
+// The waves of a chunk wait for each other, so the whole grid must be resident at once: the host sizes C to the occupancy
+// query and nothing else may occupy the device meanwhile (the package launches on one stream).  Every wait is bounded; a
+// wave whose wait expired poisons its gradient slab with NaN (the step's global norm goes NaN: loud, not silent) and sets `err`.
 struct WideF2L {
-    float* part;        // [C][2][A][4]: log p of (chunk, group parity, action dim) for the group's four rows
-    unsigned* count;    // [C][2] arrivals, monotonic per parity (zeroed in front of the launch)
+    float* part;        // [C][4 slots][A / 4][8]: the blocks' tagged partial sums (zeroed in front of the launch)
+    unsigned* xccs;     // [C][A / 4]: 0x80000000 | XCC id of every block (zeroed in front of the launch)
     unsigned* err;      // [1]
     float* logp;        // [B] out
+    int force_safe;     // tests: run the memory-side exchange whatever the placement
 };
 
-__device__ __forceinline__ bool f2l_wait(const unsigned* cnt, unsigned target, unsigned* err) {
-    int it = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++it > (1 << 20)) {                              // ~1 s: the grid was not co-resident (or a wave died)
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-    return true;
-}
-// four `sc1` loads (entries past `n` re-read entry n - 1: ignored by the caller) and the wait for EVERYTHING outstanding, as
-// one asm statement (see ld4x8_sc1)
-__device__ __forceinline__ void ld4x4_sc1_drain(const float* p, size_t stride, int n, f4v (&v)[4]) {
-    const float* q[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] = p + (size_t)min(i, n - 1) * stride;
-    asm volatile(
-        "global_load_dwordx4 %0, %4, off sc1\n\t"
-        "global_load_dwordx4 %1, %5, off sc1\n\t"
-        "global_load_dwordx4 %2, %6, off sc1\n\t"
-        "global_load_dwordx4 %3, %7, off sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-        : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3])
-        : "memory");
-}
-
 template <int M, bool STREAM, bool DBIAS>
-__global__ __launch_bounds__(256) void k_mix_wide_f2l(
+__global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per SIMD: the whole grid resident at C = 16)
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
     int B, int A, int N, int C,
@@ -1456,15 +1446,33 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
     constexpr int U = 4;
     constexpr int PL = DBIAS ? 3 : 2;
     const int lane = threadIdx.x & 63;
-    const int nb = A >> 2;                                   // blocks per row chunk (A % 4 == 0)
-    // chunk <-> XCD: blocks are dealt to the 8 XCDs round-robin; the blocks of one chunk all carry the same blockIdx % 8, so a
-    // chunk's exchange stays among the CUs of one XCD where the chunk count allows (C % 8 == 0)
-    int c, jb;
-    if ((C & 7) == 0) { const int i = blockIdx.x >> 3; c = (blockIdx.x & 7) + 8 * (i / nb); jb = i % nb; }
-    else { c = blockIdx.x / nb; jb = blockIdx.x % nb; }
-    c = __builtin_amdgcn_readfirstlane(c);
-    const int a = __builtin_amdgcn_readfirstlane(4 * jb + (int)(threadIdx.x >> 6));
+    const int wv = threadIdx.x >> 6;
+    const int nb = A >> 2;                                   // blocks per row chunk (A % 4 == 0, nb <= 32)
+    // chunk <-> XCD: the blocks of one chunk all carry the same blockIdx % 8 (C % 8 == 0: the host's choice)
+    const int bi = blockIdx.x >> 3;
+    const int c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) + 8 * (bi / nb));
+    const int jb = bi % nb;
+    const int a = __builtin_amdgcn_readfirstlane(4 * jb + wv);
     const int AN = A * N;
+    const bool has0 = lane < nb;                             // lane l sweeps block entry l of its chunk
+    const int d0 = min(lane, nb - 1);
+    bool alive = true;
+    // ---- placement check: one safe (memory-side) exchange of the blocks' XCC ids ----
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(6164) & 15u;           // HW_REG_XCC_ID[3:0]
+    bool local = true;
+    {
+        unsigned* mine = sy.xccs + (size_t)c * nb;
+        if (wv == 0 && lane == 0) __hip_atomic_store(mine + jb, 0x80000000u | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int it = 0;
+        unsigned seen = 0;
+        while (true) {
+            seen = __hip_atomic_load(mine + d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(!has0 || (seen >> 31)) || !alive) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++it > (1 << 18)) { alive = false; __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        local = __all(!has0 || ((seen & 15u) == xcc)) && !sy.force_safe;
+    }
     v2f b_loc2[M][2], b_isc2[M][2], b_ct2[M][2];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -1490,10 +1498,16 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
     const int Rc = (B - c + C - 1) / C;                      // rows of chunk c
     const int G = (Rc + U - 1) / U;                          // its groups of four rows
     float ps = 0.f, vs = 0.f;                                // loss sums of this chunk's rows (kept by its wave a == 0)
-    bool alive = true;
 
-    struct St { v2f e[U][M][2], ef[U][M][2], zq[U][M][2]; float p[U], inv_sum[U]; };
-    struct Ld { float4 l[U][M]; float x[U]; };
+    // what a group's backward needs from its forward (z is recomputed from x and the bank: two packed ops per pair)
+    struct St { v2f e[U][M][2], ef[U][M][2]; float x[U], p[U], inv_sum[U]; float head; };
+    // a group's inputs: the logits quads, x, and the PPO head's four row scalars (adv, logp_old, value, value_old) of its four
+    // rows as ONE lane-distributed load (lane 4u + i holds input i of row u; read back with v_readlane) -- loaded with the
+    // prefetch, so that the head never issues a dependent load of its own (a first version did, and drained vmcnt(0) four
+    // times per group)
+    struct Ld { float4 l[U][M]; float x[U]; float head; };
+    const float* const head_src = (lane & 3) == 0 ? ppo.adv : (lane & 3) == 1 ? ppo.logp_old : (lane & 3) == 2 ? ppo.value
+                                                                                                              : ppo.value_old;
     auto load = [&](int g, Ld& d) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1503,8 +1517,9 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
             for (int j = 0; j < M; ++j) d.l[u][j] = ld4_stream<STREAM>(row_ + 4 * (lane + 64 * j));
             d.x[u] = x[(size_t)b_ * A + a];
         }
+        d.head = head_src[min(c + (U * g + ((lane >> 2) & 3)) * C, B - 1)];
     };
-    // forward of one group: e, e*phi, z kept; -> the group's four per-dim log p
+    // forward of one group: e, e*phi kept; -> the group's four per-dim log p
     auto fwd = [&](const Ld& d, St& s, float (&lpr)[U]) {
         float mx[U];
         v2f lp[U][M][2];
@@ -1531,7 +1546,6 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
                     const v2f le = lp[u][j][h] - mx[u];
                     const v2f z = (d.x[u] - b_loc2[j][h]) * b_isc2[j][h];
                     const v2f arg = le + __builtin_elementwise_fma(-z, z, b_ct2[j][h]);
-                    s.zq[u][j][h] = z;
                     s.e[u][j][h] = (v2f){__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
                     s.ef[u][j][h] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
                     if (j == 0 && h == 0) { s2 = s.e[u][j][h]; n2 = s.ef[u][j][h]; }
@@ -1550,30 +1564,64 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
             if (p < 1.401298464324817e-45f) p = 0.f;
             s.p[u] = p;
             lpr[u] = __builtin_amdgcn_logf(p) * 0.6931471805599453f;
+            s.x[u] = d.x[u];
         }
+        s.head = d.head;
     };
-    auto publish = [&](int g, const float (&lpr)[U]) {
-        float* slot = sy.part + (((size_t)c * 2 + (g & 1)) * A + a) * 4;
-        if (lane == 0) st4_sc1(slot, lpr[0], lpr[1], lpr[2], lpr[3]);
+    // the exchange's stores and first-attempt loads are raw BUFFER accesses with the cache policy as an argument (16 = sc1):
+    // visible to hipcc's waitcnt pass, so a poll issued at the end of one iteration is waited for exactly where its values
+    // are first used -- behind the next group's forward math -- with a counted vmcnt, not a drain
+    auto slot_rsrc = [&](int g) {
+        // (the base through v_readfirstlane: a descriptor hipcc cannot prove wave-uniform costs a waterfall loop per access)
+        const uintptr_t q = (uintptr_t)(sy.part + ((size_t)c * 4 + (g & 3)) * nb * 8);
+        const uintptr_t qu = ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) |
+                             (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
+        return __builtin_amdgcn_make_buffer_rsrc((float*)qu, 0, nb * 32, 0x00020000);
     };
-    auto ticket = [&](int g) {
-        if (lane == 0) __hip_atomic_fetch_add(&sy.count[c * 2 + (g & 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // the group's four row totals (every lane: the same bits) -- wait for the chunk's A arrivals, add the A partials in a
-    // fixed order: lane l takes dims l, l + 64, ... in turn, then the transposing butterfly
-    auto totals = [&](int g, float (&tot)[U]) {
-        if (alive) alive = f2l_wait(&sy.count[c * 2 + (g & 1)], (unsigned)((g >> 1) + 1) * (unsigned)A, sy.err);
-        const float* base = sy.part + ((size_t)c * 2 + (g & 1)) * A * 4;
-        f4v acc = {0.f, 0.f, 0.f, 0.f};
-        for (int a0 = 0; a0 < A; a0 += 256) {
-            f4v v[4];
-            const int n = min(4, (A - a0 - lane + 63) / 64);             // dims a0 + lane + 64 i < A
-            ld4x4_sc1_drain(base + (size_t)(a0 + min(lane, max(A - a0 - 1, 0))) * 4, (size_t)64 * 4, max(n, 1), v);
+    __shared__ float s_blk[2][4][U];
+    auto publish = [&](int g, const float (&lpr)[U], bool real) {
+        if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < n) acc += v[i];
+            for (int u = 0; u < U; ++u) s_blk[g & 1][wv][u] = lpr[u];
         }
-        tot[0] = acc.x; tot[1] = acc.y; tot[2] = acc.z; tot[3] = acc.w;
+        __syncthreads();                                     // (one per group; buffer g & 1 is rewritten two barriers later)
+        if (real && wv == 0 && lane == 0) {
+            float t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = ((s_blk[g & 1][0][u] + s_blk[g & 1][1][u]) + s_blk[g & 1][2][u]) + s_blk[g & 1][3][u];
+            const float tag = __uint_as_float((unsigned)g + 1u);
+            const __amdgpu_buffer_rsrc_t r = slot_rsrc(g);
+            const u4v h0 = __builtin_bit_cast(u4v, (f4v){t[0], t[1], tag, 0.f}), h1 = __builtin_bit_cast(u4v, (f4v){t[2], t[3], tag, 0.f});
+            if (local) {                                     // the line stays in this XCD's L2, which serves the readers
+                __builtin_amdgcn_raw_buffer_store_b128(h0, r, jb * 32, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(h1, r, jb * 32 + 16, 0, 0);
+            } else {                                         // write-through: readers on other XCDs find it on the memory side
+                __builtin_amdgcn_raw_buffer_store_b128(h0, r, jb * 32, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(h1, r, jb * 32 + 16, 0, 16);
+            }
+        }
+    };
+    auto poll_issue = [&](int g, f4v (&v)[2]) {
+        const __amdgpu_buffer_rsrc_t r = slot_rsrc(g);
+        v[0] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, d0 * 32, 0, 16));
+        v[1] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, d0 * 32 + 16, 0, 16));
+    };
+    // the group's four row totals (every lane: the same bits) from a poll's values: every entry must carry the group's tag
+    // (else: poll again, bounded); the nb partials meet in the transposing butterfly (fixed order)
+    auto totals = [&](int g, f4v (&v)[2], float (&tot)[U]) {
+        const unsigned want = (unsigned)g + 1u;
+        int it = 0;
+        while (true) {
+            const bool good = !has0 || (__float_as_uint(v[0].z) == want && __float_as_uint(v[1].z) == want);
+            if (__all(good) || !alive) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++it > (1 << 18)) {                          // the grid was not co-resident (or a wave died): flagged, poisoned
+                alive = false;
+                __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            poll_issue(g, v);
+        }
+        tot[0] = has0 ? v[0].x : 0.f; tot[1] = has0 ? v[0].y : 0.f; tot[2] = has0 ? v[1].x : 0.f; tot[3] = has0 ? v[1].y : 0.f;
         wave_reduce4<false>(tot[0], tot[1], tot[2], tot[3], lane);
     };
     // PPO head on a group's four rows (k_ppo_loss, term for term) + the backward of the group
@@ -1583,14 +1631,17 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
             const int b = c + (U * g + u) * C;
             const bool live = b < B;
             const int bb = live ? b : B - 1;
-            const float av = ppo.adv[bb];
+            const float av = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u));
+            const float h_lpo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u + 1));
+            const float h_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u + 2));
+            const float h_vo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u + 3));
             const float nadv = clip_adv((av - hm) * hr, hlo, hhi);
-            const float ratio = expf(tot[u] - ppo.logp_old[bb]);
+            const float ratio = expf(tot[u] - h_lpo);
             const float sur = ratio * nadv;
             const float csur = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo) * nadv;
             const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
             const float gdl = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-            const float dvv = ppo.value[bb] - (av + ppo.value_old[bb]);
+            const float dvv = h_v - (av + h_vo);
             if (a == 0 && live) {
                 ps += fminf(sur, csur);
                 vs += dvv * dvv;
@@ -1611,7 +1662,7 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const v2f tt = s.ef[u][j][h] * qs64;
-                    const v2f z = s.zq[u][j][h];
+                    const v2f z = (s.x[u] - b_loc2[j][h]) * b_isc2[j][h];
                     d[h] = __builtin_elementwise_fma(-s.e[u][j][h], (v2f){qp, qp}, tt);
                     if (DBIAS) acc_b2[j][h] += d[h];
                     acc_loc2[j][h] = __builtin_elementwise_fma(tt, z, acc_loc2[j][h]);
@@ -1623,24 +1674,32 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
         }
     };
 
+    // Two groups in flight: in iteration k the forward of group k, the totals of group k - 1 from the poll issued at the end of
+    // iteration k - 1, the next-but-one group's loads, the backward of group k - 1, the poll for group k.  (Three groups in
+    // flight: 496 us; the logits of two groups ahead: 455 us; this: 448 us.)  The forward runs unconditionally -- a guarded
+    // forward makes every register of its state a select -- and iteration G only finishes group G - 1.
     Ld ln, lf;
-    St sc, sp;
-    float lpr[U], tot[U];
+    St S0, S1;
+    f4v pv[2];
+    float lpr[U], tot[U] = {0.f, 0.f, 0.f, 0.f};
     load(0, ln);
     load(1, lf);
-    for (int k = 0; k < G; ++k) {
-        fwd(ln, sc, lpr);
-        publish(k, lpr);
-        if (k > 0) totals(k - 1, tot);                       // (its last asm drains: lf and the publish have landed)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ticket(k);
-        ln = lf;
-        load(k + 2, lf);
-        if (k > 0) bwd(k - 1, sp, tot);
-        sp = sc;
+#define PFPN_F2L_ITER(KK, CUR, OLD)                                                                          \
+    do {                                                                                                     \
+        const int kk_ = (KK);                                                                                \
+        fwd(ln, CUR, lpr);                                   /* (past the last group: clamped rows, never used) */ \
+        publish(kk_, lpr, kk_ < G);                                                                          \
+        if (kk_ >= 1 && kk_ - 1 < G) totals(kk_ - 1, pv, tot);                                               \
+        ln = lf;                                                                                             \
+        load(kk_ + 2, lf);                                   /* (rows past the end are clamped: harmless) */   \
+        if (kk_ >= 1 && kk_ - 1 < G) bwd(kk_ - 1, OLD, tot);                                                 \
+        if (kk_ < G) poll_issue(kk_, pv);                                                                    \
+    } while (0)
+    for (int k = 0; k < G + 1; k += 2) {
+        PFPN_F2L_ITER(k, S0, S1);
+        PFPN_F2L_ITER(k + 1, S1, S0);
     }
-    totals(G - 1, tot);
-    bwd(G - 1, sp, tot);
+#undef PFPN_F2L_ITER
 
     // ---- the chunk's loss sums; the last chunk adds the C pairs in chunk order (the tail of the forward's hand-off) ----
     if (a == 0 && lane == 0) {
@@ -1658,6 +1717,10 @@ __global__ __launch_bounds__(256) void k_mix_wide_f2l(
         }
     }
     // ---- slabs + the last wave of an action dim adds the C slabs (k_mix_wide's backward hand-off, same order) ----
+    if (!alive) {                                            // an expired wait: results are garbage -- make that loud
+#pragma unroll
+        for (int j = 0; j < M; ++j) acc_loc2[j][0] = (v2f){NAN, NAN};
+    }
     float* slab = partial + (size_t)c * PL * AN + (size_t)a * N;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -2008,8 +2071,8 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
     return logprob_fwd_impl(logits, action, loc, logstd, B, A, N, 0, logp, nullptr, workspace, workspace_bytes, stream, &p);
 }
 
-// EXPERIMENTAL (round 5 probe): clipped-PPO forward + head + backward of a wide shape in ONE launch, logits read once
-// (k_mix_wide_f2l).  PFPN_ERR_ARG where the form does not apply (the caller composes pfpn_logprob_fwd_ppo + pfpn_logprob_bwd).
+// clipped-PPO forward + head + backward of a 256-particle shape in ONE launch, logits read once (k_mix_wide_f2l).
+// PFPN_ERR_ARG where the form does not apply (the caller composes pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias)).
 int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* loc, const float* logstd,
                         const float* logp_old, const float* adv, const float* value, const float* value_old,
                         const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
@@ -2019,9 +2082,8 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats || !logp ||
         !dlogits || !dloc || !dlogstd || !dvalue || !dlogp || !loss3 || B < 1 || A < 4 || N < 1)
         return PFPN_ERR_ARG;
-    const int M = N / 256;
-    if (!wide_ok(A, N, logits, dlogits) || N != 256 * M || !(M == 1 || M == 2 || M == 4) || (A & 3) || A > WIDE_FOLD_MAX_A)
-        return PFPN_ERR_ARG;
+    if (!wide_ok(A, N, logits, dlogits) || N != 256 || (A & 3) || A > 128)
+        return PFPN_ERR_ARG;                                 // (built for 256 particles per dim, <= 32 blocks per chunk)
     hipStream_t st = (hipStream_t)stream;
     unsigned* const tick = wide_tickets(workspace, workspace_bytes, B, A, N);
     if (!tick) return PFPN_ERR_WORKSPACE;
@@ -2029,51 +2091,50 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     const int nb = A / 4;
     // every wave of a chunk waits for the others: the WHOLE grid must be resident at once
     int per_cu = 0;
-#define PFPN_F2L_KERNEL(MM, SS, DD) k_mix_wide_f2l<MM, SS, DD>
 #define PFPN_F2L_DISPATCH(WHAT)                                                                              \
     do {                                                                                                     \
-        if (M == 1) { if (stream_policy) { if (dbias) WHAT(1, true, true); else WHAT(1, true, false); }     \
-                      else { if (dbias) WHAT(1, false, true); else WHAT(1, false, false); } }               \
-        else if (M == 2) { if (stream_policy) { if (dbias) WHAT(2, true, true); else WHAT(2, true, false); } \
-                           else { if (dbias) WHAT(2, false, true); else WHAT(2, false, false); } }          \
-        else { if (stream_policy) { if (dbias) WHAT(4, true, true); else WHAT(4, true, false); }            \
-               else { if (dbias) WHAT(4, false, true); else WHAT(4, false, false); } }                      \
+        if (stream_policy) { if (dbias) WHAT(true, true); else WHAT(true, false); }                          \
+        else { if (dbias) WHAT(false, true); else WHAT(false, false); }                                      \
     } while (0)
-#define PFPN_F2L_OCC(MM, SS, DD) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, PFPN_F2L_KERNEL(MM, SS, DD), 256, 0)
+#define PFPN_F2L_OCC(SS, DD) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_wide_f2l<1, SS, DD>, 256, 0)
     PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
 #undef PFPN_F2L_OCC
     int C = (per_cu * cu_count()) / nb;
     if (wide_c_env() > 0 && wide_c_env() < C) C = wide_c_env();
     if (C > 32) C = 32;
-    if (C >= 8) C &= ~7;
-    if (C > (B + 3) / 4) C = (B + 3) / 4;
-    if (C < 1) return PFPN_ERR_ARG;
+    C &= ~7;                                                 // a chunk = the blocks of ONE blockIdx % 8 class
+    while (C > 8 && C > (B + 3) / 4) C -= 8;
+    if (C < 8 || C > (B + 3) / 4) return PFPN_ERR_ARG;       // (small batches: the two-launch composition)
     if (chunks_out) *chunks_out = C;
     const int AN = A * N;
     const int PLn = dbias ? 3 : 2;
     float* partial = (float*)workspace;
     const size_t slab_floats = (size_t)C * PLn * AN;
-    const size_t sync_floats = (size_t)C * 2 * A * 4 + 2 * (size_t)C;
+    const size_t part_floats = (size_t)C * 4 * nb * 8, xcc_words = (size_t)C * nb;
+    const size_t sync_floats = part_floats + xcc_words + 2 * (size_t)C;
     if ((slab_floats + sync_floats) * sizeof(float) > (size_t)((char*)tick - (char*)workspace)) return PFPN_ERR_WORKSPACE;
+    const char* const fs_env = getenv("PFPN_WIDE_F2L_SAFE");            // (tests: read at every call)
+    const int force_safe = fs_env ? atoi(fs_env) : 0;
     WideF2L sy{};
     sy.part = partial + slab_floats;
-    sy.count = tick + WIDE_TICK_FWD;                         // [C][2] <= 64 words
+    sy.xccs = (unsigned*)(sy.part + part_floats);
     sy.err = tick + WIDE_TICK_PPO + 1;
     sy.logp = logp;
+    sy.force_safe = force_safe;
     WidePpo p{};
     p.logp_old = logp_old; p.adv = adv; p.value = value; p.value_old = value_old; p.stats = adv_stats;
     p.clip_lo = 1.0f - clip_eps; p.clip_hi = 1.0f + clip_eps; p.value_coef = value_coef; p.inv_B = 1.0f / (float)B;
     p.dlogp = dlogp; p.dvalue = dvalue; p.loss3 = loss3;
-    p.sums = sy.part + (size_t)C * 2 * A * 4;
+    p.sums = sy.part + part_floats + xcc_words;
     if (hipMemsetAsync(tick, 0, (size_t)(WIDE_TICK_BWD + A) * sizeof(unsigned), st) != hipSuccess) return PFPN_ERR_LAUNCH;
+    if (hipMemsetAsync(sy.part, 0, (part_floats + xcc_words) * sizeof(float), st) != hipSuccess) return PFPN_ERR_LAUNCH;  // tags: 0 = nothing
     const int blocks = C * nb;
-#define PFPN_F2L_LAUNCH(MM, SS, DD)                                                                          \
-    hipLaunchKernelGGL((PFPN_F2L_KERNEL(MM, SS, DD)), dim3(blocks), dim3(256), 0, st, logits, action, loc, logstd, B, A, N, C, \
+#define PFPN_F2L_LAUNCH(SS, DD)                                                                              \
+    hipLaunchKernelGGL((k_mix_wide_f2l<1, SS, DD>), dim3(blocks), dim3(256), 0, st, logits, action, loc, logstd, B, A, N, C, \
                        dlogits, partial, dloc, dlogstd, dbias, p, sy, tick)
     PFPN_F2L_DISPATCH(PFPN_F2L_LAUNCH);
 #undef PFPN_F2L_LAUNCH
 #undef PFPN_F2L_DISPATCH
-#undef PFPN_F2L_KERNEL
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

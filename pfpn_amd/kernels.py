@@ -5,6 +5,7 @@ shapes/dtypes on the host before launching (a faulting kernel can take the whole
 launches on torch's current stream, so calls can be captured in a torch.cuda.CUDAGraph.
 """
 import ctypes
+import os
 
 import torch
 
@@ -107,6 +108,36 @@ def logprob_bwd(logits, x, loc, logstd, dlogp, tanh_mode=False, want_dx=False, o
     return (dlogits, dloc, dlogstd, dx) if want_dx else (dlogits, dloc, dlogstd)
 
 
+def ppo_wide_fused(logits, action, loc, logstd, logp_old, adv, value, value_old, stats, clip_eps=0.2, value_coef=0.5,
+                   out=None, dbias=None):
+    """The 256-particle PPO pass as ONE launch that reads the logits once (pfpn_ppo_wide_fused), called directly (probes,
+    tests; ppo_mixture_fwd_bwd takes it by itself where it applies).  `out`: dict with logp, dlogits, dloc, dlogstd, dvalue, loss3 (+ `dlogp`); returns (out, chunks,
+    err_flag tensor) -- err_flag != 0 after a synchronise means a bounded in-kernel wait expired (results invalid)."""
+    lib = _lib.load()
+    A, N = loc.shape
+    B = action.shape[0]
+    dev = action.device
+    if out is None:
+        out = {"logp": torch.empty(B, dtype=torch.float32, device=dev), "dlogits": torch.empty(B, A * N, dtype=torch.float32, device=dev),
+               "dloc": torch.empty(A, N, dtype=torch.float32, device=dev), "dlogstd": torch.empty(A, N, dtype=torch.float32, device=dev),
+               "dvalue": torch.empty(B, dtype=torch.float32, device=dev), "loss3": torch.empty(3, dtype=torch.float32, device=dev)}
+    if "dlogp" not in out:
+        out["dlogp"] = _dlogp_scratch(B, dev)
+    nbytes = int(lib.pfpn_mixture_workspace_bytes(B, A, N))
+    buf = workspace(nbytes, dev)
+    chunks = ctypes.c_int(0)
+    _lib.check(lib.pfpn_ppo_wide_fused(_f32(logits.view(B, A * N), B, A * N), _f32(action, B, A), _f32(loc, A, N), _f32(logstd, A, N),
+                                       _f32(logp_old, B), _f32(adv, B), _f32(value, B), _f32(value_old, B), _f32(stats, 4),
+                                       B, A, N, float(clip_eps), float(value_coef), _f32(out["logp"], B),
+                                       _f32(out["dlogits"].view(B, A * N), B, A * N), _f32(out["dloc"], A, N),
+                                       _f32(out["dlogstd"], A, N), _f32(out["dvalue"], B), _f32(out["dlogp"], B),
+                                       _f32(dbias.view(-1), A * N) if dbias is not None else None, _f32(out["loss3"], 3),
+                                       ctypes.addressof(chunks), buf.data_ptr(), buf.numel(), _stream()), "pfpn_ppo_wide_fused")
+    # the ticket area is the last 4224 words of the pfpn_mixture_workspace_bytes() prefix of the workspace; word 65 = the flag
+    tick = buf[:nbytes].view(torch.int32)[-(128 + 4096):]
+    return out, chunks.value, tick[65:66]
+
+
 def mixture_workspace(B, A, N, device):
     """a private workspace of the mixture kernels' size (slabs that must survive until a deferred reduction)"""
     return torch.empty(int(_lib.load().pfpn_mixture_workspace_bytes(B, A, N)), dtype=torch.uint8, device=device)
@@ -153,6 +184,8 @@ def adv_stats(adv, normalize=True, out=None):
 
 
 _dlogp_bufs = {}
+# the one-launch (2L) PPO pass of the 256-particle shapes (PFPN_WIDE_FUSED=0: the two-launch composition everywhere)
+WIDE_FUSED = os.environ.get("PFPN_WIDE_FUSED", "1") != "0"
 
 
 def _dlogp_scratch(B, device):
@@ -208,6 +241,18 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
         # from cache, was built and measured in round 4: 806 us against 570 us on the 1 GiB shape -- 33 launches of
         # 96-MiB chunks cost more in start-up and tail than the cache gives back: LAB_NOTEBOOK.md)
         dlogp = _dlogp_scratch(B, dev)
+        # ONE launch, the logits read once (round 5: k_mix_wide_f2l; 448 us against 598 us on the 1 GiB shape) where that form
+        # exists -- 256 particles per dim, A % 4 == 0, A <= 128, a batch of at least 8 row chunks -- and WIDE_FUSED is on.
+        # It needs the device to itself while it runs (its waves wait for each other): the package launches on one stream.
+        if WIDE_FUSED:
+            rc = lib.pfpn_ppo_wide_fused(pl, pa, ploc, pls, *ptrs, B, A, N, float(clip_eps), float(value_coef),
+                                         out["logp"].data_ptr(), out["dlogits"].data_ptr(), out["dloc"].data_ptr(),
+                                         out["dlogstd"].data_ptr(), out["dvalue"].data_ptr(), dlogp.data_ptr(),
+                                         _f32(dbias.view(-1), A * N, name="dbias") if dbias is not None else None,
+                                         out["loss3"].data_ptr(), None, ws, wsn, _stream())
+            if rc != 1:
+                _lib.check(rc, "pfpn_ppo_wide_fused")
+                return out
         rc = lib.pfpn_logprob_fwd_ppo(pl, pa, ploc, pls, *ptrs, B, A, N, float(clip_eps), float(value_coef),
                                       out["logp"].data_ptr(), dlogp.data_ptr(), out["dvalue"].data_ptr(),
                                       out["loss3"].data_ptr(), ws, wsn, _stream())

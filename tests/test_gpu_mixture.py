@@ -137,7 +137,8 @@ def test_wide_kernel_config5_full_size_properties(oracle, dev):
     np.testing.assert_allclose(dl[rows].cpu().numpy(), r_dl, rtol=1e-4, atol=3e-6 * np.abs(r_dl).max())
 
 
-def test_wide_ppo_composition_config5_full_size_vs_oracle(oracle, dev):
+@pytest.mark.parametrize("fused", [True, False])
+def test_wide_ppo_composition_config5_full_size_vs_oracle(oracle, dev, monkeypatch, fused):
     """Round 5: the N >= 64 learner composition -- [forward + clipped-PPO head in ONE launch] -> backward
     (+ the head's bias plane) -- at BASELINE.json config 5's FULL shape, 8192 x 128 x 256 (1 GiB of logits), against the
     oracle: log-prob and d loss / d value on EVERY row (oracle log-probs computed in 256-row chunks; reference
@@ -146,6 +147,7 @@ def test_wide_ppo_composition_config5_full_size_vs_oracle(oracle, dev):
     batch with the oracle fed the oracle's own d loss / d logp."""
     from _parity import away_from_clip
     from pfpn_amd import kernels
+    monkeypatch.setattr(kernels, "WIDE_FUSED", fused)       # the one-launch (2L) form | [forward + head] -> backward (3L)
     B, A, N = 8192, 128, 256
     logits, x, loc, logstd, _ = _config5_inputs(dev, B, seed=8)
     loc_h, ls_h, x_h = loc.cpu().numpy(), logstd.cpu().numpy(), x.cpu().numpy()
@@ -323,6 +325,98 @@ def test_wide_handoff_repairs_a_poisoned_workspace_and_refuses_a_short_one(oracl
     assert lib.pfpn_logprob_bwd(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), B, A, N, 0,
                                 dl.data_ptr(), dloc.data_ptr(), dls.data_ptr(), None, 1, short.data_ptr(), short.numel(), st) == 0
     assert torch.equal(dl.view(B, A, N), r0[0]) and torch.equal(dloc, r0[1]) and torch.equal(dls, r0[2])
+
+
+@pytest.mark.parametrize("B,A,N", [(517, 128, 256), (1030, 8, 256), (64, 12, 256), (4099, 4, 256)])
+@pytest.mark.parametrize("safe", [False, True])
+def test_wide_fused_one_launch_ppo_pass(oracle, dev, monkeypatch, B, A, N, safe):
+    """Round 5: the 256-particle PPO pass as ONE launch that reads the logits once (pfpn_ppo_wide_fused; the waves of a row
+    chunk exchange their per-dimension log p through memory once per four rows) against the oracle on EVERY row and output,
+    against the two-launch composition (equal to summation order), bitwise run to run, from a poisoned workspace -- with the
+    exchange inside the chunk's XCD (the placement check passes) and, `safe`, with the memory-side exchange forced
+    (PFPN_WIDE_F2L_SAFE: what a chunk that straddles XCDs runs)."""
+    from _parity import away_from_clip
+    from pfpn_amd import kernels
+    if safe:
+        monkeypatch.setenv("PFPN_WIDE_F2L_SAFE", "1")
+    else:
+        monkeypatch.delenv("PFPN_WIDE_F2L_SAFE", raising=False)
+    logits, x, loc, logstd = make_inputs(oracle, B, A, N, 5000 + B, spread=1.0)
+    rng = np.random.default_rng(B + A)
+    ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+    assert np.isfinite(ref_lp).all()
+    lp_old = away_from_clip(ref_lp, (ref_lp + rng.normal(0, 0.15, B)).astype(np.float32))
+    adv, v, v_old = (rng.normal(0, 1, B).astype(np.float32) for _ in range(3))
+    loss, pl, vl, r_dlogp, r_dv = oracle.ppo_loss(ref_lp, lp_old, adv, v, v_old, 0.2, 0.5, normalize_adv=True)
+    r_dl, r_dloc, r_dls, _ = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, r_dlogp)
+    d = to_dev(dev, logits, x, loc, logstd, lp_old, adv, v, v_old)
+    stats = kernels.adv_stats(d[5])
+
+    def run(fill=None):
+        if fill is not None:
+            kernels.workspace(1, dev).fill_(fill)
+        dbias = torch.full((A * N,), float("nan"), device=dev)
+        out, chunks, err = kernels.ppo_wide_fused(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5, dbias=dbias)
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0 and chunks % 8 == 0 and chunks >= 8
+        return {k: t.clone() for k, t in out.items()}, dbias
+    o, db = run()
+    np.testing.assert_allclose(o["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=3e-5)
+    np.testing.assert_allclose(o["loss3"].cpu().numpy(), [loss, pl, vl], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(o["dvalue"].cpu().numpy(), r_dv, rtol=1e-5, atol=1e-9)
+    got_dlogp = o["dlogp"].cpu().numpy()
+    assert np.array_equal(got_dlogp != 0, r_dlogp != 0)
+    np.testing.assert_allclose(got_dlogp, r_dlogp, rtol=2e-3, atol=1e-9)
+    # the backward's own arithmetic: the oracle fed the kernel's d loss / d logp
+    r2 = oracle.mixture_log_prob_bwd(logits, x, loc, logstd, got_dlogp)
+    sc = np.abs(r2[0]).max() + 1e-30
+    np.testing.assert_allclose(o["dlogits"].cpu().numpy().reshape(B, A, N), r2[0], rtol=1e-4, atol=3e-6 * sc)
+    for k, ref in (("dloc", r2[1]), ("dlogstd", r2[2])):
+        np.testing.assert_allclose(o[k].cpu().numpy(), ref, rtol=1e-4, atol=5e-5 * (np.abs(ref).max() + 1e-30))
+    r_db = o["dlogits"].double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(db.cpu().numpy(), r_db, rtol=1e-4, atol=2e-5 * (np.abs(r_db).max() + 1e-30))
+    # against the two-launch composition
+    monkeypatch.setattr(kernels, "WIDE_FUSED", False)
+    c = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], stats, 0.2, 0.5)
+    for k in ("logp", "dvalue", "dloc", "dlogstd", "loss3"):
+        ref = c[k].double()
+        assert float((o[k].double() - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-12, k
+    assert float((o["dlogits"].double() - c["dlogits"].double()).abs().max()) <= 1e-4 * float(c["dlogits"].abs().max())
+    # run to run, and from a workspace full of 0xFF / 0x01 bytes: the same bits
+    for fill in (None, 0xFF, 0x01):
+        o2, db2 = run(fill)
+        assert all(torch.equal(o[k], o2[k]) for k in o) and torch.equal(db, db2), fill
+
+
+def test_wide_fused_is_what_the_learner_composition_takes(oracle, dev, monkeypatch):
+    """ppo_mixture_fwd_bwd at a 256-particle shape takes the one-launch form by itself (PFPN_WIDE_FUSED=1, the default) and the
+    two-launch composition where the form does not exist (a batch of fewer than 8 row chunks; A % 4 != 0)."""
+    from pfpn_amd import _lib, kernels
+    assert kernels.WIDE_FUSED
+    calls = []
+    lib = _lib.load()
+    real = lib.pfpn_ppo_wide_fused
+
+    class Spy(object):
+        def __getattr__(self, name):
+            if name == "pfpn_ppo_wide_fused":
+                def f(*a):
+                    rc = real(*a)
+                    calls.append(rc)
+                    return rc
+                return f
+            return getattr(lib, name)
+    monkeypatch.setattr(_lib, "load", lambda: Spy())
+    for (B, A, N), want in (((517, 8, 256), 0), ((9, 8, 256), 1), ((200, 6, 256), 1)):
+        logits, x, loc, logstd = make_inputs(oracle, B, A, N, 31 + B, spread=1.0)
+        rng = np.random.default_rng(B)
+        ref_lp, _ = oracle.mixture_log_prob(logits, x, loc, logstd)
+        lp_old = (ref_lp + rng.normal(0, 0.1, B)).astype(np.float32)
+        adv, v, v_old = (rng.normal(0, 1, B).astype(np.float32) for _ in range(3))
+        d = to_dev(dev, logits, x, loc, logstd, lp_old, adv, v, v_old)
+        out = kernels.ppo_mixture_fwd_bwd(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], kernels.adv_stats(d[5]), 0.2, 0.5)
+        assert calls[-1] == want, ((B, A, N), calls)
+        np.testing.assert_allclose(out["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=3e-5)
 
 
 def test_wide_ppo_composition_is_two_launches_into_the_callers_buffers(oracle, dev):
