@@ -88,6 +88,15 @@ def rocprof_kernel_us(kernel_substring):
     return None
 
 
+def stress_traffic(kernel):
+    """HBM bytes per launch of a stress-shape kernel from the newest committed PMC passes (profiles/rNN_pmc_traffic.json) or None"""
+    path, _ = latest_profile("pmc_traffic.json")
+    try:
+        return json.load(open(path))["kernels"][kernel]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def timeline_launches(suffix):
     """launch count of one step in the newest committed rocprofv3 timeline profiles/rNN_<suffix> -> (n, file) or (None, None)"""
     import re
@@ -208,7 +217,11 @@ def compact_line(out, budget=LINE_BUDGET):
         line["digest"] = digest(out)
         return json.dumps(line, separators=(",", ":"))
     s = render()
-    for k in _DROP_ORDER:
+    keep = {"config", "roofline", "cpu_baseline", "roofline_stress", "rccl"}          # the contract's objects + the stress target
+    order = [k for k in _DROP_ORDER if k in c]
+    order += sorted((k for k, v in c.items() if isinstance(v, (dict, list)) and k not in keep and k not in order),
+                    key=lambda k: -len(json.dumps(c[k])))
+    for k in order + ["roofline_stress"]:
         if len(s) <= budget:
             break
         if k in c:
@@ -878,6 +891,8 @@ def main():
                               "us_per_launch": u2, "algorithmic_bytes": nb2, "achieved": nb2 / u2 / 1e3, "unit": "GB/s",
                               "peak": HBM_PEAK_GBS, "frac": nb2 / u2 / 1e3 / HBM_PEAK_GBS,
                               "frac_on_3l_bytes": nb3 / u2 / 1e3 / HBM_PEAK_GBS, "speedup_vs_3l_form": u3 / u2,
+                              "traffic": stress_traffic("k_mix_wide_f2l"),
+                              "traffic_source": "profiles/rNN_pmc_traffic.json (tools/f2l_traffic.sh; NOT measured in this run)",
                               "note": "frac: on its own (2L) algorithmic bytes; frac_on_3l_bytes: the bytes of the two-launch "
                                       "form it replaces over this launch's time"}
             else:

@@ -954,6 +954,10 @@ constexpr int WIDE_TICK_BWD = 128;                   // [4096] one per action di
 constexpr int WIDE_FOLD_MAX_A = 4096;
 constexpr int WIDE_FOLD_MAX_LDS = 32 * 1024;
 constexpr size_t WIDE_TICK_WORDS = WIDE_TICK_BWD + WIDE_FOLD_MAX_A;
+// pfpn_ppo_wide_fused's exchange area, in front of the tickets: [C <= 32][4 slots][nb <= 32][8] tagged partials, [C][nb] XCC ids,
+// [C][2] loss sums
+constexpr size_t WIDE_F2L_PART_WORDS = (size_t)32 * 4 * 32 * 8, WIDE_F2L_XCC_WORDS = 32 * 32;
+constexpr size_t WIDE_F2L_SYNC_WORDS = WIDE_F2L_PART_WORDS + WIDE_F2L_XCC_WORDS + 64;
 
 __device__ __forceinline__ void st4_sc1(float* p, float a, float b, float c, float d) {
     const f4v v = {a, b, c, d};
@@ -1951,8 +1955,9 @@ size_t pfpn_mixture_workspace_bytes(int B, int A, int N) {
     // slabs: tile path <= 1024 blocks x (3AN+4); wave/wide path C<=64 chunks x 2AN; + lpseg [B*A]
     const size_t AN = (size_t)A * N;
     const size_t slabs = (N <= 64 ? (size_t)1024 : (size_t)64) * (3 * AN + 4);
-    // ... + the wide kernels' hand-off tickets as the LAST WIDE_TICK_WORDS words (wide_tickets())
-    return (((slabs + (size_t)B * A + 64) * sizeof(float) + 15) & ~(size_t)15) + WIDE_TICK_WORDS * sizeof(unsigned);
+    // ... + the one-launch PPO pass's exchange area (pfpn_ppo_wide_fused) and, as the LAST WIDE_TICK_WORDS words, the wide
+    // kernels' hand-off tickets (wide_tickets()): adjacent, so that the fused pass zeroes both with ONE memset node
+    return (((slabs + (size_t)B * A + 64) * sizeof(float) + 15) & ~(size_t)15) + (WIDE_F2L_SYNC_WORDS + WIDE_TICK_WORDS) * sizeof(unsigned);
 }
 
 // the ticket area of a caller's workspace: at a place that depends on (B, A, N) alone -- the end of the size
@@ -2110,14 +2115,13 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     const int PLn = dbias ? 3 : 2;
     float* partial = (float*)workspace;
     const size_t slab_floats = (size_t)C * PLn * AN;
-    const size_t part_floats = (size_t)C * 4 * nb * 8, xcc_words = (size_t)C * nb;
-    const size_t sync_floats = part_floats + xcc_words + 2 * (size_t)C;
-    if ((slab_floats + sync_floats) * sizeof(float) > (size_t)((char*)tick - (char*)workspace)) return PFPN_ERR_WORKSPACE;
+    float* const sync = (float*)tick - WIDE_F2L_SYNC_WORDS;                 // [partials | XCC ids | loss sums] | tickets
+    if (slab_floats * sizeof(float) > (size_t)((char*)sync - (char*)workspace)) return PFPN_ERR_WORKSPACE;
     const char* const fs_env = getenv("PFPN_WIDE_F2L_SAFE");            // (tests: read at every call)
     const int force_safe = fs_env ? atoi(fs_env) : 0;
     WideF2L sy{};
-    sy.part = partial + slab_floats;
-    sy.xccs = (unsigned*)(sy.part + part_floats);
+    sy.part = sync;
+    sy.xccs = (unsigned*)(sync + WIDE_F2L_PART_WORDS);
     sy.err = tick + WIDE_TICK_PPO + 1;
     sy.logp = logp;
     sy.force_safe = force_safe;
@@ -2125,9 +2129,10 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     p.logp_old = logp_old; p.adv = adv; p.value = value; p.value_old = value_old; p.stats = adv_stats;
     p.clip_lo = 1.0f - clip_eps; p.clip_hi = 1.0f + clip_eps; p.value_coef = value_coef; p.inv_B = 1.0f / (float)B;
     p.dlogp = dlogp; p.dvalue = dvalue; p.loss3 = loss3;
-    p.sums = sy.part + part_floats + xcc_words;
-    if (hipMemsetAsync(tick, 0, (size_t)(WIDE_TICK_BWD + A) * sizeof(unsigned), st) != hipSuccess) return PFPN_ERR_LAUNCH;
-    if (hipMemsetAsync(sy.part, 0, (part_floats + xcc_words) * sizeof(float), st) != hipSuccess) return PFPN_ERR_LAUNCH;  // tags: 0 = nothing
+    p.sums = sync + WIDE_F2L_PART_WORDS + WIDE_F2L_XCC_WORDS;
+    // ONE memset node: the exchange area (tags 0 = nothing published) and the tickets this launch draws
+    if (hipMemsetAsync(sync, 0, (WIDE_F2L_SYNC_WORDS + WIDE_TICK_BWD + (size_t)A) * sizeof(unsigned), st) != hipSuccess)
+        return PFPN_ERR_LAUNCH;
     const int blocks = C * nb;
 #define PFPN_F2L_LAUNCH(SS, DD)                                                                              \
     hipLaunchKernelGGL((k_mix_wide_f2l<1, SS, DD>), dim3(blocks), dim3(256), 0, st, logits, action, loc, logstd, B, A, N, C, \

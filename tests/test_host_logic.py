@@ -423,6 +423,25 @@ def test_bench_reads_the_committed_profiles():
     tpath, _ = bench.latest_profile("pmc_traffic.json")
     t = json.load(open(tpath))["kernels"]["k_mix_tile<35,PPO>"]["traffic_bytes"]
     assert bench.algorithmic_bytes_fused(4096) <= t <= 1.2 * bench.algorithmic_bytes_fused(4096)
+    # the printed line: a full result dict of a real run (committed) comes out under the driver's ~8.6 KB window, numbers intact,
+    # the digest LAST with the figures round 4's truncated record lost
+    full_path, _ = bench.latest_profile("bench_line_full.json")
+    full = json.load(open(full_path or os.path.join(root, "profiles", "r04_bench_line.json")))
+    line = bench.compact_line(full)
+    assert len(line) <= 8000 and "\n" not in line
+    d = json.loads(line)
+    assert list(d)[-1] == "digest" and len(json.dumps(d["digest"])) <= 700
+    assert d["value"] > 1000 and d["metric"].startswith("DPPO learner steps/sec") and d["config"]["workload"]
+    assert {"stress_fwd", "stress_bwd", "stress_ppo", "sac_ms_1024", "sac_ms_256", "config5_ms", "value_200", "ms_min",
+            "ms_median", "ms_max", "shard_us_512", "mfma_busy"} <= set(d["digest"])
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["sample"]
+    for leg in ("fwd", "bwd", "ppo"):
+        assert 0 < d["roofline_stress"][leg]["frac"] < 1
+    assert "note" not in json.dumps(d)                     # the prose lives in profiles/README.md
+    # a line that would still be too long loses whole blocks, least essential first, and says which
+    fat = dict(full, padding={"k%d" % i: "x" * 90 for i in range(60)})
+    cut = json.loads(bench.compact_line(fat))
+    assert len(bench.compact_line(fat)) <= bench.LINE_BUDGET and cut["dropped"] and "value" in cut and "digest" in cut
     # multiply-accumulates per row of the DeepMimic MLPs (5,889,536 per row forward + backward incl. the critic's
     # 512-wide fc3, which runs inside an epilogue here and is not counted as GEMM work)
     f, dw, dx = bench.dense_macs(197, (1024, 512), 1260)

@@ -43,6 +43,8 @@ def counters(path):
             m = re.search(r"k_mix_wide<(\d+), (\d+)", k)
             if m:
                 name = "k_mix_wide<%s,%s>" % (m.group(1), {0: "FWD", 1: "BWD", 2: "PPO"}[int(m.group(2))])
+            elif "k_mix_wide_f2l<" in k:
+                name = "k_mix_wide_f2l"                      # the one-launch (2L) PPO pass of the 256-particle shapes
         if name:
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
