@@ -1196,6 +1196,13 @@ def main():
                 cdl = torch.randn(cB, device=dev)
                 us_cb = time_in_graph(lambda: kernels.logprob_bwd(cnet.logits, ct["action"], cnet.loc, cnet.logstd, cdl,
                                                                   out=cnet.train_out), per_graph=10)
+                # ... and the one-launch PPO pass the step actually runs at this shape (the memset node in front of it included)
+                us_c2 = None
+                if kernels.WIDE_FUSED:
+                    c_stats = kernels.adv_stats(ct["advantage"])
+                    us_c2 = time_in_graph(lambda: kernels.ppo_mixture_fwd_bwd(
+                        cnet.logits, ct["action"], cnet.loc, cnet.logstd, c_lp, ct["advantage"], c_v, c_v,
+                        c_stats, out=cnet.train_out, dbias=cnet.store.g("actor/fc_policy/bias")), per_graph=10)
                 # launches per step: the runtime's dump of the captured graph where it can print one, else the committed
                 # rocprofv3 timeline of tools/config5_trace.py (profiles/rNN_config5_step_timeline.txt; NOT counted in this run)
                 c5_launches = ((cstep.kernel_nodes() or 0) / CK or None) if claunch != "eager" else None
@@ -1218,6 +1225,10 @@ def main():
                                                         "k_mix_wide<BWD> (slab sums inside)": {
                                                             "us": us_cb, "algorithmic_bytes": 2 * cL + cX + 2 * cV + 2 * cP,
                                                             "frac": (2 * cL + cX + 2 * cV + 2 * cP) / us_cb / 1e3 / HBM_PEAK_GBS},
+                                                        **({"k_mix_wide_f2l (forward + PPO head + backward, one launch)": {
+                                                            "us": us_c2, "algorithmic_bytes": 2 * cL + cX + 6 * cV + 2 * cP,
+                                                            "frac": (2 * cL + cX + 6 * cV + 2 * cP) / us_c2 / 1e3 / HBM_PEAK_GBS}}
+                                                           if us_c2 else {}),
                                                         "note": "128 MiB of logits fit the 256 MiB infinity cache: a fraction above "
                                                                 "the HBM figure of the 1 GiB shape is cache, not HBM"}}}
                 del cnet, copt
