@@ -447,3 +447,47 @@ def test_bench_reads_the_committed_profiles():
     f, dw, dx = bench.dense_macs(197, (1024, 512), 1260)
     assert f == 197 * 1024 + 1024 * 512 + 512 * 1260 and dx == f - 197 * 1024
     assert bench.gemm_flops(4096) == 2.0 * 4096 * (5889536 - 3 * 512)
+
+
+def test_reach_environment_has_the_documented_optimum():
+    """pfpn_amd.envs.SyntheticReachEnv (the second learning-test environment): the optimum a = g(s) collects reward 1 per step,
+    the best state-blind policy (a = 0) ~ 0.67, uniform random actions ~ 0.18; episodes end by the time limit only."""
+    import numpy as np
+    from pfpn_amd.envs import SyntheticReachEnv, make_env
+    env = make_env("SyntheticReach-v0", seed=3)
+    assert isinstance(env, SyntheticReachEnv) and env.observation_space.shape == (197,) and env.action_space.shape == (36,)
+    rng = np.random.RandomState(0)
+    totals = {}
+    for name, policy in (("optimal", lambda s: env.target(s)), ("zero", lambda s: np.zeros(36, np.float32)),
+                         ("random", lambda s: rng.uniform(-1, 1, 36).astype(np.float32))):
+        s, ret, steps, done = env.reset(), 0.0, 0, False
+        while not done:
+            s, r, done, info = env.step(policy(s))
+            ret += r
+            steps += 1
+        assert steps == 200 and info.get("TimeLimit.truncated") is True
+        totals[name] = ret
+    assert abs(totals["optimal"] - 200.0) < 1e-3 and 110 < totals["zero"] < 160 and 20 < totals["random"] < 60, totals
+
+
+def test_sac_autograd_twin_starts_from_the_uniform_mixture():
+    """tools/sac_twin_torch.py (the independent SAC-PFPN implementation the GPU learning test compares the product with) runs on
+    the CPU and starts where the algorithm must start: log_alpha = 0, the tanh-mode particle grid with uniform weights --
+    log-prob of its own 36-dim sample ~ -24.7, mean |a| ~ 0.5, Q ~ 0 -- and its first learner step happens when the replay ring
+    holds one minibatch."""
+    import importlib.util
+    import os
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sac_twin_torch", os.path.join(root, "tools", "sac_twin_torch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    threads = torch.get_num_threads()
+    try:
+        rows, episodes = mod.run(steps=3, every=1, seed=5, threads=4, verbose=False)
+    finally:
+        torch.set_num_threads(threads)
+    assert [r["step"] for r in rows] == [0, 1, 2] and not episodes              # 256 + 3 environment steps: no episode ended
+    r0 = rows[0]
+    assert abs(r0["alpha"] - 1.0) < 1e-6 and abs(r0["logp"] + 24.7) < 0.8 and 0.4 < r0["abs_a"] < 0.6 and abs(r0["q_pi"]) < 0.1
+    assert all(abs(r["alpha"] - 1.0) < 1e-3 and r["value_loss"] > 100 for r in rows)

@@ -210,9 +210,10 @@ def run(steps=1500, every=25, seed=33406, env_name="DeepMimicKick-v0", log_alpha
             mean = d * mean + (1 - d) * m_
             std = torch.clamp(d * std + (1 - d) * torch.sqrt(v_), min=1e-6)
         if step % every == 0:
-            row = {"step": step, "alpha": float(alpha), "logp": float(logp.mean()), "abs_a": float(a_pi.abs().mean()),
-                   "edge": float((a_pi.abs() > 0.95).float().mean()), "q_pi": float(torch.minimum(q1p, q2p).mean()),
-                   "reward": float(b["reward"].mean()), "policy_loss": float(policy_loss), "value_loss": float(value_loss),
+            row = {"step": step, "alpha": float(alpha), "logp": float(logp.detach().mean()),
+                   "abs_a": float(a_pi.detach().abs().mean()), "edge": float((a_pi.detach().abs() > 0.95).float().mean()),
+                   "q_pi": float(torch.minimum(q1p, q2p).detach().mean()), "reward": float(b["reward"].mean()),
+                   "policy_loss": float(policy_loss.detach()), "value_loss": float(value_loss.detach()),
                    "sec": round(time.time() - t0, 1)}
             rows.append(row)
             if verbose:
