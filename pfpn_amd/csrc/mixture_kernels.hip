@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 // =====================================================================================================================
 // The clipped-PPO learner pass of the 256-particle shapes as ONE launch that reads the logits once and writes dlogits once
 // (2L; round 5).  The composition [forward + PPO head] -> backward reads the logits twice (3L): 598 us for 8192 x 128 x 256;
-// this kernel: 448 us (tools/f2l_probe.py, profiles/r05_wide_2l_probe.txt).
+// this kernel: 415-429 us (tools/f2l_probe.py, profiles/r05_wide_2l_probe.txt).
 //
 // The obstacle is the row sum: log p of a row = the sum over its A action dims, and the wide kernels give every action dim to
 // its own wave (bank + gradient accumulators of ONE dim in registers while it walks the rows): A = 128 waves on 32 blocks.  Here
@@ -1421,7 +1421,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 // under any placement -- 704-850 us (every wave of a chunk re-reads the chunk's partials from the memory side once per group:
 // 1 GiB of loads on a few hot lines; a tagged hand-off costs ~3 us under streaming load, MI355X_MICROARCH.md row
 // handoff-1to1); the same with atomics on one arrival counter per chunk: 6.8 ms (128 arrivals serialise).  Plain stores + `sc1`
-// loads keep the exchange INSIDE the chunk's XCD (the stores stay in that XCD's L2, which serves the loads): 448 us.  That
+// loads keep the exchange INSIDE the chunk's XCD (the stores stay in that XCD's L2, which serves the loads): 448 us (415 us with
+// the per-row tails computed once per group: at 2 waves per SIMD the kernel had become VALU-bound).  That
 // needs all waves of a chunk on one XCD.  Blocks are dealt to the XCDs round-robin (observed, not promised), so a chunk takes
 // the blocks of one blockIdx % 8 class -- and the kernel CHECKS: before the first group every block publishes its XCC id the
 // safe way (`sc1` store, memory-side); a chunk whose blocks do not all report the same id runs the safe exchange (slow,
@@ -1504,11 +1505,14 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     float ps = 0.f, vs = 0.f;                                // loss sums of this chunk's rows (kept by its wave a == 0)
 
     // what a group's backward needs from its forward (z is recomputed from x and the bank: two packed ops per pair)
-    struct St { v2f e[U][M][2], ef[U][M][2]; float x[U], p[U], inv_sum[U]; float head; };
+    // p, 1 / sum e and the head's row scalars stay DISTRIBUTED: lane l holds row l >> 4 of the group's four (what
+    // wave_reduce4_dist leaves), so the per-row tails -- v_rcp, v_log, the whole PPO head with its expf -- run ONCE across the
+    // four rows instead of four times on wave-uniform values; the backward reads the few scalars it needs with v_readlane
+    struct St { v2f e[U][M][2], ef[U][M][2]; float x[U]; float p, inv_sum; float head; };
     // a group's inputs: the logits quads, x, and the PPO head's four row scalars (adv, logp_old, value, value_old) of its four
-    // rows as ONE lane-distributed load (lane 4u + i holds input i of row u; read back with v_readlane) -- loaded with the
-    // prefetch, so that the head never issues a dependent load of its own (a first version did, and drained vmcnt(0) four
-    // times per group)
+    // rows as ONE lane-distributed load (lane l: input l & 3 of row l >> 4; a quad-permute broadcast hands each lane its row's
+    // four) -- loaded with the prefetch, so that the head never issues a dependent load of its own (a first version did, and
+    // drained vmcnt(0) four times per group)
     struct Ld { float4 l[U][M]; float x[U]; float head; };
     const float* const head_src = (lane & 3) == 0 ? ppo.adv : (lane & 3) == 1 ? ppo.logp_old : (lane & 3) == 2 ? ppo.value
                                                                                                               : ppo.value_old;
@@ -1521,10 +1525,10 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             for (int j = 0; j < M; ++j) d.l[u][j] = ld4_stream<STREAM>(row_ + 4 * (lane + 64 * j));
             d.x[u] = x[(size_t)b_ * A + a];
         }
-        d.head = head_src[min(c + (U * g + ((lane >> 2) & 3)) * C, B - 1)];
+        d.head = head_src[min(c + (U * g + (lane >> 4)) * C, B - 1)];
     };
     // forward of one group: e, e*phi kept; -> the group's four per-dim log p
-    auto fwd = [&](const Ld& d, St& s, float (&lpr)[U]) {
+    auto fwd = [&](const Ld& d, St& s, float& lpr) {
         float mx[U];
         v2f lp[U][M][2];
 #pragma unroll
@@ -1559,17 +1563,15 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             sum[u] = s2.x + s2.y;
             num[u] = n2.x + n2.y;
         }
-        wave_reduce4<false>(sum[0], sum[1], sum[2], sum[3], lane);
-        wave_reduce4<false>(num[0], num[1], num[2], num[3], lane);
+        const float ks = wave_reduce4_dist<false>(sum[0], sum[1], sum[2], sum[3], lane);
+        const float kn = wave_reduce4_dist<false>(num[0], num[1], num[2], num[3], lane);
+        s.inv_sum = __builtin_amdgcn_rcpf(ks);
+        float p = (kn * two_m64) * s.inv_sum;
+        if (p < 1.401298464324817e-45f) p = 0.f;
+        s.p = p;
+        lpr = __builtin_amdgcn_logf(p) * 0.6931471805599453f;               // (lane l: row l >> 4)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            s.inv_sum[u] = __builtin_amdgcn_rcpf(sum[u]);
-            float p = (num[u] * two_m64) * s.inv_sum[u];
-            if (p < 1.401298464324817e-45f) p = 0.f;
-            s.p[u] = p;
-            lpr[u] = __builtin_amdgcn_logf(p) * 0.6931471805599453f;
-            s.x[u] = d.x[u];
-        }
+        for (int u = 0; u < U; ++u) s.x[u] = d.x[u];
         s.head = d.head;
     };
     // the exchange's stores and first-attempt loads are raw BUFFER accesses with the cache policy as an argument (16 = sc1):
@@ -1583,11 +1585,8 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         return __builtin_amdgcn_make_buffer_rsrc((float*)qu, 0, nb * 32, 0x00020000);
     };
     __shared__ float s_blk[2][4][U];
-    auto publish = [&](int g, const float (&lpr)[U], bool real) {
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) s_blk[g & 1][wv][u] = lpr[u];
-        }
+    auto publish = [&](int g, float lpr, bool real) {
+        if ((lane & 15) == 0) s_blk[g & 1][wv][lane >> 4] = lpr;
         __syncthreads();                                     // (one per group; buffer g & 1 is rewritten two barriers later)
         if (real && wv == 0 && lane == 0) {
             float t[U];
@@ -1612,7 +1611,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     };
     // the group's four row totals (every lane: the same bits) from a poll's values: every entry must carry the group's tag
     // (else: poll again, bounded); the nb partials meet in the transposing butterfly (fixed order)
-    auto totals = [&](int g, f4v (&v)[2], float (&tot)[U]) {
+    auto totals = [&](int g, f4v (&v)[2], float& tot) {               // -> lane l: the total of row l >> 4
         const unsigned want = (unsigned)g + 1u;
         int it = 0;
         while (true) {
@@ -1625,40 +1624,43 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             }
             poll_issue(g, v);
         }
-        tot[0] = has0 ? v[0].x : 0.f; tot[1] = has0 ? v[0].y : 0.f; tot[2] = has0 ? v[1].x : 0.f; tot[3] = has0 ? v[1].y : 0.f;
-        wave_reduce4<false>(tot[0], tot[1], tot[2], tot[3], lane);
+        tot = wave_reduce4_dist<false>(has0 ? v[0].x : 0.f, has0 ? v[0].y : 0.f, has0 ? v[1].x : 0.f, has0 ? v[1].y : 0.f, lane);
     };
-    // PPO head on a group's four rows (k_ppo_loss, term for term) + the backward of the group
-    auto bwd = [&](int g, const St& s, const float (&tot)[U]) {
+    // PPO head on a group's four rows (k_ppo_loss, term for term; ONCE, lane l working on row l >> 4) + the backward of the group
+    auto bwd = [&](int g, const St& s, float tot) {
+        const int ur = lane >> 4;
+        const int b_r = c + (U * g + ur) * C;
+        const bool live_r = b_r < B;
+        // the row's four head inputs out of its quad (lane l holds input l & 3 of row l >> 4)
+        const float av = dpp_shift<0x00, 0xf>(s.head, 0.f), h_lpo = dpp_shift<0x55, 0xf>(s.head, 0.f);
+        const float h_v = dpp_shift<0xAA, 0xf>(s.head, 0.f), h_vo = dpp_shift<0xFF, 0xf>(s.head, 0.f);
+        const float nadv = clip_adv((av - hm) * hr, hlo, hhi);
+        const float ratio = expf(tot - h_lpo);
+        const float sur = ratio * nadv;
+        const float csur = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo) * nadv;
+        const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
+        const float gdl = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
+        const float dvv = h_v - (av + h_vo);
+        if (a == 0 && live_r) {
+            ps += fminf(sur, csur);                          // (lane l: the sums of rows l >> 4 of every group; joined at the end)
+            vs += dvv * dvv;
+            if ((lane & 15) == 0) {
+                sy.logp[b_r] = tot;
+                ppo.dlogp[b_r] = gdl;
+                ppo.dvalue[b_r] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
+            }
+        }
+        const float q_ = live_r ? guard_finite(gdl * __builtin_amdgcn_rcpf(s.p)) : 0.f;
+        const float qs_d = q_ * s.inv_sum;
+        const float qp_d = qs_d * s.p;
+        const float qs64_d = qs_d * two_m64;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = c + (U * g + u) * C;
             const bool live = b < B;
             const int bb = live ? b : B - 1;
-            const float av = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u));
-            const float h_lpo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u + 1));
-            const float h_v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u + 2));
-            const float h_vo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s.head), 4 * u + 3));
-            const float nadv = clip_adv((av - hm) * hr, hlo, hhi);
-            const float ratio = expf(tot[u] - h_lpo);
-            const float sur = ratio * nadv;
-            const float csur = fmaxf(fminf(ratio, ppo.clip_hi), ppo.clip_lo) * nadv;
-            const bool pass = (sur <= csur) || (ratio >= ppo.clip_lo && ratio <= ppo.clip_hi);
-            const float gdl = pass ? (-ppo.inv_B * nadv) * ratio : 0.f;
-            const float dvv = h_v - (av + h_vo);
-            if (a == 0 && live) {
-                ps += fminf(sur, csur);
-                vs += dvv * dvv;
-                if (lane == 0) {
-                    sy.logp[b] = tot[u];
-                    ppo.dlogp[b] = gdl;
-                    ppo.dvalue[b] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
-                }
-            }
-            const float q_ = live ? guard_finite(gdl * __builtin_amdgcn_rcpf(s.p[u])) : 0.f;
-            const float qs = q_ * s.inv_sum[u];
-            const float qp = qs * s.p[u];
-            const float qs64 = qs * two_m64;
+            const float qp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qp_d), 16 * u));
+            const float qs64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qs64_d), 16 * u));
             float* drow = dlogits + (size_t)bb * AN + (size_t)a * N;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
@@ -1685,7 +1687,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     Ld ln, lf;
     St S0, S1;
     f4v pv[2];
-    float lpr[U], tot[U] = {0.f, 0.f, 0.f, 0.f};
+    float lpr = 0.f, tot = 0.f;
     load(0, ln);
     load(1, lf);
 #define PFPN_F2L_ITER(KK, CUR, OLD)                                                                          \
@@ -1706,6 +1708,11 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
 #undef PFPN_F2L_ITER
 
     // ---- the chunk's loss sums; the last chunk adds the C pairs in chunk order (the tail of the forward's hand-off) ----
+    if (a == 0) {                                            // rows l >> 4 = 0, 1, 2, 3 of the chunk's groups, in that order
+        const auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        ps = ((rl(ps, 0) + rl(ps, 16)) + rl(ps, 32)) + rl(ps, 48);
+        vs = ((rl(vs, 0) + rl(vs, 16)) + rl(vs, 32)) + rl(vs, 48);
+    }
     if (a == 0 && lane == 0) {
         __hip_atomic_store(ppo.sums + 2 * c, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(ppo.sums + 2 * c + 1, vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
