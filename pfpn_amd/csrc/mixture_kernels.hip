@@ -1690,6 +1690,13 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     float lpr = 0.f, tot = 0.f;
     load(0, ln);
     load(1, lf);
+#if defined(PFPN_F2L_AHEAD) && PFPN_F2L_AHEAD == 2           // A/B build knob: the logits of TWO groups in flight per wave
+    Ld lg;
+    load(2, lg);
+#define PFPN_F2L_NEXT(K_) do { lf = lg; load((K_) + 3, lg); } while (0)
+#else
+#define PFPN_F2L_NEXT(K_) load((K_) + 2, lf)                 /* (rows past the end are clamped: harmless) */
+#endif
 #define PFPN_F2L_ITER(KK, CUR, OLD)                                                                          \
     do {                                                                                                     \
         const int kk_ = (KK);                                                                                \
@@ -1697,7 +1704,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         publish(kk_, lpr, kk_ < G);                                                                          \
         if (kk_ >= 1 && kk_ - 1 < G) totals(kk_ - 1, pv, tot);                                               \
         ln = lf;                                                                                             \
-        load(kk_ + 2, lf);                                   /* (rows past the end are clamped: harmless) */   \
+        PFPN_F2L_NEXT(kk_);                                                                                  \
         if (kk_ >= 1 && kk_ - 1 < G) bwd(kk_ - 1, OLD, tot);                                                 \
         if (kk_ < G) poll_issue(kk_, pv);                                                                    \
     } while (0)
@@ -1706,6 +1713,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         PFPN_F2L_ITER(k + 1, S1, S0);
     }
 #undef PFPN_F2L_ITER
+#undef PFPN_F2L_NEXT
 
     // ---- the chunk's loss sums; the last chunk adds the C pairs in chunk order (the tail of the forward's hand-off) ----
     if (a == 0) {                                            // rows l >> 4 = 0, 1, 2, 3 of the chunk's groups, in that order
