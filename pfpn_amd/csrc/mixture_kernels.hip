@@ -1435,7 +1435,7 @@ struct WideF2L {
     unsigned* xccs;     // [C][A / 4]: 0x80000000 | XCC id of every block (zeroed in front of the launch)
     unsigned* err;      // [1]
     float* logp;        // [B] out
-    int force_safe;     // tests: run the memory-side exchange whatever the placement
+    int force_safe;     // tests: 1 = run the memory-side exchange whatever the placement; 2 = spread every chunk over all XCDs
 };
 
 template <int M, bool STREAM, bool DBIAS>
@@ -1454,9 +1454,11 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     const int wv = threadIdx.x >> 6;
     const int nb = A >> 2;                                   // blocks per row chunk (A % 4 == 0, nb <= 32)
     // chunk <-> XCD: the blocks of one chunk all carry the same blockIdx % 8 (C % 8 == 0: the host's choice)
+    // (force_safe == 2, tests: chunks of CONSECUTIVE blocks instead -- every chunk then straddles all eight XCDs, the placement
+    // check below must find that out by itself and the safe exchange must carry the launch)
     const int bi = blockIdx.x >> 3;
-    const int c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) + 8 * (bi / nb));
-    const int jb = bi % nb;
+    const int c = __builtin_amdgcn_readfirstlane(sy.force_safe == 2 ? (int)blockIdx.x / nb : (int)(blockIdx.x & 7) + 8 * (bi / nb));
+    const int jb = sy.force_safe == 2 ? (int)blockIdx.x % nb : bi % nb;
     const int a = __builtin_amdgcn_readfirstlane(4 * jb + wv);
     const int AN = A * N;
     const bool has0 = lane < nb;                             // lane l sweeps block entry l of its chunk
@@ -1476,7 +1478,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             __builtin_amdgcn_s_sleep(2);
             if (++it > (1 << 18)) { alive = false; __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
-        local = __all(!has0 || ((seen & 15u) == xcc)) && !sy.force_safe;
+        local = __all(!has0 || ((seen & 15u) == xcc)) && sy.force_safe != 1;
     }
     v2f b_loc2[M][2], b_isc2[M][2], b_ct2[M][2];
 #pragma unroll

@@ -328,17 +328,18 @@ def test_wide_handoff_repairs_a_poisoned_workspace_and_refuses_a_short_one(oracl
 
 
 @pytest.mark.parametrize("B,A,N", [(517, 128, 256), (1030, 8, 256), (64, 12, 256), (4099, 4, 256)])
-@pytest.mark.parametrize("safe", [False, True])
+@pytest.mark.parametrize("safe", [0, 1, 2])
 def test_wide_fused_one_launch_ppo_pass(oracle, dev, monkeypatch, B, A, N, safe):
     """Round 5: the 256-particle PPO pass as ONE launch that reads the logits once (pfpn_ppo_wide_fused; the waves of a row
     chunk exchange their per-dimension log p through memory once per four rows) against the oracle on EVERY row and output,
     against the two-launch composition (equal to summation order), bitwise run to run, from a poisoned workspace -- with the
-    exchange inside the chunk's XCD (the placement check passes) and, `safe`, with the memory-side exchange forced
-    (PFPN_WIDE_F2L_SAFE: what a chunk that straddles XCDs runs)."""
+    exchange inside the chunk's XCD (the placement check passes); `safe` = 1: with the memory-side exchange forced
+    (PFPN_WIDE_F2L_SAFE); `safe` = 2: with every chunk made of CONSECUTIVE blocks, i.e. spread over all eight XCDs -- the
+    in-kernel placement check must notice by itself and the memory-side exchange must carry the launch ACROSS XCDs."""
     from _parity import away_from_clip
     from pfpn_amd import kernels
     if safe:
-        monkeypatch.setenv("PFPN_WIDE_F2L_SAFE", "1")
+        monkeypatch.setenv("PFPN_WIDE_F2L_SAFE", str(safe))
     else:
         monkeypatch.delenv("PFPN_WIDE_F2L_SAFE", raising=False)
     logits, x, loc, logstd = make_inputs(oracle, B, A, N, 5000 + B, spread=1.0)

@@ -117,7 +117,8 @@ def log_prob(logits, loc, logstd, s_):                            # utils.py:108
     return lp.sum(-1)
 
 
-def run(steps=1500, every=25, seed=33406, env_name="DeepMimicKick-v0", log_alpha0=0.0, threads=6, verbose=True):
+def run(steps=1500, every=25, seed=33406, env_name="DeepMimicKick-v0", log_alpha0=0.0, threads=6, verbose=True,
+        lr_actor=1e-4, lr_critic=1e-4):
     """-> (rows, episodes): one diagnostics row every `every` learner steps, (step, length, return) per finished episode"""
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(seed)
@@ -131,8 +132,8 @@ def run(steps=1500, every=25, seed=33406, env_name="DeepMimicKick-v0", log_alpha
     log_alpha = torch.tensor(float(log_alpha0), requires_grad=True)
     actor_vars = actor + [loc, logstd, log_alpha]
     critic_vars = q1 + q2
-    opt_c = torch.optim.Adam(critic_vars, lr=1e-4, eps=1e-8)
-    opt_a = torch.optim.Adam(actor_vars, lr=1e-4, eps=1e-8)
+    opt_c = torch.optim.Adam(critic_vars, lr=lr_critic, eps=1e-8)
+    opt_a = torch.optim.Adam(actor_vars, lr=lr_actor, eps=1e-8)
     mean, std = torch.zeros(S), torch.ones(S)
     gamma, tau, Bsz = 0.95, 0.005, 256
 
@@ -230,9 +231,12 @@ def main():
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--log-alpha", type=float, default=0.0, help="initial log_alpha (reference: 0)")
     ap.add_argument("--env", default="DeepMimicKick-v0", help="DeepMimic*: the synthetic stand-in; SyntheticReach-v0")
+    ap.add_argument("--lr-actor", type=float, default=1e-4)
+    ap.add_argument("--lr-critic", type=float, default=1e-4)
     ap.add_argument("--out", default=os.path.join(R, "gpurun_out", "sac_twin_torch.jsonl"))
     args = ap.parse_args()
-    rows, episodes = run(args.steps, args.every, args.seed, args.env, args.log_alpha, args.threads)
+    rows, episodes = run(args.steps, args.every, args.seed, args.env, args.log_alpha, args.threads, lr_actor=args.lr_actor,
+                         lr_critic=args.lr_critic)
     out = {"run": "sac-twin-torch:%d:%d" % (args.seed, args.steps), "env": args.env, "log_alpha0": args.log_alpha, "rows": rows,
            "episodes": episodes[:80]}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
