@@ -878,7 +878,10 @@ def main():
             fused_default = kernels.WIDE_FUSED
             # the two-launch composition (3L: the backward reads the logits again) ...
             kernels.WIDE_FUSED = False
-            u3 = time_ppo()
+            try:
+                u3 = time_ppo()
+            finally:
+                kernels.WIDE_FUSED = fused_default
             res["ppo_3l"] = {"kernel": "k_mix_wide<FWD + PPO head> + k_mix_wide<BWD> (two launches, results in the caller's buffers)",
                              "us_per_launch": u3, "algorithmic_bytes": nb3, "achieved": nb3 / u3 / 1e3, "unit": "GB/s",
                              "peak": HBM_PEAK_GBS, "frac": nb3 / u3 / 1e3 / HBM_PEAK_GBS}

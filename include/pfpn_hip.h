@@ -82,10 +82,11 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
  * memory once per four rows (k_mix_wide_f2l; 415 us against 598 us for 8192 x 128 x 256).  Same outputs as the two entry points
  * (+ dlogp [B] = d loss / d logp); sums in a fixed order: bitwise reproducible run to run, equal to the two-launch composition to
  * summation order.  dbias optional (NULL: no bias plane).  *chunks_out (optional) receives the chunk count.
- * CONCURRENCY: the launch's waves wait for each other, so its whole grid must be resident at once: the entry point sizes the
- * grid to the device's occupancy, and NOTHING else may occupy the device while it runs (not a second call on another stream,
- * not another kernel).  Every in-kernel wait is bounded (~0.2 s): on expiry the gradients come out NaN and word 65 of the
- * workspace's ticket area is set -- a loud failure, not a hang.  PFPN_ERR_ARG for shapes outside the form (compose the two
+ * CONCURRENCY: the waves of a row chunk wait for each other, so a chunk's blocks (8 * A / 4 consecutive blocks of the dispatch
+ * order) must be resident together: the entry point sizes the grid to the device's occupancy, and NOTHING else may occupy the
+ * device while it runs (not a second call on another stream, not another kernel).  Every in-kernel wait is bounded (~0.2 s):
+ * on expiry the gradients come out NaN and word 65 of the workspace's ticket area is set -- a loud failure, not a hang
+ * (tests/test_gpu_mixture.py forces it).  PFPN_ERR_ARG for shapes outside the form (compose the two
  * entry points). */
 int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* loc, const float* logstd,
                         const float* logp_old, const float* adv, const float* value, const float* value_old,

@@ -1457,8 +1457,12 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     // (force_safe == 2, tests: chunks of CONSECUTIVE blocks instead -- every chunk then straddles all eight XCDs, the placement
     // check below must find that out by itself and the safe exchange must carry the launch)
     const int bi = blockIdx.x >> 3;
-    const int c = __builtin_amdgcn_readfirstlane(sy.force_safe == 2 ? (int)blockIdx.x / nb : (int)(blockIdx.x & 7) + 8 * (bi / nb));
-    const int jb = sy.force_safe == 2 ? (int)blockIdx.x % nb : bi % nb;
+    // (force_safe == 3, tests, with an oversubscribed grid: a chunk takes every C-th block, so that its partners span the whole
+    // grid and half of them cannot be resident -- the bounded waits must expire.  The shipped mapping keeps a chunk inside 8 nb
+    // consecutive blocks: in dispatch order a chunk is complete long before the device is full)
+    const int c = __builtin_amdgcn_readfirstlane(sy.force_safe == 2 ? (int)blockIdx.x / nb
+                                                 : sy.force_safe == 3 ? (int)blockIdx.x % C : (int)(blockIdx.x & 7) + 8 * (bi / nb));
+    const int jb = sy.force_safe == 2 ? (int)blockIdx.x % nb : sy.force_safe == 3 ? (int)blockIdx.x / C : bi % nb;
     const int a = __builtin_amdgcn_readfirstlane(4 * jb + wv);
     const int AN = A * N;
     const bool has0 = lane < nb;                             // lane l sweeps block entry l of its chunk
@@ -2112,17 +2116,22 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     const bool stream_policy = wide_stream(B, A, N);
     const int nb = A / 4;
     // every wave of a chunk waits for the others: the WHOLE grid must be resident at once
-    int per_cu = 0;
+    static int per_cu_cache[2][2] = {{0, 0}, {0, 0}};       // (the occupancy query costs host time: once per variant)
+    int& per_cu = per_cu_cache[stream_policy ? 1 : 0][dbias ? 1 : 0];
 #define PFPN_F2L_DISPATCH(WHAT)                                                                              \
     do {                                                                                                     \
         if (stream_policy) { if (dbias) WHAT(true, true); else WHAT(true, false); }                          \
         else { if (dbias) WHAT(false, true); else WHAT(false, false); }                                      \
     } while (0)
 #define PFPN_F2L_OCC(SS, DD) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_wide_f2l<1, SS, DD>, 256, 0)
-    PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
+    if (per_cu <= 0) PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
 #undef PFPN_F2L_OCC
     int C = (per_cu * cu_count()) / nb;
     if (wide_c_env() > 0 && wide_c_env() < C) C = wide_c_env();
+    // (tests only: a grid TWICE the device's capacity -- half of every chunk's partners cannot be resident, the bounded waits
+    // must expire, poison the gradients and set the flag instead of hanging)
+    const char* const os_env = getenv("PFPN_WIDE_F2L_OVERSUBSCRIBE");
+    if (os_env && atoi(os_env) == 1) C *= 2;
     if (C > 32) C = 32;
     C &= ~7;                                                 // a chunk = the blocks of ONE blockIdx % 8 class
     while (C > 8 && C > (B + 3) / 4) C -= 8;

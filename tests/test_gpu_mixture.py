@@ -389,6 +389,41 @@ def test_wide_fused_one_launch_ppo_pass(oracle, dev, monkeypatch, B, A, N, safe)
         assert all(torch.equal(o[k], o2[k]) for k in o) and torch.equal(db, db2), fill
 
 
+def test_wide_fused_pass_fails_loudly_when_its_waves_cannot_meet(oracle, dev, monkeypatch):
+    """The one-launch pass's waves wait for each other.  If a chunk's partners are NOT all resident -- here forced: a grid twice
+    the device's capacity (PFPN_WIDE_F2L_OVERSUBSCRIBE) whose chunks take every C-th block (PFPN_WIDE_F2L_SAFE=3), so that half
+    of every chunk's partners wait behind the resident half -- the bounded waits expire: the launch ENDS (no hang), the flag is
+    set, the gradients are NaN (the step's global norm goes NaN: loud), and the next normal launch is clean and bitwise the
+    one before.  (With the shipped block -> chunk mapping even the oversubscribed grid is fine: a chunk is complete within
+    8 * A / 4 consecutive blocks of the dispatch order.)"""
+    from pfpn_amd import kernels
+    B, A, N = 2048, 128, 256
+    logits, x, loc, logstd, _ = _config5_inputs(dev, B, seed=21)
+    lp0 = kernels.logprob_fwd(logits, x, loc, logstd).clone()
+    g = torch.Generator(device=dev).manual_seed(3)
+    adv = torch.randn(B, device=dev, generator=g)
+    v = torch.zeros(B, device=dev)
+    stats = kernels.adv_stats(adv)
+
+    def run():
+        out, chunks, err = kernels.ppo_wide_fused(logits.view(B, A * N), x, loc, logstd, lp0, adv, v, v, stats)
+        torch.cuda.synchronize()
+        return {k: t.clone() for k, t in out.items()}, chunks, int(err.item())
+    o0, c0, e0 = run()
+    assert e0 == 0 and bool(torch.isfinite(o0["dloc"]).all())
+    monkeypatch.setenv("PFPN_WIDE_F2L_OVERSUBSCRIBE", "1")
+    o1, c1, e1 = run()                                       # shipped mapping, oversubscribed: chunks complete in dispatch order
+    assert e1 == 0 and c1 == 2 * c0 and bool(torch.isfinite(o1["dloc"]).all())
+    np.testing.assert_allclose(o1["logp"].cpu().numpy(), o0["logp"].cpu().numpy(), rtol=1e-6, atol=1e-5)
+    monkeypatch.setenv("PFPN_WIDE_F2L_SAFE", "3")
+    o2, c2, e2 = run()
+    assert e2 == 1 and c2 == 2 * c0 and int(torch.isnan(o2["dloc"]).sum().item()) > 0       # loud, and it ended
+    monkeypatch.delenv("PFPN_WIDE_F2L_OVERSUBSCRIBE")
+    monkeypatch.delenv("PFPN_WIDE_F2L_SAFE")
+    o3, c3, e3 = run()
+    assert e3 == 0 and c3 == c0 and all(torch.equal(o0[k], o3[k]) for k in o0)
+
+
 def test_wide_fused_is_what_the_learner_composition_takes(oracle, dev, monkeypatch):
     """ppo_mixture_fwd_bwd at a 256-particle shape takes the one-launch form by itself (PFPN_WIDE_FUSED=1, the default) and the
     two-launch composition where the form does not exist (a batch of fewer than 8 row chunks; A % 4 != 0)."""
