@@ -1,10 +1,11 @@
-"""The same DPPO-PFPN training loop as tools/learn_curve.py, on the CPU with the NumPy oracle (test infrastructure): one
+"""Test infrastructure (lives under tests/: only tests, smoke() and bench.py's cpu_baseline leg may touch oracle/).
+The same DPPO-PFPN training loop as tools/learn_curve.py, on the CPU with the NumPy oracle: one
 environment, 512-step unrolls, GAE, 16 shuffled 32-row minibatches per round, resample tick -- the reference worker's schedule
 (models/workers/ppo.py:43-73, models/distributed_model.py:320-352) with the oracle's restated kernels.  Not a parity check (the two
 sides draw different random numbers): a STATISTICAL twin -- does the learning curve of the HIP product have the shape the algorithm
 itself produces on this environment?
 
-  python tools/learn_curve_oracle.py --seed 34114 --steps 4000 [--lr 1e-4] [--resample-interval 150]
+  python tests/learn_curve_oracle.py --seed 34114 --steps 4000 [--lr 1e-4] [--resample-interval 150]
 """
 import argparse
 import json

@@ -19,7 +19,7 @@ resample tick) trains on the synthetic DeepMimic-shaped environment and the test
 
 Hyper-parameters: the shipped settings, except `resample_interval` (150 / 300 learner steps instead of 368 / 6000, so that
 ticks fall inside a 20-second run) and, for DPPO, `lr_actor = 5e-4` (the setting's 1e-4 learns too -- 388 -> 543 in 6000
-steps on seed 34114, with the same dip-then-rise curve the NumPy oracle twin tools/learn_curve_oracle.py shows -- but not on
+steps on seed 34114, with the same dip-then-rise curve the NumPy oracle twin tests/learn_curve_oracle.py shows -- but not on
 every seed within the test's budget; curves of both in profiles/r05_learning.json).
 """
 import importlib.util
