@@ -76,8 +76,8 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
                          float* logp, float* dlogp, float* dvalue, float* loss3,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias) of a 256-particle grid (N == 256, A % 4 == 0, A <= 128, a batch of at least 8
- * row chunks of 4 rows) as ONE launch that reads the logits once and writes dlogits once (reference networks/utils.py:108-134 +
+/* pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias) of a wide particle grid (64 <= N <= 256, N % 4 == 0, A % 4 == 0, A <= 128, a
+ * batch of at least 8 row chunks of 4 rows) as ONE launch that reads the logits once and writes dlogits once (reference networks/utils.py:108-134 +
  * its autodiff, ppo.py:31-54, actor_critic.py:132-184): the waves of a row chunk exchange their per-dimension log p through
  * memory once per four rows (k_mix_wide_f2l; 415 us against 598 us for 8192 x 128 x 256).  Same outputs as the two entry points
  * (+ dlogp [B] = d loss / d logp); sums in a fixed order: bitwise reproducible run to run, equal to the two-launch composition to

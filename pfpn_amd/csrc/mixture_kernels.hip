@@ -1438,7 +1438,7 @@ struct WideF2L {
     int force_safe;     // tests: 1 = run the memory-side exchange whatever the placement; 2 = spread every chunk over all XCDs
 };
 
-template <int M, bool STREAM, bool DBIAS>
+template <int M, bool STREAM, bool DBIAS, bool FULLN>
 __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per SIMD: the whole grid resident at C = 16)
     const float* __restrict__ logits, const float* __restrict__ x,
     const float* __restrict__ loc, const float* __restrict__ logstd,
@@ -1465,6 +1465,12 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     const int jb = sy.force_safe == 2 ? (int)blockIdx.x % nb : sy.force_safe == 3 ? (int)blockIdx.x / C : bi % nb;
     const int a = __builtin_amdgcn_readfirstlane(4 * jb + wv);
     const int AN = A * N;
+    // FULLN: N == 256 M, every lane owns four particles per float4 slot; else (64 <= N < 256, N % 4 == 0) the lanes past
+    // N / 4 idle: their loads are clamped, their exponentials forced to 0, nothing of theirs is stored or summed
+    const int nq = N >> 2;
+    bool ok[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) ok[j] = FULLN || lane + 64 * j < nq;
     const bool has0 = lane < nb;                             // lane l sweeps block entry l of its chunk
     const int d0 = min(lane, nb - 1);
     bool alive = true;
@@ -1487,7 +1493,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     v2f b_loc2[M][2], b_isc2[M][2], b_ct2[M][2];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const int o = a * N + 4 * (lane + 64 * j);
+        const int o = a * N + 4 * (ok[j] ? lane + 64 * j : 0);
         const float4 lo = ld4(loc + o), ls = ld4(logstd + o);
         const float lo_[4] = {lo.x, lo.y, lo.z, lo.w}, ls_[4] = {ls.x, ls.y, ls.z, ls.w};
 #pragma unroll
@@ -1528,7 +1534,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             const int b_ = min(c + (U * g + u) * C, B - 1);  // clamped: loads unconditional
             const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;
 #pragma unroll
-            for (int j = 0; j < M; ++j) d.l[u][j] = ld4_stream<STREAM>(row_ + 4 * (lane + 64 * j));
+            for (int j = 0; j < M; ++j) d.l[u][j] = ld4_stream<STREAM>(row_ + 4 * (ok[j] ? lane + 64 * j : 0));
             d.x[u] = x[(size_t)b_ * A + a];
         }
         d.head = head_src[min(c + (U * g + (lane >> 4)) * C, B - 1)];
@@ -1544,8 +1550,10 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             for (int j = 0; j < M; ++j) {
                 lp[u][j][0] = (v2f){d.l[u][j].x, d.l[u][j].y} * PFPN_LOG2E;
                 lp[u][j][1] = (v2f){d.l[u][j].z, d.l[u][j].w} * PFPN_LOG2E;
-                mx[u] = fmaxf(fmaxf(lp[u][j][0].x, lp[u][j][0].y), mx[u]);
-                mx[u] = fmaxf(fmaxf(lp[u][j][1].x, lp[u][j][1].y), mx[u]);
+                if (ok[j]) {
+                    mx[u] = fmaxf(fmaxf(lp[u][j][0].x, lp[u][j][0].y), mx[u]);
+                    mx[u] = fmaxf(fmaxf(lp[u][j][1].x, lp[u][j][1].y), mx[u]);
+                }
             }
         }
         wave_reduce4<true>(mx[0], mx[1], mx[2], mx[3], lane);
@@ -1562,6 +1570,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
                     const v2f arg = le + __builtin_elementwise_fma(-z, z, b_ct2[j][h]);
                     s.e[u][j][h] = (v2f){__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
                     s.ef[u][j][h] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+                    if (!FULLN && !ok[j]) { s.e[u][j][h] = (v2f){0.f, 0.f}; s.ef[u][j][h] = (v2f){0.f, 0.f}; }
                     if (j == 0 && h == 0) { s2 = s.e[u][j][h]; n2 = s.ef[u][j][h]; }
                     else { s2 += s.e[u][j][h]; n2 += s.ef[u][j][h]; }
                 }
@@ -1681,7 +1690,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
                     acc_ls2[j][h] = __builtin_elementwise_fma(
                         tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}), acc_ls2[j][h]);
                 }
-                if (live) st4_row<STREAM>(drow, 4 * N, lane + 64 * j, d[0].x, d[0].y, d[1].x, d[1].y);
+                if (live && ok[j]) st4_row<STREAM>(drow, 4 * N, lane + 64 * j, d[0].x, d[0].y, d[1].x, d[1].y);
             }
         }
     };
@@ -1749,6 +1758,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     float* slab = partial + (size_t)c * PL * AN + (size_t)a * N;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
+        if (!ok[j]) continue;
         const v2f d0 = acc_loc2[j][0] * (b_isc2[j][0] * PFPN_2LN2), d1 = acc_loc2[j][1] * (b_isc2[j][1] * PFPN_2LN2);
         st4_sc1(slab + 4 * (lane + 64 * j), d0.x, d0.y, d1.x, d1.y);
         st4_sc1(slab + AN + 4 * (lane + 64 * j), acc_ls2[j][0].x, acc_ls2[j][0].y, acc_ls2[j][1].x, acc_ls2[j][1].y);
@@ -1765,6 +1775,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         float* dst = (pl == 0 ? fin0 : pl == 1 ? fin1 : finb) + (size_t)a * N;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
+            if (!ok[j]) continue;
             f4v run[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) run[r] = (f4v){0.f, 0.f, 0.f, 0.f};
@@ -2108,22 +2119,24 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats || !logp ||
         !dlogits || !dloc || !dlogstd || !dvalue || !dlogp || !loss3 || B < 1 || A < 4 || N < 1)
         return PFPN_ERR_ARG;
-    if (!wide_ok(A, N, logits, dlogits) || N != 256 || (A & 3) || A > 128)
-        return PFPN_ERR_ARG;                                 // (built for 256 particles per dim, <= 32 blocks per chunk)
+    if (!wide_ok(A, N, logits, dlogits) || N > 256 || (A & 3) || A > 128)
+        return PFPN_ERR_ARG;                                 // (one float4 slot per lane: 64 <= N <= 256; <= 32 blocks per chunk)
+    const bool fulln = N == 256;
     hipStream_t st = (hipStream_t)stream;
     unsigned* const tick = wide_tickets(workspace, workspace_bytes, B, A, N);
     if (!tick) return PFPN_ERR_WORKSPACE;
     const bool stream_policy = wide_stream(B, A, N);
     const int nb = A / 4;
     // every wave of a chunk waits for the others: the WHOLE grid must be resident at once
-    static int per_cu_cache[2][2] = {{0, 0}, {0, 0}};       // (the occupancy query costs host time: once per variant)
-    int& per_cu = per_cu_cache[stream_policy ? 1 : 0][dbias ? 1 : 0];
+    static int per_cu_cache[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};      // (the occupancy query costs host time: once per variant)
+    int& per_cu = per_cu_cache[stream_policy ? 1 : 0][dbias ? 1 : 0][fulln ? 1 : 0];
+#define PFPN_F2L_DISPATCH2(WHAT, SS, DD) do { if (fulln) WHAT(SS, DD, true); else WHAT(SS, DD, false); } while (0)
 #define PFPN_F2L_DISPATCH(WHAT)                                                                              \
     do {                                                                                                     \
-        if (stream_policy) { if (dbias) WHAT(true, true); else WHAT(true, false); }                          \
-        else { if (dbias) WHAT(false, true); else WHAT(false, false); }                                      \
+        if (stream_policy) { if (dbias) PFPN_F2L_DISPATCH2(WHAT, true, true); else PFPN_F2L_DISPATCH2(WHAT, true, false); } \
+        else { if (dbias) PFPN_F2L_DISPATCH2(WHAT, false, true); else PFPN_F2L_DISPATCH2(WHAT, false, false); } \
     } while (0)
-#define PFPN_F2L_OCC(SS, DD) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_wide_f2l<1, SS, DD>, 256, 0)
+#define PFPN_F2L_OCC(SS, DD, FF) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_wide_f2l<1, SS, DD, FF>, 256, 0)
     if (per_cu <= 0) PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
 #undef PFPN_F2L_OCC
     int C = (per_cu * cu_count()) / nb;
@@ -2160,12 +2173,13 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     if (hipMemsetAsync(sync, 0, (WIDE_F2L_SYNC_WORDS + WIDE_TICK_BWD + (size_t)A) * sizeof(unsigned), st) != hipSuccess)
         return PFPN_ERR_LAUNCH;
     const int blocks = C * nb;
-#define PFPN_F2L_LAUNCH(SS, DD)                                                                              \
-    hipLaunchKernelGGL((k_mix_wide_f2l<1, SS, DD>), dim3(blocks), dim3(256), 0, st, logits, action, loc, logstd, B, A, N, C, \
+#define PFPN_F2L_LAUNCH(SS, DD, FF)                                                                          \
+    hipLaunchKernelGGL((k_mix_wide_f2l<1, SS, DD, FF>), dim3(blocks), dim3(256), 0, st, logits, action, loc, logstd, B, A, N, C, \
                        dlogits, partial, dloc, dlogstd, dbias, p, sy, tick)
     PFPN_F2L_DISPATCH(PFPN_F2L_LAUNCH);
 #undef PFPN_F2L_LAUNCH
 #undef PFPN_F2L_DISPATCH
+#undef PFPN_F2L_DISPATCH2
     PFPN_CHECK_LAUNCH();
     return PFPN_OK;
 }

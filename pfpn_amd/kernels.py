@@ -242,7 +242,7 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
         # 96-MiB chunks cost more in start-up and tail than the cache gives back: LAB_NOTEBOOK.md)
         dlogp = _dlogp_scratch(B, dev)
         # ONE launch, the logits read once (round 5: k_mix_wide_f2l; 415 us against 598 us on the 1 GiB shape) where that form
-        # exists -- 256 particles per dim, A % 4 == 0, A <= 128, a batch of at least 8 row chunks -- and WIDE_FUSED is on.
+        # exists -- 64 <= N <= 256 particles per dim, A % 4 == 0, A <= 128, a batch of at least 8 row chunks -- and WIDE_FUSED is on.
         # It needs the device to itself while it runs (its waves wait for each other): the package launches on one stream.
         if WIDE_FUSED:
             rc = lib.pfpn_ppo_wide_fused(pl, pa, ploc, pls, *ptrs, B, A, N, float(clip_eps), float(value_coef),

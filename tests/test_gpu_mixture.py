@@ -327,7 +327,8 @@ def test_wide_handoff_repairs_a_poisoned_workspace_and_refuses_a_short_one(oracl
     assert torch.equal(dl.view(B, A, N), r0[0]) and torch.equal(dloc, r0[1]) and torch.equal(dls, r0[2])
 
 
-@pytest.mark.parametrize("B,A,N", [(517, 128, 256), (1030, 8, 256), (64, 12, 256), (4099, 4, 256)])
+@pytest.mark.parametrize("B,A,N", [(517, 128, 256), (1030, 8, 256), (64, 12, 256), (4099, 4, 256),
+                                   (1030, 8, 128), (333, 20, 64), (77, 12, 100)])        # (N < 256: the lanes past N / 4 idle)
 @pytest.mark.parametrize("safe", [0, 1, 2])
 def test_wide_fused_one_launch_ppo_pass(oracle, dev, monkeypatch, B, A, N, safe):
     """Round 5: the 256-particle PPO pass as ONE launch that reads the logits once (pfpn_ppo_wide_fused; the waves of a row
@@ -455,10 +456,13 @@ def test_wide_fused_is_what_the_learner_composition_takes(oracle, dev, monkeypat
         np.testing.assert_allclose(out["logp"].cpu().numpy(), ref_lp, rtol=RTOL, atol=3e-5)
 
 
-def test_wide_ppo_composition_is_two_launches_into_the_callers_buffers(oracle, dev):
-    """N >= 64: ppo_mixture_fwd_bwd composes [forward + PPO head in one launch] -> backward; every result lands in `out`
-    directly; the in-launch head gives the per-row outputs of the stand-alone head bit for bit."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_wide_ppo_composition_is_two_launches_into_the_callers_buffers(oracle, dev, monkeypatch, fused):
+    """N >= 64: ppo_mixture_fwd_bwd composes [forward + PPO head in one launch] -> backward (`fused` = False; with the
+    one-launch form of round 5 on -- 64 <= N <= 256 -- the same call is ONE launch); every result lands in `out` directly;
+    the in-launch head gives the per-row outputs of the stand-alone head bit for bit."""
     from pfpn_amd import kernels
+    monkeypatch.setattr(kernels, "WIDE_FUSED", fused)
     B, A, N = 300, 8, 128
     logits, x, loc, logstd = make_inputs(oracle, B, A, N, 77, spread=1.0)
     rng = np.random.default_rng(3)

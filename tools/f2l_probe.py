@@ -51,9 +51,11 @@ def main():
     ap.add_argument("--rows", type=int, default=8192)
     ap.add_argument("--dbias", action="store_true")
     ap.add_argument("--no-time", action="store_true")
+    ap.add_argument("--dims", type=int, default=128)
+    ap.add_argument("--particles", type=int, default=256)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    B, A, N = args.rows, 128, 256
+    B, A, N = args.rows, args.dims, args.particles
     g = torch.Generator(device=dev).manual_seed(11)
     logits, dlogits = kernels.stream_pair(B, A * N, dev)
     logits.normal_(generator=g)
