@@ -185,6 +185,20 @@ def _dig(o, *path):
     return _sig(o, 4) if isinstance(o, float) else o
 
 
+def wall_ms(call, n, windows=3):
+    """Wall-clock ms per call of an informational block (NOT the headline, whose K steps are timed once as the contract says):
+    the quietest of three windows of n calls, so that one host hiccup does not end up in the line."""
+    import torch
+    best = float("inf")
+    for _ in range(windows):
+        t_s = time.perf_counter()
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t_s) / n * 1e3)
+    return best
+
+
 def digest(out):
     """<= 600 bytes: the figures the review reads first"""
     d = {"stress_fwd": _dig(out, "roofline_stress", "fwd", "frac"), "stress_bwd": _dig(out, "roofline_stress", "bwd", "frac"),
@@ -1091,22 +1105,14 @@ def main():
                     for _ in range(4):
                         sstep()
                     torch.cuda.synchronize()
-                    t_s = time.perf_counter()
-                    for _ in range(25):
-                        sstep()
-                    torch.cuda.synchronize()
-                    sms = (time.perf_counter() - t_s) / (25 * SK) * 1e3
+                    sms = wall_ms(sstep, 10) / SK
                     # the same step as ONE step per replay with its noise drawn by a launch of its own between replays -- the
                     # form the off-policy worker runs (one learner step per environment step, `workers/ddpg.py`)
                     s1 = graphs.GraphedLearnerStep(snet, sopt, *sb, noise=snet.make_train_noise(SB))
                     for _ in range(5):
                         s1()
                     torch.cuda.synchronize()
-                    t_s = time.perf_counter()
-                    for _ in range(100):
-                        s1()
-                    torch.cuda.synchronize()
-                    sms1 = (time.perf_counter() - t_s) / 100 * 1e3
+                    sms1 = wall_ms(s1, 40)
                     del s1
                     s_nodes = sstep.kernel_nodes()         # (None where the runtime cannot print a captured graph: this image)
                     s_launches, s_src = (s_nodes / SK, "kernel nodes of the captured %d-step hipGraph / %d" % (SK, SK)) \
@@ -1184,11 +1190,7 @@ def main():
                 for _ in range(3):
                     cstep()
                 torch.cuda.synchronize()
-                t_c = time.perf_counter()
-                for _ in range(8):
-                    cstep()
-                torch.cuda.synchronize()
-                cms = (time.perf_counter() - t_c) / (8 * CK) * 1e3
+                cms = wall_ms(cstep, 4) / CK
                 cl3 = cnet.train_out["loss3"].cpu().numpy()
                 mac = S * 2048 + 2 * 1024 * 512 + 512 * cA * cN
                 flops = 2.0 * cB * (mac + S * 2048 + 2 * 2 * 1024 * 512 + 2 * 512 * cA * cN)

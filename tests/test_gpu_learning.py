@@ -6,7 +6,8 @@ path (`main.parse` -> `main.build` -> `model.start`: per-step `run()`, GAE, `fla
 resample tick) trains on the synthetic DeepMimic-shaped environment and the test looks at it from outside (tests/_learning.py):
 
 * DPPO-PFPN, three of benchmark.sh's seeds: the return of the last episodes exceeds the first ones' AND a frozen
-  random-init policy's by a stated margin; A3C-PFPN likewise (a path with no reference graph behind the oracle);
+  random-init policy's by a stated margin; A3C-PFPN likewise (a path with no reference graph behind the oracle); DPPO-PFPN
+  with 64 particles per action dim likewise -- the N >= 64 kernels, the one-launch PPO pass in every learner step;
 * resample ticks fire IN training with naturally dead particles (statistics from the rollouts, never hand-set), keep the
   unnormalised mixture mass of {source + clones}, copy the source's weight column, move only dead particles; particles leave
   the initial grid; nothing goes non-finite;
@@ -38,6 +39,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(ROOT, "gpurun_out", "learning.jsonl")
 SEEDS = (34114, 33406, 35723)                # benchmark.sh:13-15
 DPPO_STEPS, A3C_STEPS = (6000, 5000, 5000), 6000       # (the first run is the one whose end state the parity tests use)
+WIDE_STEPS = 6000                            # the 64-particle run (the N >= 64 kernels)
 MARGIN = 80.0                                # return units (600-step episodes: random ~385, best state-blind policy ~590)
 
 
@@ -82,6 +84,38 @@ def a3c_run(dev):
     return worker, rec
 
 
+@pytest.fixture(scope="module")
+def wide_run(dev):
+    """DPPO-PFPN with 64 particles per action dim: the N >= 64 kernels, and the clipped-PPO pass of every learner step as the
+    ONE launch of round 5 (pfpn_ppo_wide_fused: the waves of a row chunk meet through the XCD's L2).  Every call of the entry
+    point is recorded with its return code (0 = the fused launch ran, 1 = not this shape: the two-launch composition)."""
+    import _learning
+    from pfpn_amd import _lib
+    lib, calls = _lib.load(), []
+
+    class Spy(object):
+        def __getattr__(self, name):
+            f = getattr(lib, name)
+            if name != "pfpn_ppo_wide_fused":
+                return f
+
+            def g(*a):
+                rc = f(*a)
+                calls.append(rc)
+                return rc
+            return g
+    plain = _lib.load
+    _lib.load = lambda: Spy()
+    try:
+        worker, rec = _learning.launch("dppo", SEEDS[0], WIDE_STEPS, worker_over={"lr_actor": 5e-4},
+                                       net_over={"resample_interval": 150}, particles=64)
+    finally:
+        _lib.load = plain
+    _note(dict(_line("dppo_64_particles_seed%d" % SEEDS[0], worker, rec), fused_entry_calls=len(calls),
+               fused_entry_refusals=sum(1 for c in calls if c != 0)))
+    return worker, rec, calls
+
+
 def _check_learned(rec, frozen_mean, tag):
     r = rec.returns(full_length=600)
     assert len(r) >= 100 and rec.finite, tag
@@ -108,10 +142,23 @@ def test_a3c_pfpn_learns(dppo_runs, a3c_run):
     assert rec.grid_moved == 36 * 35 and rec.grid_shift > 1e-3
 
 
-def test_resample_ticks_fire_in_training_with_naturally_dead_particles(dppo_runs, a3c_run):
+def test_dppo_pfpn_learns_through_the_one_launch_ppo_pass(dppo_runs, wide_run):
+    """64 particles per action dim: every learner step's mixture work is the wide kernels' and its clipped-PPO pass is
+    k_mix_wide_f2l (the entry point answered 0 every time it was asked: at capture and on every eager step)."""
+    worker, rec, calls = wide_run
+    assert worker.global_step >= WIDE_STEPS and worker.global_net.particles == 64
+    assert len(calls) >= 1 and all(c == 0 for c in calls), calls[:8]
+    frozen = dppo_runs[1].returns(full_length=600)     # (random-init mixture policy: uniform weights on a uniform grid)
+    _check_learned(rec, float(frozen.mean()), "dppo, 64 particles")
+    assert rec.grid_moved == 36 * 64 and rec.grid_shift > 1e-3
+
+
+def test_resample_ticks_fire_in_training_with_naturally_dead_particles(dppo_runs, a3c_run, wide_run):
     recs = [rec for _, rec in dppo_runs[0]] + [a3c_run[1]]
     ticks = [t for rec in recs for t in rec.ticks]
     assert len(ticks) >= sum(n // 150 for n in DPPO_STEPS) + A3C_STEPS // 300
+    ticks += wide_run[1].ticks       # (64 particles: the threshold is 0.05 / 64 -- whether one dies inside the run depends on
+    #                                   the trajectory; profiles/r05_learning.json has runs with 47 ... 504 dead per tick)
     dead = [t for t in ticks if t["dead"] > 0]
     assert len(dead) >= 2 and sum(t["groups"] for t in dead) >= 4, [t["dead"] for t in ticks]
     for t in ticks:

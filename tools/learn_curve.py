@@ -1,7 +1,7 @@
 """Learning curves of the assembled learner through the real launcher (tests/_learning.py), written as JSON lines.
 
   python tools/learn_curve.py dppo:34114:4000 dppo:34114:300:frozen sac:33406:6000 a3c:3:3000 --out gpurun_out/learn.jsonl \
-      [--net resample_interval=150] [--worker lr_actor=3e-4]
+      [--net resample_interval=150] [--worker lr_actor=3e-4] [--particles 128]
 
 Every positional is family:seed:max_iterations[:frozen].  One line per run: the settings, every episode's return
 (20-episode means as `curve`), every resample tick that fired with its naturally dead particles and the mass check,
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--net", action="append")
     ap.add_argument("--worker", action="append")
     ap.add_argument("--group", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=35)     # (>= 64: the wide kernels and the one-launch PPO pass)
     args, _ = ap.parse_known_args()
     import _learning
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
@@ -42,10 +43,10 @@ def main():
         frozen = len(parts) > 3 and parts[3] == "frozen"
         t0 = time.time()
         worker, rec = _learning.launch(family, seed, iters, worker_over=kv(args.worker), net_over=kv(args.net),
-                                       frozen=frozen, quiet=False)
+                                       frozen=frozen, quiet=False, particles=args.particles)
         r = rec.returns()
         g = args.group
-        line = {"run": spec, "net": kv(args.net), "worker": kv(args.worker), "global_step": int(worker.global_step),
+        line = {"run": spec, "particles": args.particles, "net": kv(args.net), "worker": kv(args.worker), "global_step": int(worker.global_step),
                 "env_steps": int(worker.total_samples), "seconds": round(time.time() - t0, 1), "finite": rec.finite,
                 "curve": [round(float(r[i:i + g].mean()), 2) for i in range(0, len(r) - g + 1, g)],
                 "summary": rec.summary(), "ticks": rec.ticks,
