@@ -676,7 +676,7 @@ def main():
             with torch.cuda.stream(side_):
                 call()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g_, stream=side_):
+                with torch.cuda.graph(g_, stream=side_, **graphs._capture_mode()):
                     for _ in range(per_graph):
                         call()
             torch.cuda.synchronize()
@@ -708,7 +708,7 @@ def main():
             with torch.cuda.stream(side):
                 call()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g, stream=side):
+                with torch.cuda.graph(g, stream=side, **graphs._capture_mode()):
                     for _ in range(per_graph):
                         call()
             torch.cuda.synchronize()
@@ -817,7 +817,7 @@ def main():
                 with torch.cuda.stream(sideq):
                     callq()
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(gqr, stream=sideq):
+                    with torch.cuda.graph(gqr, stream=sideq, **graphs._capture_mode()):
                         for _ in range(10):
                             callq()
                 torch.cuda.synchronize()

@@ -79,7 +79,9 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
 /* pfpn_logprob_fwd_ppo + pfpn_logprob_bwd(_bias) of a wide particle grid (64 <= N <= 256, N % 4 == 0, A % 4 == 0, A <= 128, a
  * batch of at least 8 row chunks of 4 rows) as ONE launch that reads the logits once and writes dlogits once (reference networks/utils.py:108-134 +
  * its autodiff, ppo.py:31-54, actor_critic.py:132-184): the waves of a row chunk exchange their per-dimension log p through
- * memory once per four rows (k_mix_wide_f2l; 415 us against 598 us for 8192 x 128 x 256).  Same outputs as the two entry points
+ * memory once per four rows (k_mix_wide_f2l; 379 us against 598 us for 8192 x 128 x 256).  A row chunk = (B + C - 1) / C CONSECUTIVE
+ * rows, which a wave addresses through one 32-bit buffer window: PFPN_ERR_ARG when a chunk's rows span 2 GiB or more
+ * (> 16384 rows per chunk at A * N = 32768).  Same outputs as the two entry points
  * (+ dlogp [B] = d loss / d logp); sums in a fixed order: bitwise reproducible run to run, equal to the two-launch composition to
  * summation order.  dbias optional (NULL: no bias plane).  *chunks_out (optional) receives the chunk count.
  * CONCURRENCY: the waves of a row chunk wait for each other, so a chunk's blocks (8 * A / 4 consecutive blocks of the dispatch

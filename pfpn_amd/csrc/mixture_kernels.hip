@@ -919,6 +919,7 @@ __device__ __forceinline__ float4 ld4_stream(const float* p) {
 // gfx940+) and is visible to hipcc's waitcnt pass (an asm store is not; a volatile store, `sc0 sc1`, makes hipcc drain
 // vmcnt(0) in front of every store).
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
+typedef float f3v __attribute__((ext_vector_type(3)));
 template <bool NT>
 __device__ __forceinline__ void st4_row(float* row, int seg_bytes, int q, float a, float b, float c, float d) {
     if (NT) {
@@ -1400,8 +1401,8 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 
 // =====================================================================================================================
 // The clipped-PPO learner pass of the 256-particle shapes as ONE launch that reads the logits once and writes dlogits once
-// (2L; round 5).  The composition [forward + PPO head] -> backward reads the logits twice (3L): 598 us for 8192 x 128 x 256;
-// this kernel: 415-429 us (tools/f2l_probe.py, profiles/r05_wide_2l_probe.txt).
+// (2L; round 5).  The composition [forward + PPO head] -> backward reads the logits twice (3L): 598-617 us for 8192 x 128 x 256;
+// this kernel: 379-390 us = 0.70-0.71 of 8 TB/s on its own 2.15 GB (tools/f2l_probe.py, profiles/r05_wide_2l_probe.txt).
 //
 // The obstacle is the row sum: log p of a row = the sum over its A action dims, and the wide kernels give every action dim to
 // its own wave (bank + gradient accumulators of ONE dim in registers while it walks the rows): A = 128 waves on 32 blocks.  Here
@@ -1409,24 +1410,40 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 //   * a block's four waves add their per-dim log p in LDS (fixed order); wave 0 publishes ONE 32-byte entry per block -- two
 //     16-byte stores {l0, l1, tag, 0 | l2, l3, tag, 0}, tag = the group's sequence number.  A half is valid exactly when its
 //     own tag says so: no ordering between stores is needed (16-byte stores are observed untorn on gfx950);
-//   * every wave sweeps the chunk's A / 4 entries (1 KiB at A = 128) with `sc1` loads (they bypass the CU's L1), finds every
-//     tag equal to the sequence it waits for (else polls again, bounded), adds the partials in a fixed order, runs the PPO head
-//     on the four row totals (redundantly: uniform scalar work) and finishes the backward of THAT group from the e / e*phi it
-//     kept in registers;
+//   * every wave sweeps the chunk's A / 4 entries with ONE `sc1` load (it bypasses the CU's L1; lanes 0..31 the first halves,
+//     lanes 32..63 the second), finds every tag equal to the sequence it waits for (else polls again, bounded), adds the
+//     partials in a fixed order (one lane swap + four DPP steps), runs the PPO head on the four row totals (once: lane l works
+//     on row l >> 4) and finishes the backward of THAT group from the e / e*phi it kept in registers;
 //   * two groups are in flight per wave: forward of group k, then the backward of group k - 1 with the poll issued at the end
-//     of iteration k - 1 (compiler-visible raw buffer loads: waited for with a counted vmcnt exactly where first used, behind
-//     the forward math).  Four slots per (chunk, block), group g in slot g % 4: a wave that writes group k has passed its wait
+//     of iteration k - 1.  Four slots per (chunk, block), group g in slot g % 4: a wave that writes group k has passed its wait
 //     for group k - 1, so every wave of the chunk has published k - 1, i.e. finished reading k - 2 -- and k - 4.
 // Where the exchange lives decides everything (measured, same kernel): write-through stores + memory-side loads -- correct
 // under any placement -- 704-850 us (every wave of a chunk re-reads the chunk's partials from the memory side once per group:
 // 1 GiB of loads on a few hot lines; a tagged hand-off costs ~3 us under streaming load, MI355X_MICROARCH.md row
 // handoff-1to1); the same with atomics on one arrival counter per chunk: 6.8 ms (128 arrivals serialise).  Plain stores + `sc1`
-// loads keep the exchange INSIDE the chunk's XCD (the stores stay in that XCD's L2, which serves the loads): 448 us (415 us with
-// the per-row tails computed once per group: at 2 waves per SIMD the kernel had become VALU-bound).  That
+// loads keep the exchange INSIDE the chunk's XCD (the stores stay in that XCD's L2, which serves the loads): 448 us.  That
 // needs all waves of a chunk on one XCD.  Blocks are dealt to the XCDs round-robin (observed, not promised), so a chunk takes
 // the blocks of one blockIdx % 8 class -- and the kernel CHECKS: before the first group every block publishes its XCC id the
 // safe way (`sc1` store, memory-side); a chunk whose blocks do not all report the same id runs the safe exchange (slow,
 // correct) instead.
+// What bounds it after that is the wave's own instruction stream at two waves per SIMD, and in it the VECTOR-MEMORY
+// instructions count several times over (measured with alternating builds on one box, profiles/r05_wide_2l_probe.txt):
+//   448 -> 415 us   the per-row tails (v_rcp, v_log, the PPO head with its expf) once per group on lane-distributed rows;
+//   415 -> 392 us   a chunk takes CONSECUTIVE rows and addresses them through ONE buffer window per wave (a
+//                   row that does not exist loads zeros and stores nothing: no clamps, no per-row address arithmetic --
+//                   ~250 -> ~100 SALU instructions per group), x and the head's four row scalars arrive in one
+//                   lane-distributed load, the exchange is polled by one load instead of two, and nothing is issued that is
+//                   then dropped.  On the way: nine more (mostly out-of-range, i.e. dropped) memory instructions per group
+//                   cost +6 %, as much as 150 scalar instructions fewer gave back; exact vmcnt waits (every access
+//                   unconditional, a true two-iteration prefetch distance) gave nothing by themselves; a second, early poll
+//                   in front of the iteration's loads served 45 % of the groups and still lost 3 %; without the lock-step
+//                   of the exchange (diagnostic build, wrong results) the kernel is SLOWER (430 us): the waves of a chunk
+//                   reading one row together is what the memory system likes; without its dlogits stores it runs 315 us,
+//                   the box's copy kernel moves the same bytes in 358 us;
+//   392 -> 379 us   the ORDER of the memory instructions (vmcnt retires loads and stores together, in order): a group's row
+//                   stores and the prefetch are issued after the exchange's poll, at the top of the next iteration, so that the
+//                   wait for the poll is not a wait for them; and the first look at a poll sits outside the retry loop (merged
+//                   with the loop's back edge its wait came out as vmcnt(0)).
 // The waves of a chunk wait for each other, so the whole grid must be resident at once: the host sizes C to the occupancy
 // query and nothing else may occupy the device meanwhile (the package launches on one stream).  Every wait is bounded; a
 // wave whose wait expired poisons its gradient slab with NaN (the step's global norm goes NaN: loud, not silent) and sets `err`.
@@ -1471,8 +1488,8 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     bool ok[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) ok[j] = FULLN || lane + 64 * j < nq;
-    const bool has0 = lane < nb;                             // lane l sweeps block entry l of its chunk
-    const int d0 = min(lane, nb - 1);
+    const bool has0 = (lane & 31) < nb;                      // lane l sweeps half (l >> 5) of block entry l & 31 of its chunk
+    const int d0 = min(lane & 31, nb - 1);
     bool alive = true;
     // ---- placement check: one safe (memory-side) exchange of the blocks' XCC ids ----
     const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(6164) & 15u;           // HW_REG_XCC_ID[3:0]
@@ -1512,8 +1529,23 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         }
     const float two_m64 = 5.421010862427522e-20f;
     const float hm = ppo.stats[0], hr = ppo.stats[1], hlo = ppo.stats[2], hhi = ppo.stats[3];
-    const int Rc = (B - c + C - 1) / C;                      // rows of chunk c
+    // A chunk takes CONSECUTIVE rows (the wide kernels deal rows round-robin): the chunk's rows are ONE window per wave -- a
+    // buffer descriptor over this wave's action-dim segment in the chunk's rows, row r at byte offset r * pitch in the VGPR
+    // offset (range-checked: a row that does not exist -- r < 0 in the first iteration, r >= Rc past the end -- loads zeros
+    // and stores nothing, with no clamp, no predicate and no address arithmetic on the scalar unit)
+    const int Rq = (B + C - 1) / C;
+    const int r0 = c * Rq;
+    const int Rc = max(0, min(B, r0 + Rq) - r0);             // rows of chunk c: r0 ... r0 + Rc - 1
     const int G = (Rc + U - 1) / U;                          // its groups of four rows
+    const unsigned pitch = (unsigned)AN * 4u;
+    const unsigned span = Rc > 0 ? (unsigned)(Rc - 1) * pitch + (unsigned)N * 4u : 0u;    // (< 2^31: the host checks)
+    const __amdgpu_buffer_rsrc_t r_lg = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(logits) + (size_t)r0 * AN + (size_t)a * N, 0, (int)span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dl = __builtin_amdgcn_make_buffer_rsrc(dlogits + (size_t)r0 * AN + (size_t)a * N, 0, (int)span, 0x00020000);
+    constexpr int OOB = 0x40000000;                          // an offset beyond any window: the hardware drops the access
+    unsigned qoff[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) qoff[j] = ok[j] ? 16u * (unsigned)(lane + 64 * j) : (unsigned)OOB;
     float ps = 0.f, vs = 0.f;                                // loss sums of this chunk's rows (kept by its wave a == 0)
 
     // what a group's backward needs from its forward (z is recomputed from x and the bank: two packed ops per pair)
@@ -1521,28 +1553,34 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     // wave_reduce4_dist leaves), so the per-row tails -- v_rcp, v_log, the whole PPO head with its expf -- run ONCE across the
     // four rows instead of four times on wave-uniform values; the backward reads the few scalars it needs with v_readlane
     struct St { v2f e[U][M][2], ef[U][M][2]; float x[U]; float p, inv_sum; float head; };
-    // a group's inputs: the logits quads, x, and the PPO head's four row scalars (adv, logp_old, value, value_old) of its four
-    // rows as ONE lane-distributed load (lane l: input l & 3 of row l >> 4; a quad-permute broadcast hands each lane its row's
-    // four) -- loaded with the prefetch, so that the head never issues a dependent load of its own (a first version did, and
-    // drained vmcnt(0) four times per group)
-    struct Ld { float4 l[U][M]; float x[U]; float head; };
-    const float* const head_src = (lane & 3) == 0 ? ppo.adv : (lane & 3) == 1 ? ppo.logp_old : (lane & 3) == 2 ? ppo.value
-                                                                                                              : ppo.value_old;
+    // a group's inputs: the logits quads, and ONE lane-distributed load of its rows' scalars: lane l holds input l & 15 of row
+    // l >> 4 -- 0..3 the PPO head's (adv, logp_old, value, value_old; a quad-permute broadcast hands each lane its row's four),
+    // 4 the row's action x[row, a] (read out with v_readlane) -- loaded with the prefetch, two iterations before its use
+    struct Ld { float4 l[U][M]; float xh; };
+    const int lj = lane & 15;
+    const float* const xh_src = lj == 0 ? ppo.adv : lj == 1 ? ppo.logp_old : lj == 2 ? ppo.value : lj == 3 ? ppo.value_old : x + a;
+    const unsigned xh_stride = lj < 4 ? 1u : (unsigned)A;
     auto load = [&](int g, Ld& d) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int b_ = min(c + (U * g + u) * C, B - 1);  // clamped: loads unconditional
-            const float* row_ = logits + (size_t)b_ * AN + (size_t)a * N;
+            const unsigned ro = (unsigned)(U * g + u) * pitch;
 #pragma unroll
-            for (int j = 0; j < M; ++j) d.l[u][j] = ld4_stream<STREAM>(row_ + 4 * (ok[j] ? lane + 64 * j : 0));
-            d.x[u] = x[(size_t)b_ * A + a];
+            for (int j = 0; j < M; ++j) {
+                const u4v q = __builtin_amdgcn_raw_buffer_load_b128(r_lg, ro + qoff[j], 0, STREAM ? 2 : 0);     // (2 = nt)
+                const f4v f = __builtin_bit_cast(f4v, q);
+                d.l[u][j] = make_float4(f.x, f.y, f.z, f.w);
+            }
         }
-        d.head = head_src[min(c + (U * g + (lane >> 4)) * C, B - 1)];
+        const unsigned row = min((unsigned)(r0 + U * g + (lane >> 4)), (unsigned)(B - 1));     // (no such row: any row's)
+        d.xh = xh_src[(size_t)row * xh_stride];
     };
     // forward of one group: e, e*phi kept; -> the group's four per-dim log p
     auto fwd = [&](const Ld& d, St& s, float& lpr) {
         float mx[U];
         v2f lp[U][M][2];
+        float xs[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xs[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d.xh), 16 * u + 4));
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             mx[u] = -INFINITY;
@@ -1566,7 +1604,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const v2f le = lp[u][j][h] - mx[u];
-                    const v2f z = (d.x[u] - b_loc2[j][h]) * b_isc2[j][h];
+                    const v2f z = (xs[u] - b_loc2[j][h]) * b_isc2[j][h];
                     const v2f arg = le + __builtin_elementwise_fma(-z, z, b_ct2[j][h]);
                     s.e[u][j][h] = (v2f){__builtin_amdgcn_exp2f(le.x), __builtin_amdgcn_exp2f(le.y)};
                     s.ef[u][j][h] = (v2f){__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
@@ -1586,12 +1624,15 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         s.p = p;
         lpr = __builtin_amdgcn_logf(p) * 0.6931471805599453f;               // (lane l: row l >> 4)
 #pragma unroll
-        for (int u = 0; u < U; ++u) s.x[u] = d.x[u];
-        s.head = d.head;
+        for (int u = 0; u < U; ++u) s.x[u] = xs[u];
+        s.head = d.xh;                                       // (a copy of a load two iterations old: no wait of its own)
     };
     // the exchange's stores and first-attempt loads are raw BUFFER accesses with the cache policy as an argument (16 = sc1):
-    // visible to hipcc's waitcnt pass, so a poll issued at the end of one iteration is waited for exactly where its values
-    // are first used -- behind the next group's forward math -- with a counted vmcnt, not a drain
+    // visible to hipcc's waitcnt pass (an asm load is not).  (vmcnt counts loads and stores together, in order, and wherever
+    // paths with different numbers of accesses merge hipcc must assume the fewest: with the exchange's stores behind a
+    // wave-uniform branch the loop's waits come out as vmcnt(0) at the poll.  Version 14 issued EVERY access unconditionally --
+    // out-of-range offsets for the ones that must not happen -- and got exact waits, vmcnt(24+) for a group's logits: a true
+    // two-iteration prefetch distance.  It was no faster, and the dropped accesses cost 6 %: see the header.)
     auto slot_rsrc = [&](int g) {
         // (the base through v_readfirstlane: a descriptor hipcc cannot prove wave-uniform costs a waterfall loop per access)
         const uintptr_t q = (uintptr_t)(sy.part + ((size_t)c * 4 + (g & 3)) * nb * 8);
@@ -1599,53 +1640,89 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
                              (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)q);
         return __builtin_amdgcn_make_buffer_rsrc((float*)qu, 0, nb * 32, 0x00020000);
     };
+    const __amdgpu_buffer_rsrc_t r_logp = __builtin_amdgcn_make_buffer_rsrc(sy.logp, 0, B * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dlogp = __builtin_amdgcn_make_buffer_rsrc(ppo.dlogp, 0, B * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dvalue = __builtin_amdgcn_make_buffer_rsrc(ppo.dvalue, 0, B * 4, 0x00020000);
     __shared__ float s_blk[2][4][U];
     auto publish = [&](int g, float lpr, bool real) {
         if ((lane & 15) == 0) s_blk[g & 1][wv][lane >> 4] = lpr;
         __syncthreads();                                     // (one per group; buffer g & 1 is rewritten two barriers later)
-        if (real && wv == 0 && lane == 0) {
-            float t[U];
+        float t[U] = {0.f, 0.f, 0.f, 0.f};
+        if (wv == 0) {                                       // (LDS only behind this branch)
 #pragma unroll
             for (int u = 0; u < U; ++u) t[u] = ((s_blk[g & 1][0][u] + s_blk[g & 1][1][u]) + s_blk[g & 1][2][u]) + s_blk[g & 1][3][u];
-            const float tag = __uint_as_float((unsigned)g + 1u);
-            const __amdgpu_buffer_rsrc_t r = slot_rsrc(g);
-            const u4v h0 = __builtin_bit_cast(u4v, (f4v){t[0], t[1], tag, 0.f}), h1 = __builtin_bit_cast(u4v, (f4v){t[2], t[3], tag, 0.f});
+        }
+        const float tag = __uint_as_float((unsigned)g + 1u);
+        const __amdgpu_buffer_rsrc_t r = slot_rsrc(g);
+        const u4v h0 = __builtin_bit_cast(u4v, (f4v){t[0], t[1], tag, 0.f}), h1 = __builtin_bit_cast(u4v, (f4v){t[2], t[3], tag, 0.f});
+        // (an access that is dropped still costs its issue and its pass through the address unit: only the block's first wave
+        // issues the entry's two stores -- a wave-uniform branch)
+        if (wv == 0) {
+            const int o = real && lane == 0 ? jb * 32 : OOB;
             if (local) {                                     // the line stays in this XCD's L2, which serves the readers
-                __builtin_amdgcn_raw_buffer_store_b128(h0, r, jb * 32, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(h1, r, jb * 32 + 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(h0, r, o, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(h1, r, o + 16, 0, 0);
             } else {                                         // write-through: readers on other XCDs find it on the memory side
-                __builtin_amdgcn_raw_buffer_store_b128(h0, r, jb * 32, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(h1, r, jb * 32 + 16, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(h0, r, o, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(h1, r, o + 16, 0, 16);
             }
         }
     };
-    auto poll_issue = [&](int g, f4v (&v)[2]) {
-        const __amdgpu_buffer_rsrc_t r = slot_rsrc(g);
-        v[0] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, d0 * 32, 0, 16));
-        v[1] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, d0 * 32 + 16, 0, 16));
+    // ONE load per wave sweeps the chunk's entries: lanes 0..31 the first halves {l0, l1, tag}, lanes 32..63 the second
+    // halves {l2, l3, tag} (the unused fourth dword is not loaded: a dead destination register is re-used at once, and the
+    // write to it waits for the load)
+    auto poll_issue = [&](int g, f3v& v) {
+#if defined(PFPN_F2L_NOX) && PFPN_F2L_NOX == 1
+        v = (f3v){0.f, 0.f, 0.f};
+        return;
+#endif
+        v = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(slot_rsrc(g), d0 * 32 + (lane >> 5) * 16, 0, 16));
     };
-    // the group's four row totals (every lane: the same bits) from a poll's values: every entry must carry the group's tag
-    // (else: poll again, bounded); the nb partials meet in the transposing butterfly (fixed order)
-    auto totals = [&](int g, f4v (&v)[2], float& tot) {               // -> lane l: the total of row l >> 4
+    // nb partials of four rows -> lane l: the total of row l >> 4, in a fixed order: the lane swap puts rows 0 / 1 (lanes
+    // 0..31's two values) and rows 2 / 3 (lanes 32..63's) into their rows of 16 lanes, four DPP steps finish inside the row
+    auto row_totals = [&](const f3v& v) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(has0 ? v.x : 0.f), __float_as_uint(has0 ? v.y : 0.f), false, false);
+        float k = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        k = row_step_ror8<false>(k);
+        k = row_step_ror4<false>(k);
+        k = row_step_xor2<false>(k);
+        return row_step_xor1<false>(k);
+    };
+    // the group's four row totals from a poll's values: every half entry must carry the group's tag (else: poll again, bounded)
+    auto totals = [&](int g, bool need, const f3v& v, float& tot) {       // -> lane l: the total of row l >> 4
         const unsigned want = (unsigned)g + 1u;
+        tot = 0.f;
+        if (!need) return;
         int it = 0;
-        while (true) {
-            const bool good = !has0 || (__float_as_uint(v[0].z) == want && __float_as_uint(v[1].z) == want);
-            if (__all(good) || !alive) break;
+#if defined(PFPN_F2L_NOX)                                    // DIAGNOSTIC build knob (wrong results): nobody waits for the chunk --
+        alive = alive && want == 0u;                         // what the lock-step of a chunk's 128 waves costs (1: no poll either)
+#endif
+        // the first look is at the iteration's own poll, outside the retry loop: its wait is then counted (the accesses issued
+        // since -- this iteration's row stores and prefetch -- stay in flight); merged with the loop's back edge, where the poll
+        // just issued is the youngest access of the wave, it came out as vmcnt(0)
+        if (__all(!has0 || __float_as_uint(v.z) == want)) {
+            tot = row_totals(v);
+            return;
+        }
+        f3v w = v;                                           // (retries into a register of their own: `v` is written by the
+        while (alive) {                                      //  iteration's poll and by nothing else -- no copies of a poll in flight)
             __builtin_amdgcn_s_sleep(1);
             if (++it > (1 << 18)) {                          // the grid was not co-resident (or a wave died): flagged, poisoned
                 alive = false;
                 __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            poll_issue(g, v);
+            poll_issue(g, w);
+            if (__all(!has0 || __float_as_uint(w.z) == want)) break;
         }
-        tot = wave_reduce4_dist<false>(has0 ? v[0].x : 0.f, has0 ? v[0].y : 0.f, has0 ? v[1].x : 0.f, has0 ? v[1].y : 0.f, lane);
+        tot = row_totals(w);
     };
-    // PPO head on a group's four rows (k_ppo_loss, term for term; ONCE, lane l working on row l >> 4) + the backward of the group
-    auto bwd = [&](int g, const St& s, float tot) {
+    // PPO head on a group's four rows (k_ppo_loss, term for term; ONCE, lane l working on row l >> 4) + the backward of the
+    // group: dlogits of its four rows into `dd` (stored by bwd_store).  Runs for group -1 (zero state) and for the group past the
+    // end (clamped rows) too: no row of theirs is live, so q = 0, nothing accumulates and every store falls out of range
+    auto bwd = [&](int g, const St& s, float tot, v2f (&dd)[U][M][2]) {
         const int ur = lane >> 4;
-        const int b_r = c + (U * g + ur) * C;
-        const bool live_r = b_r < B;
+        const int b_r = r0 + U * g + ur;
+        const bool live_r = (unsigned)(U * g + ur) < (unsigned)Rc;
         // the row's four head inputs out of its quad (lane l holds input l & 3 of row l >> 4)
         const float av = dpp_shift<0x00, 0xf>(s.head, 0.f), h_lpo = dpp_shift<0x55, 0xf>(s.head, 0.f);
         const float h_v = dpp_shift<0xAA, 0xf>(s.head, 0.f), h_vo = dpp_shift<0xFF, 0xf>(s.head, 0.f);
@@ -1659,11 +1736,15 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         if (a == 0 && live_r) {
             ps += fminf(sur, csur);                          // (lane l: the sums of rows l >> 4 of every group; joined at the end)
             vs += dvv * dvv;
-            if ((lane & 15) == 0) {
-                sy.logp[b_r] = tot;
-                ppo.dlogp[b_r] = gdl;
-                ppo.dvalue[b_r] = 2.f * dvv * ppo.value_coef * ppo.inv_B;
-            }
+        }
+        // (an access that is dropped still costs its issue and its pass through the address unit: the three per-row outputs
+        // are stored by the chunk's first wave only -- a wave-uniform branch; it makes the waits behind it conservative by three)
+        if (a == 0)
+        {
+            const int o3 = a == 0 && live_r && (lane & 15) == 0 ? 4 * b_r : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), r_logp, o3, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gdl), r_dlogp, o3, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(2.f * dvv * ppo.value_coef * ppo.inv_B), r_dvalue, o3, 0, 0);
         }
         const float q_ = live_r ? guard_finite(gdl * __builtin_amdgcn_rcpf(s.p)) : 0.f;
         const float qs_d = q_ * s.inv_sum;
@@ -1671,64 +1752,82 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         const float qs64_d = qs_d * two_m64;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int b = c + (U * g + u) * C;
-            const bool live = b < B;
-            const int bb = live ? b : B - 1;
             const float qp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qp_d), 16 * u));
             const float qs64 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qs64_d), 16 * u));
-            float* drow = dlogits + (size_t)bb * AN + (size_t)a * N;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                v2f d[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const v2f tt = s.ef[u][j][h] * qs64;
                     const v2f z = (s.x[u] - b_loc2[j][h]) * b_isc2[j][h];
-                    d[h] = __builtin_elementwise_fma(-s.e[u][j][h], (v2f){qp, qp}, tt);
-                    if (DBIAS) acc_b2[j][h] += d[h];
+                    dd[u][j][h] = __builtin_elementwise_fma(-s.e[u][j][h], (v2f){qp, qp}, tt);
+                    if (DBIAS) acc_b2[j][h] += dd[u][j][h];
                     acc_loc2[j][h] = __builtin_elementwise_fma(tt, z, acc_loc2[j][h]);
                     acc_ls2[j][h] = __builtin_elementwise_fma(
                         tt, __builtin_elementwise_fma(z * z, (v2f){PFPN_2LN2, PFPN_2LN2}, (v2f){-1.f, -1.f}), acc_ls2[j][h]);
                 }
-                if (live && ok[j]) st4_row<STREAM>(drow, 4 * N, lane + 64 * j, d[0].x, d[0].y, d[1].x, d[1].y);
+            }
+        }
+    };
+    auto bwd_store = [&](int g, const v2f (&dd)[U][M][2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            unsigned ro = (unsigned)(U * g + u) * pitch;
+#if defined(PFPN_F2L_NOSTORE)                                // DIAGNOSTIC build knob (wrong results): dlogits written for one row in 64
+            if ((U * g + u) & 63) ro = (unsigned)OOB;
+#endif
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const f4v v = {dd[u][j][0].x, dd[u][j][0].y, dd[u][j][1].x, dd[u][j][1].y};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r_dl, ro + qoff[j], 0, STREAM ? 16 : 0);
             }
         }
     };
 
-    // Two groups in flight: in iteration k the forward of group k, the totals of group k - 1 from the poll issued at the end of
-    // iteration k - 1, the next-but-one group's loads, the backward of group k - 1, the poll for group k.  (Three groups in
-    // flight: 496 us; the logits of two groups ahead: 455 us; this: 448 us.)  The forward runs unconditionally -- a guarded
-    // forward makes every register of its state a select -- and iteration G only finishes group G - 1.
-    Ld ln, lf;
-    St S0, S1;
-    f4v pv[2];
+    // Two groups in flight.  Iteration k: the row stores of group k - 2 (computed at the end of iteration k - 1), the forward of
+    // group k, the loads of group k + 2 into the buffer the forward has just consumed (two buffers taking turns by NAME: a copy
+    // of a freshly loaded register is a wait for the load), publish k, the totals of group k - 1 from the poll issued at the
+    // end of iteration k - 1, the head and the backward math of group k - 1, the poll for group k.  The ORDER of the memory
+    // instructions is the point: vmcnt retires loads and stores together, in order, so the wait for a poll is a wait for
+    // everything issued before it -- with the row stores and the prefetch issued AFTER the poll (at the top of the next
+    // iteration) instead of in front of it, the poll has a whole iteration's worth of older traffic ahead of it and nothing
+    // younger: 391 -> 379 us.  (Three groups in flight: 496 us; the logits of a third group ahead: 455 us against 448.)
+    // Forward and backward run unconditionally -- a guarded one makes every register of its state a select -- iteration 0 works
+    // on a zero state, iteration G (+ 1) on rows that load zeros, neither with a live row.
+    Ld La, Lb;
+    St S0 = {}, S1 = {};
+    f3v pv = {0.f, 0.f, 0.f};
+    v2f dd[U][M][2] = {};
     float lpr = 0.f, tot = 0.f;
-    load(0, ln);
-    load(1, lf);
-#if defined(PFPN_F2L_AHEAD) && PFPN_F2L_AHEAD == 2           // A/B build knob: the logits of TWO groups in flight per wave
-    Ld lg;
-    load(2, lg);
-#define PFPN_F2L_NEXT(K_) do { lf = lg; load((K_) + 3, lg); } while (0)
-#else
-#define PFPN_F2L_NEXT(K_) load((K_) + 2, lf)                 /* (rows past the end are clamped: harmless) */
-#endif
-#define PFPN_F2L_ITER(KK, CUR, OLD)                                                                          \
+    load(0, La);
+    load(1, Lb);
+    // (the prologue's loads are waited for HERE, once: the loop header merges this path with the back edge, and a load still in
+    // flight on this path -- with next to nothing behind it -- turns into waits at the top of EVERY iteration, vmcnt(8..1), i.e.
+    // for the row stores and the prefetch of the iteration before: 391 -> 402 us)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+            asm volatile("" ::"v"(La.l[u][j].x), "v"(La.l[u][j].y), "v"(La.l[u][j].z), "v"(La.l[u][j].w), "v"(Lb.l[u][j].x),
+                         "v"(Lb.l[u][j].y), "v"(Lb.l[u][j].z), "v"(Lb.l[u][j].w));
+    asm volatile("" ::"v"(La.xh), "v"(Lb.xh));
+#define PFPN_F2L_ITER(KK, CUR, OLD, LC)                                                                      \
     do {                                                                                                     \
         const int kk_ = (KK);                                                                                \
-        fwd(ln, CUR, lpr);                                   /* (past the last group: clamped rows, never used) */ \
+        bwd_store(kk_ - 2, dd);                              /* (computed at the end of the iteration before) */    \
+        fwd(LC, CUR, lpr);                                   /* (past the last group: rows that load zeros, never used) */ \
+        load(kk_ + 2, LC);                                   /* (into the buffer the forward has just consumed) */  \
         publish(kk_, lpr, kk_ < G);                                                                          \
-        if (kk_ >= 1 && kk_ - 1 < G) totals(kk_ - 1, pv, tot);                                               \
-        ln = lf;                                                                                             \
-        PFPN_F2L_NEXT(kk_);                                                                                  \
-        if (kk_ >= 1 && kk_ - 1 < G) bwd(kk_ - 1, OLD, tot);                                                 \
-        if (kk_ < G) poll_issue(kk_, pv);                                                                    \
+        totals(kk_ - 1, kk_ >= 1 && kk_ - 1 < G, pv, tot);                                                   \
+        bwd(kk_ - 1, OLD, tot, dd);                                                                          \
+        poll_issue(kk_, pv);                                                                                 \
     } while (0)
     for (int k = 0; k < G + 1; k += 2) {
-        PFPN_F2L_ITER(k, S0, S1);
-        PFPN_F2L_ITER(k + 1, S1, S0);
+        PFPN_F2L_ITER(k, S0, S1, La);
+        PFPN_F2L_ITER(k + 1, S1, S0, Lb);
     }
+    bwd_store(((G + 2) & ~1) - 2, dd);                       // the rows of the last iteration's backward
 #undef PFPN_F2L_ITER
-#undef PFPN_F2L_NEXT
 
     // ---- the chunk's loss sums; the last chunk adds the C pairs in chunk order (the tail of the forward's hand-off) ----
     if (a == 0) {                                            // rows l >> 4 = 0, 1, 2, 3 of the chunk's groups, in that order
@@ -2149,6 +2248,8 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     C &= ~7;                                                 // a chunk = the blocks of ONE blockIdx % 8 class
     while (C > 8 && C > (B + 3) / 4) C -= 8;
     if (C < 8 || C > (B + 3) / 4) return PFPN_ERR_ARG;       // (small batches: the two-launch composition)
+    // (a wave addresses its chunk's rows through ONE 32-bit buffer window)
+    if ((size_t)((B + C - 1) / C) * (size_t)A * (size_t)N * sizeof(float) >= ((size_t)1 << 31)) return PFPN_ERR_ARG;
     if (chunks_out) *chunks_out = C;
     const int AN = A * N;
     const int PLn = dbias ? 3 : 2;
