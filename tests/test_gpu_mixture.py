@@ -425,6 +425,26 @@ def test_wide_fused_pass_fails_loudly_when_its_waves_cannot_meet(oracle, dev, mo
     assert e3 == 0 and c3 == c0 and all(torch.equal(o0[k], o3[k]) for k in o0)
 
 
+def test_wide_fused_refuses_a_chunk_beyond_its_buffer_window(dev):
+    """A wave addresses its chunk's rows through ONE 32-bit buffer window: a batch whose chunks would span 2 GiB or more
+    (here 2^19 rows of 128 x 256: 32768 rows = 4 GiB per chunk at 16 chunks) is refused with PFPN_ERR_ARG before anything is
+    launched or touched (the caller composes the two launches) -- the pointers below are small dummies, never dereferenced."""
+    import ctypes
+    from pfpn_amd import _lib, kernels
+    lib = _lib.load()
+    B, A, N = 1 << 19, 128, 256
+    assert (B // 32) * A * N * 4 >= 1 << 31                  # even at the largest chunk count the form takes
+    t = torch.zeros(64, device=dev)
+    nbytes = int(lib.pfpn_mixture_workspace_bytes(B, A, N))
+    ws = kernels.workspace(nbytes, dev)
+    p = ctypes.c_void_p(t.data_ptr())
+    chunks = ctypes.c_int(-1)
+    rc = lib.pfpn_ppo_wide_fused(p, p, p, p, p, p, p, p, p, B, A, N, ctypes.c_float(0.2), ctypes.c_float(0.5), p, p, p, p, p, p,
+                                 None, p, ctypes.addressof(chunks), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
+    torch.cuda.synchronize()
+    assert rc == 1 and chunks.value == -1 and float(t.abs().sum()) == 0.0
+
+
 def test_wide_fused_is_what_the_learner_composition_takes(oracle, dev, monkeypatch):
     """ppo_mixture_fwd_bwd at a 256-particle shape takes the one-launch form by itself (PFPN_WIDE_FUSED=1, the default) and the
     two-launch composition where the form does not exist (a batch of fewer than 8 row chunks; A % 4 != 0)."""

@@ -22,8 +22,11 @@ for k, c in out.items():
     if w and c.get("SQ_WAVE_CYCLES"):
         c["derived"] = {"valu_instructions_per_wave": c.get("SQ_INSTS_VALU", 0) / w,
                         "trans_instructions_per_wave": c.get("SQ_INSTS_VALU_TRANS", 0) / w,
-                        "valu_active_share_of_wave_cycles": c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / c["SQ_WAVE_CYCLES"],
-                        "wait_any_share_of_wave_cycles": c.get("SQ_WAIT_ANY", 0) * 4 / c["SQ_WAVE_CYCLES"]}
+                        "salu_instructions_per_wave": c.get("SQ_INSTS_SALU", 0) / w,
+                        # (SQ_WAVE_CYCLES, SQ_ACTIVE_INST_* and SQ_WAIT_* all count 4-clock quads on gfx950: wave cycles x 4 / clock
+                        # = the kernel's duration)
+                        "valu_active_share_of_wave_cycles": c.get("SQ_ACTIVE_INST_VALU", 0) / c["SQ_WAVE_CYCLES"],
+                        "wait_any_share_of_wave_cycles": c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"]}
 print(json.dumps(out, indent=1))
 json.dump(out, open("gpurun_out/f2l_sq.json", "w"), indent=1)
 PY
