@@ -328,7 +328,8 @@ def test_wide_handoff_repairs_a_poisoned_workspace_and_refuses_a_short_one(oracl
 
 
 @pytest.mark.parametrize("B,A,N", [(517, 128, 256), (1030, 8, 256), (64, 12, 256), (4099, 4, 256),
-                                   (1030, 8, 128), (333, 20, 64), (77, 12, 100)])        # (N < 256: the lanes past N / 4 idle)
+                                   (1030, 8, 128), (333, 20, 64), (77, 12, 100),         # (N < 256: the lanes past N / 4 idle)
+                                   (33, 8, 256), (35, 4, 128)])       # (8 chunks of 5 consecutive rows: the last one is EMPTY)
 @pytest.mark.parametrize("safe", [0, 1, 2])
 def test_wide_fused_one_launch_ppo_pass(oracle, dev, monkeypatch, B, A, N, safe):
     """Round 5: the 256-particle PPO pass as ONE launch that reads the logits once (pfpn_ppo_wide_fused; the waves of a row
