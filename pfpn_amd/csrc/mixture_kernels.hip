@@ -1543,9 +1543,12 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         const_cast<float*>(logits) + (size_t)r0 * AN + (size_t)a * N, 0, (int)span, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_dl = __builtin_amdgcn_make_buffer_rsrc(dlogits + (size_t)r0 * AN + (size_t)a * N, 0, (int)span, 0x00020000);
     constexpr int OOB = 0x40000000;                          // an offset beyond any window: the hardware drops the access
-    unsigned qoff[M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) qoff[j] = ok[j] ? 16u * (unsigned)(lane + 64 * j) : (unsigned)OOB;
+    // a lane's offset in row r of the window; a lane past N / 4 (partial grids only) takes an offset no row offset can wrap back
+    // into the window (r < 0 gives 2^32 - k * pitch: far out of range by itself, but NOT after adding a constant like OOB)
+    auto voff = [&](int r, int j) {
+        const unsigned o = (unsigned)r * pitch + 16u * (unsigned)(lane + 64 * j);
+        return (FULLN || ok[j]) ? o : 0xFFFFFFF0u;
+    };
     float ps = 0.f, vs = 0.f;                                // loss sums of this chunk's rows (kept by its wave a == 0)
 
     // what a group's backward needs from its forward (z is recomputed from x and the bank: two packed ops per pair)
@@ -1563,10 +1566,9 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     auto load = [&](int g, Ld& d) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned ro = (unsigned)(U * g + u) * pitch;
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                const u4v q = __builtin_amdgcn_raw_buffer_load_b128(r_lg, ro + qoff[j], 0, STREAM ? 2 : 0);     // (2 = nt)
+                const u4v q = __builtin_amdgcn_raw_buffer_load_b128(r_lg, voff(U * g + u, j), 0, STREAM ? 2 : 0);     // (2 = nt)
                 const f4v f = __builtin_bit_cast(f4v, q);
                 d.l[u][j] = make_float4(f.x, f.y, f.z, f.w);
             }
@@ -1772,14 +1774,14 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     auto bwd_store = [&](int g, const v2f (&dd)[U][M][2]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            unsigned ro = (unsigned)(U * g + u) * pitch;
+            int r = U * g + u;
 #if defined(PFPN_F2L_NOSTORE)                                // DIAGNOSTIC build knob (wrong results): dlogits written for one row in 64
-            if ((U * g + u) & 63) ro = (unsigned)OOB;
+            if (r & 63) r = -1;
 #endif
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 const f4v v = {dd[u][j][0].x, dd[u][j][0].y, dd[u][j][1].x, dd[u][j][1].y};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r_dl, ro + qoff[j], 0, STREAM ? 16 : 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r_dl, voff(r, j), 0, STREAM ? 16 : 0);
             }
         }
     };
