@@ -271,7 +271,10 @@ class ActorCriticNetwork(object):
         for lo, hi in cover + [(end, end)]:
             if lo > pos:
                 nfl = (lo - pos) // 4
-                jobs.append(kernels.job_sqsum(pos, nfl, max(1, min(64, nfl // 16384))))
+                # (one block per 16384 floats, at most 512: a 16.8-M-float head gradient -- 128 x 256 particles -- behind 64
+                # blocks read its 67 MB at a quarter of the chip: 28 us for the launch; every segment up to 1 M floats keeps
+                # the block count, hence the bits, it had)
+                jobs.append(kernels.job_sqsum(pos, nfl, max(1, min(512, nfl // 16384))))
             pos = max(pos, hi)
         if len(jobs) > kernels.MAX_REDUCE_JOBS:
             for j in deferred:
