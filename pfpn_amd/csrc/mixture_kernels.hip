@@ -1557,8 +1557,10 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
     // four rows instead of four times on wave-uniform values; the backward reads the few scalars it needs with v_readlane
     struct St { v2f e[U][M][2], ef[U][M][2]; float x[U]; float p, inv_sum; float head; };
     // a group's inputs: the logits quads, and ONE lane-distributed load of its rows' scalars: lane l holds input l & 15 of row
-    // l >> 4 -- 0..3 the PPO head's (adv, logp_old, value, value_old; a quad-permute broadcast hands each lane its row's four),
-    // 4 the row's action x[row, a] (read out with v_readlane) -- loaded with the prefetch, two iterations before its use
+    // l >> 4 -- 0..3 the PPO head's (adv, logp_old, value, value_old: a quad-permute broadcast hands the FIRST quad of each
+    // row of 16 lanes its row's four; the head's results are only ever read from lanes 0 / 16 / 32 / 48, the other quads
+    // compute on whatever they hold), 4..15 the row's action x[row, a] (read out of lane 16 u + 4 with v_readlane) -- loaded
+    // with the prefetch, two iterations before its use
     struct Ld { float4 l[U][M]; float xh; };
     const int lj = lane & 15;
     const float* const xh_src = lj == 0 ? ppo.adv : lj == 1 ? ppo.logp_old : lj == 2 ? ppo.value : lj == 3 ? ppo.value_old : x + a;
@@ -1725,7 +1727,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
         const int ur = lane >> 4;
         const int b_r = r0 + U * g + ur;
         const bool live_r = (unsigned)(U * g + ur) < (unsigned)Rc;
-        // the row's four head inputs out of its quad (lane l holds input l & 3 of row l >> 4)
+        // the row's four head inputs out of the first quad of its 16 lanes (meaningful in lanes 16 u ... 16 u + 3 only)
         const float av = dpp_shift<0x00, 0xf>(s.head, 0.f), h_lpo = dpp_shift<0x55, 0xf>(s.head, 0.f);
         const float h_v = dpp_shift<0xAA, 0xf>(s.head, 0.f), h_vo = dpp_shift<0xFF, 0xf>(s.head, 0.f);
         const float nadv = clip_adv((av - hm) * hr, hlo, hhi);
