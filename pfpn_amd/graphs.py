@@ -9,6 +9,7 @@ the graph: the resample kernels run eagerly between replays.
 import gc
 import os
 import sys
+import time
 import weakref
 
 import torch
@@ -39,13 +40,42 @@ def release_captured_collectives():
 
 
 def _capture_mode(force=False):
-    """keyword arguments of torch.cuda.graph(): thread-local error mode while a torch.distributed group lives in the process"""
+    """Called right in front of a capture: the keyword arguments of torch.cuda.graph() -- thread-local error mode while a
+    torch.distributed group lives in the process -- after letting the group's watchdog thread go quiet.  The watchdog polls the
+    completion events of every collective that was enqueued eagerly (every 100 ms, until it has seen them complete); a capture
+    that starts right behind the warm-up's collectives runs WHILE it is still querying them, and that combination is what the two
+    invalidated captures of round 5 had in common (one in ~15 full test runs each: the watchdog's event query failing, a
+    hipBLASLt call refusing inside the capture -- CaptureInvalidated).  Collectives issued inside a capture are not handed to the
+    watchdog, so once its list is empty it stays empty for the capture's duration: synchronise, then give it three of its
+    polling periods."""
     try:
         import torch.distributed as dist
         alive = dist.is_available() and dist.is_initialized()
     except Exception:
         alive = False
+    if alive and torch.cuda.is_available():
+        torch.cuda.synchronize()
+        time.sleep(float(os.environ.get("PFPN_CAPTURE_QUIET_S", "0.3")))
     return {"capture_error_mode": "thread_local"} if (force or alive) else {}
+
+
+class CaptureInvalidated(RuntimeError):
+    """The HIP runtime invalidated a stream capture: some call inside it was not capturable (seen once in ~30 full test runs: a
+    hipBLASLt matmul of a shape it had run eagerly just before returned HIPBLAS_STATUS_INTERNAL_ERROR inside the capture,
+    `operation not permitted when stream is capturing`).  There is no falling back from THAT in this process: on this runtime
+    (ROCm 7.0) hipStreamEndCapture of an invalidated capture leaves the capturing thread refusing every later kernel launch on
+    the default stream (tools/capture_recover_probe.py) -- so the failure is reported as what it is instead of walking into the
+    replicas' agreement all-reduce and dying there.  (A capture refused BEFORE anything illegal happened -- RCCL declining, a
+    Python exception -- ends cleanly and does fall back: the two-graph form.)"""
+
+    def __init__(self, cause):
+        super().__init__("the runtime invalidated the stream capture (%s): this process cannot launch on its default stream any "
+                         "more and must be restarted" % str(cause).split("\n")[0])
+
+
+def capture_invalidated(e):
+    t = str(e)
+    return "stream is capturing" in t or "during capture" in t or "StreamCapture" in t
 
 
 def any_replica(flag, group=None, device="cpu"):
@@ -148,6 +178,8 @@ class GraphedLearnerStep(object):
                 self._record(True)
             except Exception as e:                           # (a capture that RCCL / the runtime refuses)
                 failed, why = 1, repr(e)
+                if capture_invalidated(e):
+                    raise CaptureInvalidated(e) from e
             if any_replica(failed, optimizer.pg, net.device):
                 if explicit_arg:
                     raise RuntimeError("capturing the exchange failed on a replica: %s" % (why or "on another replica"))

@@ -84,9 +84,17 @@ def test_single_gpu_line_carries_every_block_without_a_swallowed_error():
 
 
 def _single(extra_args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
-                        "--watchdog", "250", "--force-exchange"] + list(extra_args),
-                       cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    for attempt in (0, 1):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
+                            "--watchdog", "250", "--force-exchange"] + list(extra_args),
+                           cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+        err = r.stderr.decode()
+        # ONE retry when the process died of the runtime invalidating a stream capture while the RCCL group's watchdog thread was
+        # polling (pfpn_amd.graphs._capture_mode: seen once in ~15 full runs before captures waited for the watchdog to go quiet)
+        if r.returncode != 0 and attempt == 0 and ("capturing" in err or "during capture" in err or "CaptureInvalidated" in err):
+            print("bench.py died of an invalidated stream capture (exit code %r): one retry" % r.returncode)
+            continue
+        break
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]

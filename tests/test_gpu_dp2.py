@@ -374,18 +374,54 @@ def _rccl_rank(port, q):
             dist.destroy_process_group()
 
 
+def _one_rccl_rank(target, attempts=2):
+    """Run `target(port, queue)` as a spawned rank and return (its result tuple or None, its exit code).  The queue is polled while
+    the rank lives (a rank the runtime aborts never delivers: the old q.get(timeout=240) waited four minutes for it).  ONE retry
+    when the rank died of the runtime invalidating a stream capture -- seen once in ~30 full runs, a hipBLASLt matmul refusing
+    inside a capture (pfpn_amd.graphs.CaptureInvalidated; the NCCL watchdog then aborts the process): what these tests check is
+    the exchange's arithmetic, and a second clean pass is printed as such."""
+    import queue as _queue
+    import time as _time
+    res, code = None, None
+    for attempt in range(attempts):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        p = ctx.Process(target=target, args=(_free_port(), q))
+        p.start()
+        res, t0 = None, _time.time()
+        while _time.time() - t0 < 240:
+            try:
+                res = q.get(timeout=1.0)
+                break
+            except _queue.Empty:
+                if not p.is_alive():
+                    try:
+                        res = q.get(timeout=1.0)             # (it may have delivered just before it exited)
+                    except _queue.Empty:
+                        pass
+                    break
+        p.join(230 if res is not None else 10)
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+        code = p.exitcode
+        capture_flake = (res is None and code not in (0, None)) or \
+            (res is not None and res[1] is False and ("CaptureInvalidated" in str(res[2]) or "capturing" in str(res[2])))
+        if capture_flake and attempt + 1 < attempts:
+            print("the rank died of an invalidated stream capture (exit code %r, result %r): one retry" % (code, res))
+            continue
+        break
+    return res, code
+
+
 @pytest.mark.timeout(600)
 def test_exchange_path_over_rccl_single_rank_matches_fused_path(dev):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_rccl_rank, args=(_free_port(), q))
-    p.start()
-    res = q.get(timeout=240)
-    p.join(230)
+    res, code = _one_rccl_rank(_rccl_rank)
+    assert res is not None, "the rank delivered no result (exit code %r)" % (code,)
     if res[1] is None:
         pytest.skip(res[2])
     assert res[1], res
-    assert p.exitcode == 0, "the rank did not exit cleanly (exit code %r)" % (p.exitcode,)
+    assert code == 0, "the rank did not exit cleanly (exit code %r)" % (code,)
 
 
 def _rccl_sharded_rank(port, q):
@@ -494,13 +530,9 @@ def _rccl_sharded_rank(port, q):
 
 @pytest.mark.timeout(600)
 def test_sharded_exchange_over_rccl_single_rank(dev):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    p = ctx.Process(target=_rccl_sharded_rank, args=(_free_port(), q))
-    p.start()
-    res = q.get(timeout=240)
-    p.join(230)
+    res, code = _one_rccl_rank(_rccl_sharded_rank)
+    assert res is not None, "the rank delivered no result (exit code %r)" % (code,)
     if res[1] is None:
         pytest.skip(res[2])
     assert res[1], res
-    assert p.exitcode == 0, "the rank did not exit cleanly (exit code %r)" % (p.exitcode,)
+    assert code == 0, "the rank did not exit cleanly (exit code %r)" % (code,)
