@@ -21,8 +21,10 @@
  *  - reductions over the batch use fixed-order partial slabs: results are bitwise reproducible.
  *
  * Concurrency (what may be in flight at the same time, on different streams of one process)
- *  - NO entry point keeps state in the library: every intermediate (partial slabs, in-launch hand-off tickets, staging)
- *    lives in memory the caller hands in -- the outputs and `workspace`.  Two calls are independent, and may run
+ *  - NO entry point keeps state of a CALL in the library: every intermediate (partial slabs, in-launch hand-off tickets,
+ *    staging) lives in memory the caller hands in -- the outputs and `workspace`.  (The library's only process-wide memory
+ *    is a per-device cache of device properties -- CU count, one occupancy figure, the > 64 KB LDS opt-in -- keyed by
+ *    hipGetDevice() and filled on first use with values that do not depend on the call.)  Two calls are independent, and may run
  *    concurrently on two streams, exactly when they share no output and no workspace; a workspace is exclusive to one
  *    call at a time (calls that reuse it must be ordered: same stream, or events).  Read-only inputs may be shared.
  *  - A workspace needs no initialisation and keeps no meaning between calls: the mixture entry points zero the hand-off
@@ -86,15 +88,19 @@ int pfpn_logprob_fwd_ppo(const float* logits, const float* action, const float* 
  * summation order.  dbias optional (NULL: no bias plane).  *chunks_out (optional) receives the chunk count.
  * CONCURRENCY: the waves of a row chunk wait for each other, so a chunk's blocks (8 * A / 4 consecutive blocks of the dispatch
  * order) must be resident together: the entry point sizes the grid to the device's occupancy, and NOTHING else may occupy the
- * device while it runs (not a second call on another stream, not another kernel).  Every in-kernel wait is bounded (~0.2 s):
- * on expiry the gradients come out NaN and word 65 of the workspace's ticket area is set -- a loud failure, not a hang
- * (tests/test_gpu_mixture.py forces it).  PFPN_ERR_ARG for shapes outside the form (compose the two
- * entry points). */
+ * device while it runs (not a second call on another stream, not another kernel, not another process's work: on a SHARED
+ * GPU compose the two entry points instead -- the Python package: PFPN_WIDE_FUSED=0).  Every in-kernel wait is bounded
+ * (~0.2 s): on expiry the gradients come out NaN, word 65 of the workspace's ticket area is set (that word is zeroed in
+ * front of the next launch) AND 1 is OR-ed into *fault_flag -- a device word the CALLER owns, zeroes once and reads wherever it
+ * synchronises anyway (loss read-back, checkpoint): nothing in the library ever clears it, so one expired launch stays
+ * visible however many launches follow (NULL: no sticky record).  A loud failure, not a hang (tests/test_gpu_mixture.py
+ * forces it).  PFPN_ERR_ARG for shapes outside the form (compose the two entry points). */
 int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* loc, const float* logstd,
                         const float* logp_old, const float* adv, const float* value, const float* value_old,
                         const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
                         float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue, float* dlogp,
-                        float* dbias, float* loss3, int* chunks_out, void* workspace, size_t workspace_bytes, void* stream);
+                        float* dbias, float* loss3, int* chunks_out, uint32_t* fault_flag,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* TF autodiff of the above incl. the NaN/Inf guard of utils.py:109-117.
  * dlogp [B] in; dlogits [B,A*N], dloc [A,N], dlogstd [A,N] out (overwritten, not accumulated);

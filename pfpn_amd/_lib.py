@@ -18,7 +18,7 @@ _CT = {
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p, "const int32_t*": ctypes.c_void_p,
     "int32_t*": ctypes.c_void_p, "const int64_t*": ctypes.c_void_p, "int64_t*": ctypes.c_void_p,
     "const uint8_t*": ctypes.c_void_p, "uint8_t*": ctypes.c_void_p,
-    "const uint64_t*": ctypes.c_void_p, "uint64_t*": ctypes.c_void_p,
+    "const uint64_t*": ctypes.c_void_p, "uint64_t*": ctypes.c_void_p, "uint32_t*": ctypes.c_void_p,
     "const long long*": ctypes.c_void_p, "long long*": ctypes.c_void_p, "const PfpnReduceJob*": ctypes.c_void_p,
     "const PfpnStatePrologue*": ctypes.c_void_p, "const PfpnSacLoss*": ctypes.c_void_p,
     "const PfpnEpilogueJob*": ctypes.c_void_p,

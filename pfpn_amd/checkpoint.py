@@ -338,6 +338,8 @@ def network_tensors(net, optimizer=None, n_workers=0, total_samples=0, episodes=
     """Everything the reference's Saver stores for a DPPO-PFPN run, under the reference's names.
     `n_workers` > 0 also writes the per-worker local copies (`worker_k/...`) the reference graph expects."""
     cpu = lambda t: t.detach().cpu().numpy()
+    from . import kernels
+    kernels.check_faults()          # never write the parameters of a run a waiting kernel has poisoned (kernels.DeviceFault)
     out = OrderedDict()
     var = net.variables()
     for name, t in var.items():

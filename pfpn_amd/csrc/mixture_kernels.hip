@@ -22,6 +22,7 @@
 // a fixed-order finalize kernel: results are bitwise reproducible (no float atomics).
 #include "pfpn_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace pfpn {
 
@@ -1447,10 +1448,15 @@ __global__ __launch_bounds__(256) void k_mix_wide(
 // The waves of a chunk wait for each other, so the whole grid must be resident at once: the host sizes C to the occupancy
 // query and nothing else may occupy the device meanwhile (the package launches on one stream).  Every wait is bounded; a
 // wave whose wait expired poisons its gradient slab with NaN (the step's global norm goes NaN: loud, not silent) and sets `err`.
+__device__ __forceinline__ void f2l_flag_expiry(unsigned* err, unsigned* sticky) {
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sticky) __hip_atomic_fetch_or(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct WideF2L {
     float* part;        // [C][4 slots][A / 4][8]: the blocks' tagged partial sums (zeroed in front of the launch)
     unsigned* xccs;     // [C][A / 4]: 0x80000000 | XCC id of every block (zeroed in front of the launch)
-    unsigned* err;      // [1]
+    unsigned* err;      // [1] this launch's flag (in the ticket area: zeroed in front of every launch)
+    unsigned* sticky;   // [1] or nullptr: the CALLER'S fault word -- 1 is OR-ed in, nothing here ever clears it
     float* logp;        // [B] out
     int force_safe;     // tests: 1 = run the memory-side exchange whatever the placement; 2 = spread every chunk over all XCDs
 };
@@ -1503,7 +1509,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             seen = __hip_atomic_load(mine + d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__all(!has0 || (seen >> 31)) || !alive) break;
             __builtin_amdgcn_s_sleep(2);
-            if (++it > (1 << 18)) { alive = false; __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (++it > (1 << 18)) { alive = false; f2l_flag_expiry(sy.err, sy.sticky); }
         }
         local = __all(!has0 || ((seen & 15u) == xcc)) && sy.force_safe != 1;
     }
@@ -1713,7 +1719,7 @@ __global__ __launch_bounds__(256, 2) void k_mix_wide_f2l(      // (two waves per
             __builtin_amdgcn_s_sleep(1);
             if (++it > (1 << 18)) {                          // the grid was not co-resident (or a wave died): flagged, poisoned
                 alive = false;
-                __hip_atomic_store(sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f2l_flag_expiry(sy.err, sy.sticky);
             }
             poll_issue(g, w);
             if (__all(!has0 || __float_as_uint(w.z) == want)) break;
@@ -1968,16 +1974,24 @@ __global__ __launch_bounds__(1024) void k_adv_stats(const float* __restrict__ ad
 // ---------------------------------------------------------------------------------------
 struct TilePlan { int R; int grid; int threads; size_t lds; int P; bool ok; int ntiles; };
 
-// compute units of the current device (MI355X: 256); asked once
+// The library's only process-wide memory: per-DEVICE caches of two device properties (the CU count, the one-launch PPO pass's
+// occupancy), filled on first use.  A slot holds 0 or the final value and two threads racing to fill it write the same value
+// (relaxed atomics); nothing a call computes depends on another call.  Devices past the table are asked every time.
+constexpr int DEV_SLOTS = 64;
+static int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+// compute units of the CURRENT device (MI355X: 256; a partitioned device reports its own share)
 static int cu_count() {
-    static int n = 0;
+    static std::atomic<int> cache[DEV_SLOTS];
+    const int dev = current_device();
+    const bool slot = dev >= 0 && dev < DEV_SLOTS;
+    int n = slot ? cache[dev].load(std::memory_order_relaxed) : 0;
     if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        if (slot) cache[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -2021,11 +2035,14 @@ static int launch_tile(int N, const TilePlan& pl, hipStream_t st, const float* l
     const int threads = pl.threads + 64 * (TK_NL + (MODE != MODE_BWD ? 1 : 0) + (MODE != MODE_FWD ? TK_NS : 0));
 #define PFPN_LAUNCH_TILE(NN)                                                                                \
     do {                                                                                                    \
-        static bool big_lds_ok = false;          /* > 64 KB of dynamic LDS needs a one-time opt-in */         \
-        if (pl.lds > 64 * 1024 && !big_lds_ok) {                                                            \
+        /* > 64 KB of dynamic LDS needs an opt-in, once per device (the attribute belongs to the device's code object) */ \
+        static std::atomic<bool> big_lds_ok[DEV_SLOTS];                                                     \
+        const int dev_ = current_device();                                                                  \
+        const bool slot_ = dev_ >= 0 && dev_ < DEV_SLOTS;                                                   \
+        if (pl.lds > 64 * 1024 && !(slot_ && big_lds_ok[dev_].load(std::memory_order_relaxed))) {           \
             (void)hipFuncSetAttribute((const void*)&k_mix_tile<NN, MODE>,                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TK_MAX_LDS);        \
-            big_lds_ok = true;                                                                              \
+            if (slot_) big_lds_ok[dev_].store(true, std::memory_order_relaxed);                             \
         }                                                                                                   \
         hipLaunchKernelGGL((k_mix_tile<NN, MODE>), dim3(pl.grid), dim3(threads), pl.lds, st, logits, x,      \
                            loc, logstd, dlogp, B, A, tanh_mode, pl.P, pl.ntiles / pl.grid,                  \
@@ -2217,7 +2234,8 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
                         const float* logp_old, const float* adv, const float* value, const float* value_old,
                         const float* adv_stats, int B, int A, int N, float clip_eps, float value_coef,
                         float* logp, float* dlogits, float* dloc, float* dlogstd, float* dvalue, float* dlogp,
-                        float* dbias, float* loss3, int* chunks_out, void* workspace, size_t workspace_bytes, void* stream) {
+                        float* dbias, float* loss3, int* chunks_out, uint32_t* fault_flag,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     PFPN_BEGIN();
     if (!logits || !action || !loc || !logstd || !logp_old || !adv || !value || !value_old || !adv_stats || !logp ||
         !dlogits || !dloc || !dlogstd || !dvalue || !dlogp || !loss3 || B < 1 || A < 4 || N < 1)
@@ -2231,8 +2249,12 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     const bool stream_policy = wide_stream(B, A, N);
     const int nb = A / 4;
     // every wave of a chunk waits for the others: the WHOLE grid must be resident at once
-    static int per_cu_cache[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};      // (the occupancy query costs host time: once per variant)
-    int& per_cu = per_cu_cache[stream_policy ? 1 : 0][dbias ? 1 : 0][fulln ? 1 : 0];
+    // (the occupancy query costs host time: once per device and variant)
+    static std::atomic<int> per_cu_cache[DEV_SLOTS][2][2][2];
+    const int dev = current_device();
+    std::atomic<int>* const per_cu_slot =
+        dev >= 0 && dev < DEV_SLOTS ? &per_cu_cache[dev][stream_policy ? 1 : 0][dbias ? 1 : 0][fulln ? 1 : 0] : nullptr;
+    int per_cu = per_cu_slot ? per_cu_slot->load(std::memory_order_relaxed) : 0;
 #define PFPN_F2L_DISPATCH2(WHAT, SS, DD) do { if (fulln) WHAT(SS, DD, true); else WHAT(SS, DD, false); } while (0)
 #define PFPN_F2L_DISPATCH(WHAT)                                                                              \
     do {                                                                                                     \
@@ -2240,7 +2262,10 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
         else { if (dbias) PFPN_F2L_DISPATCH2(WHAT, false, true); else PFPN_F2L_DISPATCH2(WHAT, false, false); } \
     } while (0)
 #define PFPN_F2L_OCC(SS, DD, FF) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mix_wide_f2l<1, SS, DD, FF>, 256, 0)
-    if (per_cu <= 0) PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
+    if (per_cu <= 0) {
+        PFPN_F2L_DISPATCH(PFPN_F2L_OCC);
+        if (per_cu_slot && per_cu > 0) per_cu_slot->store(per_cu, std::memory_order_relaxed);
+    }
 #undef PFPN_F2L_OCC
     int C = (per_cu * cu_count()) / nb;
     if (wide_c_env() > 0 && wide_c_env() < C) C = wide_c_env();
@@ -2267,6 +2292,7 @@ int pfpn_ppo_wide_fused(const float* logits, const float* action, const float* l
     sy.part = sync;
     sy.xccs = (unsigned*)(sync + WIDE_F2L_PART_WORDS);
     sy.err = tick + WIDE_TICK_PPO + 1;
+    sy.sticky = (unsigned*)fault_flag;
     sy.logp = logp;
     sy.force_safe = force_safe;
     WidePpo p{};

@@ -22,9 +22,10 @@ from . import kernels
 # deleting the graph first cures it).  So the graphs go first: `release_captured_collectives()`, called by
 # `models.distributed_model.shutdown_process_group()` and by bench.py before they destroy the group.
 _with_collectives = weakref.WeakSet()
-# tests only: the next captured-exchange attempt fails INSIDE the capture region (rehearses the fall-back) -- True: on every
-# replica; an int r: only on the replica whose optimiser carries `rank_for_tests == r` (the others learn of it through the flag)
-inject_capture_failure = False
+# tests only: the next captured-exchange attempt fails INSIDE the capture region (rehearses the fall-back) -- None / False: off;
+# True: on every replica; an int r: only on the replica whose optimiser carries `rank_for_tests == r` (the others learn of it
+# through the flag).  "invalidated": the failure carries the runtime's invalidated-capture signature (CaptureInvalidated path).
+inject_capture_failure = None
 
 
 def release_captured_collectives():
@@ -78,12 +79,50 @@ def capture_invalidated(e):
     return "stream is capturing" in t or "during capture" in t or "StreamCapture" in t
 
 
-def any_replica(flag, group=None, device="cpu"):
-    """logical OR of `flag` over the replicas of `group` (one all-reduce(MAX) every replica must reach)"""
+class ReplicaLost(RuntimeError):
+    """Another replica published that it cannot go on (its stream capture was invalidated: CaptureInvalidated there)."""
+
+
+_agreements = {}
+_FATAL = b"X"
+
+
+def any_replica(flag, group=None, device="cpu", fatal=False, timeout_s=300.0):
+    """Logical OR of `flag` over the replicas of `group`, agreed through the job's rendezvous STORE (host side: it works for a
+    replica whose GPU stream is unusable, and a replica waiting here is not parked inside a device collective).  Every replica
+    of the group must reach the call the same number of times (agreement k pairs up with the others' agreement k).
+    `fatal=True`: publish that this replica is lost and return at once (the caller raises); the others get ReplicaLost from
+    their own call instead of waiting minutes for a collective's timeout.  Falls back to an all-reduce(MAX) on `device` where
+    the store cannot be reached (never seen; the private accessor is torch's own)."""
+    import datetime
     import torch.distributed as dist
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return bool(int(t.item()))
+    pg = group if group is not None else dist.group.WORLD
+    try:
+        ranks = list(dist.get_process_group_ranks(pg))
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    if store is None:
+        if fatal:
+            return True
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return bool(int(t.item()))
+    me = dist.get_rank()
+    tag = "-".join(str(r) for r in ranks)
+    seq = _agreements[tag] = _agreements.get(tag, 0) + 1
+    key = lambda r: "pfpn/agree/%s/%d/%d" % (tag, seq, r)
+    store.set(key(me), _FATAL if fatal else (b"1" if flag else b"0"))
+    if fatal:
+        return True
+    store.wait([key(r) for r in ranks], datetime.timedelta(seconds=float(timeout_s)))
+    votes = {r: bytes(store.get(key(r))) for r in ranks}
+    lost = [r for r, v in votes.items() if v == _FATAL]
+    if lost:
+        raise ReplicaLost("replica(s) %s lost their stream capture to the runtime and cannot go on: the job must be restarted "
+                          "(launch the ranks under a launcher that ends the job when one rank fails, e.g. torch.distributed.run)"
+                          % lost)
+    return any(v != b"0" for v in votes.values())
 
 
 def refill_noise(noise, generator):
@@ -179,6 +218,9 @@ class GraphedLearnerStep(object):
             except Exception as e:                           # (a capture that RCCL / the runtime refuses)
                 failed, why = 1, repr(e)
                 if capture_invalidated(e):
+                    # the others are about to wait for this replica's vote: tell them first (host side, the store), then
+                    # fail -- they raise ReplicaLost within a store round trip instead of sitting in a collective's timeout
+                    any_replica(True, optimizer.pg, net.device, fatal=True)
                     raise CaptureInvalidated(e) from e
             if any_replica(failed, optimizer.pg, net.device):
                 if explicit_arg:
@@ -230,8 +272,13 @@ class GraphedLearnerStep(object):
     def _record(self, in_graph):
         net, optimizer, gather_from, s = self.net, self.opt, self.gather_from, self.capture_stream
         want_fail = inject_capture_failure
-        if in_graph and (want_fail is True or want_fail == getattr(optimizer, "rank_for_tests", None)):
+        rank_here = getattr(optimizer, "rank_for_tests", None)
+        # (types compared explicitly: False == 0 and True == 1 in Python -- "off" must not read as "replica 0")
+        if in_graph and (want_fail is True or
+                         (type(want_fail) is int and type(rank_here) is int and want_fail == rank_here)):
             raise RuntimeError("injected capture failure")
+        if in_graph and want_fail == "invalidated":
+            raise RuntimeError("injected: operation not permitted when stream is capturing")
         self.graph = torch.cuda.CUDAGraph()
         if self.debug_nodes:
             self.graph.enable_debug_mode()

@@ -132,7 +132,8 @@ def ppo_wide_fused(logits, action, loc, logstd, logp_old, adv, value, value_old,
                                        _f32(out["dlogits"].view(B, A * N), B, A * N), _f32(out["dloc"], A, N),
                                        _f32(out["dlogstd"], A, N), _f32(out["dvalue"], B), _f32(out["dlogp"], B),
                                        _f32(dbias.view(-1), A * N) if dbias is not None else None, _f32(out["loss3"], 3),
-                                       ctypes.addressof(chunks), buf.data_ptr(), buf.numel(), _stream()), "pfpn_ppo_wide_fused")
+                                       ctypes.addressof(chunks), fault_word(dev).data_ptr(), buf.data_ptr(), buf.numel(),
+                                       _stream()), "pfpn_ppo_wide_fused")
     # the ticket area is the last 4224 words of the pfpn_mixture_workspace_bytes() prefix of the workspace; word 65 = the flag
     tick = buf[:nbytes].view(torch.int32)[-(128 + 4096):]
     return out, chunks.value, tick[65:66]
@@ -184,8 +185,49 @@ def adv_stats(adv, normalize=True, out=None):
 
 
 _dlogp_bufs = {}
-# the one-launch (2L) PPO pass of the 256-particle shapes (PFPN_WIDE_FUSED=0: the two-launch composition everywhere)
+# the one-launch (2L) PPO pass of the 256-particle shapes (PFPN_WIDE_FUSED=0: the two-launch composition everywhere --
+# the setting for a GPU this process does not have to itself: the pass's waves wait for each other, see DeviceFault)
 WIDE_FUSED = os.environ.get("PFPN_WIDE_FUSED", "1") != "0"
+
+
+class DeviceFault(RuntimeError):
+    """A kernel whose waves wait for each other (the one-launch PPO pass) gave up a bounded wait: its gradients are NaN and
+    every parameter the optimiser touched since is invalid.  Raised by check_faults() at the next host synchronisation."""
+
+
+_fault_words = {}
+
+
+def fault_word(device):
+    """The package's sticky fault word of `device` (int32[1], zeroed once): handed to every entry point that records a
+    failure it cannot return (pfpn_ppo_wide_fused's `fault_flag`).  Nothing on the device ever clears it."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _fault_words.get(idx)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the first one-launch PPO pass of a device must run eagerly (warm-up) before a capture: "
+                               "its fault word would otherwise live in the graph's private pool")
+        w = _fault_words[idx] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def check_faults():
+    """Read the fault words (one 4-byte copy per device that has one; nothing at all for shapes that never took a waiting
+    kernel) and raise DeviceFault if a launch recorded a failure since the process started.  Called wherever the host
+    synchronises anyway: loss read-back, end of a training round, checkpoint save."""
+    for idx, w in _fault_words.items():
+        if int(w.item()):
+            raise DeviceFault(
+                "cuda:%d: a one-launch PPO pass (pfpn_ppo_wide_fused) gave up waiting for its own waves -- something else "
+                "held compute units while it ran (another process or stream, a CU mask).  Its gradients were NaN and the "
+                "optimiser has applied them: the parameters of this run are lost from that step on; restart from the last "
+                "checkpoint with PFPN_WIDE_FUSED=0 (the two-launch composition needs no co-residency)." % idx)
+
+
+def clear_faults():
+    """tests: forget recorded faults"""
+    for w in _fault_words.values():
+        w.zero_()
 
 
 def _dlogp_scratch(B, device):
@@ -244,12 +286,14 @@ def ppo_mixture_fwd_bwd(logits, action, loc, logstd, logp_old, adv, value, value
         # ONE launch, the logits read once (round 5: k_mix_wide_f2l; 415 us against 598 us on the 1 GiB shape) where that form
         # exists -- 64 <= N <= 256 particles per dim, A % 4 == 0, A <= 128, a batch of at least 8 row chunks -- and WIDE_FUSED is on.
         # It needs the device to itself while it runs (its waves wait for each other): the package launches on one stream.
+        # A wait that expires (a shared GPU) leaves NaN gradients AND a sticky mark in fault_word(dev): check_faults() raises
+        # at the next loss read-back / checkpoint.
         if WIDE_FUSED:
             rc = lib.pfpn_ppo_wide_fused(pl, pa, ploc, pls, *ptrs, B, A, N, float(clip_eps), float(value_coef),
                                          out["logp"].data_ptr(), out["dlogits"].data_ptr(), out["dloc"].data_ptr(),
                                          out["dlogstd"].data_ptr(), out["dvalue"].data_ptr(), dlogp.data_ptr(),
                                          _f32(dbias.view(-1), A * N, name="dbias") if dbias is not None else None,
-                                         out["loss3"].data_ptr(), None, ws, wsn, _stream())
+                                         out["loss3"].data_ptr(), None, fault_word(dev).data_ptr(), ws, wsn, _stream())
             if rc != 1:
                 _lib.check(rc, "pfpn_ppo_wide_fused")
                 return out

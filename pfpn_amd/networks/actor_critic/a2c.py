@@ -330,6 +330,7 @@ class ParticleFilteringA2CNetwork(A2CNetwork):
 
     def _report(self, loss4, ops):
         loss4 = loss4.cpu().numpy()
+        kernels.check_faults()      # the host has just synchronised: a recorded kernel fault surfaces here, not as a NaN log line
         ent = None
         if self.entropy_beta:
             ent = self._entropy_value()

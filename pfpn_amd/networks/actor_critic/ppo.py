@@ -189,6 +189,7 @@ def clip_ppo_network_wrapper(a2c_base_class):
                 steps.append(self.global_step)
                 i += 1
             host = losses.cpu().numpy()
+            kernels.check_faults()
             wanted = list(ops) if hasattr(ops, "__len__") else ([ops] if ops else [])
             return [((float(l[0]), None, float(l[1]), float(l[2])),
                      [st if o in ("global_step", "step") else (o() if callable(o) else None) for o in wanted])

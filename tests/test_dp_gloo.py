@@ -104,6 +104,19 @@ def _rank_main(rank, world, port, q):
         # to the two-graph form; nobody failing leaves everybody where they are
         from pfpn_amd.graphs import any_replica
         ok &= any_replica(rank == world - 1) is True and any_replica(False) is False
+        # a replica whose capture the runtime invalidated cannot vote through a device collective: it publishes that it is lost
+        # (host side, the rendezvous store) and raises; the others get ReplicaLost from their agreement call at once instead
+        # of waiting in an all-reduce for a rank that will never arrive
+        from pfpn_amd.graphs import ReplicaLost
+        if rank == world - 1:
+            ok &= any_replica(True, fatal=True) is True
+        else:
+            try:
+                any_replica(False, timeout_s=60)
+                ok &= False
+            except ReplicaLost as e:
+                ok &= str(world - 1) in str(e)
+        dist.barrier()
         q.put((rank, bool(ok), float(net.store.bucket.sum())))
     except Exception as e:                 # report instead of leaving the parent waiting for its timeout
         import traceback

@@ -3,6 +3,7 @@ the complete data-parallel learner step -- per-rank clip, bucket all-reduce of [
 TF-Adam with 1/W, statistics unpack, resample tick -- against oracle.dppo_learner_step with two shards."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -299,7 +300,7 @@ def _rccl_rank(port, q):
         dflt.close()
         graphs.inject_capture_failure = True
         fb = GraphedLearnerStep(fpair[0], fopt[0], *tin)
-        graphs.inject_capture_failure = False
+        graphs.inject_capture_failure = None
         ok &= fb.split and not fb.in_graph_exchange and "injected" in (fb.exchange_fallback or "")
         # the injection can name ONE replica (round 5: the failure sits inside the capture region, behind the warm-up's real
         # collectives, so that a replica failing alone still reaches the flag's all-reduce in step with the others): another
@@ -314,6 +315,22 @@ def _rccl_rank(port, q):
         graphs.inject_capture_failure = False
         ok &= mine.split and "injected" in (mine.exchange_fallback or "")
         mine.close()
+        # "off" spelt False must not read as "replica 0" (False == 0 in Python): with rank_for_tests == 0 still set, the
+        # captured form is what this stepper gets
+        off = GraphedLearnerStep(fpair[0], fopt[0], *tin)
+        ok &= off.in_graph_exchange and off.exchange_fallback is None
+        off.close()
+        graphs.inject_capture_failure = None
+        # a capture the RUNTIME invalidated is not a fall-back case: the replica publishes that it is lost (the store), then
+        # raises; the mark it left is what the others' agreement call reads
+        graphs.inject_capture_failure = "invalidated"
+        try:
+            GraphedLearnerStep(fpair[0], fopt[0], *tin)
+            ok &= False
+        except graphs.CaptureInvalidated:
+            pass
+        finally:
+            graphs.inject_capture_failure = None
         for _ in range(2):
             fb()
             fpair[1].train_device(fopt[1], *tin)
@@ -374,19 +391,35 @@ def _rccl_rank(port, q):
             dist.destroy_process_group()
 
 
+_CAPTURE_SIGNATURE = ("CaptureInvalidated", "stream is capturing", "during capture", "StreamCapture")
+
+
+def _rank_with_stderr_file(target, errpath, port, q):
+    """child entry: everything the rank (and the runtime's own threads: the NCCL watchdog aborts through stderr) writes to
+    fd 2 lands in `errpath`, which the parent reads to tell WHY a rank that delivered nothing died"""
+    fd = os.open(errpath, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+    os.dup2(fd, 2)
+    os.close(fd)
+    target(port, q)
+
+
 def _one_rccl_rank(target, attempts=2):
     """Run `target(port, queue)` as a spawned rank and return (its result tuple or None, its exit code).  The queue is polled while
     the rank lives (a rank the runtime aborts never delivers: the old q.get(timeout=240) waited four minutes for it).  ONE retry
-    when the rank died of the runtime invalidating a stream capture -- seen once in ~30 full runs, a hipBLASLt matmul refusing
-    inside a capture (pfpn_amd.graphs.CaptureInvalidated; the NCCL watchdog then aborts the process): what these tests check is
-    the exchange's arithmetic, and a second clean pass is printed as such."""
+    when -- and only when -- the rank died of the runtime invalidating a stream capture (seen once in ~30 full runs, a hipBLASLt
+    matmul refusing inside a capture: pfpn_amd.graphs.CaptureInvalidated; the NCCL watchdog then aborts the process): the
+    signature must stand in the rank's result or in what it wrote to stderr.  Any other death (a segfault, a GPU fault, an
+    out-of-memory kill) fails the test on the first attempt, with the rank's stderr tail in the message."""
     import queue as _queue
+    import tempfile
     import time as _time
     res, code = None, None
     for attempt in range(attempts):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
-        p = ctx.Process(target=target, args=(_free_port(), q))
+        errfile = tempfile.NamedTemporaryFile(prefix="pfpn_rank_", suffix=".err", delete=False)
+        errfile.close()
+        p = ctx.Process(target=_rank_with_stderr_file, args=(target, errfile.name, _free_port(), q))
         p.start()
         res, t0 = None, _time.time()
         while _time.time() - t0 < 240:
@@ -405,11 +438,19 @@ def _one_rccl_rank(target, attempts=2):
             p.kill()
             p.join(10)
         code = p.exitcode
-        capture_flake = (res is None and code not in (0, None)) or \
-            (res is not None and res[1] is False and ("CaptureInvalidated" in str(res[2]) or "capturing" in str(res[2])))
+        try:
+            err = open(errfile.name, errors="replace").read()
+        finally:
+            os.unlink(errfile.name)
+        sys.stderr.write(err[-4000:])                        # (the rank's stderr still reaches the test log)
+        failed = (res is None and code not in (0, None)) or (res is not None and res[1] is False)
+        text = err + (str(res[2]) if res is not None else "")
+        capture_flake = failed and any(sig in text for sig in _CAPTURE_SIGNATURE)
         if capture_flake and attempt + 1 < attempts:
             print("the rank died of an invalidated stream capture (exit code %r, result %r): one retry" % (code, res))
             continue
+        if res is None and code not in (0, None):
+            res = (0, False, "the rank died without a result (exit code %r); its stderr ends: %s" % (code, err[-1500:]), "")
         break
     return res, code
 

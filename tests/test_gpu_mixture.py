@@ -424,6 +424,17 @@ def test_wide_fused_pass_fails_loudly_when_its_waves_cannot_meet(oracle, dev, mo
     monkeypatch.delenv("PFPN_WIDE_F2L_SAFE")
     o3, c3, e3 = run()
     assert e3 == 0 and c3 == c0 and all(torch.equal(o0[k], o3[k]) for k in o0)
+    # the per-launch flag is gone with the next launch (e3 == 0), the CALLER'S fault word is not: the expired launch stays on
+    # record however many clean launches follow, and the package raises at its next host synchronisation (loss read-back,
+    # end of a training round, checkpoint save) instead of training on with NaN parameters
+    assert int(kernels.fault_word(dev).item()) == 1
+    with pytest.raises(kernels.DeviceFault, match="PFPN_WIDE_FUSED=0"):
+        kernels.check_faults()
+    with pytest.raises(kernels.DeviceFault):
+        from pfpn_amd import checkpoint
+        checkpoint.network_tensors(None)                     # (refuses before it looks at the network)
+    kernels.clear_faults()
+    kernels.check_faults()
 
 
 def test_wide_fused_refuses_a_chunk_beyond_its_buffer_window(dev):
@@ -441,7 +452,8 @@ def test_wide_fused_refuses_a_chunk_beyond_its_buffer_window(dev):
     p = ctypes.c_void_p(t.data_ptr())
     chunks = ctypes.c_int(-1)
     rc = lib.pfpn_ppo_wide_fused(p, p, p, p, p, p, p, p, p, B, A, N, ctypes.c_float(0.2), ctypes.c_float(0.5), p, p, p, p, p, p,
-                                 None, p, ctypes.addressof(chunks), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), None)
+                                 None, p, ctypes.addressof(chunks), None, ctypes.c_void_p(ws.data_ptr()),
+                                 ctypes.c_size_t(ws.numel()), None)
     torch.cuda.synchronize()
     assert rc == 1 and chunks.value == -1 and float(t.abs().sum()) == 0.0
 
