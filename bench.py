@@ -658,6 +658,44 @@ def main():
         if dist.get_backend() == "nccl" and "captured inside" in launch and safe is None:
             extra("exchange_two_graphs", two_graph_block)
 
+    # ---- N > 1: the roofline object of rank 0's shard (local launches only: no collective; the other ranks wait at the
+    # closing barrier meanwhile).  The N = 1 line carries the full set (traffic, rocprof agreement, stress shape, GEMMs).
+    if rank == 0 and world > 1:
+        try:
+            def shard_call():
+                kernels.ppo_mixture_fwd_bwd(net.logits, action, net.loc, net.logstd, logp_old, adv, net.value_buf, value_old,
+                                            net.adv_stats, 0.2, 0.5, out=net.train_out,
+                                            dbias=net.store.g("actor/fc_policy/bias"), finalize=False)
+            for _ in range(3):
+                shard_call()
+            torch.cuda.synchronize()
+            side_ = torch.cuda.Stream()
+            side_.wait_stream(torch.cuda.current_stream())
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side_):
+                shard_call()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g_, stream=side_, **graphs._capture_mode()):
+                    for _ in range(20):
+                        shard_call()
+            torch.cuda.synchronize()
+            g_.replay()
+            torch.cuda.synchronize()
+            ea_, eb_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea_.record()
+            for _ in range(10):
+                g_.replay()
+            eb_.record()
+            torch.cuda.synchronize()
+            us_ = ea_.elapsed_time(eb_) * 1e3 / 200
+            ab_ = algorithmic_bytes_fused(rows)
+            out["roofline"] = {"kernel": "k_mix_tile<35,PPO>", "bound": "hbm", "achieved": ab_ / us_ / 1e3,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab_ / us_ / 1e3 / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes": ab_, "us_per_launch": us_, "launches_timed": 200, "rows": rows}
+            del g_
+        except Exception as e:
+            out["roofline"] = {"error": repr(e)}
+
     # ---- roofline of the dominant hand-written kernel, and of the GEMMs (rank 0, N=1 only) ----------
     if rank == 0 and world == 1:
         logits = net.logits

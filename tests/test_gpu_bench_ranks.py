@@ -45,6 +45,8 @@ def test_two_rank_bench_line():
     assert d["exchange_sharded"]["value"] > 0
     assert "two hipGraphs around the RCCL all-reduce" in d["config"]["launch"]        # gloo: the fall-back form of the exchange
     assert "extras_timed_out" not in d
+    # the multi-rank line carries rank 0's roofline object too (its 2048-row shard through the fused mixture kernel)
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["rows"] == 2048
 
 
 def test_headline_survives_a_rank_failing_in_an_extra():
