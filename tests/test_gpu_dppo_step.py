@@ -332,3 +332,41 @@ def test_config5_shaped_learner_step_matches_oracle(oracle, dev):
             close_scaled(G[name].cpu().numpy(), g_ref, 1e-3, "grad " + name)
         for name, v in net.variables().items():       # within 5 % of one Adam step (lr = 1e-4; see the step test above)
             close_scaled(v.cpu().numpy(), st.P[name], 5e-6, name, floor=1.0)
+
+
+def test_learner_raises_instead_of_training_on_after_an_expired_one_launch_pass(dev, monkeypatch, tmp_path):
+    """the one-launch PPO pass of the wide grids needs the device to itself; a wait that expires makes
+    its gradients NaN, and the optimiser applies them.  The expiry leaves a sticky mark in the device's fault word and the
+    learner RAISES at the loss read-back of that very step (not a NaN line in the [TRAIN] log); a checkpoint save refuses too.
+    Forced as in tests/test_gpu_mixture.py: a grid twice the device's capacity whose chunks take every C-th block."""
+    from pfpn_amd import checkpoint, kernels
+    from pfpn_amd.models import SyncReplicasApplier
+    A, N, B = 128, 256, 2048
+    monkeypatch.setenv("PFPN_GRAPH_TRAIN", "0")              # eager steps: the knobs below are read at every launch
+    net = make_net(dev, A=A, particles=N)
+    opt = SyncReplicasApplier(net, [{"names": None, "lr": 1e-4}], norm_clip=1.0, world_size=1)
+    rng = np.random.default_rng(11)
+    batch = make_batch(rng, B, A=A)
+    batch["action"] = rng.uniform(-1.0, 1.0, (B, A)).astype(F)
+    with torch.no_grad():                                    # old log-prob = the initial policy's own: ratios of 1
+        policy, _, _ = net._forward(torch.from_numpy(batch["state"]).to(dev))
+        batch["log_prob"] = policy.log_prob(torch.from_numpy(batch["action"]).to(dev)).cpu().numpy()
+    args = (batch["state"], batch["action"], batch["value"], batch["log_prob"], batch["advantage"])
+    kernels.check_faults()
+    loss, _ = net.train(None, opt, [], *args)                # a clean step through the one-launch pass
+    assert np.isfinite(loss[0]) and bool(torch.isfinite(net.store.flat).all())
+    monkeypatch.setenv("PFPN_WIDE_F2L_OVERSUBSCRIBE", "1")
+    monkeypatch.setenv("PFPN_WIDE_F2L_SAFE", "3")
+    try:
+        with pytest.raises(kernels.DeviceFault, match="PFPN_WIDE_FUSED=0"):
+            net.train(None, opt, [], *args)
+        assert not bool(torch.isfinite(net.store.flat).all())     # what the exception is about: the run IS poisoned
+        monkeypatch.delenv("PFPN_WIDE_F2L_OVERSUBSCRIBE")
+        monkeypatch.delenv("PFPN_WIDE_F2L_SAFE")
+        with pytest.raises(kernels.DeviceFault):                  # sticky: later (clean) launches do not clear it
+            net.train(None, opt, [], *args)
+        with pytest.raises(kernels.DeviceFault):
+            checkpoint.save(str(tmp_path / "model.ckpt-1"), net, opt)
+        assert not list(tmp_path.iterdir())                       # nothing was written
+    finally:
+        kernels.clear_faults()
