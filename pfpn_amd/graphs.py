@@ -110,7 +110,9 @@ def any_replica(flag, group=None, device="cpu", fatal=False, timeout_s=300.0):
         return bool(int(t.item()))
     me = dist.get_rank()
     tag = "-".join(str(r) for r in ranks)
-    seq = _agreements[tag] = _agreements.get(tag, 0) + 1
+    last, of_store = _agreements.get(tag, (0, None))
+    seq = 1 if of_store is not store else last + 1           # (a process group created anew starts its count anew, everywhere)
+    _agreements[tag] = (seq, store)
     key = lambda r: "pfpn/agree/%s/%d/%d" % (tag, seq, r)
     store.set(key(me), _FATAL if fatal else (b"1" if flag else b"0"))
     if fatal:
