@@ -418,8 +418,9 @@ def main():
                     one()
                     n -= 1
         run_steps.prepare = prepare
+        lib_ = "RCCL" if (not dist.is_initialized() or dist.get_backend() == "nccl") else dist.get_backend()
         what = ("two hipGraphs around the %s" % ("sharded exchange (all-to-all | owner Adam | all-gather)"
-                                                 if getattr(opt_, "sharded", False) else "RCCL all-reduce")) if one.split else \
+                                                 if getattr(opt_, "sharded", False) else "%s all-reduce" % lib_)) if one.split else \
             ("hipGraph, %d learner steps per replay (remainder as one shorter replay)" % spg_ if spg_ > 1 else "hipGraph")
         if one.in_graph_exchange:
             what += ", the RCCL all-reduce captured inside"
@@ -514,7 +515,8 @@ def main():
                        "step": "state-norm, MLP fwd (+critic head), fused mixture logp+PPO+bwd, MLP bwd, one deferred "
                                "reduction launch (bias grads, particle grads, loss, state-norm EMA), clip, "
                                + (("sharded exchange (all-to-all, owner Adam, all-gather), " if getattr(opt, "sharded", False)
-                                   else "RCCL all-reduce, ") if (world > 1 or args.force_exchange) else "")
+                                   else "%s all-reduce, " % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend()))
+                                  if (world > 1 or args.force_exchange) else "")
                                + "TF-Adam, resample tick"},
         }
 

@@ -43,7 +43,7 @@ def test_two_rank_bench_line():
     assert d["rccl"]["ranks_seen"] == 2 and d["rccl"]["world"] == 2
     assert d["weak_scaling"]["value"] > 0 and d["weak_scaling"]["global_batch"] == 8192
     assert d["exchange_sharded"]["value"] > 0
-    assert "two hipGraphs around the RCCL all-reduce" in d["config"]["launch"]        # gloo: the fall-back form of the exchange
+    assert "two hipGraphs around the gloo all-reduce" in d["config"]["launch"]        # gloo: the fall-back form of the exchange
     assert "extras_timed_out" not in d
     # the multi-rank line carries rank 0's roofline object too (its 2048-row shard through the fused mixture kernel)
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["rows"] == 2048
