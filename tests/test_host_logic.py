@@ -491,3 +491,15 @@ def test_sac_autograd_twin_starts_from_the_uniform_mixture():
     r0 = rows[0]
     assert abs(r0["alpha"] - 1.0) < 1e-6 and abs(r0["logp"] + 24.7) < 0.8 and 0.4 < r0["abs_a"] < 0.6 and abs(r0["q_pi"]) < 0.1
     assert all(abs(r["alpha"] - 1.0) < 1e-3 and r["value_loss"] > 100 for r in rows)
+
+
+def test_fault_check_costs_nothing_where_no_waiting_kernel_ever_ran():
+    """kernels.check_faults() sits on every loss read-back and in front of every checkpoint: with no fault word handed out
+    (no GPU here; on a GPU: no wide particle grid ever took the one-launch PPO pass) it reads nothing and raises nothing, and
+    the agreement of the replicas (graphs.any_replica) counts its rounds per process group."""
+    from pfpn_amd import graphs, kernels
+    assert kernels._fault_words == {}
+    kernels.check_faults()
+    kernels.clear_faults()
+    assert issubclass(kernels.DeviceFault, RuntimeError) and issubclass(graphs.ReplicaLost, RuntimeError)
+    assert graphs.inject_capture_failure is None              # "off" is None (False == 0 would read as "replica 0")
