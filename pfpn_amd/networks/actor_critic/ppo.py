@@ -102,7 +102,17 @@ def clip_ppo_network_wrapper(a2c_base_class):
         def train(self, sess, optimizer, ops, state, action, value, log_prob, advantage):
             """reference ppo.py:64-72 + actor_critic.py:382-404.
             Returns ((loss, entropy-or-None, policy_loss, value_loss), extra_fetches)."""
-            args = [self._to_dev(a) for a in (state, action, value, log_prob, advantage)]
+            host = (state, action, value, log_prob, advantage)
+            if not any(isinstance(a, torch.Tensor) for a in host):
+                # the step of this minibatch size is already a hipGraph: the host arrays go STRAIGHT into its static inputs
+                # (no staging tensors on the device, no device-to-device copies: five host-to-device copies and a replay)
+                B = len(advantage)
+                g = self._train_graphs.get((B, id(optimizer)) + tuple(self._graph_phase()))
+                if g is not None and g.K == 1 and g.noise is None:
+                    for dst, src in zip(g.inputs, host):
+                        dst.copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(src, dtype=np.float32))).view(dst.shape))
+                    return self._report(g(), ops)
+            args = [self._to_dev(a) for a in host]
             args[0] = args[0].view(-1, self.S)
             args[1] = args[1].view(-1, self.n_actions)
             loss3 = self.graphed_train(optimizer, args)
